@@ -1,0 +1,175 @@
+/*
+ * dspfx_oracle.h -- CPU restatement of simmsb/dsp-stuff's per-block effect-node
+ * evaluation loop.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, the smoke check in
+ * __graft_entry__.py and bench.py's cpu_baseline leg may load it; it is the
+ * checker, never the thing measured or shipped.  The product (libdspfx.so, HIP)
+ * never links or calls anything in this directory.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ *  and its Rust-nightly toolchain is absent from this
+ * image, so the restatement cannot be checked against outputs of the reference
+ * itself.  It is pinned only by known-answer tests derived from the cited source
+ * lines (tests/test_oracle_kat.py) and by an independent numpy-float32 model
+ * (oracle/numpy_model.py).
+ *
+ * Third-party arithmetic that is NOT under /root/reference and is restated from
+ * its published definition (Cargo.lock pins):
+ *   - biquad 0.4.2  DirectForm1<f32>::{new,run,reset_state,update_coefficients}
+ *   - rivulet @b2416e5 circular_buffer (FIFO semantics + initial zero fill only)
+ *   - Rust std f32 math on linux-gnu == glibc libm (tanhf/sinf/atanf/expf)
+ *   - Rust std VecDeque<f64> growth policy (for Fir's a/b slice split)
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (Rust never contracts a*b+c).
+ * All citations are relative to /root/reference/.
+ */
+#ifndef DSPFX_ORACLE_H
+#define DSPFX_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* dsp-stuff/src/node.rs:257 */
+#define ORC_BUF_SIZE 128
+
+/* Node kinds.  Numeric values are shared with include/dspfx.h (dspfx_kind). */
+enum {
+    ORC_GAIN = 0,      /* nodes/gain.rs */
+    ORC_BIQUAD = 1,    /* nodes/biquad.rs */
+    ORC_LOW_PASS = 2,  /* nodes/low_pass.rs */
+    ORC_HIGH_PASS = 3, /* nodes/high_pass.rs */
+    ORC_REVERB = 4,    /* nodes/reverb.rs (feedback delay line) */
+    ORC_DISTORT = 5,   /* nodes/distort.rs */
+    ORC_OVERDRIVE = 6, /* nodes/overdrive.rs */
+    ORC_CHEBYSHEV = 7, /* nodes/chebyshev.rs */
+    ORC_FIR = 8,       /* nodes/fir.rs */
+    ORC_ADD = 9,       /* nodes/add.rs */
+    ORC_MIX = 10,      /* nodes/mix.rs */
+    ORC_N_KINDS = 11
+};
+
+/* nodes/distort.rs:18-28, in declaration order (repr(u8)). */
+enum {
+    ORC_DIST_HARD_CLIP = 0,
+    ORC_DIST_SOFT_CLIP = 1,
+    ORC_DIST_TANH = 2,
+    ORC_DIST_RECIP_SOFT_CLIP = 3,
+    ORC_DIST_FUZZ = 4,
+    ORC_DIST_SIN = 5,
+    ORC_DIST_ATAN = 6,
+    ORC_DIST_SQUARE = 7,
+    ORC_DIST_CHEBYSHEV4 = 8
+};
+
+/* nodes/fir.rs Mode */
+enum { ORC_FIR_BALANCED = 0, ORC_FIR_AVERAGE = 1 };
+
+/*
+ * One node instance for ONE mono channel: parameters (the reference's slider
+ * atomics) + DSP state.  Parameter slots by kind (same slot numbering as
+ * dspfx_node_desc.params in include/dspfx.h):
+ *   GAIN       p[0]=level
+ *   BIQUAD     p[0..5]=a0,a1,a2,b0,b1,b2 (raw sliders, normalised by a0)
+ *   LOW_PASS   p[0]=ratio      HIGH_PASS p[0]=ratio
+ *   REVERB     p[0]=decay, ip[0]=D (delay length in samples, explicit)
+ *   DISTORT    p[0]=level, mode
+ *   OVERDRIVE  p[0]=boost, p[1]=drive, p[2]=level
+ *   CHEBYSHEV  p[0]=level_pos, p[1]=level_neg
+ *   FIR        taps (time-reversed, as stored by fir.rs:163,168), mode
+ *   ADD        -              MIX p[0]=ratio
+ */
+typedef struct orc_node {
+    int kind;
+    int mode;
+    float p[8];
+    uint32_t ip[2];
+
+    /* biquad: normalised coefficients + DirectForm1 state */
+    float bq_a1, bq_a2, bq_b0, bq_b1, bq_b2;
+    float bq_x1, bq_x2, bq_y1, bq_y2;
+    /* one-pole z (low_pass.rs:23 / high_pass.rs:23) */
+    float z;
+    /* reverb ring: exactly D samples, FIFO (read oldest, append newest) */
+    float *ring;
+    uint32_t ring_len, ring_pos;
+    /* fir: taps (reversed) + VecDeque<f64> emulation */
+    double *taps;
+    uint32_t n_taps;
+    double *dq;
+    uint32_t dq_cap, dq_head, dq_len;
+} orc_node;
+
+/* ---- node lifecycle ---------------------------------------------------- */
+/* Create with the reference's defaults for `kind` (derive `default=`). */
+orc_node *orc_node_new(int kind);
+void orc_node_free(orc_node *n);
+/* Set slot `idx`; runs the reference's after_settings_change hook where one
+ * exists (biquad.rs:62-76: renormalise + RESET state; reverb is resized via
+ * orc_reverb_set_len). */
+void orc_node_set_param(orc_node *n, int idx, float v);
+void orc_node_set_mode(orc_node *n, int mode);
+/* reverb.rs:55-71 with D explicit: fresh zero-filled ring of D samples. */
+void orc_reverb_set_len(orc_node *n, uint32_t d);
+/* reverb.rs:58 helper: max((seconds*48000f32) as usize, 128); page_round!=0
+ * additionally rounds up to whole 4 KiB pages (1024 f32) -- the two candidate
+ * readings of rivulet's capacity rounding. */
+uint32_t orc_delay_len(float seconds, int page_round);
+/* fir.rs:61-62,163,168: taps are given ALREADY time-reversed (as stored). */
+void orc_fir_set_taps(orc_node *n, const double *taps_reversed, uint32_t n_taps);
+/* Zero all DSP state (fresh node). */
+void orc_node_reset(orc_node *n);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* node.rs:162-194: out[i] = (sum_k in_k[i]) / (0.0001f + n_connected), out is
+ * expected pre-zeroed (node.rs:288). Returns `present`. */
+int orc_collect_and_average(float *out, const float *const *ins, int n_ins, size_t buf_size);
+/* The f32 divisor collect_and_average ends with for n connected pipes. */
+float orc_link_divisor(uint64_t n_connected);
+/* derive lib.rs:135-153: control-port helper.  `ctl` NULL => port absent =>
+ * fill with *atomic.  Otherwise map [-1,1] -> [lo,hi] per sample and latch
+ * out[0] into *atomic. */
+void orc_slider_input(float *out, const float *ctl, float lo, float hi, float *atomic, size_t n);
+
+/* SimpleNode::process for one 128-frame block of one channel.
+ *   in_a : "in" (or "a" for Add/Mix), in_b : "b" (Add/Mix) else NULL
+ *   ctl  : per-slider control-port blocks in field order (may be NULL / hold
+ *          NULLs for unconnected ports)                                     */
+void orc_node_process(orc_node *n, const float *in_a, const float *in_b,
+                      const float *const *ctl, float *out, size_t n_frames);
+
+/* A linear chain Input->n0->n1->...->Output for one channel, evaluated the way
+ * the reference does it: block-of-128 at a time, node at a time, each hop
+ * going through collect_and_average with one connected pipe when `link_scale`
+ * (node.rs:290-299), outputs pre-zeroed (node.rs:272).  `side` feeds port "b"
+ * of Add/Mix nodes (NULL => unconnected => zeros).  n_frames must be a multiple
+ * of block (block is normally ORC_BUF_SIZE). */
+void orc_chain_run(orc_node **nodes, int n_nodes, int link_scale, const float *in,
+                   const float *side, float *out, size_t n_frames, size_t block);
+
+/* ---- synthetic input --------------------------------------------------- */
+/* x[c,n] = (float)(h>>8) * 2^-23 - 1, h = fmix32(seed ^ c*0x9E3779B9 ^ n*0x85EBCA6B) */
+float orc_noise(uint32_t seed, uint32_t channel, uint32_t n_abs);
+
+/* ---- multi-channel drivers (cpu_baseline + big parity checks) ---------- */
+/* Runs `n_channels` independent copies of the chain described by `proto`
+ * (cloned per channel, fresh state) over `n_blocks` blocks of hashed noise,
+ * channels [c0, c0+n_channels).  If out != NULL it receives [n_frames][n_channels]
+ * frame-major f32.  If mix != NULL it receives the f64-accumulated per-frame sum
+ * over channels of the final output (caller applies the link divisor).
+ * n_threads<=1 => scalar single thread. Returns 0. */
+int orc_run_noise_channels(orc_node **proto, int n_nodes, int link_scale, uint32_t seed,
+                           uint32_t c0, uint32_t n_channels, uint32_t n_abs0,
+                           uint32_t n_blocks, uint32_t block, float *out, double *mix,
+                           int n_threads);
+
+orc_node *orc_node_clone(const orc_node *n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,276 @@
+"""Known-answer tests pinning the CPU oracle to the reference source lines
+(SURVEY.md 8c KAT-1..10).  The reference ships no tests (PARITY UNPINNED), so
+every expectation here is derived from the cited lines by hand / closed form,
+and cross-checked against the independent numpy-float32 model."""
+import math
+
+import numpy as np
+import pytest
+
+import numpy_model as M
+import oracle as O
+
+F = np.float32
+
+
+def bits(a):
+    return np.asarray(a, F).view(np.uint32)
+
+
+def test_kat1_gain_bit_exact():
+    # gain.rs:33-37  out = in * level
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal(128).astype(F)
+    x[:6] = [0.0, -0.0, 1e-42, -1e-42, np.inf, -np.inf]
+    for level in (0.0, 0.8, 1.0, 10.0, 3.3333):
+        n = O.Node(O.GAIN, [level])
+        y = n.process(x)
+        assert np.array_equal(bits(y), bits(x * F(level)))
+        assert np.array_equal(bits(y), bits(M.gain(x, level)))
+    assert math.isnan(O.Node(O.GAIN, [2.0]).process(np.array([np.nan], F))[0])
+
+
+def test_kat2_link_scale():
+    # node.rs:166,179,190: one pipe => divisor f32(0.0001 + 1.0) = 0x1.00068ep+0
+    div = O.link_divisor(1)
+    assert float(div).hex() == "0x1.00068e0000000p+0"
+    n = O.Node(O.GAIN, [1.0])
+    y = O.chain_run([n], np.array([0.5, -0.0, 1.0], F), link_flags=O.LINK_INPUT)
+    assert float(y[0]).hex() == "0x1.fff2e40000000p-2"
+    assert bits(y)[1] == 0  # 0.0 + (-0.0) = +0.0
+    # k hops = k successive divisions
+    nodes = [O.Node(O.GAIN, [1.0]) for _ in range(5)]
+    y5 = O.chain_run(nodes, np.array([0.5], F), link_flags=3)
+    e = F(0.5)
+    for _ in range(5):
+        e = F(e / div)
+    assert bits(y5)[0] == bits(e)
+    # internal-only: 4 hops for 5 nodes
+    nodes = [O.Node(O.GAIN, [1.0]) for _ in range(5)]
+    y4 = O.chain_run(nodes, np.array([0.5], F), link_flags=O.LINK_INTERNAL)
+    e = F(0.5)
+    for _ in range(4):
+        e = F(e / div)
+    assert bits(y4)[0] == bits(e)
+    # mix-bus divisor: sequential f32 increments (node.rs:179)
+    assert O.link_divisor(0) == F(0.0001)
+    assert O.link_divisor(2) == F(F(F(0.0001) + F(1)) + F(1))
+    assert O.link_divisor(1 << 20) == F(1 << 20)
+
+
+def test_kat3_biquad_defaults_impulse():
+    # biquad.rs:48-60: a1=-0.24, b0=0.758 => y[n] = 0.758*x[n] + 0.24*y[n-1]
+    n = O.Node(O.BIQUAD)
+    x = np.zeros(64, F)
+    x[0] = 1
+    y = n.process(x)
+    e = np.empty(64, F)
+    prev = F(0)
+    for i in range(64):
+        prev = F(F(F(F(F(0.758) * x[i]) + F(0)) + F(0)) - F(F(-0.24) * prev)) - F(0)
+        e[i] = prev
+    assert np.array_equal(bits(y), bits(e))
+    assert abs(float(y[5]) - 0.758 * 0.24 ** 5) < 1e-7
+    # state reset on any param change (biquad.rs:74)
+    n.set_param(3, 0.758)
+    y2 = n.process(x)
+    assert np.array_equal(bits(y2), bits(y))
+
+
+def test_kat4_biquad_general_vs_numpy_and_scipy():
+    from scipy.signal import lfilter
+    rng = np.random.default_rng(4)
+    x = rng.uniform(-1, 1, 128).astype(F)
+    for _ in range(8):
+        # stable poles inside unit circle
+        r, th = rng.uniform(0.1, 0.95), rng.uniform(0.1, 3.0)
+        a0 = rng.uniform(0.5, 2.0)
+        a = np.array([1.0, -2 * r * math.cos(th), r * r]) * a0
+        b = rng.uniform(-1, 1, 3) * a0
+        p = [a[0], a[1], a[2], b[0], b[1], b[2]]
+        n = O.Node(O.BIQUAD, p)
+        y = n.process(x)
+        m = M.Biquad(*p)
+        assert np.array_equal(bits(y), bits(m.run(x)))
+        ref = lfilter(np.array(b, F).astype(np.float64) / F(a[0]), np.array(a, F).astype(np.float64) / F(a[0]), x.astype(np.float64))
+        assert np.max(np.abs(ref - y)) < 5e-5
+
+
+def test_kat5_one_pole():
+    x = np.ones(128, F)
+    for r in (0.0, 0.5, 0.9, 1.0):
+        lp = O.Node(O.LOW_PASS, [r]).process(x)
+        hp = O.Node(O.HIGH_PASS, [r]).process(x)
+        assert np.array_equal(bits(lp), bits(M.OnePole(r).run(x)))
+        assert np.array_equal(bits(hp), bits(M.OnePole(r, high=True).run(x)))
+        k = np.arange(1, 129)
+        assert np.allclose(lp, 1 - r ** k, atol=1e-5)       # step response 1 - r^(n+1)
+        assert np.allclose(hp, r ** k, atol=1e-5)
+    # state carries across blocks (low_pass.rs:34,41)
+    n = O.Node(O.LOW_PASS, [0.5])
+    a = n.process(x[:64])
+    b = n.process(x[:64])
+    assert np.array_equal(np.concatenate([a, b]), O.Node(O.LOW_PASS, [0.5]).process(x))
+
+
+@pytest.mark.parametrize("D", [128, 1024, 24000])
+def test_kat6_delay_impulse(D):
+    # reverb.rs:86-103: y[n] = x[n] + decay*y[n-D]
+    nblk = (3 * D) // 128 + 2
+    x = np.zeros(nblk * 128, F)
+    x[0] = 1
+    n = O.Node(O.REVERB, [0.5], delay_len=D)
+    y = O.chain_run([n], x, link_flags=0)
+    e = np.zeros_like(x)
+    for k in range(len(e) // D + 1):
+        if k * D < len(e):
+            e[k * D] = 0.5 ** k
+    assert np.array_equal(bits(y), bits(e))
+    m = M.Reverb(D, 0.5)
+    assert np.array_equal(bits(m.run(x)), bits(e))
+
+
+def test_kat6_delay_block_invariance():
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-1, 1, 1024).astype(F)
+    ys = []
+    for blk in (128, 64, 32):
+        n = O.Node(O.REVERB, [0.7], delay_len=128)
+        ys.append(O.chain_run([n], x, link_flags=0, block=blk))
+    assert np.array_equal(ys[0], ys[1]) and np.array_equal(ys[0], ys[2])
+
+
+def test_kat6_delay_len_helper():
+    # reverb.rs:58
+    assert O.delay_len(0.5) == 24000
+    assert O.delay_len(0.5, True) == 24576
+    assert O.delay_len(0.0) == 128
+    assert O.delay_len(1.0) == 48000
+    assert O.delay_len(0.001) == 128
+    # default node keeps make_buffer()'s 128-sample ring (reverb.rs:44-52)
+    n = O.Node(O.REVERB)
+    x = np.zeros(256, F)
+    x[0] = 1
+    y = O.chain_run([n], x, link_flags=0)
+    assert y[128] == F(0.5) and y[0] == 1
+
+
+def test_kat7_distort_tables():
+    xs = np.array([0, -0.0, 0.25, -0.25, 0.5, -0.5, 1, -1, 2, -2], F)
+    two_thirds = F(2.0) / F(3.0)
+    assert float(two_thirds).hex() == "0x1.5555560000000p-1"
+    for mode in (0, 1, 2, 3, 5, 6, 7, 8):
+        for L in (0.0, 0.0009, 0.001, 1.0, 3.0, 30.0):
+            y = O.Node(O.DISTORT, [L], mode=mode).process(xs)
+            m = M.distort(xs, L, mode)
+            if F(L) < F(0.001):   # bypass threshold (distort.rs:64 etc.)
+                assert np.array_equal(bits(y), bits(xs))
+                continue
+            if mode in (2, 5, 6):  # libm: glibc vs numpy may differ by an ulp
+                assert np.allclose(y, m, rtol=3e-7, atol=1e-7)
+            else:
+                assert np.array_equal(bits(y), bits(m)), (mode, L)
+    # SoftClip plateaus +-(2/3)/L, HardClip saturation
+    y = O.Node(O.DISTORT, [3.0], mode=O.SOFT_CLIP).process(np.array([2, -2], F))
+    assert y[0] == F(two_thirds / F(3)) and y[1] == F(-two_thirds / F(3))
+    y = O.Node(O.DISTORT, [3.0], mode=O.HARD_CLIP).process(np.array([2, -2, 0.1], F))
+    assert y[0] == F(F(1) / F(3)) and y[1] == F(F(-1) / F(3)) and y[2] == F(F(F(0.1) * F(3)) / F(3))
+    # Chebyshev4(0) = 1 ; signum(+-0) = +-1
+    assert O.Node(O.DISTORT, [1.0], mode=O.CHEBYSHEV4).process(np.array([0], F))[0] == 1
+    y = O.Node(O.DISTORT, [1.0], mode=O.RECIP_SOFT_CLIP).process(np.array([0.0, -0.0], F))
+    assert bits(y)[0] == 0 and bits(y)[1] == 0x80000000   # +-1 * (1 - 1/1) = +-0
+    y = O.Node(O.DISTORT, [1.0], mode=O.SQUARE).process(np.array([0.5, -0.5, -0.0], F))
+    assert y[0] == F(0.25) and y[1] == F(-0.25) and bits(y)[2] == 0x80000000
+    # SoftClip default mode, level default 0 => bypass (distort.rs:46-50)
+    assert np.array_equal(O.Node(O.DISTORT).process(xs), xs)
+
+
+def test_kat7_fuzz():
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, 128).astype(F)
+    y = O.Node(O.DISTORT, [3.0], mode=O.FUZZ).process(x)
+    m = M.distort(x, 3.0, O.FUZZ)
+    assert np.allclose(y, m, rtol=2e-6, atol=1e-7)
+    assert np.all(y <= 0) and abs(np.abs(y).max() - np.abs(x).max()) < 1e-6
+    # silent block => NaN (0/0)
+    assert np.all(np.isnan(O.Node(O.DISTORT, [3.0], mode=O.FUZZ).process(np.zeros(128, F))))
+    # Fuzz ignores the bypass threshold (no `level < 0.001` test in distort.rs:146-172)
+    assert not np.array_equal(O.Node(O.DISTORT, [0.0], mode=O.FUZZ).process(x), x)
+
+
+def test_kat7_overdrive_chebyshev():
+    rng = np.random.default_rng(8)
+    x = rng.uniform(-1, 1, 128).astype(F)
+    y = O.Node(O.OVERDRIVE, [5.0, 0.7, 0.9]).process(x)
+    assert np.allclose(y, M.overdrive(x, 5.0, 0.7, 0.9), rtol=3e-7, atol=1e-7)
+    assert np.array_equal(O.Node(O.OVERDRIVE, [5.0, 0.7, 0.0009]).process(x), x)
+    assert np.array_equal(O.Node(O.OVERDRIVE).process(x), x)  # defaults: level 0 => bypass
+    y = O.Node(O.CHEBYSHEV, [4.0, 0.0]).process(x)
+    m = M.chebyshev(x, 4.0, 0.0)
+    assert np.allclose(y, m, rtol=5e-7, atol=1e-7)
+    assert np.array_equal(y[x < 0], x[x < 0])   # level_neg < 0.001 => negative half untouched
+
+
+def test_kat8_fir():
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, 256).astype(F)
+    # default taps [1.0] => identity (fir.rs:61-62)
+    assert np.array_equal(O.chain_run([O.Node(O.FIR)], x, link_flags=0), x)
+    # integer taps/samples: exact; taps stored reversed (fir.rs:163,168)
+    h = np.array([1, 2, 3, 4], np.float64)          # impulse response h[0..3]
+    xi = rng.integers(-8, 8, 256).astype(F)
+    y = O.chain_run([O.Node(O.FIR, taps_reversed=h[::-1])], xi, link_flags=0)
+    causal = np.convolve(xi.astype(np.float64), h)[:256]
+    assert np.array_equal(y[3:], causal[3:].astype(F))            # steady state
+    # warm-up quirk: state[k] pairs with taps_rev[k]  => y[n] = sum_{k<=n} x[k]*h[T-1-k]
+    T = 4
+    for nn in range(T - 1):
+        e = sum(float(xi[k]) * h[T - 1 - k] for k in range(nn + 1))
+        assert y[nn] == F(e)
+    assert np.array_equal(y, M.Fir(h[::-1]).run(xi))
+    # Average mode: * (1/len as f32) (fir.rs:188)
+    ya = O.chain_run([O.Node(O.FIR, mode=O.FIR_AVERAGE, taps_reversed=h[::-1])], xi, link_flags=0)
+    assert np.array_equal(ya, (y * (F(1) / F(4))).astype(F))
+    # T = 512 random vs exact (fsum) reference: RMS tolerance
+    T = 512
+    hh = rng.uniform(-1, 1, T) * np.exp(-6.9 * np.arange(T) / T)
+    xx = rng.uniform(-1, 1, 1024).astype(F)
+    y = O.chain_run([O.Node(O.FIR, taps_reversed=hh[::-1])], xx, link_flags=0)
+    ref = np.array([math.fsum(hh[j] * float(xx[n - j]) for j in range(T)) for n in range(T - 1, 1024)])
+    err = y[T - 1:].astype(np.float64) - ref
+    assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref ** 2)) < 1e-7
+
+
+def test_kat9_control_port():
+    # derive lib.rs:141-148
+    ctl = np.array([-1, 0, 1, 2, -3], F)
+    n = O.Node(O.GAIN, [1.0])
+    y = n.process(np.ones(5, F), ctl=[ctl])
+    assert np.array_equal(y, np.array([0, 5, 10, 10, 0], F))
+    assert np.array_equal(M.slider_input(ctl, 0, 10), y)
+    # latched element 0 is used once the port is disconnected again
+    y2 = n.process(np.ones(3, F))
+    assert np.array_equal(y2, np.zeros(3, F))
+    n = O.Node(O.MIX, [0.5])
+    y = n.process(np.full(2, 2, F), np.full(2, 4, F), ctl=[np.array([1, -1], F)])
+    assert np.array_equal(y, np.array([4, 2], F))
+
+
+def test_add_mix():
+    rng = np.random.default_rng(11)
+    a, b = rng.uniform(-1, 1, 128).astype(F), rng.uniform(-1, 1, 128).astype(F)
+    assert np.array_equal(O.Node(O.ADD).process(a, b), M.add(a, b))
+    assert np.array_equal(O.Node(O.MIX, [0.3]).process(a, b), M.mix(a, b, 0.3))
+    # unconnected "b" => zeros (node.rs:288)
+    assert np.array_equal(O.Node(O.ADD).process(a), a)
+
+
+def test_noise_generator():
+    x = O.noise(0x5EED0001, np.arange(4), np.arange(8))
+    assert x.shape == (8, 4) and x.dtype == F
+    for c in range(4):
+        for n in range(8):
+            assert x[n, c] == F(O.lib().orc_noise(0x5EED0001, c, n))
+    big = O.noise(0x5EED0001, np.arange(256), np.arange(4096))
+    assert -1 <= big.min() and big.max() < 1 and abs(big.mean()) < 5e-3
+    assert abs(big.var() - 1 / 3) < 5e-3
