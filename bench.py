@@ -1,0 +1,279 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the effect-chain hot path on MI355X.
+
+Metric (BASELINE.json): mono-channel-samples/sec through the 5-node chain at
+128-frame blocks on 1/2/4/8 GPUs.  One "step" = one 128-frame block through the
+whole chain for every channel this rank owns (inputs resident in HBM), including
+the mix-bus reduction (and, for N>1, its RCCL all-reduce over xGMI).
+
+Default workload (per GPU; weak scaling): BASELINE config 5's shard --
+1 048 576 channels, biquad(LP 1 kHz) -> distort(SoftClip, 3.0) -> delay(D=24000,
+decay .5) -> biquad(HP 80 Hz) -> gain(.5), B=128, link scaling on every hop,
+mix bus.  Other BASELINE configs are parity-test cases; `--config` can time them
+for DESIGN.md but the driver's line is the default.
+
+    python bench.py --gpus 1 --steps 200 --warmup 200
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+        --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 200
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
+SEED = 0x5EED0001
+
+CONFIGS = {
+    # name: (channels per GPU, frames per block, chain, delay, description)
+    "cfg5": dict(channels=1 << 20, frames=128, chain="chain5", delay=24000,
+                 desc="BASELINE config 5 shard: 1048576 ch/GPU, biquad>softclip>delay(24000)>biquad>gain, B=128, mix bus"),
+    "cfg3": dict(channels=1 << 20, frames=256, chain="chain5", delay=24000,
+                 desc="BASELINE config 3: 1048576 ch, 5-node chain, B=256"),
+    "cfg2": dict(channels=1 << 16, frames=128, chain="chain3", delay=24000,
+                 desc="BASELINE config 2: 65536 ch, gain>biquad>delay(24000), B=128"),
+    "cfg4": dict(channels=1 << 18, frames=128, chain="fir", delay=0, taps=4096,
+                 desc="BASELINE config 4: 262144 ch, 4096-tap FIR, B=128"),
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=200)   # >= 188 blocks fills the 24000-sample rings with real data
+    ap.add_argument("--config", default="cfg5", choices=sorted(CONFIGS))
+    ap.add_argument("--channels", type=int, default=None, help="override channels per GPU")
+    ap.add_argument("--frames", type=int, default=None)
+    ap.add_argument("--delay", type=int, default=None)
+    ap.add_argument("--taps", type=int, default=None)
+    ap.add_argument("--no-mix", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--link-flags", type=int, default=3)
+    return ap.parse_args()
+
+
+def build_chain(pkg, cfg):
+    import chains
+    if cfg["chain"] == "chain5":
+        return chains.chain5(pkg, cfg["delay"])
+    if cfg["chain"] == "chain3":
+        return chains.chain3(pkg, cfg["delay"])
+    if cfg["chain"] == "fir":
+        return [pkg.Fir(chains.fir_taps(cfg["taps"]))]
+    raise ValueError(cfg["chain"])
+
+
+def cpu_baseline(chain, cfg, link_flags, target_s):
+    """The reference CPU path stand-in: the C restatement (oracle/), built -O3
+    -march=native -ffp-contract=off ON THIS BOX, channel-at-a-time / node-at-a-time /
+    128-frame blocks like node.rs:267-352, threaded over channels on all host cores."""
+    from __graft_entry__ import load_oracle
+    O = load_oracle()
+    cores = os.cpu_count() or 1
+    native = False
+    try:   # rebuild for this host's ISA (the in-tree native .so was built elsewhere)
+        tmp = tempfile.mkdtemp(prefix="dspfx_cpu_")
+        so = os.path.join(tmp, "liboracle_native.so")
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
+                               "-std=c11", "-shared", "-o", so, os.path.join(ROOT, "oracle", "dspfx_oracle.c"),
+                               "-lm", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        import ctypes
+        L = O._bind(ctypes.CDLL(so))
+        native = True
+    except Exception:
+        L = O.lib()
+    descs = [n.oracle_desc() for n in chain]
+    block = 128
+
+    def run(n_channels, n_blocks):
+        import ctypes as C
+        protos = [O.node_from_desc(d, _lib=L) for d in descs]
+        hs = (C.c_void_p * len(protos))(*[p.h for p in protos])
+        t0 = time.perf_counter()
+        L.orc_run_noise_channels(hs, len(protos), link_flags, SEED, 0, n_channels, 0, n_blocks, block, None, None, cores)
+        return time.perf_counter() - t0
+
+    is_fir = cfg["chain"] == "fir"
+    ch, nb = (cores * 2, 8) if is_fir else (cores * 64, 64)
+    run(cores, 1)                                     # touch code/pages
+    t = run(ch, nb)                                   # probe
+    rate = ch * nb * block / max(t, 1e-6)
+    # scale the sample to ~target_s of CPU work; keep >= 1 ring period of blocks for the delay chains
+    nb2 = nb if is_fir else 256
+    ch2 = int(max(cores, min(1 << 16, rate * target_s / (nb2 * block))))
+    ch2 -= ch2 % cores or 0
+    ch2 = max(ch2, cores)
+    t2 = run(ch2, nb2)
+    return {"value": ch2 * nb2 * block / t2, "unit": "samples/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{ch2} channels x {nb2} blocks of 128 frames, same chain/params/noise, {t2:.1f} s; "
+                      f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
+                      f"pthreads over channels; excludes the reference's tokio/ring/pool overhead"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = load_package()
+    cfg = dict(CONFIGS[args.config])
+    for k in ("channels", "frames", "delay", "taps"):
+        if getattr(args, k) is not None:
+            cfg[k] = getattr(args, k)
+    N, B = cfg["channels"], cfg["frames"]
+    use_mix = not args.no_mix
+    chain = build_chain(pkg, cfg)
+
+    eng = pkg.Engine(N, B, link_flags=args.link_flags, device=local_rank, channel_offset=rank * N)
+    eng.set_chain(chain)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    n_in = 2
+    xs = [torch.empty((B, N), dtype=torch.float32, device=dev) for _ in range(n_in)]
+    for i, x in enumerate(xs):
+        eng.fill_noise(x, B, i * B, SEED, stream)
+    y = torch.empty((B, N), dtype=torch.float32, device=dev)
+    mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if use_mix else [None, None]
+    total_channels = N * world
+    pending = [None]
+
+    def step(k):
+        m = mixes[k & 1]
+        eng.process(xs[k % n_in], out=y, mix=m, n_frames=B, stream=stream)
+        if use_mix:
+            if world > 1:
+                # overlap: the all-reduce of block k runs beside block k+1's chain kernel
+                work = dist.all_reduce(m, op=dist.ReduceOp.SUM, async_op=True)
+                if pending[0] is not None:
+                    pw, pm = pending[0]
+                    pw.wait()
+                    eng.mix_finish(pm, B, total_channels, stream)
+                pending[0] = (work, m)
+            else:
+                eng.mix_finish(m, B, total_channels, stream)
+
+    def drain():
+        if pending[0] is not None:
+            pw, pm = pending[0]
+            pw.wait()
+            eng.mix_finish(pm, B, total_channels, stream)
+            pending[0] = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
+    fence()
+    eng.profile_enable(True)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for k in range(args.steps):
+        step(k)
+    drain()
+    ev1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+    kern_ms_total, kern_launches, kern_name = eng.profile_read()
+    region_ms = ev0.elapsed_time(ev1)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    samples = float(total_channels) * B * args.steps
+    value = samples / dt
+    bps = eng.algorithmic_bytes_per_sample(B)
+    kern_ms = kern_ms_total / max(kern_launches, 1)
+    is_fir = cfg["chain"] == "fir"
+    if is_fir:
+        flops = 2.0 * cfg["taps"] * N * B
+        achieved = flops / (kern_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_F32_PEAK_TFLOPS}
+    else:
+        achieved = bps * N * B / (kern_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS}
+    roof.update({"kernel": kern_name, "kernel_ms_avg": kern_ms, "launches": kern_launches,
+                 "algorithmic_bytes_per_sample": bps, "traffic": None})
+    # HBM bytes per launch from the committed PMC pass of this same command, if one exists
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            t = json.load(open(tr))
+            ent = t.get(f"{args.config}:{N}:{B}")
+            if ent:
+                roof["traffic"] = ent["hbm_bytes_per_launch"]
+                roof["traffic_source"] = ent.get("source")
+        except Exception:
+            pass
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    line = {
+        "metric": "mono-channel-samples/sec through 5-node chain @128-frame blocks" if args.config == "cfg5"
+                  else f"mono-channel-samples/sec ({args.config})",
+        "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
+                   "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
+                   "mix_bus": use_mix, "parallelism": f"channel-shard x{world}",
+                   "plan": eng.describe().strip().split("\n")[1:]},
+        "roofline": roof,
+        "realtime_channels": value / 48000.0,
+        "block_latency_ms": dt * 1e3 / args.steps, "block_budget_ms": B / 48.0,
+        "gpu_event_ms_per_step": region_ms / args.steps,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            line["cpu_baseline"] = cpu_baseline(chain, cfg, args.link_flags, args.cpu_seconds)
+            line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
+        except Exception as ex:   # the baseline is reporting only; never lose the GPU line
+            line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+                                    "sample": f"failed: {ex}"}
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

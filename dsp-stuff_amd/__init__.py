@@ -1,0 +1,336 @@
+"""dsp-stuff_amd -- Python binding of the MI355X-native effect-chain engine.
+
+A thin ctypes layer over the C ABI in include/dspfx.h (csrc/libdspfx.so, hand-written
+HIP for gfx950).  Node constructors carry the reference's names, slider fields,
+ranges and defaults (dsp-stuff/src/nodes/*.rs) so tests read like the reference's
+node definitions.  There is no CPU fallback: importing works anywhere (so the
+symbol table can be checked), but creating an Engine without a HIP device raises.
+
+The directory name has a hyphen (it is the repo's package directory, not an
+importable identifier): load it with `__graft_entry__.load_package()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass, field
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdspfx.so")
+
+BUF_SIZE = 128  # dsp-stuff/src/node.rs:257
+ABI_VERSION = 1
+
+# dspfx_kind
+GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX = range(11)
+# dspfx_distort_mode (nodes/distort.rs:18-28)
+HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
+DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"]
+FIR_BALANCED, FIR_AVERAGE = 0, 1
+LINK_INTERNAL, LINK_INPUT = 1, 2
+
+# every symbol include/dspfx.h declares
+EXPORTS = [
+    "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
+    "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
+    "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
+    "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_state_size",
+    "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
+    "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read",
+]
+
+
+class DspfxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"dspfx error {status}: {msg}")
+        self.status = status
+
+
+class _EngineDesc(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("channels", C.c_uint32),
+                ("max_frames", C.c_uint32), ("link_flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("channel_offset", C.c_uint64)]
+
+
+class _NodeDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("mode", C.c_int32), ("params", C.c_float * 8),
+                ("delay_len", C.c_uint32), ("n_taps", C.c_uint32), ("taps", C.POINTER(C.c_double))]
+
+
+_lib = None
+
+
+def lib():
+    """Load csrc/libdspfx.so; fails loudly when the HIP library has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
+                          "(or __graft_entry__.build()); there is no fallback implementation")
+    L = C.CDLL(LIB_PATH)
+    vp, f32p = C.c_void_p, C.c_void_p
+    L.dspfx_abi_version.restype = C.c_uint32
+    L.dspfx_strerror.restype = C.c_char_p
+    L.dspfx_strerror.argtypes = [C.c_int]
+    L.dspfx_device_count.restype = C.c_int
+    L.dspfx_node_defaults.argtypes = [C.c_int, C.POINTER(_NodeDesc)]
+    L.dspfx_delay_len.restype = C.c_uint32
+    L.dspfx_delay_len.argtypes = [C.c_float, C.c_int]
+    L.dspfx_link_divisor.restype = C.c_float
+    L.dspfx_link_divisor.argtypes = [C.c_uint64]
+    L.dspfx_engine_create.argtypes = [C.POINTER(_EngineDesc), C.POINTER(vp)]
+    L.dspfx_engine_destroy.argtypes = [vp]
+    L.dspfx_engine_destroy.restype = None
+    L.dspfx_last_error.restype = C.c_char_p
+    L.dspfx_last_error.argtypes = [vp]
+    L.dspfx_chain_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int]
+    L.dspfx_chain_len.argtypes = [vp]
+    L.dspfx_set_param.argtypes = [vp, C.c_int, C.c_int, C.c_float]
+    L.dspfx_set_mode.argtypes = [vp, C.c_int, C.c_int]
+    L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
+    L.dspfx_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.c_int]
+    L.dspfx_reset.argtypes = [vp]
+    L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
+    L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
+    L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_state_size.restype = C.c_int64
+    L.dspfx_state_size.argtypes = [vp, C.c_int]
+    L.dspfx_state_export.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.dspfx_state_import.argtypes = [vp, C.c_int, vp, C.c_size_t]
+    L.dspfx_fill_noise.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.dspfx_sync.argtypes = [vp, vp]
+    L.dspfx_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.dspfx_profile_enable.argtypes = [vp, C.c_int]
+    L.dspfx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.c_int]
+    L.dspfx_algorithmic_bytes_per_sample.restype = C.c_double
+    L.dspfx_algorithmic_bytes_per_sample.argtypes = [vp, C.c_uint32]
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(lib().dspfx_device_count())
+
+
+def delay_len(seconds: float, page_round: bool = False) -> int:
+    """reverb.rs:58 (and the page-rounded reading of rivulet's ring capacity)."""
+    return int(lib().dspfx_delay_len(float(seconds), int(page_round)))
+
+
+def link_divisor(n_connected: int) -> np.float32:
+    return np.float32(lib().dspfx_link_divisor(int(n_connected)))
+
+
+# --------------------------------------------------------------------------- nodes
+
+@dataclass
+class NodeSpec:
+    kind: int
+    params: Sequence[float] = field(default_factory=list)
+    mode: int = 0
+    delay_len: int = 0
+    taps_reversed: Optional[np.ndarray] = None   # as fir.rs:163,168 stores them
+
+    def oracle_desc(self) -> dict:
+        """Same node for the CPU oracle (tests only)."""
+        return {"kind": self.kind, "params": list(self.params), "mode": self.mode,
+                "delay_len": self.delay_len or None, "taps_reversed": self.taps_reversed}
+
+
+def Gain(level: float = 1.0) -> NodeSpec:
+    """nodes/gain.rs: slider level 0..=10, default 1.0"""
+    return NodeSpec(GAIN, [level])
+
+
+def BiQuad(a0=1.0, a1=-0.24, a2=0.0, b0=0.758, b1=0.0, b2=0.0) -> NodeSpec:
+    """nodes/biquad.rs:18-41: raw sliders, each -10..=10; normalised by a0 on the engine."""
+    return NodeSpec(BIQUAD, [a0, a1, a2, b0, b1, b2])
+
+
+def LowPass(ratio: float = 0.5) -> NodeSpec:
+    """nodes/low_pass.rs: slider ratio 0..=1, default 0.5"""
+    return NodeSpec(LOW_PASS, [ratio])
+
+
+def HighPass(ratio: float = 0.5) -> NodeSpec:
+    """nodes/high_pass.rs"""
+    return NodeSpec(HIGH_PASS, [ratio])
+
+
+def Reverb(seconds: Optional[float] = None, decay: float = 0.5, delay_samples: Optional[int] = None,
+           page_round: bool = False) -> NodeSpec:
+    """nodes/reverb.rs: feedback delay.  `seconds` goes through reverb.rs:58; with neither
+    argument the node keeps make_buffer()'s 128-sample ring (reverb.rs:44-52)."""
+    if delay_samples is None:
+        delay_samples = 128 if seconds is None else delay_len(seconds, page_round)
+    return NodeSpec(REVERB, [decay], delay_len=int(delay_samples))
+
+
+def Distort(level: float = 0.0, mode: int = SOFT_CLIP) -> NodeSpec:
+    """nodes/distort.rs: slider level 0..=30 default 0.0 (=> bypass), mode default SoftClip"""
+    return NodeSpec(DISTORT, [level], mode=mode)
+
+
+def Overdrive(boost: float = 0.0, drive: float = 0.0, level: float = 0.0) -> NodeSpec:
+    """nodes/overdrive.rs:21-28 (field order boost, drive, level)"""
+    return NodeSpec(OVERDRIVE, [boost, drive, level])
+
+
+def Chebyshev(level_pos: float = 0.0, level_neg: float = 0.0) -> NodeSpec:
+    """nodes/chebyshev.rs:21-25"""
+    return NodeSpec(CHEBYSHEV, [level_pos, level_neg])
+
+
+def Fir(impulse_response=(1.0,), mode: int = FIR_BALANCED) -> NodeSpec:
+    """nodes/fir.rs: `impulse_response` is h[0..T) in natural order (what the WAV holds);
+    it is stored time-reversed exactly like fir.rs:163,168."""
+    h = np.ascontiguousarray(impulse_response, dtype=np.float64)
+    return NodeSpec(FIR, [], mode=mode, taps_reversed=np.ascontiguousarray(h[::-1]))
+
+
+def Add() -> NodeSpec:
+    """nodes/add.rs: out = a + b (b = the engine's side input)"""
+    return NodeSpec(ADD)
+
+
+def Mix(ratio: float = 0.5) -> NodeSpec:
+    """nodes/mix.rs: out = b*ratio + a*(1-ratio)"""
+    return NodeSpec(MIX, [ratio])
+
+
+# -------------------------------------------------------------------------- engine
+
+def _ptr(x):
+    if x is None:
+        return None
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):        # torch tensor on the device
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(f"expected a device tensor or raw pointer, got {type(x)}")
+
+
+class Engine:
+    """N independent mono channels through one effect chain (include/dspfx.h)."""
+
+    def __init__(self, channels: int, max_frames: int = BUF_SIZE, link_flags: int = LINK_INTERNAL | LINK_INPUT,
+                 device: int = 0, channel_offset: int = 0):
+        self.L = lib()
+        self.channels, self.max_frames = int(channels), int(max_frames)
+        self.h = C.c_void_p()
+        d = _EngineDesc(ABI_VERSION, device, channels, max_frames, link_flags, 0, channel_offset)
+        rc = self.L.dspfx_engine_create(C.byref(d), C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise DspfxError(rc, self.L.dspfx_strerror(rc).decode())
+        self._keep = []
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise DspfxError(rc, self.L.dspfx_last_error(self.h).decode() or self.L.dspfx_strerror(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.dspfx_engine_destroy(self.h)
+            self.h = C.c_void_p()
+
+    __del__ = close
+
+    def set_chain(self, nodes: Sequence[NodeSpec]):
+        arr = (_NodeDesc * max(1, len(nodes)))()
+        self._keep = []
+        for i, n in enumerate(nodes):
+            arr[i].kind, arr[i].mode = n.kind, n.mode
+            for k, v in enumerate(n.params):
+                arr[i].params[k] = float(v)
+            arr[i].delay_len = int(n.delay_len)
+            if n.taps_reversed is not None:
+                t = np.ascontiguousarray(n.taps_reversed, dtype=np.float64)
+                self._keep.append(t)
+                arr[i].n_taps = len(t)
+                arr[i].taps = t.ctypes.data_as(C.POINTER(C.c_double))
+        self._chk(self.L.dspfx_chain_set(self.h, arr, len(nodes)))
+        self.nodes = list(nodes)
+
+    def set_param(self, node: int, param: int, value: float):
+        self._chk(self.L.dspfx_set_param(self.h, node, param, float(value)))
+
+    def set_mode(self, node: int, mode: int):
+        self._chk(self.L.dspfx_set_mode(self.h, node, int(mode)))
+
+    def set_delay_len(self, node: int, d: int):
+        self._chk(self.L.dspfx_set_delay_len(self.h, node, int(d)))
+
+    def set_taps(self, node: int, impulse_response, mode: int = FIR_BALANCED):
+        t = np.ascontiguousarray(np.asarray(impulse_response, np.float64)[::-1])
+        self._chk(self.L.dspfx_set_taps(self.h, node, t.ctypes.data_as(C.POINTER(C.c_double)), len(t), mode))
+
+    def reset(self):
+        self._chk(self.L.dspfx_reset(self.h))
+
+    def process(self, x, out=None, side=None, mix=None, n_frames: Optional[int] = None, stream: int = 0):
+        """Device path: x/out/side are [n_frames][channels] f32 device tensors (or raw pointers)."""
+        if n_frames is None:
+            n_frames = x.shape[0]
+        if out is None:
+            out = x
+        self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames),
+                                       C.c_void_p(stream) if stream else None))
+        return out
+
+    def process_host(self, x: np.ndarray, side: Optional[np.ndarray] = None, want_mix: bool = False):
+        """Host path (numpy in / numpy out): H2D, process, D2H."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        assert x.ndim == 2 and x.shape[1] == self.channels, x.shape
+        out = np.empty_like(x)
+        s = np.ascontiguousarray(side, dtype=np.float32) if side is not None else None
+        mix = np.empty(x.shape[0], np.float32) if want_mix else None
+        self._chk(self.L.dspfx_process_host(self.h, x.ctypes.data, s.ctypes.data if s is not None else None,
+                                            out.ctypes.data, mix.ctypes.data if want_mix else None, x.shape[0]))
+        return (out, mix) if want_mix else out
+
+    def mix_finish(self, mix, n_frames: int, n_connected: int, stream: int = 0):
+        self._chk(self.L.dspfx_mix_finish(self.h, _ptr(mix), int(n_frames), int(n_connected),
+                                          C.c_void_p(stream) if stream else None))
+
+    def state_export(self, node: int) -> np.ndarray:
+        n = int(self.L.dspfx_state_size(self.h, node))
+        if n < 0:
+            self._chk(n)
+        buf = np.empty(n, np.uint8)
+        if n:
+            self._chk(self.L.dspfx_state_export(self.h, node, buf.ctypes.data, n))
+        return buf
+
+    def state_import(self, node: int, buf: np.ndarray):
+        buf = np.ascontiguousarray(buf).view(np.uint8)
+        self._chk(self.L.dspfx_state_import(self.h, node, buf.ctypes.data, buf.size))
+
+    def fill_noise(self, dst, n_frames: int, n_abs0: int, seed: int = 0x5EED0001, stream: int = 0):
+        self._chk(self.L.dspfx_fill_noise(self.h, _ptr(dst), int(n_frames), int(n_abs0) & 0xFFFFFFFF, seed,
+                                          C.c_void_p(stream) if stream else None))
+
+    def sync(self, stream: int = 0):
+        self._chk(self.L.dspfx_sync(self.h, C.c_void_p(stream) if stream else None))
+
+    def describe(self) -> str:
+        buf = C.create_string_buffer(4096)
+        self._chk(self.L.dspfx_describe(self.h, buf, 4096))
+        return buf.value.decode()
+
+    def profile_enable(self, on: bool = True):
+        self._chk(self.L.dspfx_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset: bool = True):
+        """(total kernel ms, launches, kernel name) of the dominant stage since the last reset."""
+        ms, n = C.c_double(), C.c_uint32()
+        name = C.create_string_buffer(128)
+        self._chk(self.L.dspfx_profile_read(self.h, C.byref(ms), C.byref(n), name, 128, int(reset)))
+        return ms.value, n.value, name.value.decode()
+
+    def algorithmic_bytes_per_sample(self, n_frames: int) -> float:
+        return float(self.L.dspfx_algorithmic_bytes_per_sample(self.h, int(n_frames)))

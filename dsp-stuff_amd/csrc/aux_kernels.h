@@ -1,0 +1,27 @@
+// aux_kernels.h -- launchers of the non-template kernels (aux_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dspfx {
+
+// distort.rs:146-172 (Fuzz), block-global over reference blocks of 128 frames.
+struct FuzzArgs {
+    const float *in;
+    float *out;
+    unsigned N;
+    unsigned nframes;   // multiple of 128
+    float level;
+    float hop_div;
+    int hop;
+};
+void launch_fuzz(const FuzzArgs &a, hipStream_t s);
+// mix[f] = fixed-order sum of part[f][0..stride)
+void launch_mix_reduce(const float *part, float *mix, unsigned nframes, unsigned stride, hipStream_t s);
+// node.rs:189-191: mix[i] /= div
+void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s);
+// dst[f][c] = noise(seed, c0 + c, n_abs0 + f)
+void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
+                  hipStream_t s);
+
+}  // namespace dspfx

@@ -1,0 +1,112 @@
+// aux_kernels.hip -- Fuzz, the mix-bus second stage, and the synthetic-noise fill.
+// Compiled with -ffp-contract=off like every kernel of this library.
+#include "aux_kernels.h"
+#include "chain_kernels.hip.h"
+
+namespace dspfx {
+
+__device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+
+// One lane = one channel; the 128 samples of a reference block stay in registers
+// across the three max-reductions (distort.rs:147-171).  In-place safe.
+__global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
+    const size_t c = (size_t)blockIdx.x * WG + threadIdx.x;
+    if (c >= a.N) return;
+    for (unsigned b0 = 0; b0 < a.nframes; b0 += 128) {
+        float x[128];
+        float lv[1];
+        lv[0] = a.level;
+        unsigned m = 0;
+#pragma unroll
+        for (int f = 0; f < 128; ++f) {
+            float t = a.in[(size_t)(b0 + f) * a.N + c];
+            if (a.hop) t = link_hop(t, a.hop_div);
+            x[f] = t;
+            const unsigned bts = abs_bits(t);      // max_by(total_cmp) over |x| == integer max of the bits
+            m = bts >= m ? bts : m;
+        }
+        const float mx = __uint_as_float(m);
+        unsigned mzb = 0;
+#pragma unroll
+        for (int f = 0; f < 128; ++f) {
+            const float q = clip1(x[f] * lv[0]) / mx;            // 158
+            const float e = expf(-fabsf(q));                     // q.copysign(-1.0).exp()
+            const float z = -fabsf(1.0f - e);                    // (1.0 - e).copysign(-1.0)
+            x[f] = z;
+            const unsigned bts = abs_bits(z);
+            mzb = bts >= mzb ? bts : mzb;
+        }
+        const float mz = __uint_as_float(mzb);
+        unsigned myb = 0;
+#pragma unroll
+        for (int f = 0; f < 128; ++f) {
+            const float y = clip1(x[f] * mx) / mz;               // 167
+            x[f] = y;
+            const unsigned bts = abs_bits(y);
+            myb = bts >= myb ? bts : myb;
+        }
+        const float my = __uint_as_float(myb);
+#pragma unroll
+        for (int f = 0; f < 128; ++f) a.out[(size_t)(b0 + f) * a.N + c] = x[f] * mx / my;   // 171
+    }
+}
+
+// Deterministic fixed-order sum of the per-wave partials of one frame.
+__global__ void __launch_bounds__(WG) mix_reduce_kernel(const float *part, float *mix, unsigned stride) {
+    __shared__ float sh[WG];
+    const unsigned f = blockIdx.x;
+    const float *row = part + (size_t)f * stride;
+    float acc = 0.0f;
+    for (unsigned i = threadIdx.x; i < stride; i += WG) acc = acc + row[i];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = WG / 2; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) mix[f] = sh[0];
+}
+
+__global__ void mix_finish_kernel(float *mix, unsigned n, float div) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) mix[i] = mix[i] / div;
+}
+
+// SURVEY 8d generator; same integer hash as oracle/dspfx_oracle.c:orc_noise
+__device__ __forceinline__ float noise1(uint32_t seed, uint32_t channel, uint32_t n_abs) {
+    uint32_t h = seed ^ (channel * 0x9E3779B9u) ^ (n_abs * 0x85EBCA6Bu);
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return (float)(h >> 8) * 0x1p-23f - 1.0f;
+}
+__global__ void __launch_bounds__(WG) noise_kernel(float *dst, unsigned N, unsigned nframes, uint32_t c0,
+                                                   uint32_t n_abs0, uint32_t seed) {
+    const size_t total = (size_t)N * nframes;
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+        const uint32_t f = (uint32_t)(i / N), c = (uint32_t)(i % N);
+        dst[i] = noise1(seed, c0 + c, n_abs0 + f);
+    }
+}
+
+void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
+    hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + WG - 1) / WG), dim3(WG), 0, s, a);
+}
+void launch_mix_reduce(const float *part, float *mix, unsigned nframes, unsigned stride, hipStream_t s) {
+    hipLaunchKernelGGL(mix_reduce_kernel, dim3(nframes), dim3(WG), 0, s, part, mix, stride);
+}
+void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s) {
+    hipLaunchKernelGGL(mix_finish_kernel, dim3((n + 127) / 128), dim3(128), 0, s, mix, n, div);
+}
+void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
+                  hipStream_t s) {
+    const size_t total = (size_t)N * nframes;
+    size_t blocks = (total + WG - 1) / WG;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, dst, N, nframes, c0, n_abs0, seed);
+}
+
+}  // namespace dspfx

@@ -1,0 +1,557 @@
+// chain_kernels.hip.h -- gfx950 device code for the fused effect chain.
+//
+// One wavefront lane owns CPL adjacent channels; a workgroup of 256 lanes owns
+// 256*CPL adjacent channels.  Samples are frame-major [frame][channel], so every
+// load/store a wave issues is one coalesced burst of 64*CPL consecutive floats.
+// The time axis is walked in chunks of F frames held in registers; every node of
+// the chain is applied to the chunk before the next chunk is touched, so samples
+// make exactly one HBM round trip per block (16 B/sample with one delay line).
+// Filter state lives in registers for the whole block (loaded/stored once).
+//
+// Arithmetic follows the reference literally (file:line cited per function,
+// relative to /root/reference/): f32, left-to-right, NO fused multiply-add
+// (the translation unit is compiled with -ffp-contract=off), IEEE division.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <type_traits>
+
+namespace dspfx {
+
+constexpr int MAX_SLOTS = 8;   // nodes fused into one kernel launch
+constexpr int WG = 256;        // workgroup size (4 waves)
+
+// kinds: numeric values == dspfx_kind in include/dspfx.h
+enum : int {
+    K_GAIN = 0, K_BIQUAD = 1, K_LOW_PASS = 2, K_HIGH_PASS = 3, K_REVERB = 4, K_DISTORT = 5,
+    K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10
+};
+enum : int {
+    D_HARD_CLIP = 0, D_SOFT_CLIP = 1, D_TANH = 2, D_RECIP_SOFT_CLIP = 3, D_FUZZ = 4, D_SIN = 5,
+    D_ATAN = 6, D_SQUARE = 7, D_CHEBYSHEV4 = 8
+};
+
+// Per-node kernel arguments (wave-uniform: they live in SGPRs).
+//   BIQUAD : p = {a1,a2,b0,b1,b2} already divided by a0 on the host (biquad.rs:62-76)
+//   REVERB : p[0] = decay; state = ring [D][N]; pos = ring row of the block's first frame
+//   others : p = the reference's slider values in field order
+struct SlotArgs {
+    int kind;
+    int mode;
+    float p[6];
+    float *state;
+    unsigned D;
+    unsigned pos;
+    int hop;     // apply collect_and_average (one pipe) to this node's input
+    int pad_;
+};
+
+struct ChainArgs {
+    const float *in;
+    const float *side;   // port "b" of ADD/MIX, or nullptr
+    float *out;
+    float *mixpart;      // [nframes][mix_stride] per-wave partial sums, or nullptr
+    unsigned N;
+    unsigned nframes;
+    float hop_div;       // f32(0.0001 + 1.0)  (node.rs:166,179)
+    int n_slots;
+    int side_hop;
+    unsigned mix_stride; // row length of mixpart = number of waves over all launches
+    unsigned c_base;     // first channel of this launch
+    unsigned n_launch;   // channels covered by this launch
+    unsigned wave_base;  // mixpart column of this launch's first wave
+    unsigned pad_;
+    SlotArgs slot[MAX_SLOTS];
+};
+
+// ---- static signature encoding ------------------------------------------------
+// A slot signature is either SIG_DYN (kind/mode/hop read from SlotArgs at run time,
+// wave-uniform switch) or a compile-time triple packed by sig().
+constexpr int SIG_DYN = -1;
+constexpr int SIG_NONE = -2;
+constexpr int sig(int kind, int mode = 0, int hop = 0) { return kind | (mode << 8) | (hop << 16); }
+constexpr int sig_kind(int s) { return s & 0xff; }
+constexpr int sig_mode(int s) { return (s >> 8) & 0xff; }
+constexpr int sig_hop(int s) { return (s >> 16) & 1; }
+
+template <int CPL> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<2> { using type = float2; };
+template <> struct VecT<4> { using type = float4; };
+
+template <int CPL>
+__device__ __forceinline__ void load_vec_raw(const float *p, float (&v)[CPL]) {
+    using V = typename VecT<CPL>::type;
+    V t = *reinterpret_cast<const V *>(p);
+    if constexpr (CPL == 1) { v[0] = t; }
+    else if constexpr (CPL == 2) { v[0] = t.x; v[1] = t.y; }
+    else { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+}
+template <int CPL>
+__device__ __forceinline__ void store_vec_raw(float *p, const float (&v)[CPL]) {
+    using V = typename VecT<CPL>::type;
+    V t;
+    if constexpr (CPL == 1) { t = v[0]; }
+    else if constexpr (CPL == 2) { t.x = v[0]; t.y = v[1]; }
+    else { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
+    *reinterpret_cast<V *>(p) = t;
+}
+
+// GUARD=true is the one-wave tail launch for N % (64*CPL) != 0: out-of-range lanes
+// stay alive (the mix-bus reduction shuffles across the wave), read zeros and
+// store nothing.  GUARD=false launches cover whole waves only.
+template <int CPL, bool GUARD>
+__device__ __forceinline__ void load_vec(const float *p, float (&v)[CPL], bool active) {
+    if constexpr (GUARD) {
+        if (active) load_vec_raw<CPL>(p, v);
+        else {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[j] = 0.0f;
+        }
+    } else {
+        load_vec_raw<CPL>(p, v);
+    }
+}
+template <int CPL, bool GUARD>
+__device__ __forceinline__ void store_vec(float *p, const float (&v)[CPL], bool active) {
+    if constexpr (GUARD) {
+        if (active) store_vec_raw<CPL>(p, v);
+    } else {
+        store_vec_raw<CPL>(p, v);
+    }
+}
+
+// ---- reference arithmetic, one sample ------------------------------------------
+
+// node.rs:162-194 with one connected pipe: buf = 0.0; buf += x; buf /= 0.0001f + 1.0f
+__device__ __forceinline__ float link_hop(float x, float div) { return (0.0f + x) / div; }
+
+// distort.rs:53-61
+__device__ __forceinline__ float clip1(float s) { return s < -1.0f ? -1.0f : (s > 1.0f ? 1.0f : s); }
+// f32::signum: +-1 by sign bit, NaN stays NaN
+__device__ __forceinline__ float rs_signum(float x) {
+    return x != x ? x : (__float_as_uint(x) >> 31 ? -1.0f : 1.0f);
+}
+
+// distort.rs:63-145, every mode except Fuzz.  `level < 0.001` => bypass.
+template <int MODE>
+__device__ __forceinline__ float distort1(float sample, float level) {
+    if (level < 0.001f) return sample;
+    if constexpr (MODE == D_HARD_CLIP) {          // 63-69
+        return clip1(sample * level) / level;
+    } else if constexpr (MODE == D_SOFT_CLIP) {   // 71-86
+        float s = sample * level;
+        float r;
+        if (s > 1.0f) r = 2.0f / 3.0f;
+        else if (s >= -1.0f && s <= 1.0f) r = s - (((s * s) * s) / 3.0f);   // powi(3) = (s*s)*s
+        else r = -2.0f / 3.0f;
+        return clip1(r) / level;
+    } else if constexpr (MODE == D_TANH) {        // 104-110
+        return tanhf(sample * level);
+    } else if constexpr (MODE == D_RECIP_SOFT_CLIP) {   // 96-102
+        return rs_signum(sample) * (1.0f - 1.0f / (fabsf(sample) * level + 1.0f));
+    } else if constexpr (MODE == D_SIN) {         // 112-118
+        return sinf(sample * level);
+    } else if constexpr (MODE == D_ATAN) {        // 120-126
+        return atanf(sample * level);
+    } else if constexpr (MODE == D_SQUARE) {      // 128-134
+        float v = sample * level;
+        return (v * v) * rs_signum(v);
+    } else {                                      // D_CHEBYSHEV4, 136-144
+        float v = sample * level;
+        float v2 = v * v;
+        return 8.0f * (v2 * v2) - 8.0f * v2 + 1.0f;
+    }
+}
+
+// overdrive.rs:31-43
+__device__ __forceinline__ float overdrive1(float sample, float boost, float drive, float level) {
+    if (level < 0.001f) return sample;
+    const float FRAC_PI_4 = 0.785398163397448309615660845819875721f;
+    const float FRAC_2_PI = 0.636619772367581343075535053490057448f;
+    float a = sample * boost;
+    float b = FRAC_PI_4 * a;
+    float c = atanf(b);
+    float d = FRAC_2_PI * c;
+    float mix = drive * d + (1.0f - drive) * sample;
+    return mix * level;
+}
+
+// chebyshev.rs:28-42
+__device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
+    if (sample >= 0.0f) {
+        if (lp < 0.001f) return sample;
+        return tanhf(sample * lp) / tanhf(lp);
+    } else {
+        if (ln < 0.001f) return sample;
+        return tanhf(sample * ln) / tanhf(ln);
+    }
+}
+
+// ---- per-lane chunk context ------------------------------------------------------
+struct Ctx {
+    size_t c;        // first channel of this lane
+    size_t N;
+    unsigned f0;     // first frame of the chunk
+    float hop_div;
+    const float *side;
+    int side_hop;
+    bool active;     // false only for padding lanes of the guarded tail launch
+};
+
+// Apply one node to a chunk v[F][CPL]; st[][] is the node's per-channel state.
+template <int KIND, int MODE, int F, int CPL, bool GUARD>
+__device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
+                                           const Ctx &cx) {
+    if constexpr (KIND == K_GAIN) {               // gain.rs:33-37
+        const float level = s.p[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] * level;
+    } else if constexpr (KIND == K_BIQUAD) {      // biquad.rs:87 -> DirectForm1::run
+        const float a1 = s.p[0], a2 = s.p[1], b0 = s.p[2], b1 = s.p[3], b2 = s.p[4];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const float x = v[f][j];
+                const float y = b0 * x + b1 * st[0][j] + b2 * st[1][j] - a1 * st[2][j] - a2 * st[3][j];
+                st[1][j] = st[0][j];
+                st[0][j] = x;
+                st[3][j] = st[2][j];
+                st[2][j] = y;
+                v[f][j] = y;
+            }
+    } else if constexpr (KIND == K_LOW_PASS) {    // low_pass.rs:36-39
+        const float r = s.p[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const float y = v[f][j] * (1.0f - r) + r * st[0][j];
+                st[0][j] = y;
+                v[f][j] = y;
+            }
+    } else if constexpr (KIND == K_HIGH_PASS) {   // high_pass.rs:36-39
+        const float r = s.p[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const float z = v[f][j] * (1.0f - r) + r * st[0][j];
+                st[0][j] = z;
+                v[f][j] = v[f][j] - z;
+            }
+    } else if constexpr (KIND == K_REVERB) {      // reverb.rs:86-103: y = x + tap*decay; ring <- y
+        const float decay = s.p[0];
+        float tap[F][CPL];
+        size_t row[F];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
+            r = r >= s.D ? r - s.D : r;
+            row[f] = (size_t)r * cx.N + cx.c;
+            load_vec<CPL, GUARD>(s.state + row[f], tap[f], cx.active);
+        }
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap[f][j] * decay;
+            store_vec<CPL, GUARD>(s.state + row[f], v[f], cx.active);
+        }
+    } else if constexpr (KIND == K_DISTORT) {     // distort.rs:176-194 (Fuzz has its own kernel)
+        const float level = s.p[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = distort1<MODE>(v[f][j], level);
+    } else if constexpr (KIND == K_OVERDRIVE) {   // overdrive.rs:58-72
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = overdrive1(v[f][j], s.p[0], s.p[1], s.p[2]);
+    } else if constexpr (KIND == K_CHEBYSHEV) {   // chebyshev.rs:52-62
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = chebyshev1(v[f][j], s.p[0], s.p[1]);
+    } else if constexpr (KIND == K_ADD || KIND == K_MIX) {   // add.rs:29-33, mix.rs:41-46
+        const float ratio = s.p[0];
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            float b[CPL];
+            if (cx.side) {
+                load_vec<CPL, GUARD>(cx.side + (size_t)(cx.f0 + f) * cx.N + cx.c, b, cx.active);
+                if (cx.side_hop) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) b[j] = link_hop(b[j], cx.hop_div);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) b[j] = 0.0f;    // unconnected port: zeros (node.rs:288)
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                if constexpr (KIND == K_ADD) v[f][j] = v[f][j] + b[j];
+                else v[f][j] = (b[j] * ratio) + (v[f][j] * (1.0f - ratio));
+            }
+        }
+    }
+}
+
+template <int F, int CPL>
+__device__ __forceinline__ void apply_hop(float (&v)[F][CPL], float div) {
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = link_hop(v[f][j], div);
+}
+
+template <int F, int CPL, bool GUARD>
+__device__ __forceinline__ void apply_distort_dyn(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
+                                                  const Ctx &cx) {
+    switch (s.mode) {
+    case D_HARD_CLIP: apply_node<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_SOFT_CLIP: apply_node<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_TANH: apply_node<K_DISTORT, D_TANH, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_RECIP_SOFT_CLIP: apply_node<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_SIN: apply_node<K_DISTORT, D_SIN, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_ATAN: apply_node<K_DISTORT, D_ATAN, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_SQUARE: apply_node<K_DISTORT, D_SQUARE, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_CHEBYSHEV4: apply_node<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD>(s, v, st, cx); break;
+    default: break;
+    }
+}
+
+// One slot: static signature => everything folds at compile time; SIG_DYN => a
+// wave-uniform switch (scalar branches, no divergence).
+template <int SIG, int F, int CPL, bool GUARD>
+__device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
+                                         const Ctx &cx) {
+    if constexpr (SIG == SIG_NONE) {
+        return;
+    } else if constexpr (SIG == SIG_DYN) {
+        if (s.hop) apply_hop<F, CPL>(v, cx.hop_div);
+        switch (s.kind) {
+        case K_GAIN: apply_node<K_GAIN, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_BIQUAD: apply_node<K_BIQUAD, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_LOW_PASS: apply_node<K_LOW_PASS, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_HIGH_PASS: apply_node<K_HIGH_PASS, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_REVERB: apply_node<K_REVERB, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_DISTORT: apply_distort_dyn<F, CPL, GUARD>(s, v, st, cx); break;
+        case K_OVERDRIVE: apply_node<K_OVERDRIVE, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_CHEBYSHEV: apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        default: break;
+        }
+    } else {
+        if constexpr (sig_hop(SIG)) apply_hop<F, CPL>(v, cx.hop_div);
+        apply_node<sig_kind(SIG), sig_mode(SIG), F, CPL, GUARD>(s, v, st, cx);
+    }
+}
+
+template <int SIG>
+__device__ __forceinline__ int slot_nstate(const SlotArgs &s) {
+    if constexpr (SIG == SIG_NONE) return 0;
+    else if constexpr (SIG == SIG_DYN) return s.kind == K_BIQUAD ? 4 : ((s.kind == K_LOW_PASS || s.kind == K_HIGH_PASS) ? 1 : 0);
+    else return sig_kind(SIG) == K_BIQUAD ? 4 : ((sig_kind(SIG) == K_LOW_PASS || sig_kind(SIG) == K_HIGH_PASS) ? 1 : 0);
+}
+
+template <int SIG, int CPL, bool GUARD>
+__device__ __forceinline__ void load_state(const SlotArgs &s, float (&st)[4][CPL], size_t c, size_t N, bool active) {
+    const int n = slot_nstate<SIG>(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < n) load_vec<CPL, GUARD>(s.state + (size_t)k * N + c, st[k], active);
+}
+template <int SIG, int CPL, bool GUARD>
+__device__ __forceinline__ void store_state(const SlotArgs &s, const float (&st)[4][CPL], size_t c, size_t N, bool active) {
+    const int n = slot_nstate<SIG>(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < n) store_vec<CPL, GUARD>(s.state + (size_t)k * N + c, st[k], active);
+}
+
+// Wave-level reduce-scatter of F per-lane values over the 64 lanes: after it,
+// r[0] of lane l holds the wave total of frame  mixbus_frame_of_lane<F>(l).
+// 2F-2+max(0,6-log2F) adds instead of 6F; fixed order => deterministic.
+template <int F>
+__device__ __forceinline__ void wave_reduce_scatter(float (&r)[F], int lane) {
+    int n = F;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        if (n > 1) {
+            const int h = n / 2;
+            const bool up = (lane & o) != 0;
+#pragma unroll
+            for (int i = 0; i < F / 2; ++i) {
+                if (i < h) {
+                    const float keep = up ? r[h + i] : r[i];
+                    const float send = up ? r[i] : r[h + i];
+                    r[i] = keep + __shfl_xor(send, o, 64);
+                }
+            }
+            n = h;
+        } else {
+            r[0] = r[0] + __shfl_xor(r[0], o, 64);
+        }
+    }
+}
+template <int F>
+__device__ __forceinline__ int mixbus_frame_of_lane(int lane) {
+    int f = 0, n = F;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        if (n > 1) {
+            n /= 2;
+            if (lane & o) f += n;
+        }
+    }
+    return f;
+}
+template <int F>
+__device__ __forceinline__ bool mixbus_lane_writes(int lane) {
+    // lanes that differ only in the bits consumed by the plain-butterfly tail hold duplicates
+    int n = F, mask = 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        if (n > 1) n /= 2;
+        else mask |= o;
+    }
+    return (lane & mask) == 0;
+}
+
+// ---- the fused chain kernel, statically specialised ---------------------------------
+#define DSPFX_FOR_SLOTS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
+
+template <int... SIGS> struct SigList {
+    static constexpr int v[MAX_SLOTS] = {SIGS...};
+};
+
+template <int F, int CPL>
+__device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (&v)[F][CPL], bool live,
+                                               unsigned f0, int lane, unsigned wave_global) {
+    float r[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float sacc = v[f][0];
+#pragma unroll
+        for (int j = 1; j < CPL; ++j) sacc = sacc + v[f][j];
+        r[f] = live ? sacc : 0.0f;
+    }
+    wave_reduce_scatter<F>(r, lane);
+    if (mixbus_lane_writes<F>(lane))
+        a.mixpart[(size_t)(f0 + mixbus_frame_of_lane<F>(lane)) * a.mix_stride + wave_global] = r[0];
+}
+
+template <int F, int CPL, class SL>
+__device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c,
+                                            unsigned f0, int lane, unsigned wave_global) {
+    float v[F][CPL];
+#pragma unroll
+    for (int f = 0; f < F; ++f) load_vec<CPL, false>(a.in + (size_t)(f0 + f) * a.N + c, v[f], true);
+    const Ctx cx{c, a.N, f0, a.hop_div, a.side, a.side_hop, true};
+#define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false>(a.slot[I], v, st[I], cx);
+    DSPFX_FOR_SLOTS(DSPFX_RUN)
+#undef DSPFX_RUN
+#pragma unroll
+    for (int f = 0; f < F; ++f) store_vec<CPL, false>(a.out + (size_t)(f0 + f) * a.N + c, v[f], true);
+    if (a.mixpart) mixbus_partial<F, CPL>(a, v, true, f0, lane, wave_global);
+}
+
+// Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
+template <int F, int CPL, class SL>
+__global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
+    const unsigned tid = blockIdx.x * WG + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const size_t rel = (size_t)tid * CPL;
+    if (rel >= a.n_launch) return;                 // whole-wave uniform by construction
+    const size_t c = a.c_base + rel;
+    float st[MAX_SLOTS][4][CPL];
+#define DSPFX_LD(I) load_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
+    DSPFX_FOR_SLOTS(DSPFX_LD)
+#undef DSPFX_LD
+    unsigned f0 = 0;
+    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL>(a, st, c, f0, lane, wave_global);
+    if constexpr (F > 1)
+        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL>(a, st, c, f0, lane, wave_global);
+#define DSPFX_ST(I) store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
+    DSPFX_FOR_SLOTS(DSPFX_ST)
+#undef DSPFX_ST
+}
+
+// ---- the fused chain kernel, interpreting any chain ----------------------------------
+// One lane = one channel.  The node loop runs at run time (wave-uniform scalar
+// branches); per-node filter state is staged in LDS ([row][lane], conflict-free)
+// for the whole block and touched once per chunk per stateful node.
+// GUARD=true: one-wave tail launch whose out-of-range lanes stay alive with zeros.
+template <int F, bool GUARD>
+__device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, bool active, unsigned f0,
+                                          int lane, unsigned wave_global) {
+    float v[F][1];
+#pragma unroll
+    for (int f = 0; f < F; ++f) load_vec<1, GUARD>(a.in + (size_t)(f0 + f) * a.N + c, v[f], active);
+    const Ctx cx{c, a.N, f0, a.hop_div, a.side, a.side_hop, active};
+    int row = 0;
+#pragma unroll 1
+    for (int s = 0; s < a.n_slots; ++s) {
+        const SlotArgs &sl = a.slot[s];
+        const int ns = slot_nstate<SIG_DYN>(sl);
+        float st[4][1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) st[k][0] = (k < ns) ? lds[(row + k) * WG + threadIdx.x] : 0.0f;
+        run_slot<SIG_DYN, F, 1, GUARD>(sl, v, st, cx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) lds[(row + k) * WG + threadIdx.x] = st[k][0];
+        row += ns;
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) store_vec<1, GUARD>(a.out + (size_t)(f0 + f) * a.N + c, v[f], active);
+    if (a.mixpart) mixbus_partial<F, 1>(a, v, !GUARD || active, f0, lane, wave_global);
+}
+
+template <int F, bool GUARD>
+__global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
+    extern __shared__ float lds[];   // [state rows][WG]
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const bool active = tid < a.n_launch;
+    if (!GUARD && !active) return;                 // whole-wave uniform by construction
+    const size_t c = a.c_base + (active ? tid : 0);
+    {
+        int row = 0;
+#pragma unroll 1
+        for (int s = 0; s < a.n_slots; ++s) {
+            const int ns = slot_nstate<SIG_DYN>(a.slot[s]);
+            for (int k = 0; k < ns; ++k) {
+                float t[1];
+                load_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
+                lds[(row + k) * WG + threadIdx.x] = t[0];
+            }
+            row += ns;
+        }
+    }
+    unsigned f0 = 0;
+    for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD>(a, lds, c, active, f0, lane, wave_global);
+    if constexpr (F > 1)
+        for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD>(a, lds, c, active, f0, lane, wave_global);
+    {
+        int row = 0;
+#pragma unroll 1
+        for (int s = 0; s < a.n_slots; ++s) {
+            const int ns = slot_nstate<SIG_DYN>(a.slot[s]);
+            for (int k = 0; k < ns; ++k) {
+                float t[1] = {lds[(row + k) * WG + threadIdx.x]};
+                store_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
+            }
+            row += ns;
+        }
+    }
+}
+
+}  // namespace dspfx

@@ -1,0 +1,822 @@
+// dspfx.hip -- host side of the C ABI declared in include/dspfx.h.
+//
+// Owns parameters, coefficients and every piece of DSP state in HBM, plans the
+// chain into stages (fused chain kernel | Fuzz | FIR) and launches them on the
+// caller's stream.  No CPU fallback exists: without a HIP device every entry
+// point that needs one returns DSPFX_ERR_NO_DEVICE.
+#include "../../include/dspfx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.h"
+#include "fir_kernels.h"
+#include "variants.h"
+
+using namespace dspfx;
+
+namespace {
+
+enum StageType { ST_FUSED = 0, ST_FUZZ = 1, ST_FIR = 2 };
+
+struct Node {
+    dspfx_node_desc d{};
+    // BIQUAD: normalised coefficients (biquad.rs:62-76)
+    float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N], REVERB ring [D][N], FIR history
+    size_t state_bytes = 0;
+    uint32_t D = 0, pos = 0;  // REVERB
+    // FIR
+    std::vector<double> taps;      // reversed, as given
+    FirState fir;
+};
+
+struct Stage {
+    StageType type;
+    int first, count;
+    const Variant *var = nullptr;   // ST_FUSED
+};
+
+}  // namespace
+
+struct dspfx_engine {
+    dspfx_engine_desc desc{};
+    int device = 0;
+    std::vector<Node> nodes;
+    std::vector<Stage> stages;
+    std::string err;
+    float hop_div = 1.0f;
+    float *mixpart = nullptr;
+    size_t mixpart_cols = 0;
+    // staging for dspfx_process_host
+    float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
+    const Variant *tail = nullptr, *dyn = nullptr;
+    bool has_fuzz = false;
+    uint32_t min_delay = 0xffffffffu;
+    // profiling: event pairs per stage
+    bool profiling = false;
+    std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;   // [stage][launch]
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+hipEvent_t take_event(dspfx_engine *e) {
+    if (!e->ev_pool.empty()) {
+        hipEvent_t ev = e->ev_pool.back();
+        e->ev_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct ProfScope {   // brackets one kernel launch with events on its own stream
+    dspfx_engine *e;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    size_t stage;
+    ProfScope(dspfx_engine *e_, size_t stage_, hipStream_t s_) : e(e_), s(s_), stage(stage_) {
+        if (!e->profiling) return;
+        a = take_event(e);
+        b = take_event(e);
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        if (e->prof.size() <= stage) e->prof.resize(stage + 1);
+        e->prof[stage].emplace_back(a, b);
+    }
+};
+
+int fail(dspfx_engine *e, int code, const char *fmt, ...) {
+    if (e) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        e->err = buf;
+    }
+    return code;
+}
+
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess)                                                                \
+            return fail(e, err__ == hipErrorOutOfMemory ? DSPFX_ERR_OOM : DSPFX_ERR_HIP,        \
+                        "%s failed: %s", #call, hipGetErrorString(err__));                      \
+    } while (0)
+
+bool fusable(const Node &n) {
+    if (n.d.kind == DSPFX_FIR) return false;
+    if (n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ) return false;
+    return true;
+}
+
+int node_hop(const dspfx_engine *e, int idx) {
+    return idx == 0 ? ((e->desc.link_flags & DSPFX_LINK_INPUT) ? 1 : 0)
+                    : ((e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0);
+}
+
+void biquad_regenerate(Node &n) {   // biquad.rs:62-76
+    const float a0 = n.d.params[0];
+    n.a1 = n.d.params[1] / a0;
+    n.a2 = n.d.params[2] / a0;
+    n.b0 = n.d.params[3] / a0;
+    n.b1 = n.d.params[4] / a0;
+    n.b2 = n.d.params[5] / a0;
+}
+
+void free_node(Node &n) {
+    if (n.state) (void)hipFree(n.state);
+    n.state = nullptr;
+    n.state_bytes = 0;
+    fir_free(n.fir);
+}
+
+void collect_variants(std::vector<const Variant *> &out) {
+    int n = 0;
+    const Variant *v = variants_dyn(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+    v = variants_static3(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+    v = variants_static5(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+}
+
+// DSPFX_VARIANT="f=8,cpl=2,static=1" narrows the choice (tuning / A-B runs).
+struct Pref {
+    int f = -1, cpl = -1, stat = -1;
+};
+Pref read_pref() {
+    Pref p;
+    const char *s = getenv("DSPFX_VARIANT");
+    if (!s) return p;
+    const char *q;
+    if ((q = strstr(s, "f="))) p.f = atoi(q + 2);
+    if ((q = strstr(s, "cpl="))) p.cpl = atoi(q + 4);
+    if ((q = strstr(s, "static="))) p.stat = atoi(q + 7);
+    return p;
+}
+
+const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    const Pref pref = read_pref();
+    const uint32_t N = e->desc.channels;
+    const Variant *best = nullptr;
+    int best_score = -1;
+    for (const Variant *v : all) {
+        if (v->guard) continue;
+        const bool is_dyn = v->sigs[0] == SIG_DYN;
+        if (!is_dyn) {
+            if (pref.stat == 0) continue;
+            if (v->n_slots != st.count) continue;
+            bool ok = true;
+            for (int i = 0; i < st.count && ok; ++i) {
+                const Node &n = e->nodes[st.first + i];
+                const int mode = n.d.kind == DSPFX_DISTORT ? n.d.mode : 0;
+                ok = v->sigs[i] == sig(n.d.kind, mode, node_hop(e, st.first + i));
+            }
+            if (!ok) continue;
+            if (N % (64u * v->cpl) != 0 && N < 64u * v->cpl) continue;
+            if (N % v->cpl != 0) continue;   // vector loads need aligned rows
+        }
+        int score = is_dyn ? 0 : 100;
+        // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
+        if (pref.f > 0 ? v->f == pref.f : v->f == 8) score += 10;
+        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == (is_dyn ? 1 : 2)) score += 5;
+        if (score > best_score) {
+            best_score = score;
+            best = v;
+        }
+    }
+    return best;
+}
+
+int plan(dspfx_engine *e) {
+    e->stages.clear();
+    e->has_fuzz = false;
+    e->min_delay = 0xffffffffu;
+    const int n = (int)e->nodes.size();
+    int i = 0;
+    while (i < n) {
+        Stage st{};
+        if (fusable(e->nodes[i])) {
+            st.type = ST_FUSED;
+            st.first = i;
+            while (i < n && fusable(e->nodes[i]) && i - st.first < MAX_SLOTS) ++i;
+            st.count = i - st.first;
+        } else {
+            st.type = e->nodes[i].d.kind == DSPFX_FIR ? ST_FIR : ST_FUZZ;
+            st.first = i;
+            st.count = 1;
+            ++i;
+        }
+        e->stages.push_back(st);
+    }
+    // the mix bus is reduced in the epilogue of a fused stage: make sure one is last
+    if (e->stages.empty() || e->stages.back().type != ST_FUSED) {
+        Stage st{};
+        st.type = ST_FUSED;
+        st.first = n;
+        st.count = 0;
+        e->stages.push_back(st);
+    }
+    for (Stage &st : e->stages)
+        if (st.type == ST_FUSED) {
+            st.var = pick_variant(e, st);
+            if (!st.var) return fail(e, DSPFX_ERR_UNSUPPORTED, "no kernel variant for stage");
+        }
+    for (const Node &nd : e->nodes) {
+        if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
+        if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
+    }
+    return DSPFX_OK;
+}
+
+int alloc_node_state(dspfx_engine *e, Node &n) {
+    const size_t N = e->desc.channels;
+    size_t bytes = 0;
+    switch (n.d.kind) {
+    case DSPFX_BIQUAD: bytes = 4 * N * sizeof(float); break;
+    case DSPFX_LOW_PASS:
+    case DSPFX_HIGH_PASS: bytes = N * sizeof(float); break;
+    case DSPFX_REVERB: bytes = (size_t)n.D * N * sizeof(float); break;
+    default: break;
+    }
+    if (n.state && n.state_bytes != bytes) {
+        (void)hipFree(n.state);
+        n.state = nullptr;
+    }
+    if (bytes && !n.state) HIPCHK(e, hipMalloc((void **)&n.state, bytes));
+    n.state_bytes = bytes;
+    if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
+    n.pos = 0;
+    if (n.d.kind == DSPFX_FIR) {
+        const int rc = fir_configure(n.fir, n.taps.data(), (uint32_t)n.taps.size(), n.d.mode, (uint32_t)N,
+                                     e->desc.max_frames);
+        if (rc != 0) return fail(e, rc, "FIR configure failed: %s", fir_last_error());
+    }
+    return DSPFX_OK;
+}
+
+int validate_node(dspfx_engine *e, const dspfx_node_desc &d) {
+    if (d.kind < 0 || d.kind >= DSPFX_N_KINDS) return fail(e, DSPFX_ERR_INVALID, "unknown node kind %d", d.kind);
+    if (d.kind == DSPFX_DISTORT && (d.mode < 0 || d.mode > DSPFX_DIST_CHEBYSHEV4))
+        return fail(e, DSPFX_ERR_INVALID, "unknown distort mode %d", d.mode);
+    if (d.kind == DSPFX_REVERB && d.delay_len < DSPFX_BUF_SIZE)
+        return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128 (reverb.rs:58 clamps to >= 128)", d.delay_len);
+    if (d.kind == DSPFX_FIR && (d.n_taps == 0 || !d.taps))
+        return fail(e, DSPFX_ERR_INVALID, "FIR node needs taps");
+    return DSPFX_OK;
+}
+
+void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
+    const Node &n = e->nodes[idx];
+    memset(&s, 0, sizeof s);
+    s.kind = n.d.kind;
+    s.mode = n.d.mode;
+    s.state = n.state;
+    s.D = n.D;
+    s.pos = n.pos;
+    s.hop = node_hop(e, idx);
+    switch (n.d.kind) {
+    case DSPFX_BIQUAD:
+        s.p[0] = n.a1; s.p[1] = n.a2; s.p[2] = n.b0; s.p[3] = n.b1; s.p[4] = n.b2;
+        break;
+    default:
+        for (int k = 0; k < 6; ++k) s.p[k] = n.d.params[k];
+    }
+}
+
+int state_rows(const Node &n) {
+    return n.d.kind == DSPFX_BIQUAD ? 4 : ((n.d.kind == DSPFX_LOW_PASS || n.d.kind == DSPFX_HIGH_PASS) ? 1 : 0);
+}
+
+// One sub-block (nframes <= every delay length) through all stages.
+int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                 uint32_t nframes, hipStream_t stream) {
+    const uint32_t N = e->desc.channels;
+    const float *src = in;
+    for (size_t si = 0; si < e->stages.size(); ++si) {
+        const Stage &st = e->stages[si];
+        const bool last = si + 1 == e->stages.size();
+        if (st.type == ST_FUSED) {
+            if (st.count == 0 && !(last && mix) && src == out) continue;   // nothing to do
+            ChainArgs a;
+            memset(&a, 0, sizeof a);
+            a.in = src;
+            a.side = side;
+            a.out = out;
+            a.N = N;
+            a.nframes = nframes;
+            a.hop_div = e->hop_div;
+            a.n_slots = st.count;
+            a.side_hop = (side && (e->desc.link_flags & DSPFX_LINK_INTERNAL)) ? 1 : 0;
+            int rows = 0;
+            for (int k = 0; k < st.count; ++k) {
+                fill_slot(e, st.first + k, a.slot[k]);
+                rows += state_rows(e->nodes[st.first + k]);
+            }
+            const Variant *v = st.var;
+            const uint32_t per_wave = 64u * v->cpl;
+            const uint32_t n_main = N - N % per_wave;
+            const uint32_t waves_main = n_main / per_wave;
+            a.mixpart = (last && mix) ? e->mixpart : nullptr;
+            a.mix_stride = waves_main + (N - n_main + 63) / 64;
+            if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
+            if (n_main) {
+                a.c_base = 0;
+                a.n_launch = n_main;
+                a.wave_base = 0;
+                const unsigned grid = (waves_main * 64 + WG - 1) / WG;
+                ProfScope ps(e, si, stream);
+                v->launch(a, grid, WG, (unsigned)(rows * WG * sizeof(float)), stream);
+            }
+            if (N % per_wave) {   // ragged tail: guarded one-wave blocks, lane per channel
+                const uint32_t n_tail = N - n_main;
+                a.c_base = n_main;
+                a.n_launch = n_tail;
+                a.wave_base = waves_main;
+                e->tail->launch(a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
+            }
+            HIPCHK(e, hipGetLastError());
+            if (a.mixpart) {
+                launch_mix_reduce(e->mixpart, mix, nframes, a.mix_stride, stream);
+                HIPCHK(e, hipGetLastError());
+            }
+        } else if (st.type == ST_FUZZ) {
+            const Node &n = e->nodes[st.first];
+            FuzzArgs f{src, out, N, nframes, n.d.params[0], e->hop_div, node_hop(e, st.first)};
+            ProfScope ps(e, si, stream);
+            launch_fuzz(f, stream);
+            HIPCHK(e, hipGetLastError());
+        } else {   // ST_FIR
+            Node &n = e->nodes[st.first];
+            ProfScope ps(e, si, stream);
+            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, stream);
+            if (rc != 0) return fail(e, rc, "FIR: %s", fir_last_error());
+        }
+        src = out;
+    }
+    // advance the delay rings (FIFO: the block's rows now hold the newest samples)
+    for (Node &n : e->nodes)
+        if (n.d.kind == DSPFX_REVERB) n.pos = (uint32_t)(((uint64_t)n.pos + nframes) % n.D);
+    return DSPFX_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ library
+
+extern "C" uint32_t dspfx_abi_version(void) { return DSPFX_ABI_VERSION; }
+
+extern "C" const char *dspfx_strerror(int status) {
+    switch (status) {
+    case DSPFX_OK: return "ok";
+    case DSPFX_ERR_INVALID: return "invalid argument";
+    case DSPFX_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+    case DSPFX_ERR_HIP: return "HIP runtime error";
+    case DSPFX_ERR_OOM: return "out of device memory";
+    case DSPFX_ERR_UNSUPPORTED: return "unsupported";
+    case DSPFX_ERR_STATE: return "invalid engine state";
+    default: return "unknown status";
+    }
+}
+
+extern "C" int dspfx_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int dspfx_node_defaults(int kind, dspfx_node_desc *d) {
+    if (!d || kind < 0 || kind >= DSPFX_N_KINDS) return DSPFX_ERR_INVALID;
+    memset(d, 0, sizeof *d);
+    d->kind = kind;
+    switch (kind) {
+    case DSPFX_GAIN: d->params[0] = 1.0f; break;                       // gain.rs:21
+    case DSPFX_BIQUAD:                                                  // biquad.rs:18-41
+        d->params[0] = 1.0f; d->params[1] = -0.24f; d->params[2] = 0.0f;
+        d->params[3] = 0.758f; d->params[4] = 0.0f; d->params[5] = 0.0f;
+        break;
+    case DSPFX_LOW_PASS:
+    case DSPFX_HIGH_PASS: d->params[0] = 0.5f; break;                  // low_pass.rs:20
+    case DSPFX_REVERB: d->params[0] = 0.5f; d->delay_len = 128; break; // reverb.rs:37, 44-52 (make_buffer)
+    case DSPFX_DISTORT: d->mode = DSPFX_DIST_SOFT_CLIP; break;         // distort.rs:46-50
+    case DSPFX_MIX: d->params[0] = 0.5f; break;                        // mix.rs:22-28
+    default: break;
+    }
+    return DSPFX_OK;
+}
+
+extern "C" uint32_t dspfx_delay_len(float seconds, int page_round) {
+    // reverb.rs:58: ((seconds * 48000.0) as usize).max(128); `as` truncates and saturates
+    const float s = seconds * 48000.0f;
+    uint32_t d;
+    if (!(s > 0.0f)) d = 0;
+    else if (s >= 4294967040.0f) d = 0xffffffffu;
+    else d = (uint32_t)s;
+    if (d < 128) d = 128;
+    if (page_round) d = (d + 1023u) / 1024u * 1024u;
+    return d;
+}
+
+extern "C" float dspfx_link_divisor(uint64_t n_connected) {
+    // node.rs:166,179: sequential f32 increments; saturates once 1.0 < ulp/2
+    float num_frames = 0.0001f;
+    for (uint64_t i = 0; i < n_connected; ++i) {
+        const float next = num_frames + 1.0f;
+        if (next == num_frames) break;   // further increments are no-ops
+        num_frames = next;
+    }
+    return num_frames;
+}
+
+// ---------------------------------------------------------------- lifecycle
+
+extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine **out) {
+    if (!desc || !out) return DSPFX_ERR_INVALID;
+    *out = nullptr;
+    if (desc->abi_version != DSPFX_ABI_VERSION) return DSPFX_ERR_INVALID;
+    if (desc->channels == 0 || desc->max_frames == 0) return DSPFX_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
+    if (desc->device < 0 || desc->device >= ndev) return DSPFX_ERR_INVALID;
+    if (hipSetDevice(desc->device) != hipSuccess) return DSPFX_ERR_HIP;
+    dspfx_engine *e = new dspfx_engine();
+    e->desc = *desc;
+    e->device = desc->device;
+    e->hop_div = dspfx_link_divisor(1);
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    for (const Variant *v : all) {
+        if (v->guard) e->tail = v;
+        if (!v->guard && v->sigs[0] == SIG_DYN && v->f == 8) e->dyn = v;
+    }
+    e->mixpart_cols = (size_t)desc->channels / 64 + 8;
+    if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess) {
+        delete e;
+        return DSPFX_ERR_OOM;
+    }
+    plan(e);
+    *out = e;
+    return DSPFX_OK;
+}
+
+extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    for (Node &n : e->nodes) free_node(n);
+    if (e->mixpart) (void)hipFree(e->mixpart);
+    if (e->h_in) (void)hipFree(e->h_in);
+    if (e->h_side) (void)hipFree(e->h_side);
+    if (e->h_out) (void)hipFree(e->h_out);
+    if (e->h_mix) (void)hipFree(e->h_mix);
+    for (auto &st : e->prof)
+        for (auto &p : st) {
+            (void)hipEventDestroy(p.first);
+            (void)hipEventDestroy(p.second);
+        }
+    for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    delete e;
+}
+
+extern "C" const char *dspfx_last_error(const dspfx_engine *e) { return e ? e->err.c_str() : "null engine"; }
+
+extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (n_nodes < 0 || n_nodes > DSPFX_MAX_NODES || (n_nodes > 0 && !nodes))
+        return fail(e, DSPFX_ERR_INVALID, "chain length %d out of range", n_nodes);
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int i = 0; i < n_nodes; ++i) {
+        const int rc = validate_node(e, nodes[i]);
+        if (rc) return rc;
+    }
+    for (Node &n : e->nodes) free_node(n);
+    e->nodes.clear();
+    e->nodes.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) {
+        Node &n = e->nodes[(size_t)i];
+        n.d = nodes[i];
+        n.d.taps = nullptr;
+        if (n.d.kind == DSPFX_BIQUAD) biquad_regenerate(n);
+        if (n.d.kind == DSPFX_REVERB) n.D = nodes[i].delay_len;
+        if (n.d.kind == DSPFX_FIR) n.taps.assign(nodes[i].taps, nodes[i].taps + nodes[i].n_taps);
+        const int rc = alloc_node_state(e, n);
+        if (rc) return rc;
+    }
+    return plan(e);
+}
+
+extern "C" int dspfx_chain_len(const dspfx_engine *e) { return e ? (int)e->nodes.size() : DSPFX_ERR_INVALID; }
+
+extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size() || param < 0 || param >= 8)
+        return fail(e, DSPFX_ERR_INVALID, "set_param(%d,%d) out of range", node, param);
+    Node &n = e->nodes[(size_t)node];
+    n.d.params[param] = value;
+    if (n.d.kind == DSPFX_BIQUAD) {   // after_settings_change: renormalise + reset_state (biquad.rs:62-76)
+        biquad_regenerate(n);
+        HIPCHK(e, hipSetDevice(e->device));
+        HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
+    }
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_set_mode(dspfx_engine *e, int node, int mode) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
+    Node &n = e->nodes[(size_t)node];
+    dspfx_node_desc d = n.d;
+    d.mode = mode;
+    d.taps = n.taps.data();
+    const int rc = validate_node(e, d);
+    if (rc) return rc;
+    n.d.mode = mode;
+    if (n.d.kind == DSPFX_FIR) n.fir.mode = mode;
+    return plan(e);   // Fuzz <-> other modes changes the stage split
+}
+
+extern "C" int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_REVERB)
+        return fail(e, DSPFX_ERR_INVALID, "node %d is not a REVERB node", node);
+    if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
+    HIPCHK(e, hipSetDevice(e->device));
+    Node &n = e->nodes[(size_t)node];
+    n.D = delay_len;   // reverb.rs:55-71: a brand-new zero-filled ring
+    n.d.delay_len = delay_len;
+    const int rc = alloc_node_state(e, n);
+    if (rc) return rc;
+    return plan(e);
+}
+
+extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_FIR)
+        return fail(e, DSPFX_ERR_INVALID, "node %d is not a FIR node", node);
+    if (!taps_reversed || n_taps == 0) return fail(e, DSPFX_ERR_INVALID, "FIR node needs taps");
+    HIPCHK(e, hipSetDevice(e->device));
+    Node &n = e->nodes[(size_t)node];
+    n.taps.assign(taps_reversed, taps_reversed + n_taps);
+    n.d.n_taps = n_taps;
+    n.d.mode = mode;
+    return alloc_node_state(e, n);
+}
+
+extern "C" int dspfx_reset(dspfx_engine *e) {
+    if (!e) return DSPFX_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    for (Node &n : e->nodes) {
+        if (n.state) HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
+        n.pos = 0;
+        if (n.d.kind == DSPFX_FIR) fir_reset(n.fir);
+    }
+    return DSPFX_OK;
+}
+
+// ------------------------------------------------------------- the hot path
+
+extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                             uint32_t n_frames, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
+    if (n_frames == 0) return DSPFX_OK;
+    if (n_frames > e->desc.max_frames)
+        return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
+    if (e->has_fuzz && n_frames % DSPFX_BUF_SIZE)
+        return fail(e, DSPFX_ERR_INVALID, "Fuzz is block-global over 128 frames: n_frames %u %% 128 != 0", n_frames);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    // a block's delay taps must not depend on the same launch's outputs: split at min delay
+    uint32_t sub = std::min(n_frames, e->min_delay);
+    if (e->has_fuzz) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
+    const size_t N = e->desc.channels;
+    for (uint32_t f0 = 0; f0 < n_frames; f0 += sub) {
+        const uint32_t nf = std::min(sub, n_frames - f0);
+        const int rc = run_subblock(e, in + (size_t)f0 * N, side ? side + (size_t)f0 * N : nullptr,
+                                    out + (size_t)f0 * N, mix ? mix + f0 : nullptr, nf, s);
+        if (rc) return rc;
+    }
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                                  uint32_t n_frames) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
+    if (n_frames > e->desc.max_frames)
+        return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t cap = (size_t)e->desc.max_frames * e->desc.channels * sizeof(float);
+    const size_t bytes = (size_t)n_frames * e->desc.channels * sizeof(float);
+    if (!e->h_in) HIPCHK(e, hipMalloc((void **)&e->h_in, cap));
+    if (!e->h_out) HIPCHK(e, hipMalloc((void **)&e->h_out, cap));
+    if (side && !e->h_side) HIPCHK(e, hipMalloc((void **)&e->h_side, cap));
+    if (mix && !e->h_mix) HIPCHK(e, hipMalloc((void **)&e->h_mix, e->desc.max_frames * sizeof(float)));
+    HIPCHK(e, hipMemcpy(e->h_in, in, bytes, hipMemcpyHostToDevice));
+    if (side) HIPCHK(e, hipMemcpy(e->h_side, side, bytes, hipMemcpyHostToDevice));
+    const int rc = dspfx_process(e, e->h_in, side ? e->h_side : nullptr, e->h_out, mix ? e->h_mix : nullptr,
+                                 n_frames, nullptr);
+    if (rc) return rc;
+    HIPCHK(e, hipStreamSynchronize(nullptr));
+    HIPCHK(e, hipMemcpy(out, e->h_out, bytes, hipMemcpyDeviceToHost));
+    if (mix) HIPCHK(e, hipMemcpy(mix, e->h_mix, n_frames * sizeof(float), hipMemcpyDeviceToHost));
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream) {
+    if (!e || !mix) return DSPFX_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    launch_mix_finish(mix, n_frames, dspfx_link_divisor(n_connected), (hipStream_t)stream);
+    HIPCHK(e, hipGetLastError());
+    return DSPFX_OK;
+}
+
+// -------------------------------------------------------------------- state
+
+extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
+    if (!e || node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;
+    const Node &n = e->nodes[(size_t)node];
+    if (n.d.kind == DSPFX_FIR) return (int64_t)fir_state_bytes(n.fir);
+    return (int64_t)n.state_bytes;
+}
+
+extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, size_t size) {
+    if (!e || !host_dst) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
+    Node &n = e->nodes[(size_t)node];
+    const int64_t need = dspfx_state_size(e, node);
+    if ((int64_t)size != need) return fail(e, DSPFX_ERR_INVALID, "state size %zu != %lld", size, (long long)need);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    if (n.d.kind == DSPFX_FIR) {
+        const int rc = fir_state_export(n.fir, host_dst);
+        return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
+    }
+    if (n.d.kind == DSPFX_REVERB) {   // rotate so that row 0 is the oldest sample
+        const size_t row = (size_t)e->desc.channels * sizeof(float);
+        const size_t head = (size_t)(n.D - n.pos) * row;
+        HIPCHK(e, hipMemcpy(host_dst, (char *)n.state + (size_t)n.pos * row, head, hipMemcpyDeviceToHost));
+        if (n.pos) HIPCHK(e, hipMemcpy((char *)host_dst + head, n.state, (size_t)n.pos * row, hipMemcpyDeviceToHost));
+        return DSPFX_OK;
+    }
+    if (need) HIPCHK(e, hipMemcpy(host_dst, n.state, (size_t)need, hipMemcpyDeviceToHost));
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_src, size_t size) {
+    if (!e || !host_src) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
+    Node &n = e->nodes[(size_t)node];
+    const int64_t need = dspfx_state_size(e, node);
+    if ((int64_t)size != need) return fail(e, DSPFX_ERR_INVALID, "state size %zu != %lld", size, (long long)need);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    if (n.d.kind == DSPFX_FIR) {
+        const int rc = fir_state_import(n.fir, host_src);
+        return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
+    }
+    if (need) HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
+    n.pos = 0;
+    return DSPFX_OK;
+}
+
+// ---------------------------------------------------------------- utilities
+
+extern "C" int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, uint32_t n_abs0, uint32_t seed,
+                                void *stream) {
+    if (!e || !dst) return DSPFX_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    launch_noise(dst, e->desc.channels, n_frames, (uint32_t)e->desc.channel_offset, n_abs0, seed, (hipStream_t)stream);
+    HIPCHK(e, hipGetLastError());
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_sync(dspfx_engine *e, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_profile_enable(dspfx_engine *e, int enable) {
+    if (!e) return DSPFX_ERR_INVALID;
+    e->profiling = enable != 0;
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_profile_read(dspfx_engine *e, double *total_ms, uint32_t *launches, char *kernel_name,
+                                  size_t cap, int reset) {
+    if (!e) return DSPFX_ERR_INVALID;
+    HIPCHK(e, hipSetDevice(e->device));
+    double best = -1.0;
+    uint32_t best_n = 0;
+    size_t best_stage = 0;
+    for (size_t si = 0; si < e->prof.size(); ++si) {
+        double tot = 0.0;
+        for (auto &p : e->prof[si]) {
+            HIPCHK(e, hipEventSynchronize(p.second));
+            float ms = 0.0f;
+            HIPCHK(e, hipEventElapsedTime(&ms, p.first, p.second));
+            tot += ms;
+        }
+        if (tot > best) {
+            best = tot;
+            best_n = (uint32_t)e->prof[si].size();
+            best_stage = si;
+        }
+    }
+    if (total_ms) *total_ms = best < 0 ? 0.0 : best;
+    if (launches) *launches = best_n;
+    if (kernel_name && cap) {
+        const char *nm = "";
+        if (best_stage < e->stages.size()) {
+            const Stage &st = e->stages[best_stage];
+            nm = st.type == ST_FUSED ? (st.var ? st.var->name : "fused")
+                 : st.type == ST_FUZZ ? "fuzz_kernel" : fir_kernel_name(e->nodes[(size_t)st.first].fir);
+        }
+        snprintf(kernel_name, cap, "%s", nm);
+    }
+    if (reset) {
+        for (auto &st : e->prof) {
+            for (auto &p : st) {
+                e->ev_pool.push_back(p.first);
+                e->ev_pool.push_back(p.second);
+            }
+            st.clear();
+        }
+    }
+    return DSPFX_OK;
+}
+
+extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint32_t n_frames) {
+    // 4 B in + 4 B out, + 8 B per delay line (tap read + write),
+    // + per-block state traffic / n_frames, + 4 B side input for ADD/MIX,
+    // FIR: + 4 B history write + 4*(T-1)/n_frames history re-read.
+    if (!e || n_frames == 0) return 0.0;
+    double b = 8.0;
+    bool side = false;
+    for (const Node &n : e->nodes) {
+        switch (n.d.kind) {
+        case DSPFX_BIQUAD: b += 32.0 / n_frames; break;
+        case DSPFX_LOW_PASS:
+        case DSPFX_HIGH_PASS: b += 8.0 / n_frames; break;
+        case DSPFX_REVERB: b += 8.0; break;
+        case DSPFX_FIR: b += 4.0 + 4.0 * ((double)n.taps.size() - 1.0) / n_frames; break;
+        case DSPFX_ADD:
+        case DSPFX_MIX: side = true; break;
+        default: break;
+        }
+    }
+    if (side) b += 4.0;
+    return b;
+}
+
+extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
+    if (!e || !dst || cap == 0) return DSPFX_ERR_INVALID;
+    static const char *kn[] = {"gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "overdrive",
+                               "chebyshev", "fir", "add", "mix"};
+    std::string s;
+    char buf[256];
+    snprintf(buf, sizeof buf, "engine: N=%u max_frames=%u link_flags=%u\n", e->desc.channels, e->desc.max_frames,
+             e->desc.link_flags);
+    s += buf;
+    for (size_t i = 0; i < e->stages.size(); ++i) {
+        const Stage &st = e->stages[i];
+        if (st.type == ST_FUSED) {
+            snprintf(buf, sizeof buf, "stage %zu: fused kernel %s (F=%d, CPL=%d):", i, st.var ? st.var->name : "?",
+                     st.var ? st.var->f : 0, st.var ? st.var->cpl : 0);
+            s += buf;
+            for (int k = 0; k < st.count; ++k) {
+                s += " ";
+                s += kn[e->nodes[(size_t)(st.first + k)].d.kind];
+            }
+            s += "\n";
+        } else if (st.type == ST_FUZZ) {
+            snprintf(buf, sizeof buf, "stage %zu: fuzz kernel\n", i);
+            s += buf;
+        } else {
+            snprintf(buf, sizeof buf, "stage %zu: fir kernel %s (T=%zu)\n", i,
+                     fir_kernel_name(e->nodes[(size_t)st.first].fir), e->nodes[(size_t)st.first].taps.size());
+            s += buf;
+        }
+    }
+    snprintf(dst, cap, "%s", s.c_str());
+    return DSPFX_OK;
+}

@@ -1,0 +1,37 @@
+// fir_kernels.h -- FIR convolution stage (nodes/fir.rs:179-225) over N channels.
+//
+// History lives in HBM as a time-major ring  ring[(t mod R)][channel], f32 (the
+// reference widens f32 samples to f64, so f32 storage is exact), R = T-1+max_frames:
+// a block first appends its own samples, then every output is a dot product over
+// the T most recent rows.  The reference's warm-up quirk (fir.rs:193-214: while the
+// VecDeque holds L < T samples, state[k] pairs with taps[k]) is reproduced by the
+// index map  w(m, n) = taps_rev[m - max(0, n-T+1)]  for max(0, n-T+1) <= m <= n.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace dspfx {
+
+struct FirState {
+    float *ring = nullptr;        // [R][N]
+    double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
+    float *taps32 = nullptr;      // [T + 2*pad] zero-padded f32 copy for the MFMA path
+    uint32_t T = 0, R = 0, N = 0, max_frames = 0, pad = 0;
+    int mode = 0;                 // 0 Balanced, 1 Average (fir.rs:187-190)
+    uint64_t n_seen = 0;          // samples consumed since the history was last empty
+    int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
+};
+
+int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,
+                  uint32_t max_frames);
+void fir_free(FirState &s);
+void fir_reset(FirState &s);
+int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
+                hipStream_t stream);
+size_t fir_state_bytes(const FirState &s);
+int fir_state_export(FirState &s, void *host_dst);
+int fir_state_import(FirState &s, const void *host_src);
+const char *fir_kernel_name(const FirState &s);
+const char *fir_last_error();
+
+}  // namespace dspfx

@@ -1,0 +1,43 @@
+// variants.h -- registry of compiled chain-kernel variants.
+//
+// A variant = (slot signatures, frames per chunk F, channels per lane CPL, guard).
+// Static variants are fully specialised at compile time for one chain shape (all
+// node switches fold away, state and coefficients sit in registers/SGPRs); the
+// dynamic variant interprets any chain of up to MAX_SLOTS nodes with wave-uniform
+// switches.  Both are built from the same per-node device functions.
+#pragma once
+#include "chain_kernels.hip.h"
+
+namespace dspfx {
+
+struct Variant {
+    const char *name;
+    int sigs[MAX_SLOTS];   // SIG_DYN in [0] => dynamic
+    int n_slots;           // static: exact chain length
+    int f;
+    int cpl;
+    bool guard;
+    void (*launch)(const ChainArgs &, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t);
+};
+
+template <int F, int CPL, class SL>
+void launch_static(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
+    (void)lds_bytes;
+    hipLaunchKernelGGL((chain_kernel<F, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
+}
+template <int F, bool GUARD>
+void launch_dyn(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
+    hipLaunchKernelGGL((chain_dyn_kernel<F, GUARD>), dim3(grid), dim3(block), lds_bytes, s, a);
+}
+
+// each variants_*.hip translation unit exports one of these
+const Variant *variants_dyn(int *n);
+const Variant *variants_static3(int *n);
+const Variant *variants_static5(int *n);
+
+#define DSPFX_STATIC_VARIANT(NAME, NSLOTS, F, CPL, ...) \
+    Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
+#define DSPFX_DYN_VARIANT(NAME, F, GUARD) \
+    Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, &launch_dyn<F, GUARD> }
+
+}  // namespace dspfx

@@ -1,0 +1,19 @@
+// Static specialisations of BASELINE config 2's chain: gain -> biquad -> delay,
+// with (h) and without (n) the per-hop collect_and_average scaling.
+#include "variants.h"
+namespace dspfx {
+#define S3H sig(K_GAIN, 0, 1), sig(K_BIQUAD, 0, 1), sig(K_REVERB, 0, 1), SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE
+#define S3N sig(K_GAIN, 0, 0), sig(K_BIQUAD, 0, 0), sig(K_REVERB, 0, 0), SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE
+static const Variant k_s3[] = {
+    DSPFX_STATIC_VARIANT("s3h_f8_c1", 3, 8, 1, S3H),
+    DSPFX_STATIC_VARIANT("s3h_f8_c2", 3, 8, 2, S3H),
+    DSPFX_STATIC_VARIANT("s3h_f8_c4", 3, 8, 4, S3H),
+    DSPFX_STATIC_VARIANT("s3h_f16_c1", 3, 16, 1, S3H),
+    DSPFX_STATIC_VARIANT("s3h_f16_c2", 3, 16, 2, S3H),
+    DSPFX_STATIC_VARIANT("s3h_f4_c4", 3, 4, 4, S3H),
+    DSPFX_STATIC_VARIANT("s3n_f8_c1", 3, 8, 1, S3N),
+    DSPFX_STATIC_VARIANT("s3n_f8_c2", 3, 8, 2, S3N),
+    DSPFX_STATIC_VARIANT("s3n_f8_c4", 3, 8, 4, S3N),
+};
+const Variant *variants_static3(int *n) { *n = (int)(sizeof(k_s3) / sizeof(k_s3[0])); return k_s3; }
+}  // namespace dspfx

@@ -1,0 +1,19 @@
+// Static specialisations of BASELINE config 3/5's chain:
+// biquad -> distort(SoftClip) -> delay -> biquad -> gain, with (h) / without (n) hop scaling.
+#include "variants.h"
+namespace dspfx {
+#define S5H sig(K_BIQUAD, 0, 1), sig(K_DISTORT, D_SOFT_CLIP, 1), sig(K_REVERB, 0, 1), sig(K_BIQUAD, 0, 1), sig(K_GAIN, 0, 1), SIG_NONE, SIG_NONE, SIG_NONE
+#define S5N sig(K_BIQUAD, 0, 0), sig(K_DISTORT, D_SOFT_CLIP, 0), sig(K_REVERB, 0, 0), sig(K_BIQUAD, 0, 0), sig(K_GAIN, 0, 0), SIG_NONE, SIG_NONE, SIG_NONE
+static const Variant k_s5[] = {
+    DSPFX_STATIC_VARIANT("s5h_f8_c1", 5, 8, 1, S5H),
+    DSPFX_STATIC_VARIANT("s5h_f8_c2", 5, 8, 2, S5H),
+    DSPFX_STATIC_VARIANT("s5h_f8_c4", 5, 8, 4, S5H),
+    DSPFX_STATIC_VARIANT("s5h_f16_c1", 5, 16, 1, S5H),
+    DSPFX_STATIC_VARIANT("s5h_f16_c2", 5, 16, 2, S5H),
+    DSPFX_STATIC_VARIANT("s5h_f4_c4", 5, 4, 4, S5H),
+    DSPFX_STATIC_VARIANT("s5n_f8_c1", 5, 8, 1, S5N),
+    DSPFX_STATIC_VARIANT("s5n_f8_c2", 5, 8, 2, S5N),
+    DSPFX_STATIC_VARIANT("s5n_f8_c4", 5, 8, 4, S5N),
+};
+const Variant *variants_static5(int *n) { *n = (int)(sizeof(k_s5) / sizeof(k_s5[0])); return k_s5; }
+}  // namespace dspfx

@@ -1,0 +1,222 @@
+/*
+ * dspfx.h -- C ABI of the MI355X-native effect-chain engine.
+ *
+ * The drop-in boundary for simmsb/dsp-stuff's per-block effect-node evaluation
+ * loop: everything `SimpleNode::process` (dsp-stuff/src/node.rs:135-146) and the
+ * blanket `Perform` wrapper (node.rs:267-352) compute for one mono channel and one
+ * 128-frame block, evaluated here for N independent channels per launch by
+ * hand-written HIP kernels (gfx950).  The reference has no FFI of its own
+ * (SURVEY.md 8b); this header is the ABI its Rust host would bind (see
+ * INTEGRATION.md for the `extern "C"` block and the `GpuChain: SimpleNode` shim).
+ *
+ * Conventions
+ *   - plain C types only; every call returns 0 (DSPFX_OK) or a negative
+ *     dspfx_status; nothing aborts or throws across the boundary (the reference
+ *     panics instead: node.rs:173,271,280).
+ *   - the caller owns sample buffers; the engine owns parameters, coefficients
+ *     and all DSP state (biquad history, one-pole z, delay rings, FIR history)
+ *     in HBM -- the same ownership split as node.rs:271-288 vs biquad.rs:43-44,
+ *     reverb.rs:40-41, fir.rs:64-65.
+ *   - sample layout is frame-major f32: buf[frame * channels + channel]
+ *     ("[B][N]"): for every frame the N channels are contiguous, so one
+ *     wavefront reads 64 consecutive channels as one coalesced burst.
+ *   - one engine is driven by one thread at a time (like one node task,
+ *     runtime.rs:718-728); distinct engines are independent.
+ *   - there is NO CPU fallback: without a HIP device every entry point that
+ *     needs one fails with DSPFX_ERR_NO_DEVICE.
+ */
+#ifndef DSPFX_H
+#define DSPFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSPFX_ABI_VERSION 1
+/* dsp-stuff/src/node.rs:257 `pub const BUF_SIZE: usize = 128;` */
+#define DSPFX_BUF_SIZE 128
+/* longest chain one engine accepts */
+#define DSPFX_MAX_NODES 32
+
+typedef struct dspfx_engine dspfx_engine;
+
+typedef enum dspfx_status {
+    DSPFX_OK = 0,
+    DSPFX_ERR_INVALID = -1,    /* bad argument / descriptor */
+    DSPFX_ERR_NO_DEVICE = -2,  /* no usable HIP device (there is no CPU fallback) */
+    DSPFX_ERR_HIP = -3,        /* a HIP runtime call failed; see dspfx_last_error */
+    DSPFX_ERR_OOM = -4,        /* device allocation failed */
+    DSPFX_ERR_UNSUPPORTED = -5,
+    DSPFX_ERR_STATE = -6       /* call not valid in the engine's current state */
+} dspfx_status;
+
+/* Node kinds = the effect variants of `enum Nodes` (nodes/mod.rs:38-63) that
+ * are on the hot path. */
+typedef enum dspfx_kind {
+    DSPFX_GAIN = 0,      /* nodes/gain.rs:25-38 */
+    DSPFX_BIQUAD = 1,    /* nodes/biquad.rs:48-88 (+ biquad 0.4.2 DirectForm1<f32>) */
+    DSPFX_LOW_PASS = 2,  /* nodes/low_pass.rs:26-42 */
+    DSPFX_HIGH_PASS = 3, /* nodes/high_pass.rs:26-42 */
+    DSPFX_REVERB = 4,    /* nodes/reverb.rs:44-111: feedback delay line */
+    DSPFX_DISTORT = 5,   /* nodes/distort.rs:53-195 */
+    DSPFX_OVERDRIVE = 6, /* nodes/overdrive.rs:31-72 */
+    DSPFX_CHEBYSHEV = 7, /* nodes/chebyshev.rs:28-62 */
+    DSPFX_FIR = 8,       /* nodes/fir.rs:179-225 */
+    DSPFX_ADD = 9,       /* nodes/add.rs:24-34  (port "b" = the side input) */
+    DSPFX_MIX = 10,      /* nodes/mix.rs:31-47  (port "b" = the side input) */
+    DSPFX_N_KINDS = 11
+} dspfx_kind;
+
+/* nodes/distort.rs:18-28 `enum Mode`, declaration order (repr(u8)) */
+typedef enum dspfx_distort_mode {
+    DSPFX_DIST_HARD_CLIP = 0,
+    DSPFX_DIST_SOFT_CLIP = 1,
+    DSPFX_DIST_TANH = 2,
+    DSPFX_DIST_RECIP_SOFT_CLIP = 3,
+    DSPFX_DIST_FUZZ = 4,
+    DSPFX_DIST_SIN = 5,
+    DSPFX_DIST_ATAN = 6,
+    DSPFX_DIST_SQUARE = 7,
+    DSPFX_DIST_CHEBYSHEV4 = 8
+} dspfx_distort_mode;
+
+/* nodes/fir.rs `enum Mode` (fir.rs:187-190) */
+typedef enum dspfx_fir_mode { DSPFX_FIR_BALANCED = 0, DSPFX_FIR_AVERAGE = 1 } dspfx_fir_mode;
+
+/* Which hops of the chain reproduce `collect_and_average` with one connected
+ * pipe (node.rs:162-194: value = (0.0 + x) / f32(0.0001 + 1.0)).
+ *   INTERNAL: the hops between consecutive nodes of the chain (what disappears
+ *             when k reference nodes are fused into one GpuChain node);
+ *   INPUT   : also the hop into the first node (whole-graph semantics: the
+ *             engine is fed by the Input node, nodes/input.rs:213-240).        */
+#define DSPFX_LINK_INTERNAL 1u
+#define DSPFX_LINK_INPUT 2u
+
+typedef struct dspfx_engine_desc {
+    uint32_t abi_version;     /* DSPFX_ABI_VERSION */
+    int32_t device;           /* HIP device ordinal */
+    uint32_t channels;        /* N: independent mono channels held by this engine */
+    uint32_t max_frames;      /* largest n_frames a process call will pass (>=1) */
+    uint32_t link_flags;      /* DSPFX_LINK_* */
+    uint32_t reserved;
+    uint64_t channel_offset;  /* global index of local channel 0 (multi-GPU shards, noise) */
+} dspfx_engine_desc;
+
+/* One node of the chain: the reference node's slider fields, in field order.
+ *   GAIN       params[0]=level (0..=10, default 1)                    gain.rs:21-22
+ *   BIQUAD     params[0..5]=a0,a1,a2,b0,b1,b2 (raw sliders -10..=10)  biquad.rs:18-41
+ *   LOW_PASS   params[0]=ratio (0..=1, default 0.5)                   low_pass.rs:20-21
+ *   HIGH_PASS  params[0]=ratio                                        high_pass.rs:20-21
+ *   REVERB     params[0]=decay (0..=1, default .5); delay_len=D       reverb.rs:29-38
+ *   DISTORT    params[0]=level (0..=30, default 0); mode              distort.rs:46-50
+ *   OVERDRIVE  params[0]=boost, [1]=drive, [2]=level                  overdrive.rs:21-28
+ *   CHEBYSHEV  params[0]=level_pos, [1]=level_neg                     chebyshev.rs:21-25
+ *   FIR        taps/n_taps (time-REVERSED, as fir.rs:163,168 stores them); mode
+ *   ADD        -
+ *   MIX        params[0]=ratio (0..=1, default .5)                    mix.rs:22-28
+ * delay_len is explicit because rivulet's capacity rounding is not in the
+ * reference tree; dspfx_delay_len() gives both readings.    */
+typedef struct dspfx_node_desc {
+    int32_t kind;        /* dspfx_kind */
+    int32_t mode;        /* dspfx_distort_mode / dspfx_fir_mode */
+    float params[8];
+    uint32_t delay_len;  /* REVERB: D >= 128 */
+    uint32_t n_taps;     /* FIR */
+    const double *taps;  /* FIR: n_taps f64 values, host memory, copied */
+} dspfx_node_desc;
+
+/* ---- library ----------------------------------------------------------- */
+uint32_t dspfx_abi_version(void);
+const char *dspfx_strerror(int status);
+/* Number of visible HIP devices (0 when there is none). */
+int dspfx_device_count(void);
+/* Fill `d` with the reference's defaults for `kind` (derive `default=`, lib.rs:196-210). */
+int dspfx_node_defaults(int kind, dspfx_node_desc *d);
+/* reverb.rs:58 `((seconds * 48000.0) as usize).max(128)`; page_round != 0 rounds
+ * up to whole 4 KiB pages (1024 f32), the other reading of rivulet's ring size. */
+uint32_t dspfx_delay_len(float seconds, int page_round);
+/* node.rs:166,179: f32 0.0001 incremented by 1.0 per connected pipe. */
+float dspfx_link_divisor(uint64_t n_connected);
+
+/* ---- engine lifecycle -------------------------------------------------- */
+int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine **out);
+void dspfx_engine_destroy(dspfx_engine *e);
+const char *dspfx_last_error(const dspfx_engine *e);
+
+/* Replace the chain (NodeStatic::new for every node, node.rs:125-133): allocates
+ * and zeroes all DSP state.  Nodes are evaluated in order, node i feeding i+1
+ * (a linear graph of runtime.rs LinkInstances). */
+int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
+int dspfx_chain_len(const dspfx_engine *e);
+
+/* Slider store + `after_settings_change` (dsp-stuff-derive/src/lib.rs:487-492,
+ * 560-568): BIQUAD renormalises by a0 and ZEROES its state (biquad.rs:62-76);
+ * other kinds just take the value from the next block on. */
+int dspfx_set_param(dspfx_engine *e, int node, int param, float value);
+int dspfx_set_mode(dspfx_engine *e, int node, int mode);
+/* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring. */
+int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
+/* Fir tap reload (fir.rs:153-171); history restarts empty. */
+int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode);
+/* Zero every node's DSP state (fresh nodes); parameters are kept. */
+int dspfx_reset(dspfx_engine *e);
+
+/* ---- the hot path ------------------------------------------------------ */
+/* One block through the whole chain for all N channels == what N reference
+ * graphs do in `Perform::perform` x chain length (node.rs:267-352).
+ *   in    : device ptr, [n_frames][N] f32
+ *   side  : device ptr or NULL, [n_frames][N]: port "b" of ADD/MIX nodes
+ *           (NULL = unconnected port = zeros, node.rs:288)
+ *   out   : device ptr, [n_frames][N] (may alias `in`)
+ *   mix   : device ptr or NULL, [n_frames] f32: receives sum over this
+ *           engine's channels of `out` per frame (the un-normalised mix bus,
+ *           node.rs:181-183 before the division; deterministic order)
+ *   stream: hipStream_t as void* (NULL = default stream); the call is
+ *           asynchronous on that stream.
+ * n_frames <= max_frames; DISTORT/Fuzz needs n_frames % 128 == 0 (it is
+ * block-global over BUF_SIZE, distort.rs:146-172). */
+int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                  uint32_t n_frames, void *stream);
+/* Same with HOST buffers (what a Rust `process(&[f32], &mut [f32])` holds):
+ * H2D copy, process, D2H copy, synchronous. */
+int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                       uint32_t n_frames);
+/* Output-node hop of the mix bus (node.rs:189-191): mix[f] /= link_divisor(n_connected),
+ * in place on the device; call after the cross-GPU all-reduce with the GLOBAL channel count. */
+int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream);
+
+/* ---- DSP state (parity tests; the reference never saves it) --- */
+/* Size in bytes of node `node`'s exported state:
+ *   BIQUAD 4*N f32 [x1|x2|y1|y2][N]; LOW/HIGH_PASS N f32; REVERB D*N f32
+ *   [D][N] oldest sample first; FIR (n_taps-1)*N f32 [t][N] oldest first + the
+ *   warm-up count; others 0. */
+int64_t dspfx_state_size(const dspfx_engine *e, int node);
+int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, size_t size);
+int dspfx_state_import(dspfx_engine *e, int node, const void *host_src, size_t size);
+
+/* ---- utilities --------------------------------------------------------- */
+/* Synthetic white noise, identical integer hash on CPU and GPU:
+ * dst[f][c] = noise(seed, channel_offset + c, n_abs0 + f), dst device [n_frames][N]. */
+int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, uint32_t n_abs0, uint32_t seed,
+                     void *stream);
+/* Block until everything queued by this engine on `stream` has finished. */
+int dspfx_sync(dspfx_engine *e, void *stream);
+/* Human-readable plan of the current chain (stages, kernels, bytes/sample). */
+int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap);
+/* Kernel timing for the roofline report: when enabled, every stage's main kernel
+ * launch is bracketed by HIP events on the stream it is launched on.  read()
+ * synchronises those events and returns, for the stage with the largest total,
+ * the summed kernel time and the number of launches (and optionally resets). */
+int dspfx_profile_enable(dspfx_engine *e, int enable);
+int dspfx_profile_read(dspfx_engine *e, double *total_ms, uint32_t *launches, char *kernel_name, size_t cap,
+                       int reset);
+/* Algorithmic HBM bytes per channel-sample of the current chain at n_frames. */
+double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint32_t n_frames);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSPFX_H */

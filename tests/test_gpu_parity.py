@@ -1,0 +1,355 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs.  Bars (BASELINE.json north_star): bit-exact for gain / pass-through /
+indexing; <= 1 ulp f32 for IIR / delay / arithmetic waveshapers; <= LIBM_ULP for the
+modes that call libm (glibc on the reference side, ocml on the GPU); stated RMS
+tolerance for FIR."""
+import numpy as np
+import pytest
+
+import oracle as O
+from chains import chain3, chain5, fir_taps, ulp_diff
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+LIBM_ULP = 4        # tanhf/sinf/atanf/expf: glibc vs ocml
+FIR_RMS_TOL = 2e-6  # relative RMS error of the f32 path vs the f64-accumulating oracle
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def run_gpu(dspfx, torch, chain, x, link_flags=3, block=128, side=None, want_mix=False, max_frames=None):
+    """x: [frames][N] numpy -> GPU engine block by block (device path)."""
+    nf, N = x.shape
+    eng = dspfx.Engine(N, max_frames or block, link_flags=link_flags)
+    eng.set_chain(chain)
+    dx = torch.from_numpy(x).cuda()
+    ds = torch.from_numpy(side).cuda() if side is not None else None
+    dy = torch.empty_like(dx)
+    dm = torch.empty(nf, dtype=torch.float32, device="cuda") if want_mix else None
+    for f0 in range(0, nf, block):
+        n = min(block, nf - f0)
+        eng.process(dx[f0:f0 + n], out=dy[f0:f0 + n], side=ds[f0:f0 + n] if ds is not None else None,
+                    mix=dm[f0:f0 + n] if want_mix else None, n_frames=n)
+    torch.cuda.synchronize()
+    y = dy.cpu().numpy()
+    eng.close()
+    return (y, dm.cpu().numpy()) if want_mix else y
+
+
+def run_oracle(chain, x, link_flags=3, side=None):
+    return O.run_channels([n.oracle_desc() for n in chain], x, link_flags, side)
+
+
+def noise_block(N, nf, seed=0x5EED0001, c0=0, n0=0):
+    return O.noise(seed, np.arange(c0, c0 + N), np.arange(n0, n0 + nf))
+
+
+# ---------------------------------------------------------------- single nodes
+
+def test_gain_bit_exact(dspfx, torch_cuda):
+    x = noise_block(256, 256)
+    x[0, :8] = [0.0, -0.0, 1e-42, -1e-42, np.inf, -np.inf, 3.4e38, 1e-38]
+    for level in (0.0, 0.8, 1.0, 10.0):
+        y = run_gpu(dspfx, torch_cuda, [dspfx.Gain(level)], x, link_flags=0)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(y.view(np.uint32), (x * F(level)).view(np.uint32)) or \
+                ulp_diff(y, x * F(level)).max() == 0
+
+
+def test_passthrough_and_link_scale(dspfx, torch_cuda):
+    x = noise_block(192, 128)
+    x[0, 0], x[0, 1] = 0.5, -0.0
+    y = run_gpu(dspfx, torch_cuda, [dspfx.Gain(1.0)], x, link_flags=0)
+    assert np.array_equal(y.view(np.uint32), x.view(np.uint32))              # bit-exact pass-through
+    y = run_gpu(dspfx, torch_cuda, [dspfx.Gain(1.0)], x, link_flags=2)
+    assert float(y[0, 0]).hex() == "0x1.fff2e40000000p-2"                   # KAT-2
+    assert y.view(np.uint32)[0, 1] == 0                                      # 0.0 + -0.0 = +0.0
+    ref = run_oracle([dspfx.Gain(1.0)], x, 2)
+    assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
+    # empty chain == wire
+    y = run_gpu(dspfx, torch_cuda, [], x, link_flags=3)
+    assert np.array_equal(y.view(np.uint32), x.view(np.uint32))
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 65, 200, 256, 1000])
+def test_ragged_channel_counts(dspfx, torch_cuda, N):
+    """N not a multiple of the wave width exercises the guarded tail launch."""
+    x = noise_block(N, 256)
+    ch = chain5(dspfx, delay=128)
+    y, mix = run_gpu(dspfx, torch_cuda, ch, x, want_mix=True)
+    ref = run_oracle(ch, x)
+    assert ulp_diff(y, ref).max() <= 1
+    assert np.allclose(mix, ref.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-4)
+
+
+def test_biquad_defaults_and_reset(dspfx, torch_cuda):
+    x = np.zeros((128, 64), F)
+    x[0] = 1
+    y = run_gpu(dspfx, torch_cuda, [dspfx.BiQuad()], x, link_flags=0)
+    ref = run_oracle([dspfx.BiQuad()], x, 0)
+    assert ulp_diff(y, ref).max() <= 1
+    assert abs(float(y[5, 0]) - 0.758 * 0.24 ** 5) < 1e-7                   # KAT-3
+    # set_param zeroes the state (biquad.rs:74)
+    eng = dspfx.Engine(64, 128, link_flags=0)
+    eng.set_chain([dspfx.BiQuad()])
+    dx = torch_cuda.from_numpy(x).cuda()
+    dy = torch_cuda.empty_like(dx)
+    eng.process(dx, out=dy)
+    eng.set_param(0, 3, 0.758)
+    eng.process(dx, out=dy)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), y)
+
+
+def test_biquad_random_coeffs(dspfx, torch_cuda):
+    rng = np.random.default_rng(4)
+    x = noise_block(128, 512)
+    for _ in range(4):
+        r, th, a0 = rng.uniform(0.1, 0.95), rng.uniform(0.1, 3.0), rng.uniform(0.5, 2.0)
+        p = [a0, -2 * r * np.cos(th) * a0, r * r * a0] + list(rng.uniform(-1, 1, 3) * a0)
+        ch = [dspfx.BiQuad(*p)]
+        assert ulp_diff(run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)).max() <= 1
+
+
+def test_one_pole(dspfx, torch_cuda):
+    x = noise_block(128, 384)
+    for r in (0.0, 0.5, 0.93, 1.0):
+        for mk in (dspfx.LowPass, dspfx.HighPass):
+            ch = [mk(r)]
+            assert ulp_diff(run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)).max() <= 1
+
+
+@pytest.mark.parametrize("D", [128, 1024, 24000])
+def test_delay_impulse(dspfx, torch_cuda, D):
+    nblk = (3 * D) // 128 + 2
+    x = np.zeros((nblk * 128, 64), F)
+    x[0] = 1
+    y = run_gpu(dspfx, torch_cuda, [dspfx.Reverb(delay_samples=D, decay=0.5)], x, 0)
+    e = np.zeros_like(x)
+    for k in range(len(e) // D + 1):
+        if k * D < len(e):
+            e[k * D] = 0.5 ** k
+    assert np.array_equal(y, e)                                              # KAT-6: exact
+
+
+def test_delay_block_size_invariance(dspfx, torch_cuda):
+    """B=64/128/256/384 give identical results, incl. B > D (engine splits at D)."""
+    x = noise_block(128, 768)
+    ch = [dspfx.Reverb(delay_samples=128, decay=0.7), dspfx.BiQuad()]
+    ys = [run_gpu(dspfx, torch_cuda, ch, x, 3, block=b) for b in (64, 128, 256, 384)]
+    ref = run_oracle(ch, x, 3)
+    for y in ys:
+        assert np.array_equal(y, ys[0])
+    assert ulp_diff(ys[0], ref).max() <= 1
+
+
+@pytest.mark.parametrize("mode", [0, 1, 3, 7, 8])
+def test_distort_arithmetic_modes(dspfx, torch_cuda, mode):
+    x = noise_block(128, 128) * F(2.5)
+    x[0, :10] = [0, -0.0, 0.25, -0.25, 0.5, -0.5, 1, -1, 2, -2]
+    for L in (0.0, 0.0009, 0.001, 1.0, 3.0, 30.0):
+        ch = [dspfx.Distort(L, mode)]
+        y, ref = run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)
+        assert ulp_diff(y, ref).max() <= 1, (mode, L)
+        if L < 0.001:
+            assert np.array_equal(y.view(np.uint32), x.view(np.uint32))      # bypass is bit-exact
+
+
+@pytest.mark.parametrize("mode", [2, 5, 6])
+def test_distort_libm_modes(dspfx, torch_cuda, mode):
+    x = noise_block(128, 128)
+    for L in (1.0, 3.0, 30.0):
+        ch = [dspfx.Distort(L, mode)]
+        y, ref = run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)
+        assert ulp_diff(y, ref).max() <= LIBM_ULP, (mode, L, ulp_diff(y, ref).max())
+
+
+def test_fuzz(dspfx, torch_cuda):
+    x = noise_block(100, 256)
+    ch = [dspfx.Gain(0.9), dspfx.Distort(3.0, dspfx.FUZZ), dspfx.Gain(0.5)]
+    y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
+    assert np.allclose(y, ref, rtol=2e-6, atol=1e-7)
+    assert ulp_diff(y, ref).max() <= 16
+    # silent block => NaN (0/0), like the reference
+    z = np.zeros((128, 64), F)
+    y = run_gpu(dspfx, torch_cuda, [dspfx.Distort(3.0, dspfx.FUZZ)], z, 0)
+    assert np.all(np.isnan(y))
+    # Fuzz needs whole 128-frame reference blocks
+    eng = dspfx.Engine(64, 128)
+    eng.set_chain([dspfx.Distort(3.0, dspfx.FUZZ)])
+    t = torch_cuda.zeros((64, 64), device="cuda")
+    with pytest.raises(dspfx.DspfxError):
+        eng.process(t, n_frames=64)
+
+
+def test_overdrive_chebyshev(dspfx, torch_cuda):
+    x = noise_block(128, 128)
+    for ch in ([dspfx.Overdrive(5.0, 0.7, 0.9)], [dspfx.Overdrive(5.0, 0.7, 0.0009)], [dspfx.Overdrive()],
+               [dspfx.Chebyshev(4.0, 0.0)], [dspfx.Chebyshev(2.0, 7.5)], [dspfx.Chebyshev()]):
+        y, ref = run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)
+        assert ulp_diff(y, ref).max() <= LIBM_ULP, ch
+
+
+def test_add_mix_side_input(dspfx, torch_cuda):
+    x, s = noise_block(128, 256), noise_block(128, 256, seed=77)
+    for ch in ([dspfx.Add()], [dspfx.Gain(0.5), dspfx.Mix(0.3), dspfx.BiQuad()]):
+        for lf in (0, 3):
+            y, ref = run_gpu(dspfx, torch_cuda, ch, x, lf, side=s), run_oracle(ch, x, lf, side=s)
+            assert ulp_diff(y, ref).max() <= 1
+        y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)      # unconnected "b" => zeros
+        assert ulp_diff(y, ref).max() <= 1
+
+
+# ----------------------------------------------------------------------- chains
+
+def test_config1_single_channel_chain(dspfx, torch_cuda):
+    """BASELINE config 1: 1 channel, gain -> biquad LP -> delay(24000), 128-frame blocks."""
+    ch = chain3(dspfx)
+    x = noise_block(1, 128 * 400)            # > 2 delay periods
+    y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
+    assert ulp_diff(y, ref).max() <= 1
+
+
+def test_chain3_and_chain5_all_variants(dspfx, torch_cuda, monkeypatch):
+    """Every compiled kernel variant (static/dynamic, F, CPL) gives the same bits."""
+    x = noise_block(512, 512)
+    for mk in (chain3, chain5):
+        ch = mk(dspfx, delay=256)
+        for lf in (0, 1, 3):
+            ref = run_oracle(ch, x, lf)
+            base = None
+            for var in ("static=0,f=8", "static=0,f=4", "static=0,f=16", "static=1,f=8,cpl=1", "static=1,f=8,cpl=2",
+                        "static=1,f=8,cpl=4", "static=1,f=16,cpl=1", "static=1,f=16,cpl=2", "static=1,f=4,cpl=4"):
+                monkeypatch.setenv("DSPFX_VARIANT", var)
+                y = run_gpu(dspfx, torch_cuda, ch, x, lf)
+                assert ulp_diff(y, ref).max() <= 1, (mk.__name__, lf, var)
+                if base is None:
+                    base = y
+                assert np.array_equal(y.view(np.uint32), base.view(np.uint32)), (mk.__name__, lf, var)
+        monkeypatch.delenv("DSPFX_VARIANT", raising=False)
+
+
+def test_long_chain_splits_into_stages(dspfx, torch_cuda):
+    """> 8 nodes => several fused launches; Fuzz in the middle => its own stage."""
+    ch = [dspfx.Gain(0.9), dspfx.BiQuad(), dspfx.LowPass(0.3), dspfx.HighPass(0.9), dspfx.Distort(2.0, dspfx.HARD_CLIP),
+          dspfx.Reverb(delay_samples=128, decay=0.4), dspfx.Distort(1.5, dspfx.SQUARE), dspfx.BiQuad(1, -0.5, 0.1, 0.3, 0.2, 0.1),
+          dspfx.Gain(1.1), dspfx.Reverb(delay_samples=384, decay=0.3), dspfx.LowPass(0.1), dspfx.Distort(4.0, dspfx.RECIP_SOFT_CLIP)]
+    x = noise_block(192, 512)
+    y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
+    assert ulp_diff(y, ref).max() <= 1
+
+
+def test_state_export_import_continues(dspfx, torch_cuda):
+    """Run k blocks, export state, import into a fresh engine, continue: identical."""
+    ch = chain5(dspfx, delay=256)
+    x = noise_block(128, 1024)
+    full = run_gpu(dspfx, torch_cuda, ch, x, 3)
+    a = dspfx.Engine(128, 128)
+    a.set_chain(ch)
+    dx = torch_cuda.from_numpy(x).cuda()
+    dy = torch_cuda.empty_like(dx)
+    for f0 in range(0, 512, 128):
+        a.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
+    states = [a.state_export(i) for i in range(len(ch))]
+    assert [len(s) for s in states] == [4 * 128 * 4, 0, 256 * 128 * 4, 4 * 128 * 4, 0]
+    b = dspfx.Engine(128, 128)
+    b.set_chain(ch)
+    for i, s in enumerate(states):
+        if len(s):
+            b.state_import(i, s)
+    for f0 in range(512, 1024, 128):
+        b.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy()[512:], full[512:])
+    # delay state export is oldest-first: row 0 == output of frame 512-256
+    ring = states[2].view(np.float32).reshape(256, 128)
+    st_only = run_oracle(ch[:3], x[:512], 3)
+    assert ulp_diff(ring, st_only[256:512]).max() <= 1
+
+
+def test_mix_bus_and_finish(dspfx, torch_cuda):
+    N = 4096
+    ch = chain5(dspfx, delay=128)
+    x = noise_block(N, 256)
+    y, mix = run_gpu(dspfx, torch_cuda, ch, x, 3, want_mix=True)
+    ref = run_oracle(ch, x, 3)
+    assert ulp_diff(y, ref).max() <= 1
+    exact = ref.astype(np.float64).sum(axis=1)
+    assert np.allclose(mix, exact, rtol=1e-5, atol=1e-3)
+    # deterministic: same bits on a second run
+    y2, mix2 = run_gpu(dspfx, torch_cuda, ch, x, 3, want_mix=True)
+    assert np.array_equal(mix.view(np.uint32), mix2.view(np.uint32))
+    # Output-node hop (node.rs:189-191)
+    eng = dspfx.Engine(N, 256)
+    dm = torch_cuda.from_numpy(mix.copy()).cuda()
+    eng.mix_finish(dm, 256, N)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dm.cpu().numpy(), (mix / O.link_divisor(N)).astype(F))
+
+
+def test_process_host_path(dspfx, torch_cuda):
+    ch = chain3(dspfx, delay=128)
+    x = noise_block(96, 128)
+    eng = dspfx.Engine(96, 128)
+    eng.set_chain(ch)
+    y, mix = eng.process_host(x, want_mix=True)
+    ref = run_oracle(ch, x, 3)
+    assert ulp_diff(y, ref).max() <= 1
+    assert np.allclose(mix, ref.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-4)
+
+
+def test_noise_fill_matches_oracle(dspfx, torch_cuda):
+    eng = dspfx.Engine(300, 128, channel_offset=12345)
+    d = torch_cuda.empty((128, 300), dtype=torch_cuda.float32, device="cuda")
+    eng.fill_noise(d, 128, 1000)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(d.cpu().numpy(), noise_block(300, 128, c0=12345, n0=1000))
+
+
+def test_error_behaviour(dspfx, torch_cuda):
+    eng = dspfx.Engine(64, 128)
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_chain([dspfx.NodeSpec(42)])
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_chain([dspfx.Reverb(delay_samples=64)])          # reverb.rs:58 clamps to >= 128
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_chain([dspfx.Distort(1.0, 9)])
+    eng.set_chain([dspfx.Gain()])
+    t = torch_cuda.zeros((256, 64), device="cuda")
+    with pytest.raises(dspfx.DspfxError):
+        eng.process(t, n_frames=256)                              # > max_frames
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_param(3, 0, 1.0)
+    with pytest.raises(dspfx.DspfxError):
+        dspfx.Engine(0)
+
+
+# -------------------------------------------------------------------------- FIR
+
+def test_fir_identity_and_small(dspfx, torch_cuda):
+    x = noise_block(64, 256)
+    y = run_gpu(dspfx, torch_cuda, [dspfx.Fir()], x, 0)
+    assert np.array_equal(y, x)                                              # taps [1.0]
+    rng = np.random.default_rng(3)
+    xi = rng.integers(-8, 8, (256, 64)).astype(F)
+    h = [1, 2, 3, 4]
+    ch = [dspfx.Fir(h)]
+    y, ref = run_gpu(dspfx, torch_cuda, ch, xi, 0), run_oracle(ch, xi, 0)
+    assert np.array_equal(y, ref)                                            # exact incl. the warm-up quirk
+    ch = [dspfx.Fir(h, dspfx.FIR_AVERAGE)]
+    assert np.array_equal(run_gpu(dspfx, torch_cuda, ch, xi, 0), run_oracle(ch, xi, 0))
+
+
+@pytest.mark.parametrize("T", [3, 100, 128, 129, 512])
+def test_fir_random_vs_oracle(dspfx, torch_cuda, T):
+    x = noise_block(64, 128 * 8)
+    ch = [dspfx.Gain(0.9), dspfx.Fir(fir_taps(T)), dspfx.Gain(1.1)]
+    y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
+    err = (y.astype(np.float64) - ref.astype(np.float64))
+    rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert rms < FIR_RMS_TOL, rms
