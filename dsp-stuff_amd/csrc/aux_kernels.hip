@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
 #pragma unroll
         for (int f = 0; f < 128; ++f) {
             const float q = clip1(x[f] * lv[0]) / mx;            // 158
-            const float e = expf(-fabsf(q));                     // q.copysign(-1.0).exp()
+            const float e = exp_cr(-fabsf(q));                     // q.copysign(-1.0).exp()
             const float z = -fabsf(1.0f - e);                    // (1.0 - e).copysign(-1.0)
             x[f] = z;
             const unsigned bts = abs_bits(z);

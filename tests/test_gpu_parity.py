@@ -11,7 +11,10 @@ from chains import chain3, chain5, fir_taps, ulp_diff
 
 pytestmark = pytest.mark.gpu
 F = np.float32
-LIBM_ULP = 4        # tanhf/sinf/atanf/expf: glibc vs ocml
+# libm-backed modes: GPU = f64 evaluation rounded once (correctly rounded f32); glibc's f32
+# routines are within 1 ulp (sinf/atanf/expf) resp. 2 ulp (tanhf) of that (measured)
+LIBM_ULP = {2: 2, 5: 1, 6: 1}   # distort mode -> bar
+LIBM_COMPOSITE_ULP = 4          # overdrive / chebyshev node: libm result feeds further f32 ops
 FIR_RMS_TOL = 2e-6  # relative RMS error of the f32 path vs the f64-accumulating oracle
 
 
@@ -166,15 +169,17 @@ def test_distort_libm_modes(dspfx, torch_cuda, mode):
     for L in (1.0, 3.0, 30.0):
         ch = [dspfx.Distort(L, mode)]
         y, ref = run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)
-        assert ulp_diff(y, ref).max() <= LIBM_ULP, (mode, L, ulp_diff(y, ref).max())
+        assert ulp_diff(y, ref).max() <= LIBM_ULP[mode], (mode, L, ulp_diff(y, ref).max())
 
 
 def test_fuzz(dspfx, torch_cuda):
     x = noise_block(100, 256)
     ch = [dspfx.Gain(0.9), dspfx.Distort(3.0, dspfx.FUZZ), dspfx.Gain(0.5)]
     y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
-    assert np.allclose(y, ref, rtol=2e-6, atol=1e-7)
-    assert ulp_diff(y, ref).max() <= 16
+    # three block-global normalisations and the cancellation in 1 - exp(-|q|) amplify a
+    # 1-ulp expf difference, so the bar is relative to the block's peak, not per-sample ulp
+    assert np.abs(y - ref).max() <= 4e-6 * np.abs(ref).max()
+    assert (ulp_diff(y, ref) > 1).mean() < 0.02
     # silent block => NaN (0/0), like the reference
     z = np.zeros((128, 64), F)
     y = run_gpu(dspfx, torch_cuda, [dspfx.Distort(3.0, dspfx.FUZZ)], z, 0)
@@ -192,7 +197,7 @@ def test_overdrive_chebyshev(dspfx, torch_cuda):
     for ch in ([dspfx.Overdrive(5.0, 0.7, 0.9)], [dspfx.Overdrive(5.0, 0.7, 0.0009)], [dspfx.Overdrive()],
                [dspfx.Chebyshev(4.0, 0.0)], [dspfx.Chebyshev(2.0, 7.5)], [dspfx.Chebyshev()]):
         y, ref = run_gpu(dspfx, torch_cuda, ch, x, 0), run_oracle(ch, x, 0)
-        assert ulp_diff(y, ref).max() <= LIBM_ULP, ch
+        assert ulp_diff(y, ref).max() <= LIBM_COMPOSITE_ULP, ch
 
 
 def test_add_mix_side_input(dspfx, torch_cuda):
