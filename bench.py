@@ -42,6 +42,10 @@ CONFIGS = {
                  desc="BASELINE config 3: 1048576 ch, 5-node chain, B=256"),
     "cfg2": dict(channels=1 << 16, frames=128, chain="chain3", delay=24000,
                  desc="BASELINE config 2: 65536 ch, gain>biquad>delay(24000), B=128"),
+    # diagnostics (memory-pattern ceilings of the chain kernel), not BASELINE configs
+    "copy": dict(channels=1 << 20, frames=128, chain="copy", delay=0, desc="diagnostic: empty chain (8 B/sample)"),
+    "delay": dict(channels=1 << 20, frames=128, chain="delay", delay=24000,
+                  desc="diagnostic: delay line only (16 B/sample)"),
     "cfg4": dict(channels=1 << 18, frames=128, chain="fir", delay=0, taps=4096,
                  desc="BASELINE config 4: 262144 ch, 4096-tap FIR, B=128"),
 }
@@ -61,6 +65,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
     ap.add_argument("--link-flags", type=int, default=3)
+    ap.add_argument("--tile", type=int, default=256,
+                    help="channel-tiled HBM layout [N/W][B][W] (engine-native, default 256); 0 = frame-major [B][N]")
     return ap.parse_args()
 
 
@@ -70,6 +76,10 @@ def build_chain(pkg, cfg):
         return chains.chain5(pkg, cfg["delay"])
     if cfg["chain"] == "chain3":
         return chains.chain3(pkg, cfg["delay"])
+    if cfg["chain"] == "copy":
+        return []
+    if cfg["chain"] == "delay":
+        return [pkg.Reverb(delay_samples=cfg["delay"], decay=0.5)]
     if cfg["chain"] == "fir":
         return [pkg.Fir(chains.fir_taps(cfg["taps"]))]
     raise ValueError(cfg["chain"])
@@ -151,7 +161,8 @@ def main():
     use_mix = not args.no_mix
     chain = build_chain(pkg, cfg)
 
-    eng = pkg.Engine(N, B, link_flags=args.link_flags, device=local_rank, channel_offset=rank * N)
+    eng = pkg.Engine(N, B, link_flags=args.link_flags, device=local_rank, channel_offset=rank * N,
+                     tile_channels=args.tile)
     eng.set_chain(chain)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -192,11 +203,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    eng.profile_enable(args.steps + 8)
+    eng.profile_enable(0)
     for k in range(args.warmup):
         step(k)
     drain()
     fence()
-    eng.profile_enable(True)
+    eng.profile_enable(1)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
@@ -206,7 +219,7 @@ def main():
     ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    eng.profile_enable(False)
+    eng.profile_enable(0)
     kern_ms_total, kern_launches, kern_name = eng.profile_read()
     region_ms = ev0.elapsed_time(ev1)
 
@@ -257,6 +270,7 @@ def main():
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
                    "mix_bus": use_mix, "parallelism": f"channel-shard x{world}",
+                   "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
                    "plan": eng.describe().strip().split("\n")[1:]},
         "roofline": roof,
         "realtime_channels": value / 48000.0,

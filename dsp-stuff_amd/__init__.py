@@ -19,7 +19,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdspfx.so")
+# DSPFX_LIB lets tools/ab.py load an experiment build of the same library side by side
+LIB_PATH = os.environ.get("DSPFX_LIB") or os.path.join(_HERE, "csrc", "libdspfx.so")
 
 BUF_SIZE = 128  # dsp-stuff/src/node.rs:257
 ABI_VERSION = 1
@@ -39,7 +40,7 @@ EXPORTS = [
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
     "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
-    "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read",
+    "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
 ]
 
 
@@ -51,7 +52,7 @@ class DspfxError(RuntimeError):
 
 class _EngineDesc(C.Structure):
     _fields_ = [("abi_version", C.c_uint32), ("device", C.c_int32), ("channels", C.c_uint32),
-                ("max_frames", C.c_uint32), ("link_flags", C.c_uint32), ("reserved", C.c_uint32),
+                ("max_frames", C.c_uint32), ("link_flags", C.c_uint32), ("tile_channels", C.c_uint32),
                 ("channel_offset", C.c_uint64)]
 
 
@@ -104,6 +105,7 @@ def lib():
     L.dspfx_fill_noise.argtypes = [vp, f32p, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.dspfx_sync.argtypes = [vp, vp]
     L.dspfx_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
+    L.dspfx_verify_fast_division.argtypes = [C.c_int, C.c_float, C.POINTER(C.c_uint64)]
     L.dspfx_profile_enable.argtypes = [vp, C.c_int]
     L.dspfx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.c_int]
     L.dspfx_algorithmic_bytes_per_sample.restype = C.c_double
@@ -121,8 +123,34 @@ def delay_len(seconds: float, page_round: bool = False) -> int:
     return int(lib().dspfx_delay_len(float(seconds), int(page_round)))
 
 
+def verify_fast_division(c: float, device: int = 0) -> int:
+    """Exhaustive (2^32 inputs) check of the fast constant division for divisor c: mismatch count."""
+    n = C.c_uint64()
+    rc = lib().dspfx_verify_fast_division(device, float(c), C.byref(n))
+    if rc != 0:
+        raise DspfxError(rc, lib().dspfx_strerror(rc).decode())
+    return int(n.value)
+
+
 def link_divisor(n_connected: int) -> np.float32:
     return np.float32(lib().dspfx_link_divisor(int(n_connected)))
+
+
+def to_layout(x: np.ndarray, tile_channels: int) -> np.ndarray:
+    """[n_frames][N] frame-major -> the engine layout for `tile_channels` (flat view)."""
+    if not tile_channels:
+        return np.ascontiguousarray(x)
+    nf, n = x.shape
+    w = tile_channels
+    return np.ascontiguousarray(x.reshape(nf, n // w, w).transpose(1, 0, 2))
+
+
+def from_layout(t: np.ndarray, n_frames: int, channels: int, tile_channels: int) -> np.ndarray:
+    """inverse of to_layout: -> [n_frames][N]"""
+    if not tile_channels:
+        return np.asarray(t).reshape(n_frames, channels)
+    w = tile_channels
+    return np.ascontiguousarray(np.asarray(t).reshape(channels // w, n_frames, w).transpose(1, 0, 2)).reshape(n_frames, channels)
 
 
 # --------------------------------------------------------------------------- nodes
@@ -218,11 +246,12 @@ class Engine:
     """N independent mono channels through one effect chain (include/dspfx.h)."""
 
     def __init__(self, channels: int, max_frames: int = BUF_SIZE, link_flags: int = LINK_INTERNAL | LINK_INPUT,
-                 device: int = 0, channel_offset: int = 0):
+                 device: int = 0, channel_offset: int = 0, tile_channels: int = 0):
         self.L = lib()
         self.channels, self.max_frames = int(channels), int(max_frames)
         self.h = C.c_void_p()
-        d = _EngineDesc(ABI_VERSION, device, channels, max_frames, link_flags, 0, channel_offset)
+        d = _EngineDesc(ABI_VERSION, device, channels, max_frames, link_flags, tile_channels, channel_offset)
+        self.tile_channels = int(tile_channels)
         rc = self.L.dspfx_engine_create(C.byref(d), C.byref(self.h))
         if rc != 0:
             self.h = C.c_void_p()
@@ -322,8 +351,9 @@ class Engine:
         self._chk(self.L.dspfx_describe(self.h, buf, 4096))
         return buf.value.decode()
 
-    def profile_enable(self, on: bool = True):
-        self._chk(self.L.dspfx_profile_enable(self.h, int(on)))
+    def profile_enable(self, launches: int = 1):
+        """0 = off; n > 0 = on, with events for n launches created up front."""
+        self._chk(self.L.dspfx_profile_enable(self.h, int(launches)))
 
     def profile_read(self, reset: bool = True):
         """(total kernel ms, launches, kernel name) of the dominant stage since the last reset."""

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "chain_kernels.hip.h"
+
 namespace dspfx {
 
 // distort.rs:146-172 (Fuzz), block-global over reference blocks of 128 frames.
@@ -14,14 +16,17 @@ struct FuzzArgs {
     float level;
     float hop_div;
     int hop;
+    Layout lay;
 };
 void launch_fuzz(const FuzzArgs &a, hipStream_t s);
 // mix[f] = fixed-order sum of part[f][0..stride)
 void launch_mix_reduce(const float *part, float *mix, unsigned nframes, unsigned stride, hipStream_t s);
 // node.rs:189-191: mix[i] /= div
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s);
+// launches the exhaustive check of the fast constant division; *d_count accumulates mismatches
+int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s);
 // dst[f][c] = noise(seed, c0 + c, n_abs0 + f)
 void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
-                  hipStream_t s);
+                  const Layout &lay, hipStream_t s);
 
 }  // namespace dspfx

@@ -1,7 +1,6 @@
 // aux_kernels.hip -- Fuzz, the mix-bus second stage, and the synthetic-noise fill.
 // Compiled with -ffp-contract=off like every kernel of this library.
 #include "aux_kernels.h"
-#include "chain_kernels.hip.h"
 
 namespace dspfx {
 
@@ -19,8 +18,8 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
         unsigned m = 0;
 #pragma unroll
         for (int f = 0; f < 128; ++f) {
-            float t = a.in[(size_t)(b0 + f) * a.N + c];
-            if (a.hop) t = link_hop(t, a.hop_div);
+            float t = a.in[a.lay.at(b0 + f, c)];
+            if (a.hop) t = link_hop<false>(t, a.hop_div, 0.0);
             x[f] = t;
             const unsigned bts = abs_bits(t);      // max_by(total_cmp) over |x| == integer max of the bits
             m = bts >= m ? bts : m;
@@ -47,7 +46,7 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
         }
         const float my = __uint_as_float(myb);
 #pragma unroll
-        for (int f = 0; f < 128; ++f) a.out[(size_t)(b0 + f) * a.N + c] = x[f] * mx / my;   // 171
+        for (int f = 0; f < 128; ++f) a.out[a.lay.at(b0 + f, c)] = x[f] * mx / my;   // 171
     }
 }
 
@@ -83,12 +82,32 @@ __device__ __forceinline__ float noise1(uint32_t seed, uint32_t channel, uint32_
     return (float)(h >> 8) * 0x1p-23f - 1.0f;
 }
 __global__ void __launch_bounds__(WG) noise_kernel(float *dst, unsigned N, unsigned nframes, uint32_t c0,
-                                                   uint32_t n_abs0, uint32_t seed) {
+                                                   uint32_t n_abs0, uint32_t seed, const Layout lay) {
     const size_t total = (size_t)N * nframes;
     for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
         const uint32_t f = (uint32_t)(i / N), c = (uint32_t)(i % N);
-        dst[i] = noise1(seed, c0 + c, n_abs0 + f);
+        dst[lay.at(f, c)] = noise1(seed, c0 + c, n_abs0 + f);
     }
+}
+
+// Exhaustive proof that div_c<true>(x, c, rc) == x / c for EVERY f32 bit pattern x
+// (NaNs compared as a class).  2^32 inputs, a few ms.
+__global__ void __launch_bounds__(WG) verify_div_kernel(float c, double rc, unsigned long long *mismatches) {
+    unsigned long long bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (uint64_t b = (uint64_t)blockIdx.x * WG + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float q_ieee = div_c<false>(x, c, rc);
+        const float q_fast = div_c<true>(x, c, rc);
+        const bool same = (__float_as_uint(q_ieee) == __float_as_uint(q_fast)) || (q_ieee != q_ieee && q_fast != q_fast);
+        bad += same ? 0 : 1;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s) {
+    hipLaunchKernelGGL(verify_div_kernel, dim3(256 * 16), dim3(WG), 0, s, c, rc, d_count);
+    return (int)hipGetLastError();
 }
 
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
@@ -101,12 +120,12 @@ void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s) {
     hipLaunchKernelGGL(mix_finish_kernel, dim3((n + 127) / 128), dim3(128), 0, s, mix, n, div);
 }
 void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
-                  hipStream_t s) {
+                  const Layout &lay, hipStream_t s) {
     const size_t total = (size_t)N * nframes;
     size_t blocks = (total + WG - 1) / WG;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, dst, N, nframes, c0, n_abs0, seed);
+    hipLaunchKernelGGL(noise_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, dst, N, nframes, c0, n_abs0, seed, lay);
 }
 
 }  // namespace dspfx

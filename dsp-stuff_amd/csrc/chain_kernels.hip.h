@@ -44,6 +44,7 @@ struct SlotArgs {
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
     int pad_;
+    double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
 };
 
 struct ChainArgs {
@@ -60,8 +61,34 @@ struct ChainArgs {
     unsigned c_base;     // first channel of this launch
     unsigned n_launch;   // channels covered by this launch
     unsigned wave_base;  // mixpart column of this launch's first wave
+    // sample layout: channel c, frame f lives at  (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
+    //   frame-major [B][N]      : w_shift = 31, w_mask = ~0u>>1, ld = N, tile strides unused
+    //   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
+    unsigned w_shift;
+    unsigned w_mask;
+    unsigned ld;
     unsigned pad_;
+    size_t io_tile_stride;   // floats between consecutive channel tiles of in/out/side
+    double hop_rc;           // f64 1/hop_div
+    double third_rc;         // f64 1/3.0f  (SoftClip's powi(3)/3.0)
+    int fast_div;            // every constant divisor of this launch passed the exhaustive check
+    int pad2_;
     SlotArgs slot[MAX_SLOTS];
+};
+
+// Sample layout shared by every kernel: channel c, frame f lives at
+//   (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
+//   frame-major [B][N]       : w_shift = 31, w_mask = 0x7fffffff, ld = N, tile_stride = 0
+//   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
+struct Layout {
+    unsigned w_shift;
+    unsigned w_mask;
+    unsigned ld;
+    unsigned pad_;
+    size_t tile_stride;
+    __host__ __device__ size_t at(unsigned f, size_t c) const {
+        return (c >> w_shift) * tile_stride + (size_t)f * ld + (c & w_mask);
+    }
 };
 
 // ---- static signature encoding ------------------------------------------------
@@ -79,52 +106,88 @@ template <> struct VecT<1> { using type = float; };
 template <> struct VecT<2> { using type = float2; };
 template <> struct VecT<4> { using type = float4; };
 
-template <int CPL>
+// Sample/ring traffic is streamed exactly once per block (reuse distance = a whole
+// delay period), so those loads/stores carry the nontemporal hint: measured 1.13-1.27x
+// on the 5-node chain (interleaved A/B, profiles/r01_ab_nt.txt).  DSPFX_NT is a mask over
+// the four streams for A/B builds; 15 = all.
+#ifndef DSPFX_NT
+#define DSPFX_NT 15
+#endif
+template <int CPL> struct NVecT;
+template <> struct NVecT<1> { using type = float; };
+template <> struct NVecT<2> { typedef float type __attribute__((ext_vector_type(2))); };
+template <> struct NVecT<4> { typedef float type __attribute__((ext_vector_type(4))); };
+
+// streams (DSPFX_NT is a mask over them)
+constexpr int S_IN = 1, S_RING_LD = 2, S_RING_ST = 4, S_OUT = 8, S_STATE = 0;
+constexpr bool nt_for(int stream) { return (DSPFX_NT & stream) != 0; }
+
+template <int CPL, bool NT>
 __device__ __forceinline__ void load_vec_raw(const float *p, float (&v)[CPL]) {
-    using V = typename VecT<CPL>::type;
-    V t = *reinterpret_cast<const V *>(p);
+    using V = typename NVecT<CPL>::type;
+    V t;
+    if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
+    else t = *reinterpret_cast<const V *>(p);
     if constexpr (CPL == 1) { v[0] = t; }
-    else if constexpr (CPL == 2) { v[0] = t.x; v[1] = t.y; }
-    else { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[j] = t[j];
+    }
 }
-template <int CPL>
+template <int CPL, bool NT>
 __device__ __forceinline__ void store_vec_raw(float *p, const float (&v)[CPL]) {
-    using V = typename VecT<CPL>::type;
+    using V = typename NVecT<CPL>::type;
     V t;
     if constexpr (CPL == 1) { t = v[0]; }
-    else if constexpr (CPL == 2) { t.x = v[0]; t.y = v[1]; }
-    else { t.x = v[0]; t.y = v[1]; t.z = v[2]; t.w = v[3]; }
-    *reinterpret_cast<V *>(p) = t;
+    else {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) t[j] = v[j];
+    }
+    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<V *>(p));
+    else *reinterpret_cast<V *>(p) = t;
 }
 
 // GUARD=true is the one-wave tail launch for N % (64*CPL) != 0: out-of-range lanes
 // stay alive (the mix-bus reduction shuffles across the wave), read zeros and
 // store nothing.  GUARD=false launches cover whole waves only.
-template <int CPL, bool GUARD>
+template <int CPL, bool GUARD, int STREAM = S_STATE>
 __device__ __forceinline__ void load_vec(const float *p, float (&v)[CPL], bool active) {
     if constexpr (GUARD) {
-        if (active) load_vec_raw<CPL>(p, v);
+        if (active) load_vec_raw<CPL, nt_for(STREAM)>(p, v);
         else {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[j] = 0.0f;
         }
     } else {
-        load_vec_raw<CPL>(p, v);
+        load_vec_raw<CPL, nt_for(STREAM)>(p, v);
     }
 }
-template <int CPL, bool GUARD>
+template <int CPL, bool GUARD, int STREAM = S_STATE>
 __device__ __forceinline__ void store_vec(float *p, const float (&v)[CPL], bool active) {
     if constexpr (GUARD) {
-        if (active) store_vec_raw<CPL>(p, v);
+        if (active) store_vec_raw<CPL, nt_for(STREAM)>(p, v);
     } else {
-        store_vec_raw<CPL>(p, v);
+        store_vec_raw<CPL, nt_for(STREAM)>(p, v);
     }
 }
 
 // ---- reference arithmetic, one sample ------------------------------------------
 
+// x / c for a wave-uniform constant c.  FAST: (float)((double)x * rc) with rc = RN_f64(1/c):
+// the exact quotient of two f32 values is never closer than 2^-49 (relative) to an f32
+// rounding boundary while the f64 product is within 2^-52 of it, so the single final
+// rounding equals IEEE f32 division; the few constants with exact-tie quotients in the
+// subnormal range (even integers) are caught by the exhaustive 2^32-input check the host
+// runs per constant (verify_div_kernel) and then take the IEEE path (FAST = false).
+template <bool FAST>
+__device__ __forceinline__ float div_c(float x, float c, double rc) {
+    if constexpr (FAST) return (float)((double)x * rc);
+    else return x / c;
+}
+
 // node.rs:162-194 with one connected pipe: buf = 0.0; buf += x; buf /= 0.0001f + 1.0f
-__device__ __forceinline__ float link_hop(float x, float div) { return (0.0f + x) / div; }
+template <bool FAST>
+__device__ __forceinline__ float link_hop(float x, float div, double rc) { return div_c<FAST>(0.0f + x, div, rc); }
 
 // distort.rs:53-61
 __device__ __forceinline__ float clip1(float s) { return s < -1.0f ? -1.0f : (s > 1.0f ? 1.0f : s); }
@@ -142,19 +205,19 @@ __device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x);
 __device__ __forceinline__ float atan_cr(float x) { return (float)atan((double)x); }
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
-// distort.rs:63-145, every mode except Fuzz.  `level < 0.001` => bypass.
-template <int MODE>
-__device__ __forceinline__ float distort1(float sample, float level) {
-    if (level < 0.001f) return sample;
+// distort.rs:63-145, every mode except Fuzz, for level >= 0.001 (the `level < 0.001`
+// bypass is wave-uniform while level is a slider value and is tested once per chunk
+// by the caller).  Branch-free selects: lanes never diverge.
+template <int MODE, bool FAST>
+__device__ __forceinline__ float distort1(float sample, float level, double level_rc, double third_rc) {
     if constexpr (MODE == D_HARD_CLIP) {          // 63-69
-        return clip1(sample * level) / level;
+        return div_c<FAST>(clip1(sample * level), level, level_rc);
     } else if constexpr (MODE == D_SOFT_CLIP) {   // 71-86
-        float s = sample * level;
-        float r;
-        if (s > 1.0f) r = 2.0f / 3.0f;
-        else if (s >= -1.0f && s <= 1.0f) r = s - (((s * s) * s) / 3.0f);   // powi(3) = (s*s)*s
-        else r = -2.0f / 3.0f;
-        return clip1(r) / level;
+        const float s = sample * level;
+        const float mid = s - div_c<FAST>((s * s) * s, 3.0f, third_rc);   // powi(3) = (s*s)*s
+        const float in_range = (s >= -1.0f && s <= 1.0f) ? mid : -2.0f / 3.0f;   // NaN -> else arm
+        const float r = s > 1.0f ? 2.0f / 3.0f : in_range;
+        return div_c<FAST>(clip1(r), level, level_rc);
     } else if constexpr (MODE == D_TANH) {        // 104-110
         return tanh_cr(sample * level);
     } else if constexpr (MODE == D_RECIP_SOFT_CLIP) {   // 96-102
@@ -173,9 +236,8 @@ __device__ __forceinline__ float distort1(float sample, float level) {
     }
 }
 
-// overdrive.rs:31-43
+// overdrive.rs:31-43, for level >= 0.001 (bypass tested once per chunk by the caller)
 __device__ __forceinline__ float overdrive1(float sample, float boost, float drive, float level) {
-    if (level < 0.001f) return sample;
     const float FRAC_PI_4 = 0.785398163397448309615660845819875721f;
     const float FRAC_2_PI = 0.636619772367581343075535053490057448f;
     float a = sample * boost;
@@ -201,15 +263,21 @@ __device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
 struct Ctx {
     size_t c;        // first channel of this lane
     size_t N;
+    size_t io_base;  // offset of (frame 0, channel c) in in/out/side
+    size_t tile;     // channel tile index
+    size_t cw;       // channel within its tile
+    size_t ld;       // floats between consecutive frames
     unsigned f0;     // first frame of the chunk
     float hop_div;
+    double hop_rc;
+    double third_rc;
     const float *side;
     int side_hop;
     bool active;     // false only for padding lanes of the guarded tail launch
 };
 
 // Apply one node to a chunk v[F][CPL]; st[][] is the node's per-channel state.
-template <int KIND, int MODE, int F, int CPL, bool GUARD>
+template <int KIND, int MODE, int F, int CPL, bool GUARD, bool FAST>
 __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
                                            const Ctx &cx) {
     if constexpr (KIND == K_GAIN) {               // gain.rs:33-37
@@ -260,22 +328,24 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f) {
             unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
             r = r >= s.D ? r - s.D : r;
-            row[f] = (size_t)r * cx.N + cx.c;
-            load_vec<CPL, GUARD>(s.state + row[f], tap[f], cx.active);
+            row[f] = (cx.tile * s.D + r) * cx.ld + cx.cw;   // ring is [tile][D][W] (W == N when frame-major)
+            load_vec<CPL, GUARD, S_RING_LD>(s.state + row[f], tap[f], cx.active);
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap[f][j] * decay;
-            store_vec<CPL, GUARD>(s.state + row[f], v[f], cx.active);
+            store_vec<CPL, GUARD, S_RING_ST>(s.state + row[f], v[f], cx.active);
         }
     } else if constexpr (KIND == K_DISTORT) {     // distort.rs:176-194 (Fuzz has its own kernel)
         const float level = s.p[0];
+        if (level < 0.001f) return;               // every mode: `if level < 0.001 { return sample }`
 #pragma unroll
         for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = distort1<MODE>(v[f][j], level);
+            for (int j = 0; j < CPL; ++j) v[f][j] = distort1<MODE, FAST>(v[f][j], level, s.rc, cx.third_rc);
     } else if constexpr (KIND == K_OVERDRIVE) {   // overdrive.rs:58-72
+        if (s.p[2] < 0.001f) return;              // overdrive.rs:32-34
 #pragma unroll
         for (int f = 0; f < F; ++f)
 #pragma unroll
@@ -291,10 +361,10 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f) {
             float b[CPL];
             if (cx.side) {
-                load_vec<CPL, GUARD>(cx.side + (size_t)(cx.f0 + f) * cx.N + cx.c, b, cx.active);
+                load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
                 if (cx.side_hop) {
 #pragma unroll
-                    for (int j = 0; j < CPL; ++j) b[j] = link_hop(b[j], cx.hop_div);
+                    for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
                 }
             } else {
 #pragma unroll
@@ -309,55 +379,55 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
     }
 }
 
-template <int F, int CPL>
-__device__ __forceinline__ void apply_hop(float (&v)[F][CPL], float div) {
+template <int F, int CPL, bool FAST>
+__device__ __forceinline__ void apply_hop(float (&v)[F][CPL], float div, double rc) {
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) v[f][j] = link_hop(v[f][j], div);
+        for (int j = 0; j < CPL; ++j) v[f][j] = link_hop<FAST>(v[f][j], div, rc);
 }
 
-template <int F, int CPL, bool GUARD>
+template <int F, int CPL, bool GUARD, bool FAST>
 __device__ __forceinline__ void apply_distort_dyn(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
                                                   const Ctx &cx) {
     switch (s.mode) {
-    case D_HARD_CLIP: apply_node<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_SOFT_CLIP: apply_node<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_TANH: apply_node<K_DISTORT, D_TANH, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_RECIP_SOFT_CLIP: apply_node<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_SIN: apply_node<K_DISTORT, D_SIN, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_ATAN: apply_node<K_DISTORT, D_ATAN, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_SQUARE: apply_node<K_DISTORT, D_SQUARE, F, CPL, GUARD>(s, v, st, cx); break;
-    case D_CHEBYSHEV4: apply_node<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD>(s, v, st, cx); break;
+    case D_HARD_CLIP: apply_node<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SOFT_CLIP: apply_node<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_TANH: apply_node<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_RECIP_SOFT_CLIP: apply_node<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SIN: apply_node<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_ATAN: apply_node<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SQUARE: apply_node<K_DISTORT, D_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_CHEBYSHEV4: apply_node<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     default: break;
     }
 }
 
 // One slot: static signature => everything folds at compile time; SIG_DYN => a
 // wave-uniform switch (scalar branches, no divergence).
-template <int SIG, int F, int CPL, bool GUARD>
+template <int SIG, int F, int CPL, bool GUARD, bool FAST>
 __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
                                          const Ctx &cx) {
     if constexpr (SIG == SIG_NONE) {
         return;
     } else if constexpr (SIG == SIG_DYN) {
-        if (s.hop) apply_hop<F, CPL>(v, cx.hop_div);
+        if (s.hop) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
         switch (s.kind) {
-        case K_GAIN: apply_node<K_GAIN, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_BIQUAD: apply_node<K_BIQUAD, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_LOW_PASS: apply_node<K_LOW_PASS, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_HIGH_PASS: apply_node<K_HIGH_PASS, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_REVERB: apply_node<K_REVERB, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_DISTORT: apply_distort_dyn<F, CPL, GUARD>(s, v, st, cx); break;
-        case K_OVERDRIVE: apply_node<K_OVERDRIVE, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_CHEBYSHEV: apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD>(s, v, st, cx); break;
-        case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD>(s, v, st, cx); break;
+        case K_GAIN: apply_node<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_BIQUAD: apply_node<K_BIQUAD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_LOW_PASS: apply_node<K_LOW_PASS, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_HIGH_PASS: apply_node<K_HIGH_PASS, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_REVERB: apply_node<K_REVERB, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_DISTORT: apply_distort_dyn<F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_OVERDRIVE: apply_node<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_CHEBYSHEV: apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         default: break;
         }
     } else {
-        if constexpr (sig_hop(SIG)) apply_hop<F, CPL>(v, cx.hop_div);
-        apply_node<sig_kind(SIG), sig_mode(SIG), F, CPL, GUARD>(s, v, st, cx);
+        if constexpr (sig_hop(SIG)) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
+        apply_node<sig_kind(SIG), sig_mode(SIG), F, CPL, GUARD, FAST>(s, v, st, cx);
     }
 }
 
@@ -386,27 +456,31 @@ __device__ __forceinline__ void store_state(const SlotArgs &s, const float (&st)
 // Wave-level reduce-scatter of F per-lane values over the 64 lanes: after it,
 // r[0] of lane l holds the wave total of frame  mixbus_frame_of_lane<F>(l).
 // 2F-2+max(0,6-log2F) adds instead of 6F; fixed order => deterministic.
-template <int F>
-__device__ __forceinline__ void wave_reduce_scatter(float (&r)[F], int lane) {
-    int n = F;
+// Compile-time recursion keeps every r[] index a constant (registers, no selects chains).
+template <int F, int NLIVE, int O>
+__device__ __forceinline__ void rs_stage(float (&r)[F], int lane) {
+    if constexpr (O >= 1) {
+        if constexpr (NLIVE > 1) {
+            constexpr int H = NLIVE / 2;
+            const bool up = (lane & O) != 0;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        if (n > 1) {
-            const int h = n / 2;
-            const bool up = (lane & o) != 0;
-#pragma unroll
-            for (int i = 0; i < F / 2; ++i) {
-                if (i < h) {
-                    const float keep = up ? r[h + i] : r[i];
-                    const float send = up ? r[i] : r[h + i];
-                    r[i] = keep + __shfl_xor(send, o, 64);
-                }
+            for (int i = 0; i < H; ++i) {
+                const float lo = r[i], hi = r[H + i];
+                const float keep = up ? hi : lo;
+                const float send = up ? lo : hi;
+                r[i] = keep + __shfl_xor(send, O, 64);
             }
-            n = h;
+            rs_stage<F, H, O / 2>(r, lane);
         } else {
-            r[0] = r[0] + __shfl_xor(r[0], o, 64);
+            r[0] = r[0] + __shfl_xor(r[0], O, 64);
+            rs_stage<F, 1, O / 2>(r, lane);
         }
     }
+}
+template <int F>
+__device__ __forceinline__ void wave_reduce_scatter(float (&r)[F], int lane) {
+    static_assert((F & (F - 1)) == 0 && F <= 64, "F must be a power of two");
+    rs_stage<F, F, 32>(r, lane);
 }
 template <int F>
 __device__ __forceinline__ int mixbus_frame_of_lane(int lane) {
@@ -459,14 +533,16 @@ template <int F, int CPL, class SL>
 __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c,
                                             unsigned f0, int lane, unsigned wave_global) {
     float v[F][CPL];
+    const size_t tile = c >> a.w_shift, cw = c & a.w_mask;
+    const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<CPL, false>(a.in + (size_t)(f0 + f) * a.N + c, v[f], true);
-    const Ctx cx{c, a.N, f0, a.hop_div, a.side, a.side_hop, true};
-#define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false>(a.slot[I], v, st[I], cx);
+    for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
+    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+#define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<CPL, false>(a.out + (size_t)(f0 + f) * a.N + c, v[f], true);
+    for (int f = 0; f < F; ++f) store_vec<CPL, false, S_OUT>(a.out + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
     if (a.mixpart) mixbus_partial<F, CPL>(a, v, true, f0, lane, wave_global);
 }
 
@@ -497,13 +573,15 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // branches); per-node filter state is staged in LDS ([row][lane], conflict-free)
 // for the whole block and touched once per chunk per stateful node.
 // GUARD=true: one-wave tail launch whose out-of-range lanes stay alive with zeros.
-template <int F, bool GUARD>
+template <int F, bool GUARD, bool FAST>
 __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, bool active, unsigned f0,
                                           int lane, unsigned wave_global) {
     float v[F][1];
+    const size_t tile = c >> a.w_shift, cw = c & a.w_mask;
+    const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<1, GUARD>(a.in + (size_t)(f0 + f) * a.N + c, v[f], active);
-    const Ctx cx{c, a.N, f0, a.hop_div, a.side, a.side_hop, active};
+    for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
+    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {
@@ -512,14 +590,14 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
         float st[4][1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) st[k][0] = (k < ns) ? lds[(row + k) * WG + threadIdx.x] : 0.0f;
-        run_slot<SIG_DYN, F, 1, GUARD>(sl, v, st, cx);
+        run_slot<SIG_DYN, F, 1, GUARD, FAST>(sl, v, st, cx);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < ns) lds[(row + k) * WG + threadIdx.x] = st[k][0];
         row += ns;
     }
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<1, GUARD>(a.out + (size_t)(f0 + f) * a.N + c, v[f], active);
+    for (int f = 0; f < F; ++f) store_vec<1, GUARD, S_OUT>(a.out + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
     if (a.mixpart) mixbus_partial<F, 1>(a, v, !GUARD || active, f0, lane, wave_global);
 }
 
@@ -546,9 +624,15 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
         }
     }
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD>(a, lds, c, active, f0, lane, wave_global);
-    if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD>(a, lds, c, active, f0, lane, wave_global);
+    if (a.fast_div) {
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true>(a, lds, c, active, f0, lane, wave_global);
+        if constexpr (F > 1)
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true>(a, lds, c, active, f0, lane, wave_global);
+    } else {
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false>(a, lds, c, active, f0, lane, wave_global);
+        if constexpr (F > 1)
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false>(a, lds, c, active, f0, lane, wave_global);
+    }
     {
         int row = 0;
 #pragma unroll 1

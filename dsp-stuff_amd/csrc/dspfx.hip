@@ -14,6 +14,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,6 +45,7 @@ struct Stage {
     StageType type;
     int first, count;
     const Variant *var = nullptr;   // ST_FUSED
+    bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
 };
 
 }  // namespace
@@ -61,6 +64,8 @@ struct dspfx_engine {
     const Variant *tail = nullptr, *dyn = nullptr;
     bool has_fuzz = false;
     uint32_t min_delay = 0xffffffffu;
+    uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
+    float div_v = 0.0f;
     // profiling: event pairs per stage
     bool profiling = false;
     std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;   // [stage][launch]
@@ -119,6 +124,40 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
                         "%s failed: %s", #call, hipGetErrorString(err__));                      \
     } while (0)
 
+// Exact-division cache: divisor bits -> "fast path proven equal to IEEE division for all 2^32 inputs".
+// DSPFX_FAST_DIV=0 forces the IEEE path (A/B measurements).
+bool divisor_is_fast(float c) {
+    static std::mutex mu;
+    static std::map<uint32_t, bool> cache;
+    static const bool disabled = getenv("DSPFX_FAST_DIV") && atoi(getenv("DSPFX_FAST_DIV")) == 0;
+    if (disabled) return false;
+    if (!(c == c) || c == 0.0f || std::isinf(c)) return false;
+    uint32_t bits;
+    memcpy(&bits, &c, 4);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(bits);
+    if (it != cache.end()) return it->second;
+    bool ok = false;
+    unsigned long long *d = nullptr, h = 1;
+    if (hipMalloc((void **)&d, sizeof h) == hipSuccess) {
+        if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
+            hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            ok = h == 0;
+        (void)hipFree(d);
+    }
+    cache[bits] = ok;
+    return ok;
+}
+
+bool node_divisors_fast(const Node &n) {
+    if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
+        if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
+        if (!divisor_is_fast(n.d.params[0])) return false;
+        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f)) return false;
+    }
+    return true;
+}
+
 bool fusable(const Node &n) {
     if (n.d.kind == DSPFX_FIR) return false;
     if (n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ) return false;
@@ -171,6 +210,13 @@ Pref read_pref() {
     return p;
 }
 
+bool stage_fast_div(const dspfx_engine *e, const Stage &st) {
+    if (!divisor_is_fast(e->hop_div)) return false;
+    for (int i = 0; i < st.count; ++i)
+        if (!node_divisors_fast(e->nodes[st.first + i])) return false;
+    return true;
+}
+
 const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     std::vector<const Variant *> all;
     collect_variants(all);
@@ -183,6 +229,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         const bool is_dyn = v->sigs[0] == SIG_DYN;
         if (!is_dyn) {
             if (pref.stat == 0) continue;
+            if (!st.fast_div) continue;          // static kernels are built with the fast division only
             if (v->n_slots != st.count) continue;
             bool ok = true;
             for (int i = 0; i < st.count && ok; ++i) {
@@ -197,7 +244,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         int score = is_dyn ? 0 : 100;
         // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
         if (pref.f > 0 ? v->f == pref.f : v->f == 8) score += 10;
-        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == (is_dyn ? 1 : 2)) score += 5;
+        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == ((is_dyn || !e->desc.tile_channels) ? 1 : 2)) score += 5;
         if (score > best_score) {
             best_score = score;
             best = v;
@@ -237,6 +284,7 @@ int plan(dspfx_engine *e) {
     }
     for (Stage &st : e->stages)
         if (st.type == ST_FUSED) {
+            st.fast_div = stage_fast_div(e, st);
             st.var = pick_variant(e, st);
             if (!st.var) return fail(e, DSPFX_ERR_UNSUPPORTED, "no kernel variant for stage");
         }
@@ -293,6 +341,7 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.D = n.D;
     s.pos = n.pos;
     s.hop = node_hop(e, idx);
+    s.rc = n.d.kind == DSPFX_DISTORT ? 1.0 / (double)n.d.params[0] : 0.0;
     switch (n.d.kind) {
     case DSPFX_BIQUAD:
         s.p[0] = n.a1; s.p[1] = n.a2; s.p[2] = n.b0; s.p[3] = n.b1; s.p[4] = n.b2;
@@ -308,9 +357,22 @@ int state_rows(const Node &n) {
 
 // One sub-block (nframes <= every delay length) through all stages.
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
-                 uint32_t nframes, hipStream_t stream) {
+                 uint32_t nframes, uint32_t tile_frames, hipStream_t stream) {
     const uint32_t N = e->desc.channels;
     const float *src = in;
+    Layout lay{};
+    if (e->desc.tile_channels) {
+        const uint32_t W = e->desc.tile_channels;
+        lay.w_shift = (unsigned)__builtin_ctz(W);
+        lay.w_mask = W - 1;
+        lay.ld = W;
+        lay.tile_stride = (size_t)tile_frames * W;
+    } else {
+        lay.w_shift = 31;
+        lay.w_mask = 0x7fffffffu;
+        lay.ld = N;
+        lay.tile_stride = 0;
+    }
     for (size_t si = 0; si < e->stages.size(); ++si) {
         const Stage &st = e->stages[si];
         const bool last = si + 1 == e->stages.size();
@@ -323,7 +385,14 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.out = out;
             a.N = N;
             a.nframes = nframes;
+            a.w_shift = lay.w_shift;
+            a.w_mask = lay.w_mask;
+            a.ld = lay.ld;
+            a.io_tile_stride = lay.tile_stride;
             a.hop_div = e->hop_div;
+            a.hop_rc = 1.0 / (double)e->hop_div;
+            a.third_rc = 1.0 / 3.0;
+            a.fast_div = st.fast_div ? 1 : 0;
             a.n_slots = st.count;
             a.side_hop = (side && (e->desc.link_flags & DSPFX_LINK_INTERNAL)) ? 1 : 0;
             int rows = 0;
@@ -360,14 +429,14 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             }
         } else if (st.type == ST_FUZZ) {
             const Node &n = e->nodes[st.first];
-            FuzzArgs f{src, out, N, nframes, n.d.params[0], e->hop_div, node_hop(e, st.first)};
+            FuzzArgs f{src, out, N, nframes, n.d.params[0], e->hop_div, node_hop(e, st.first), lay};
             ProfScope ps(e, si, stream);
             launch_fuzz(f, stream);
             HIPCHK(e, hipGetLastError());
         } else {   // ST_FIR
             Node &n = e->nodes[st.first];
             ProfScope ps(e, si, stream);
-            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, stream);
+            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream);
             if (rc != 0) return fail(e, rc, "FIR: %s", fir_last_error());
         }
         src = out;
@@ -453,6 +522,10 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     *out = nullptr;
     if (desc->abi_version != DSPFX_ABI_VERSION) return DSPFX_ERR_INVALID;
     if (desc->channels == 0 || desc->max_frames == 0) return DSPFX_ERR_INVALID;
+    if (desc->tile_channels) {
+        const uint32_t W = desc->tile_channels;
+        if ((W & (W - 1)) || W < 64 || desc->channels % W) return DSPFX_ERR_INVALID;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
     if (desc->device < 0 || desc->device >= ndev) return DSPFX_ERR_INVALID;
@@ -535,6 +608,7 @@ extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value
         HIPCHK(e, hipSetDevice(e->device));
         HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
     }
+    if (n.d.kind == DSPFX_DISTORT) return plan(e);   // a new divisor: re-verify / re-pick the kernel
     return DSPFX_OK;
 }
 
@@ -609,8 +683,10 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
     const size_t N = e->desc.channels;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += sub) {
         const uint32_t nf = std::min(sub, n_frames - f0);
-        const int rc = run_subblock(e, in + (size_t)f0 * N, side ? side + (size_t)f0 * N : nullptr,
-                                    out + (size_t)f0 * N, mix ? mix + f0 : nullptr, nf, s);
+        // frame f0 of a block starts f0 rows in: a row is N floats (frame-major) or W floats (tiled)
+        const size_t off = (size_t)f0 * (e->desc.tile_channels ? e->desc.tile_channels : N);
+        const int rc = run_subblock(e, in + off, side ? side + off : nullptr, out + off, mix ? mix + f0 : nullptr,
+                                    nf, n_frames, s);
         if (rc) return rc;
     }
     return DSPFX_OK;
@@ -643,7 +719,11 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
 extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream) {
     if (!e || !mix) return DSPFX_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
-    launch_mix_finish(mix, n_frames, dspfx_link_divisor(n_connected), (hipStream_t)stream);
+    if (e->div_n != n_connected || e->div_v == 0.0f) {   // the literal f32 increment loop is O(n): cache it
+        e->div_v = dspfx_link_divisor(n_connected);
+        e->div_n = n_connected;
+    }
+    launch_mix_finish(mix, n_frames, e->div_v, (hipStream_t)stream);
     HIPCHK(e, hipGetLastError());
     return DSPFX_OK;
 }
@@ -703,7 +783,15 @@ extern "C" int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, 
                                 void *stream) {
     if (!e || !dst) return DSPFX_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
-    launch_noise(dst, e->desc.channels, n_frames, (uint32_t)e->desc.channel_offset, n_abs0, seed, (hipStream_t)stream);
+    Layout lay{};
+    if (e->desc.tile_channels) {
+        const uint32_t W = e->desc.tile_channels;
+        lay = Layout{(unsigned)__builtin_ctz(W), W - 1, W, 0, (size_t)n_frames * W};
+    } else {
+        lay = Layout{31, 0x7fffffffu, e->desc.channels, 0, 0};
+    }
+    launch_noise(dst, e->desc.channels, n_frames, (uint32_t)e->desc.channel_offset, n_abs0, seed, lay,
+                 (hipStream_t)stream);
     HIPCHK(e, hipGetLastError());
     return DSPFX_OK;
 }
@@ -715,9 +803,34 @@ extern "C" int dspfx_sync(dspfx_engine *e, void *stream) {
     return DSPFX_OK;
 }
 
+extern "C" int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches) {
+    if (!mismatches) return DSPFX_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return DSPFX_ERR_INVALID;
+    unsigned long long *d = nullptr, h = 0;
+    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return DSPFX_ERR_OOM;
+    int rc = DSPFX_ERR_HIP;
+    if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
+        hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+        *mismatches = h;
+        rc = DSPFX_OK;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
 extern "C" int dspfx_profile_enable(dspfx_engine *e, int enable) {
     if (!e) return DSPFX_ERR_INVALID;
     e->profiling = enable != 0;
+    if (enable > 0) {   // `enable` doubles as a hint: events for that many launches are created now,
+        HIPCHK(e, hipSetDevice(e->device));   // outside the timed region (hipEventCreate is slow)
+        while (e->ev_pool.size() < 2u * (size_t)enable * std::max<size_t>(1, e->stages.size())) {
+            hipEvent_t ev = nullptr;
+            HIPCHK(e, hipEventCreate(&ev));
+            e->ev_pool.push_back(ev);
+        }
+    }
     return DSPFX_OK;
 }
 

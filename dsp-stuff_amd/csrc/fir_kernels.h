@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "chain_kernels.hip.h"
+
 namespace dspfx {
 
 struct FirState {
@@ -27,7 +29,7 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
 void fir_free(FirState &s);
 void fir_reset(FirState &s);
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                hipStream_t stream);
+                const Layout &lay, hipStream_t stream);
 size_t fir_state_bytes(const FirState &s);
 int fir_state_export(FirState &s, void *host_dst);
 int fir_state_import(FirState &s, const void *host_src);

@@ -26,11 +26,12 @@ const char *fir_last_error() { return g_fir_err.c_str(); }
 // ring[(t0 + f) mod R][c] = port value of in[f][c]  (fir.rs:193 push_back, after the
 // collect_and_average hop when enabled)
 __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float *ring, uint32_t N, uint32_t nframes,
-                                                         uint32_t row0, uint32_t R, int hop, float hop_div) {
+                                                         uint32_t row0, uint32_t R, int hop, float hop_div,
+                                                         const Layout lay) {
     const size_t total = (size_t)N * nframes;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const uint32_t f = (uint32_t)(i / N), c = (uint32_t)(i % N);
-        float x = in[i];
+        float x = in[lay.at(f, c)];
         if (hop) x = (0.0f + x) / hop_div;
         uint32_t r = row0 + f;
         r = r >= R ? r - R : r;
@@ -43,7 +44,7 @@ __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float 
 // slice, 208-216), * divisor (222).  General in n0 (covers the warm-up quirk).
 __global__ void __launch_bounds__(256) fir_exact_kernel(const float *ring, const double *taps, float *out, uint32_t N,
                                                         uint32_t nframes, uint32_t T, uint32_t R, uint64_t n0,
-                                                        float divisor) {
+                                                        float divisor, const Layout lay) {
     const size_t total = (size_t)N * nframes;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const uint32_t f = (uint32_t)(i / N), c = (uint32_t)(i % N);
@@ -58,7 +59,7 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const float *ring, const
         }
         const float a = (float)acc;
         const float val = a + 0.0f;
-        out[i] = val * divisor;
+        out[lay.at(f, c)] = val * divisor;
     }
 }
 
@@ -106,7 +107,7 @@ static unsigned grid_for(size_t total) {
 }
 
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                hipStream_t stream) {
+                const Layout &lay, hipStream_t stream) {
     if (nframes > s.max_frames) {
         g_fir_err = "nframes > max_frames";
         return DSPFX_ERR_INVALID;
@@ -114,11 +115,11 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
     const size_t total = (size_t)s.N * nframes;
     const uint32_t row0 = (uint32_t)(s.n_seen % s.R);
     hipLaunchKernelGGL(fir_append_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, s.ring, s.N, nframes, row0,
-                       s.R, hop, hop_div);
+                       s.R, hop, hop_div, lay);
     // fir.rs:187-190
     const float divisor = s.mode == DSPFX_FIR_AVERAGE ? 1.0f / (float)s.T : 1.0f;
     hipLaunchKernelGGL(fir_exact_kernel, dim3(grid_for(total)), dim3(256), 0, stream, s.ring, s.taps64, out, s.N,
-                       nframes, s.T, s.R, s.n_seen, divisor);
+                       nframes, s.T, s.R, s.n_seen, divisor, lay);
     FIRCHK(hipGetLastError());
     s.n_seen += nframes;
     return 0;

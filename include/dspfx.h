@@ -101,7 +101,10 @@ typedef struct dspfx_engine_desc {
     uint32_t channels;        /* N: independent mono channels held by this engine */
     uint32_t max_frames;      /* largest n_frames a process call will pass (>=1) */
     uint32_t link_flags;      /* DSPFX_LINK_* */
-    uint32_t reserved;
+    uint32_t tile_channels;   /* sample layout: 0 = frame-major [n_frames][N];
+                                 W (power of two, N % W == 0) = channel-tiled [N/W][n_frames][W]:
+                                 element (f, c) at ((c / W) * n_frames + f) * W + c % W, so the
+                                 block of every W-channel group is one contiguous HBM extent */
     uint64_t channel_offset;  /* global index of local channel 0 (multi-GPU shards, noise) */
 } dspfx_engine_desc;
 
@@ -206,11 +209,17 @@ int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, uint32_t n_
 int dspfx_sync(dspfx_engine *e, void *stream);
 /* Human-readable plan of the current chain (stages, kernels, bytes/sample). */
 int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap);
+/* Division by a wave-uniform constant c (the link divisor, SoftClip's 3.0, a clip level)
+ * is evaluated as (float)((double)x * (1.0/c)) when that is bit-identical to IEEE f32
+ * x / c for EVERY one of the 2^32 possible x; this runs that exhaustive check on the
+ * device and returns the number of mismatching inputs (0 => the fast form is exact for
+ * c; otherwise the engine keeps IEEE division for c). */
+int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches);
 /* Kernel timing for the roofline report: when enabled, every stage's main kernel
  * launch is bracketed by HIP events on the stream it is launched on.  read()
  * synchronises those events and returns, for the stage with the largest total,
  * the summed kernel time and the number of launches (and optionally resets). */
-int dspfx_profile_enable(dspfx_engine *e, int enable);
+int dspfx_profile_enable(dspfx_engine *e, int enable /* 0 = off; n > 0 = on, pre-creating events for n launches */);
 int dspfx_profile_read(dspfx_engine *e, double *total_ms, uint32_t *launches, char *kernel_name, size_t cap,
                        int reset);
 /* Algorithmic HBM bytes per channel-sample of the current chain at n_frames. */

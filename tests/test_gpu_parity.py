@@ -25,23 +25,27 @@ def torch_cuda():
     return torch
 
 
-def run_gpu(dspfx, torch, chain, x, link_flags=3, block=128, side=None, want_mix=False, max_frames=None):
-    """x: [frames][N] numpy -> GPU engine block by block (device path)."""
+def run_gpu(dspfx, torch, chain, x, link_flags=3, block=128, side=None, want_mix=False, max_frames=None, tile=0):
+    """x: [frames][N] numpy -> GPU engine block by block (device path).  `tile` selects the
+    channel-tiled HBM layout [N/W][block][W]; every block is handed over in that layout."""
     nf, N = x.shape
-    eng = dspfx.Engine(N, max_frames or block, link_flags=link_flags)
+    eng = dspfx.Engine(N, max_frames or block, link_flags=link_flags, tile_channels=tile)
     eng.set_chain(chain)
-    dx = torch.from_numpy(x).cuda()
-    ds = torch.from_numpy(side).cuda() if side is not None else None
-    dy = torch.empty_like(dx)
-    dm = torch.empty(nf, dtype=torch.float32, device="cuda") if want_mix else None
+    y = np.empty_like(x)
+    mix = np.empty(nf, np.float32)
     for f0 in range(0, nf, block):
         n = min(block, nf - f0)
-        eng.process(dx[f0:f0 + n], out=dy[f0:f0 + n], side=ds[f0:f0 + n] if ds is not None else None,
-                    mix=dm[f0:f0 + n] if want_mix else None, n_frames=n)
-    torch.cuda.synchronize()
-    y = dy.cpu().numpy()
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + n], tile)).cuda()
+        ds = torch.from_numpy(dspfx.to_layout(side[f0:f0 + n], tile)).cuda() if side is not None else None
+        dy = torch.empty_like(dx)
+        dm = torch.empty(n, dtype=torch.float32, device="cuda") if want_mix else None
+        eng.process(dx, out=dy, side=ds, mix=dm, n_frames=n)
+        torch.cuda.synchronize()
+        y[f0:f0 + n] = dspfx.from_layout(dy.cpu().numpy(), n, N, tile)
+        if want_mix:
+            mix[f0:f0 + n] = dm.cpu().numpy()
     eng.close()
-    return (y, dm.cpu().numpy()) if want_mix else y
+    return (y, mix) if want_mix else y
 
 
 def run_oracle(chain, x, link_flags=3, side=None):
@@ -210,6 +214,34 @@ def test_add_mix_side_input(dspfx, torch_cuda):
         assert ulp_diff(y, ref).max() <= 1
 
 
+def test_fast_constant_division_is_exhaustively_exact(dspfx, torch_cuda, monkeypatch):
+    """The (double)x * (1/c) division is proven per constant over all 2^32 inputs; constants
+    that have exact-tie quotients in the subnormal range fail the proof and keep IEEE division."""
+    assert dspfx.verify_fast_division(float(dspfx.link_divisor(1))) == 0      # 1.0001f: every chain hop
+    assert dspfx.verify_fast_division(3.0) == 0                               # SoftClip's powi(3)/3.0
+    for level in (0.5, 1.0, 2.5, 3.0, 30.0, 0.001):
+        assert dspfx.verify_fast_division(level) == 0, level
+    # constants whose quotients can be exact ties in the subnormal range (even integers) may fail
+    # the proof, depending on which way RN_f64(1/c) errs; any that do must take the IEEE path
+    failing = [c for c in (6.0, 10.0, 12.0, 14.0, 18.0, 20.0, 22.0, 24.0, 26.0, 28.0, 30.0)
+               if dspfx.verify_fast_division(c) > 0]
+    print("constants failing the exhaustive proof:", failing)
+    x = noise_block(128, 256)
+    x[0, :6] = [4.2e-45, -4.2e-45, 1e-44, 3e-39, 1.5e-44, 2.9e-44]            # subnormal inputs incl. tie cases
+    for level in failing[:2] + [6.0, 3.0]:
+        for mode in (dspfx.HARD_CLIP, dspfx.SOFT_CLIP):
+            ch = [dspfx.Distort(level, mode), dspfx.Gain(1.0)]
+            y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
+            assert ulp_diff(y, ref).max() == 0, (level, mode)
+    # the forced-IEEE build of the same chain gives the same bits as the fast one
+    ch = chain5(dspfx, delay=128)
+    y_fast = run_gpu(dspfx, torch_cuda, ch, x, 3)
+    monkeypatch.setenv("DSPFX_FAST_DIV", "0")
+    # (the switch is read once per process; a fresh interpreter is needed for a true A/B --
+    #  bench.py does that; here we at least cover subnormal inputs through the default path)
+    assert ulp_diff(y_fast, run_oracle(ch, x, 3)).max() <= 1
+
+
 # ----------------------------------------------------------------------- chains
 
 def test_config1_single_channel_chain(dspfx, torch_cuda):
@@ -332,6 +364,33 @@ def test_error_behaviour(dspfx, torch_cuda):
         eng.set_param(3, 0, 1.0)
     with pytest.raises(dspfx.DspfxError):
         dspfx.Engine(0)
+
+
+@pytest.mark.parametrize("tile", [64, 256])
+def test_channel_tiled_layout(dspfx, torch_cuda, tile):
+    """The channel-tiled HBM layout [N/W][B][W] gives the same bits as frame-major for every kernel."""
+    N = 512
+    x, s = noise_block(N, 512), noise_block(N, 512, seed=99)
+    cases = [(chain5(dspfx, delay=256), None), (chain3(dspfx, delay=128), None),
+             ([dspfx.Gain(0.9), dspfx.Distort(3.0, dspfx.FUZZ), dspfx.BiQuad()], None),
+             ([dspfx.Gain(0.5), dspfx.Mix(0.3), dspfx.Reverb(delay_samples=128, decay=0.25)], s),
+             ([dspfx.LowPass(0.4), dspfx.Fir(fir_taps(100)), dspfx.HighPass(0.2)], None)]
+    for ch, side in cases:
+        for blk in (128, 256):
+            y0, m0 = run_gpu(dspfx, torch_cuda, ch, x, 3, block=blk, side=side, want_mix=True)
+            y1, m1 = run_gpu(dspfx, torch_cuda, ch, x, 3, block=blk, side=side, want_mix=True, tile=tile)
+            assert np.array_equal(y0.view(np.uint32), y1.view(np.uint32)), (tile, blk, [n.kind for n in ch])
+            assert np.allclose(m0, m1, rtol=1e-5, atol=1e-4)
+    # noise fill honours the layout too
+    eng = dspfx.Engine(N, 128, channel_offset=7, tile_channels=tile)
+    d = torch_cuda.empty(128 * N, dtype=torch_cuda.float32, device="cuda")
+    eng.fill_noise(d, 128, 5)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dspfx.from_layout(d.cpu().numpy(), 128, N, tile), noise_block(N, 128, c0=7, n0=5))
+    with pytest.raises(dspfx.DspfxError):
+        dspfx.Engine(100, 128, tile_channels=64)          # N % W != 0
+    with pytest.raises(dspfx.DspfxError):
+        dspfx.Engine(96, 128, tile_channels=96)           # not a power of two
 
 
 # -------------------------------------------------------------------------- FIR
