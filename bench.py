@@ -120,11 +120,13 @@ def cpu_baseline(chain, cfg, link_flags, target_s):
     run(cores, 1)                                     # touch code/pages
     t = run(ch, nb)                                   # probe
     rate = ch * nb * block / max(t, 1e-6)
-    # scale the sample to ~target_s of CPU work; keep >= 1 ring period of blocks for the delay chains
+    # scale the sample to ~target_s of CPU work: >= 1 ring period of blocks for the delay chains,
+    # channels capped so the per-channel delay rings (96 KB each at D=24000) stay within ~6 GB of host RAM
     nb2 = nb if is_fir else 256
     ch2 = int(max(cores, min(1 << 16, rate * target_s / (nb2 * block))))
     ch2 -= ch2 % cores or 0
     ch2 = max(ch2, cores)
+    nb2 = int(max(nb2, min(1 << 14, rate * target_s / (ch2 * block))))
     t2 = run(ch2, nb2)
     return {"value": ch2 * nb2 * block / t2, "unit": "samples/s", "cores": cores,
             "kind": "port",

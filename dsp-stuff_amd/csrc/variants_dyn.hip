@@ -1,7 +1,13 @@
 // Dynamic (interpreting) chain kernels: any chain of <= MAX_SLOTS fusable nodes.
 #include "variants.h"
 namespace dspfx {
+// "copy" = the empty chain, statically specialised: a known-traffic (8 B/sample) kernel with
+// exactly the chain kernels' access widths, used to calibrate the PMC byte counters.
+#define NONE8 SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE
 static const Variant k_dyn[] = {
+    DSPFX_STATIC_VARIANT("copy_f8_c1", 0, 8, 1, NONE8),
+    DSPFX_STATIC_VARIANT("copy_f8_c2", 0, 8, 2, NONE8),
+    DSPFX_STATIC_VARIANT("copy_f8_c4", 0, 8, 4, NONE8),
     DSPFX_DYN_VARIANT("dyn_f8", 8, false),
     DSPFX_DYN_VARIANT("dyn_f4", 4, false),
     DSPFX_DYN_VARIANT("dyn_f16", 16, false),

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<round>/ (tools/gpu_profile.sh) into the committed summaries under profiles/:
+  <round>_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the headline bench command
+  <round>_pmc.json           FETCH_SIZE / WRITE_SIZE per launch, calibration and corrected HBM bytes
+  traffic.json               what bench.py reports as roofline.traffic
+Calibration (MI355X_MICROARCH.md, HBM section): the empty chain through the same kernel structure
+and access width moves exactly 4 B in + 4 B out per sample; the counter/known ratio of that run
+corrects the counters of the real kernel."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(ROOT, "gpurun_out", f"prof_{rnd}")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+shutil.copy(os.path.join(src, "trace", "cfg5_kernel_stats.csv"), os.path.join(dst, f"{rnd}_kernel_stats.csv"))
+
+N, B = 1 << 20, 128
+
+
+def per_launch(path, counter):
+    vals = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter and "chain_kernel" in r["Kernel_Name"]:
+            vals[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    (name, v), = vals.items()
+    tail = v[-100:]
+    return name, sum(tail) / len(tail)
+
+
+out = {"round": rnd, "command": "python3 bench.py --steps 100 --warmup 200 --no-cpu-baseline (under rocprofv3 --pmc <counter> --kernel-trace)",
+       "units": "counter values are KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "counters": {}}
+known = N * B * 4 / 1024.0   # KiB read == KiB written by the calibration (copy) kernel
+total = 0.0
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    kname, val = per_launch(os.path.join(src, f"pmc_{c}", "cfg5_counter_collection.csv"), c)
+    cname, cal = per_launch(os.path.join(src, f"pmc_{c}_copy", "copy_counter_collection.csv"), c)
+    factor = known / cal
+    out["counters"][c] = {"kernel": kname, "raw_kib_per_launch": val, "calibration_kernel": cname,
+                          "calibration_raw_kib": cal, "calibration_known_kib": known, "correction_factor": factor,
+                          "corrected_bytes_per_launch": val * factor * 1024.0}
+    total += val * factor * 1024.0
+algo = 16.5 * N * B
+out["hbm_bytes_per_launch"] = total
+out["algorithmic_bytes_per_launch"] = algo
+out["traffic_over_algorithmic"] = total / algo
+json.dump(out, open(os.path.join(dst, f"{rnd}_pmc.json"), "w"), indent=1)
+tr_path = os.path.join(dst, "traffic.json")
+tr = json.load(open(tr_path)) if os.path.exists(tr_path) else {}
+tr[f"cfg5:{N}:{B}"] = {"hbm_bytes_per_launch": total, "source": f"profiles/{rnd}_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, "
+                       "calibrated on the copy kernel: FETCH_SIZE x2, WRITE_SIZE x1)"}
+json.dump(tr, open(tr_path, "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
