@@ -435,8 +435,14 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             HIPCHK(e, hipGetLastError());
         } else {   // ST_FIR
             Node &n = e->nodes[st.first];
-            ProfScope ps(e, si, stream);
-            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream);
+            hipEvent_t ea = nullptr, eb = nullptr;
+            if (e->profiling) {
+                ea = take_event(e);
+                eb = take_event(e);
+                if (e->prof.size() <= si) e->prof.resize(si + 1);
+                e->prof[si].emplace_back(ea, eb);
+            }
+            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream, ea, eb);
             if (rc != 0) return fail(e, rc, "FIR: %s", fir_last_error());
         }
         src = out;

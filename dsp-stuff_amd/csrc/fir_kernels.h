@@ -35,8 +35,9 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
                   uint32_t max_frames);
 void fir_free(FirState &s);
 void fir_reset(FirState &s);
+// ev_begin/ev_end (optional) are recorded around the compute kernel(s) only, not the append pass
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                const Layout &lay, hipStream_t stream);
+                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 size_t fir_state_bytes(const FirState &s);
 int fir_state_export(FirState &s, void *host_dst);
 int fir_state_import(FirState &s, const void *host_src);

@@ -133,47 +133,58 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[jt][r] = 0.0f; tot[jt][r] = 0.0f; }
 
+    // History rows of one chunk.  The chunk's first row is wave-uniform (scalar); unless the
+    // chunk straddles the ring's wrap point (once per K sweep) every load is base + immediate.
+    const float *hlane = hbase + (size_t)kh * TILE_C;
     auto load_chunk = [&](uint32_t kc, float (&h)[KC / 2]) {
+        uint32_t row0 = a.rb + kc;                     // < 2R: rb < R, kc < kpad <= R + KC
+        row0 = row0 >= a.R ? row0 - a.R : row0;
+        if (row0 + KC + 1 <= a.R) {
+            const float *p = hlane + (size_t)row0 * TILE_C;
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
-            uint32_t row = a.rb + kc + 2 * s + kh;
-            row = row >= a.R ? row - a.R : row;
-            row = row >= a.R ? row - a.R : row;       // kpad may run a few rows past K
-            h[s] = __builtin_nontemporal_load(hbase + (size_t)row * TILE_C);
+            for (int s = 0; s < KC / 2; ++s) h[s] = __builtin_nontemporal_load(p + (size_t)(2 * s) * TILE_C);
+        } else {
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) {
+                uint32_t row = row0 + 2 * s + kh;
+                row = row >= a.R ? row - a.R : row;
+                h[s] = __builtin_nontemporal_load(hbase + (size_t)row * TILE_C);
+            }
         }
     };
 
     float h_cur[KC / 2], h_nxt[KC / 2];
     load_chunk(0, h_nxt);
-    int since_flush = 0;
-    for (uint32_t kc = 0; kc < a.kpad; kc += KC) {
+    uint32_t kc = 0;
+    while (kc < a.kpad) {
+        // a fixed-trip inner sweep keeps the accumulators in place; its f32 chain is <= FLUSH*KC terms
+        const uint32_t kend = kc + FLUSH * KC < a.kpad ? kc + FLUSH * KC : a.kpad;
+        for (; kc < kend; kc += KC) {
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s];
-        if (kc + KC < a.kpad) load_chunk(kc + KC, h_nxt);
+            for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s];
+            if (kc + KC < a.kpad) load_chunk(kc + KC, h_nxt);
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
+            for (int s = 0; s < KC / 2; ++s) {
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt) {
-                int idx = wofs[jt] + (int)kc + 2 * s;
-                float w;
-                if constexpr (WARM) {
-                    const int lo = (int)a.pad_lo - 1;          // tp[pad_lo-1] == 0
-                    const int ic = idx < lo ? lo : idx;
-                    w = tp[ic];
-                    w = idx <= whi[jt] ? w : 0.0f;              // samples newer than n do not exist yet
-                } else {
-                    w = tp[idx];
+                for (int jt = 0; jt < 4; ++jt) {
+                    const int idx = wofs[jt] + (int)kc + 2 * s;
+                    float w;
+                    if constexpr (WARM) {
+                        const int lo = (int)a.pad_lo - 1;          // tp[pad_lo-1] == 0
+                        const int ic = idx < lo ? lo : idx;
+                        w = tp[ic];
+                        w = idx <= whi[jt] ? w : 0.0f;              // samples newer than n do not exist yet
+                    } else {
+                        w = tp[idx];
+                    }
+                    acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h_cur[s], acc[jt], 0, 0, 0);
                 }
-                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h_cur[s], acc[jt], 0, 0, 0);
             }
         }
-        if (++since_flush == FLUSH) {   // bound the f32 chain length: flush partial sums
-            since_flush = 0;
 #pragma unroll
-            for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < 4; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { tot[jt][r] = tot[jt][r] + acc[jt][r]; acc[jt][r] = 0.0f; }
-        }
+            for (int r = 0; r < 16; ++r) { tot[jt][r] = tot[jt][r] + acc[jt][r]; acc[jt][r] = 0.0f; }
     }
     const uint32_t c = tile * TILE_C + cl;
     if (c >= a.N) return;
@@ -183,8 +194,7 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         for (int r = 0; r < 16; ++r) {
             const uint32_t j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (j < a.nframes) {
-                const float sum = tot[jt][r] + acc[jt][r];
-                const float val = sum + 0.0f;                   // fir.rs:216 `a + b` with the empty b slice
+                const float val = tot[jt][r] + 0.0f;                   // fir.rs:216 `a + b` with the empty b slice
                 __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
             }
         }
@@ -198,7 +208,7 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     s.max_frames = max_frames;
     s.mode = mode;
     s.R = n_taps - 1 + max_frames;
-    if (s.R < 2 * KC) s.R = 2 * KC;                   // keeps the double wrap in load_chunk sufficient
+    if (s.R < 2 * KC) s.R = 2 * KC;                   // keeps the single wrap in load_chunk sufficient
     s.tiles = (N + TILE_C - 1) / TILE_C;
     s.pad_lo = 128;
     s.pad_hi = 128 + KC;
@@ -245,7 +255,7 @@ static unsigned grid_for(size_t total) {
 }
 
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                const Layout &lay, hipStream_t stream) {
+                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
     if (nframes > s.max_frames) {
         g_fir_err = "nframes > max_frames";
         return DSPFX_ERR_INVALID;
@@ -256,6 +266,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
                        s.R, hop, hop_div, lay);
     // fir.rs:187-190
     const float divisor = s.mode == DSPFX_FIR_AVERAGE ? 1.0f / (float)s.T : 1.0f;
+    if (ev_begin) (void)hipEventRecord(ev_begin, stream);
     if (s.kernel == 1) {
         // up to 128 output frames per launch (4 MFMA tiles); longer blocks go in slices
         for (uint32_t f0 = 0; f0 < nframes; f0 += 128) {
@@ -288,6 +299,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         hipLaunchKernelGGL(fir_exact_kernel, dim3(grid_for(total)), dim3(256), 0, stream, s.ring, s.taps64, out, s.N,
                            nframes, s.T, s.R, s.n_seen, divisor, lay);
     }
+    if (ev_end) (void)hipEventRecord(ev_end, stream);
     FIRCHK(hipGetLastError());
     s.n_seen += nframes;
     return 0;
