@@ -163,6 +163,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = load_package()
+    from dsp_stuff_amd import parallel as P
     cfg = dict(CONFIGS[args.config])
     for k in ("channels", "frames", "delay", "taps"):
         if getattr(args, k) is not None:
@@ -171,8 +172,9 @@ def main():
     use_mix = not args.no_mix
     chain = build_chain(pkg, cfg)
 
-    eng = pkg.Engine(N, B, link_flags=args.link_flags, device=local_rank, channel_offset=rank * N,
-                     tile_channels=args.tile)
+    shard = P.weak_shard(N, world, rank)      # weak scaling: N channels on every rank
+    eng = pkg.Engine(shard.channels, B, link_flags=args.link_flags, device=local_rank,
+                     channel_offset=shard.offset, tile_channels=args.tile)
     eng.set_chain(chain)
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -182,30 +184,18 @@ def main():
         eng.fill_noise(x, B, i * B, SEED, stream)
     y = torch.empty((B, N), dtype=torch.float32, device=dev)
     mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if use_mix else [None, None]
-    total_channels = N * world
-    pending = [None]
+    total_channels = shard.total_channels
+    # Output hop after the cross-GPU all-reduce; the collective of block k overlaps block k+1's kernel
+    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, stream), world=world)
 
     def step(k):
         m = mixes[k & 1]
         eng.process(xs[k % n_in], out=y, mix=m, n_frames=B, stream=stream)
         if use_mix:
-            if world > 1:
-                # overlap: the all-reduce of block k runs beside block k+1's chain kernel
-                work = dist.all_reduce(m, op=dist.ReduceOp.SUM, async_op=True)
-                if pending[0] is not None:
-                    pw, pm = pending[0]
-                    pw.wait()
-                    eng.mix_finish(pm, B, total_channels, stream)
-                pending[0] = (work, m)
-            else:
-                eng.mix_finish(m, B, total_channels, stream)
+            bus.submit(m)
 
     def drain():
-        if pending[0] is not None:
-            pw, pm = pending[0]
-            pw.wait()
-            eng.mix_finish(pm, B, total_channels, stream)
-            pending[0] = None
+        bus.drain()
 
     def fence():
         torch.cuda.synchronize()

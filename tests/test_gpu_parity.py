@@ -56,6 +56,22 @@ def noise_block(N, nf, seed=0x5EED0001, c0=0, n0=0):
     return O.noise(seed, np.arange(c0, c0 + N), np.arange(n0, n0 + nf))
 
 
+def test_golden_vectors(dspfx, torch_cuda):
+    """The HIP path against the committed golden vectors (tests/golden/), one channel replicated to 64."""
+    from golden_util import bar_for, load_all
+    for g in load_all():
+        chain = [dspfx.NodeSpec(d["kind"], d.get("params") or [], d.get("mode") or 0, d.get("delay_len") or 0,
+                                d.get("taps_reversed")) for d in g["descs"]]
+        x = np.repeat(g["x"][:, None], 64, axis=1)
+        y = run_gpu(dspfx, torch_cuda, chain, x, g["link_flags"])
+        assert np.array_equal(y, np.repeat(y[:, :1], 64, axis=1)), g["name"]      # channels are independent
+        bar = bar_for(g["name"])
+        if bar is None:
+            assert np.abs(y[:, 0] - g["y"]).max() <= 4e-6 * np.abs(g["y"]).max(), g["name"]
+        else:
+            assert ulp_diff(y[:, 0], g["y"]).max() <= bar, (g["name"], ulp_diff(y[:, 0], g["y"]).max())
+
+
 # ---------------------------------------------------------------- single nodes
 
 def test_gain_bit_exact(dspfx, torch_cuda):
