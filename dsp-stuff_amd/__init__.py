@@ -41,6 +41,7 @@ EXPORTS = [
     "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
+    "dspfx_process_partials", "dspfx_mix_collect",
 ]
 
 
@@ -98,6 +99,8 @@ def lib():
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_process_partials.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, vp]
+    L.dspfx_mix_collect.argtypes = [vp, f32p, C.c_uint32, vp]
     L.dspfx_state_size.restype = C.c_int64
     L.dspfx_state_size.argtypes = [vp, C.c_int]
     L.dspfx_state_export.argtypes = [vp, C.c_int, vp, C.c_size_t]
@@ -310,6 +313,20 @@ class Engine:
         self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames),
                                        C.c_void_p(stream) if stream else None))
         return out
+
+    def process_partials(self, x, out=None, side=None, n_frames: Optional[int] = None, stream: int = 0):
+        """Pipelined mix bus, part 1 (stream A): the chain, partial sums stay inside the engine."""
+        if n_frames is None:
+            n_frames = x.shape[0]
+        if out is None:
+            out = x
+        self._chk(self.L.dspfx_process_partials(self.h, _ptr(x), _ptr(side), _ptr(out), int(n_frames),
+                                                C.c_void_p(stream) if stream else None))
+        return out
+
+    def mix_collect(self, mix, n_frames: int, stream: int = 0):
+        """Pipelined mix bus, part 2 (stream B): wait for the chain kernel, reduce partials -> mix[n_frames]."""
+        self._chk(self.L.dspfx_mix_collect(self.h, _ptr(mix), int(n_frames), C.c_void_p(stream) if stream else None))
 
     def process_host(self, x: np.ndarray, side: Optional[np.ndarray] = None, want_mix: bool = False):
         """Host path (numpy in / numpy out): H2D, process, D2H."""

@@ -50,14 +50,20 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
     }
 }
 
-// Deterministic fixed-order sum of the per-wave partials of one frame.
+// Deterministic fixed-order sum of the per-wave partials of one frame: every lane sums a fixed
+// strided subset (4 independent accumulators keep the loads in flight), then a fixed LDS tree.
 __global__ void __launch_bounds__(WG) mix_reduce_kernel(const float *part, float *mix, unsigned stride) {
     __shared__ float sh[WG];
     const unsigned f = blockIdx.x;
     const float *row = part + (size_t)f * stride;
-    float acc = 0.0f;
-    for (unsigned i = threadIdx.x; i < stride; i += WG) acc = acc + row[i];
-    sh[threadIdx.x] = acc;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    unsigned i = threadIdx.x;
+    for (; i + 3 * WG < stride; i += 4 * WG) {
+        const float x0 = row[i], x1 = row[i + WG], x2 = row[i + 2 * WG], x3 = row[i + 3 * WG];
+        a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2; a3 = a3 + x3;
+    }
+    for (; i < stride; i += WG) a0 = a0 + row[i];
+    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     for (int o = WG / 2; o >= 1; o >>= 1) {
         if ((int)threadIdx.x < o) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + o];

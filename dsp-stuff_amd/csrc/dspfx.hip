@@ -59,6 +59,13 @@ struct dspfx_engine {
     float hop_div = 1.0f;
     float *mixpart = nullptr;
     size_t mixpart_cols = 0;
+    // pipelined mix bus (dspfx_process_partials / dspfx_mix_collect): double-buffered partials
+    float *mixpart2[2] = {nullptr, nullptr};
+    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
+    bool red_pending[2] = {false, false}, collect_due = false;
+    int flip = 0;
+    uint32_t part_stride[2] = {0, 0}, part_frames[2] = {0, 0};
+    float *partials_override = nullptr;   // set while a deferred-mix block is being launched
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
     const Variant *tail = nullptr, *dyn = nullptr;
@@ -377,7 +384,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         const Stage &st = e->stages[si];
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
-            if (st.count == 0 && !(last && mix) && src == out) continue;   // nothing to do
+            if (st.count == 0 && !(last && (mix || e->partials_override)) && src == out) continue;   // nothing to do
             ChainArgs a;
             memset(&a, 0, sizeof a);
             a.in = src;
@@ -404,7 +411,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             const uint32_t per_wave = 64u * v->cpl;
             const uint32_t n_main = N - N % per_wave;
             const uint32_t waves_main = n_main / per_wave;
-            a.mixpart = (last && mix) ? e->mixpart : nullptr;
+            const bool deferred = last && e->partials_override != nullptr;
+            a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
             a.mix_stride = waves_main + (N - n_main + 63) / 64;
             if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
             if (n_main) {
@@ -423,7 +431,10 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 e->tail->launch(a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
             }
             HIPCHK(e, hipGetLastError());
-            if (a.mixpart) {
+            if (deferred) {
+                e->part_stride[e->flip] = a.mix_stride;
+                e->part_frames[e->flip] = nframes;
+            } else if (a.mixpart) {
                 launch_mix_reduce(e->mixpart, mix, nframes, a.mix_stride, stream);
                 HIPCHK(e, hipGetLastError());
             }
@@ -561,6 +572,11 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     (void)hipSetDevice(e->device);
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
+    for (int i = 0; i < 2; ++i) {
+        if (e->mixpart2[i]) (void)hipFree(e->mixpart2[i]);
+        if (e->ev_chain[i]) (void)hipEventDestroy(e->ev_chain[i]);
+        if (e->ev_red[i]) (void)hipEventDestroy(e->ev_red[i]);
+    }
     if (e->h_in) (void)hipFree(e->h_in);
     if (e->h_side) (void)hipFree(e->h_side);
     if (e->h_out) (void)hipFree(e->h_out);
@@ -719,6 +735,52 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
     HIPCHK(e, hipStreamSynchronize(nullptr));
     HIPCHK(e, hipMemcpy(out, e->h_out, bytes, hipMemcpyDeviceToHost));
     if (mix) HIPCHK(e, hipMemcpy(mix, e->h_mix, n_frames * sizeof(float), hipMemcpyDeviceToHost));
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, float *out,
+                                      uint32_t n_frames, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (e->collect_due) return fail(e, DSPFX_ERR_STATE, "dspfx_mix_collect must follow dspfx_process_partials");
+    if (n_frames == 0 || n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "bad n_frames %u", n_frames);
+    if (n_frames > e->min_delay)
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "deferred mix needs n_frames <= shortest delay line (%u)", e->min_delay);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const int b = e->flip;
+    if (!e->mixpart2[b]) {
+        HIPCHK(e, hipMalloc((void **)&e->mixpart2[b], e->mixpart_cols * e->desc.max_frames * sizeof(float)));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_chain[b], hipEventDisableTiming));
+        HIPCHK(e, hipEventCreateWithFlags(&e->ev_red[b], hipEventDisableTiming));
+    }
+    if (e->red_pending[b]) {   // the collect that read this buffer two blocks ago must be done
+        if (hipEventQuery(e->ev_red[b]) != hipSuccess)      // normally long finished: no packet needed
+            HIPCHK(e, hipStreamWaitEvent(s, e->ev_red[b], 0));
+        e->red_pending[b] = false;
+    }
+    e->partials_override = e->mixpart2[b];
+    const int rc = dspfx_process(e, in, side, out, nullptr, n_frames, stream);
+    e->partials_override = nullptr;
+    if (rc) return rc;
+    HIPCHK(e, hipEventRecord(e->ev_chain[b], s));
+    e->collect_due = true;
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stream) {
+    if (!e || !mix) return DSPFX_ERR_INVALID;
+    if (!e->collect_due) return fail(e, DSPFX_ERR_STATE, "no partials pending: call dspfx_process_partials first");
+    const int b = e->flip;
+    if (n_frames != e->part_frames[b]) return fail(e, DSPFX_ERR_INVALID, "n_frames %u != %u of the pending block", n_frames, e->part_frames[b]);
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(e, hipStreamWaitEvent(s, e->ev_chain[b], 0));
+    launch_mix_reduce(e->mixpart2[b], mix, n_frames, e->part_stride[b], s);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipEventRecord(e->ev_red[b], s));
+    e->red_pending[b] = true;
+    e->collect_due = false;
+    e->flip ^= 1;
     return DSPFX_OK;
 }
 

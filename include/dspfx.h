@@ -187,6 +187,17 @@ int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *ou
  * H2D copy, process, D2H copy, synchronous. */
 int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                        uint32_t n_frames);
+/* Pipelined mix bus.  dspfx_process(mix != NULL) runs the second reduction stage on the same
+ * stream, i.e. on the critical path of the next block.  The split form takes it off that path:
+ *   dspfx_process_partials(stream A): the chain, leaving per-wavefront partial sums in one of two
+ *       engine-owned buffers (n_frames must not exceed the shortest delay line);
+ *   dspfx_mix_collect(stream B): B waits for that chain kernel, reduces the partials into
+ *       mix[n_frames] in fixed order.  The next block's chain kernel on A does not wait for it
+ *       (it only waits, two blocks later, before reusing the same partial buffer).
+ * Every dspfx_process_partials must be followed by exactly one dspfx_mix_collect. */
+int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, float *out,
+                           uint32_t n_frames, void *stream);
+int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stream);
 /* Output-node hop of the mix bus (node.rs:189-191): mix[f] /= link_divisor(n_connected),
  * in place on the device; call after the cross-GPU all-reduce with the GLOBAL channel count. */
 int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream);

@@ -345,6 +345,34 @@ def test_mix_bus_and_finish(dspfx, torch_cuda):
     assert np.array_equal(dm.cpu().numpy(), (mix / O.link_divisor(N)).astype(F))
 
 
+def test_pipelined_mix_bus_matches_inline(dspfx, torch_cuda):
+    """process_partials + mix_collect on a second stream == process(mix=...) bit for bit."""
+    N, B, blocks = 2048 + 64, 128, 6
+    ch = chain5(dspfx, delay=256)
+    x = noise_block(N, B * blocks)
+    y_ref, mix_ref = run_gpu(dspfx, torch_cuda, ch, x, 3, want_mix=True)
+    eng = dspfx.Engine(N, B)
+    eng.set_chain(ch)
+    dx = torch_cuda.from_numpy(x).cuda()
+    dy = torch_cuda.empty_like(dx)
+    dm = torch_cuda.zeros(B * blocks, dtype=torch_cuda.float32, device="cuda")
+    side = torch_cuda.cuda.Stream()
+    a = torch_cuda.cuda.current_stream().cuda_stream
+    for b in range(blocks):
+        eng.process_partials(dx[b * B:(b + 1) * B], out=dy[b * B:(b + 1) * B], n_frames=B, stream=a)
+        eng.mix_collect(dm[b * B:(b + 1) * B], B, stream=side.cuda_stream)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), y_ref)
+    assert np.array_equal(dm.cpu().numpy().view(np.uint32), mix_ref.view(np.uint32))
+    # protocol errors are reported, not UB
+    eng.process_partials(dx[:B], out=dy[:B], n_frames=B)
+    with pytest.raises(dspfx.DspfxError):
+        eng.process_partials(dx[:B], out=dy[:B], n_frames=B)
+    eng.mix_collect(dm[:B], B)
+    with pytest.raises(dspfx.DspfxError):
+        eng.mix_collect(dm[:B], B)
+
+
 def test_process_host_path(dspfx, torch_cuda):
     ch = chain3(dspfx, delay=128)
     x = noise_block(96, 128)
