@@ -158,8 +158,12 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
+    # exercised on a 1-GPU box (the driver launches the real N>1 runs with torch.distributed.run)
+    use_dist = world > 1 or os.environ.get("DSPFX_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = load_package()
@@ -190,7 +194,8 @@ def main():
     # on a second stream, so block k's mix bus overlaps block k+1's chain kernel
     mix_stream = torch.cuda.Stream(device=dev)
     ms = mix_stream.cuda_stream
-    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=world)
+    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms),
+                   world=2 if (use_dist and world == 1) else world)   # forced-dist: take the collective path
 
     def step(k):
         if not use_mix:
@@ -208,7 +213,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -247,7 +252,7 @@ def main():
         kern_ms_total, kern_launches, kern_name = eng.profile_read()
         kern_method = "HIP events around every launch of the dominant stage"
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -281,7 +286,7 @@ def main():
             pass
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -309,7 +314,7 @@ def main():
             line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                     "sample": f"failed: {ex}"}
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

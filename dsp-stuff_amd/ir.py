@@ -1,0 +1,88 @@
+"""Impulse-response loading for the Fir node (the step before the FIR kernel).
+
+Follows nodes/fir.rs:86-173: decode the file to f64 samples, average the channels of every
+frame (`s.iter().sum::<f64>() / num_channels as f64`, fir.rs:140-144); the reversal
+(fir.rs:163,168) happens in `Fir(...)` / `dspfx_set_taps`.  The reference decodes through
+symphonia and sinc-resamples to 48 kHz through dasp when the file has another rate
+(fir.rs:153-171); neither crate is in the reference tree, so this reader handles RIFF/WAVE PCM
+(8/16/24/32-bit integer, 32/64-bit float) and REFUSES other sample rates instead of guessing
+the resampler.  Integer samples are scaled like symphonia's SampleBuffer<f64> conversion
+(u8: (x-128)/128, i16: /2^15, i24: /2^23, i32: /2^31).
+"""
+from __future__ import annotations
+
+import struct
+
+import numpy as np
+
+
+class IrError(ValueError):
+    pass
+
+
+def read_wav(path: str):
+    """-> (frames [n][channels] float64, sample_rate)"""
+    with open(path, "rb") as f:
+        data = f.read()
+    if len(data) < 12 or data[:4] != b"RIFF" or data[8:12] != b"WAVE":
+        raise IrError("not a RIFF/WAVE file")
+    pos, fmt, pcm = 12, None, None
+    while pos + 8 <= len(data):
+        cid, size = data[pos:pos + 4], struct.unpack("<I", data[pos + 4:pos + 8])[0]
+        body = data[pos + 8:pos + 8 + size]
+        if cid == b"fmt ":
+            if size < 16:
+                raise IrError("short fmt chunk")
+            tag, ch, rate, _, _, bits = struct.unpack("<HHIIHH", body[:16])
+            if tag == 0xFFFE and size >= 26:          # WAVE_FORMAT_EXTENSIBLE: sub-format GUID's first word
+                tag = struct.unpack("<H", body[24:26])[0]
+            fmt = (tag, ch, rate, bits)
+        elif cid == b"data":
+            pcm = body
+        pos += 8 + size + (size & 1)
+    if fmt is None or pcm is None:
+        raise IrError("missing fmt or data chunk")
+    tag, ch, rate, bits = fmt
+    if ch < 1:
+        raise IrError("no channels")
+    if tag == 1:     # integer PCM
+        if bits == 8:
+            x = (np.frombuffer(pcm, np.uint8).astype(np.float64) - 128.0) / 128.0
+        elif bits == 16:
+            x = np.frombuffer(pcm[:len(pcm) // 2 * 2], "<i2").astype(np.float64) / 32768.0
+        elif bits == 24:
+            b = np.frombuffer(pcm[:len(pcm) // 3 * 3], np.uint8).reshape(-1, 3).astype(np.int32)
+            v = b[:, 0] | (b[:, 1] << 8) | (b[:, 2] << 16)
+            v = np.where(v & 0x800000, v - 0x1000000, v)
+            x = v.astype(np.float64) / 8388608.0
+        elif bits == 32:
+            x = np.frombuffer(pcm[:len(pcm) // 4 * 4], "<i4").astype(np.float64) / 2147483648.0
+        else:
+            raise IrError(f"unsupported PCM width {bits}")
+    elif tag == 3:   # IEEE float
+        if bits == 32:
+            x = np.frombuffer(pcm[:len(pcm) // 4 * 4], "<f4").astype(np.float64)
+        elif bits == 64:
+            x = np.frombuffer(pcm[:len(pcm) // 8 * 8], "<f8").astype(np.float64)
+        else:
+            raise IrError(f"unsupported float width {bits}")
+    else:
+        raise IrError(f"unsupported WAVE format tag {tag}")
+    n = len(x) // ch
+    return x[:n * ch].reshape(n, ch), rate
+
+
+def load_impulse_response(path: str) -> np.ndarray:
+    """h[0..T) in natural order, f64: channels averaged like fir.rs:140-144; 48 kHz only."""
+    frames, rate = read_wav(path)
+    if rate != 48000:
+        raise IrError(f"{rate} Hz impulse response: the reference resamples with dasp's 16-tap sinc "
+                      "(fir.rs:153-171), which is not restated here; convert the file to 48 kHz")
+    if len(frames) == 0:
+        raise IrError("empty impulse response")
+    ch = frames.shape[1]
+    # sequential f64 sum of the frame's channels, then one division (Iterator::sum order)
+    acc = np.zeros(len(frames), np.float64)
+    for c in range(ch):
+        acc = acc + frames[:, c]
+    return acc / float(ch)
