@@ -41,7 +41,7 @@ EXPORTS = [
     "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
-    "dspfx_process_partials", "dspfx_mix_collect",
+    "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
 ]
 
 
@@ -60,6 +60,10 @@ class _EngineDesc(C.Structure):
 class _NodeDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("mode", C.c_int32), ("params", C.c_float * 8),
                 ("delay_len", C.c_uint32), ("n_taps", C.c_uint32), ("taps", C.POINTER(C.c_double))]
+
+
+class _Ctl(C.Structure):
+    _fields_ = [("node", C.c_int32), ("param", C.c_int32), ("signal", C.c_void_p)]
 
 
 _lib = None
@@ -99,6 +103,7 @@ def lib():
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_process_ctl.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, C.POINTER(_Ctl), C.c_int, vp]
     L.dspfx_process_partials.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_mix_collect.argtypes = [vp, f32p, C.c_uint32, vp]
     L.dspfx_state_size.restype = C.c_int64
@@ -304,14 +309,22 @@ class Engine:
     def reset(self):
         self._chk(self.L.dspfx_reset(self.h))
 
-    def process(self, x, out=None, side=None, mix=None, n_frames: Optional[int] = None, stream: int = 0):
-        """Device path: x/out/side are [n_frames][channels] f32 device tensors (or raw pointers)."""
+    def process(self, x, out=None, side=None, mix=None, n_frames: Optional[int] = None, stream: int = 0, ctl=None):
+        """Device path: x/out/side are [n_frames][channels] f32 device tensors (or raw pointers).
+        ctl: {(node, slider): device tensor} = connected `as_input` control ports for this block."""
         if n_frames is None:
             n_frames = x.shape[0]
         if out is None:
             out = x
-        self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames),
-                                       C.c_void_p(stream) if stream else None))
+        st = C.c_void_p(stream) if stream else None
+        if ctl:
+            arr = (_Ctl * len(ctl))()
+            for i, ((node, param), sig) in enumerate(ctl.items()):
+                arr[i].node, arr[i].param, arr[i].signal = int(node), int(param), _ptr(sig).value
+            self._chk(self.L.dspfx_process_ctl(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames),
+                                               arr, len(ctl), st))
+        else:
+            self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames), st))
         return out
 
     def process_partials(self, x, out=None, side=None, n_frames: Optional[int] = None, stream: int = 0):

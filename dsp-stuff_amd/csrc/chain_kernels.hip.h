@@ -45,6 +45,11 @@ struct SlotArgs {
     int hop;     // apply collect_and_average (one pipe) to this node's input
     int pad_;
     double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
+    // control ports (`as_input` sliders, dsp-stuff-derive/src/lib.rs:122-161), slider field order:
+    const float *ctl[3];   // connected port: signal in the sample layout, else nullptr
+    float *latch[3];       // per-channel latched slider value [N] (lib.rs:148), or nullptr
+    int latch_valid;       // bit k: slider k currently holds per-channel latched values
+    int pad2_;
 };
 
 struct ChainArgs {
@@ -272,7 +277,7 @@ struct Ctx {
     double hop_rc;
     double third_rc;
     const float *side;
-    int side_hop;
+    int side_hop;      // also the hop flag of control links (both are "internal" links)
     bool active;     // false only for padding lanes of the guarded tail launch
 };
 
@@ -379,6 +384,109 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
     }
 }
 
+// ---- control ports ----------------------------------------------------------------------
+// Per-sample value of slider k (dsp-stuff-derive/src/lib.rs:135-153): a connected port maps the
+// signal [-1,1] -> [lo,hi] per sample and latches the first value of every 128-frame block into
+// the slider (per channel here); an unconnected port fills with the slider value.
+template <int F, int CPL, bool GUARD, bool FAST>
+__device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo, float hi, const Ctx &cx,
+                                              float (&p)[F][CPL]) {
+    if (s.ctl[k]) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            load_vec<CPL, GUARD, S_IN>(s.ctl[k] + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, p[f], cx.active);
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                float x = p[f][j];
+                if (cx.side_hop) x = link_hop<FAST>(x, cx.hop_div, cx.hop_rc);   // the control link's collect_and_average
+                const float y = (x + 1.0f) / 2.0f;
+                float z = y < 0.0f ? 0.0f : y;          // f32::clamp(0.0, 1.0): NaN stays NaN
+                z = z > 1.0f ? 1.0f : z;
+                p[f][j] = lo + (hi - lo) * z;
+            }
+        }
+        if ((cx.f0 & 127u) == 0) store_vec<CPL, GUARD>(s.latch[k] + cx.c, p[0], cx.active);   // lib.rs:148
+    } else if (s.latch_valid & (1 << k)) {
+        float l[CPL];
+        load_vec<CPL, GUARD>(s.latch[k] + cx.c, l, cx.active);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) p[f][j] = l[j];
+    } else {
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) p[f][j] = s.p[k];
+    }
+}
+
+// Nodes with `as_input` sliders, evaluated with per-sample slider values (IEEE division: the
+// divisor is no longer a wave-uniform constant).
+template <int KIND, int MODE, int F, int CPL, bool GUARD, bool FAST>
+__device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][CPL], const Ctx &cx) {
+    if constexpr (KIND == K_GAIN) {                 // gain.rs:27-37, slider 0..=10
+        float lv[F][CPL];
+        slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 10.0f, cx, lv);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] * lv[f][j];
+    } else if constexpr (KIND == K_DISTORT) {       // distort.rs:176-194, slider 0..=30
+        float lv[F][CPL];
+        slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 30.0f, cx, lv);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                if (!(lv[f][j] < 0.001f)) v[f][j] = distort1<MODE, false>(v[f][j], lv[f][j], 0.0, 0.0);
+    } else if constexpr (KIND == K_OVERDRIVE) {     // overdrive.rs:58-72, sliders boost 0..=30, drive 0..=1, level 0..=1
+        float bo[F][CPL], dr[F][CPL], lv[F][CPL];
+        slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 30.0f, cx, bo);
+        slider_values<F, CPL, GUARD, FAST>(s, 1, 0.0f, 1.0f, cx, dr);
+        slider_values<F, CPL, GUARD, FAST>(s, 2, 0.0f, 1.0f, cx, lv);
+#pragma unroll
+        for (int f = 0; f < F; ++f)
+#pragma unroll
+            for (int j = 0; j < CPL; ++j)
+                if (!(lv[f][j] < 0.001f)) v[f][j] = overdrive1(v[f][j], bo[f][j], dr[f][j], lv[f][j]);
+    } else if constexpr (KIND == K_MIX) {           // mix.rs:33-46, slider 0..=1
+        float ra[F][CPL];
+        slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 1.0f, cx, ra);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            float b[CPL];
+            if (cx.side) {
+                load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
+                if (cx.side_hop) {
+#pragma unroll
+                    for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) b[j] = 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = (b[j] * ra[f][j]) + (v[f][j] * (1.0f - ra[f][j]));
+        }
+    }
+}
+
+template <int F, int CPL, bool GUARD, bool FAST>
+__device__ __forceinline__ void apply_distort_mod_dyn(const SlotArgs &s, float (&v)[F][CPL], const Ctx &cx) {
+    switch (s.mode) {
+    case D_HARD_CLIP: apply_node_mod<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_SOFT_CLIP: apply_node_mod<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_TANH: apply_node_mod<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_RECIP_SOFT_CLIP: apply_node_mod<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_SIN: apply_node_mod<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_ATAN: apply_node_mod<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_SQUARE: apply_node_mod<K_DISTORT, D_SQUARE, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_CHEBYSHEV4: apply_node_mod<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD, FAST>(s, v, cx); break;
+    default: break;
+    }
+}
+
 template <int F, int CPL, bool FAST>
 __device__ __forceinline__ void apply_hop(float (&v)[F][CPL], float div, double rc) {
 #pragma unroll
@@ -412,6 +520,15 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         return;
     } else if constexpr (SIG == SIG_DYN) {
         if (s.hop) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
+        if (s.ctl[0] || s.ctl[1] || s.ctl[2] || s.latch_valid) {   // modulated / latched sliders
+            switch (s.kind) {
+            case K_GAIN: apply_node_mod<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
+            case K_DISTORT: apply_distort_mod_dyn<F, CPL, GUARD, FAST>(s, v, cx); return;
+            case K_OVERDRIVE: apply_node_mod<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
+            case K_MIX: apply_node_mod<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
+            default: break;
+            }
+        }
         switch (s.kind) {
         case K_GAIN: apply_node<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_BIQUAD: apply_node<K_BIQUAD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;

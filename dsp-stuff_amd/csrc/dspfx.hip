@@ -39,6 +39,10 @@ struct Node {
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;
+    // control ports: per-channel latched slider values (derive lib.rs:148)
+    float *latch[3] = {nullptr, nullptr, nullptr};
+    int latch_valid = 0;
+    const float *ctl_now[3] = {nullptr, nullptr, nullptr};   // signals of the call being launched
 };
 
 struct Stage {
@@ -66,6 +70,7 @@ struct dspfx_engine {
     int flip = 0;
     uint32_t part_stride[2] = {0, 0}, part_frames[2] = {0, 0};
     float *partials_override = nullptr;   // set while a deferred-mix block is being launched
+    uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
     const Variant *tail = nullptr, *dyn = nullptr;
@@ -190,6 +195,11 @@ void free_node(Node &n) {
     n.state = nullptr;
     n.state_bytes = 0;
     fir_free(n.fir);
+    for (int k = 0; k < 3; ++k) {
+        if (n.latch[k]) (void)hipFree(n.latch[k]);
+        n.latch[k] = nullptr;
+    }
+    n.latch_valid = 0;
 }
 
 void collect_variants(std::vector<const Variant *> &out) {
@@ -349,6 +359,11 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.pos = n.pos;
     s.hop = node_hop(e, idx);
     s.rc = n.d.kind == DSPFX_DISTORT ? 1.0 / (double)n.d.params[0] : 0.0;
+    for (int k = 0; k < 3; ++k) {
+        s.ctl[k] = n.ctl_now[k];
+        s.latch[k] = n.latch[k];
+    }
+    s.latch_valid = n.latch_valid;
     switch (n.d.kind) {
     case DSPFX_BIQUAD:
         s.p[0] = n.a1; s.p[1] = n.a2; s.p[2] = n.b0; s.p[3] = n.b1; s.p[4] = n.b2;
@@ -408,6 +423,10 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 rows += state_rows(e->nodes[st.first + k]);
             }
             const Variant *v = st.var;
+            for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the interpreter evaluates them
+                const Node &nd = e->nodes[st.first + k];
+                if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) v = e->dyn;
+            }
             const uint32_t per_wave = 64u * v->cpl;
             const uint32_t n_main = N - N % per_wave;
             const uint32_t waves_main = n_main / per_wave;
@@ -458,6 +477,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         }
         src = out;
     }
+    for (Node &n : e->nodes)   // a connected control port leaves per-channel latched values behind
+        for (int k = 0; k < 3; ++k)
+            if (n.ctl_now[k]) n.latch_valid |= 1 << k;
     // advance the delay rings (FIFO: the block's rows now hold the newest samples)
     for (Node &n : e->nodes)
         if (n.d.kind == DSPFX_REVERB) n.pos = (uint32_t)(((uint64_t)n.pos + nframes) % n.D);
@@ -625,6 +647,7 @@ extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value
         return fail(e, DSPFX_ERR_INVALID, "set_param(%d,%d) out of range", node, param);
     Node &n = e->nodes[(size_t)node];
     n.d.params[param] = value;
+    if (param < 3) n.latch_valid &= ~(1 << param);   // a slider store overwrites the latched values
     if (n.d.kind == DSPFX_BIQUAD) {   // after_settings_change: renormalise + reset_state (biquad.rs:62-76)
         biquad_regenerate(n);
         HIPCHK(e, hipSetDevice(e->device));
@@ -708,10 +731,56 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
         // frame f0 of a block starts f0 rows in: a row is N floats (frame-major) or W floats (tiled)
         const size_t off = (size_t)f0 * (e->desc.tile_channels ? e->desc.tile_channels : N);
         const int rc = run_subblock(e, in + off, side ? side + off : nullptr, out + off, mix ? mix + f0 : nullptr,
-                                    nf, n_frames, s);
+                                    nf, e->ctl_tile_frames ? e->ctl_tile_frames : n_frames, s);
         if (rc) return rc;
     }
     return DSPFX_OK;
+}
+
+extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                                 uint32_t n_frames, const dspfx_ctl *ctl, int n_ctl, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (n_ctl < 0 || (n_ctl > 0 && !ctl)) return fail(e, DSPFX_ERR_INVALID, "bad control-port list");
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int i = 0; i < n_ctl; ++i) {
+        const dspfx_ctl &c = ctl[i];
+        if (c.node < 0 || c.node >= (int)e->nodes.size() || !c.signal)
+            return fail(e, DSPFX_ERR_INVALID, "control port %d: bad node or null signal", i);
+        Node &n = e->nodes[(size_t)c.node];
+        int n_sliders = 0;
+        switch (n.d.kind) {
+        case DSPFX_GAIN: n_sliders = 1; break;
+        case DSPFX_DISTORT: n_sliders = n.d.mode == DSPFX_DIST_FUZZ ? 0 : 1; break;
+        case DSPFX_OVERDRIVE: n_sliders = 3; break;
+        case DSPFX_MIX: n_sliders = 1; break;
+        default: break;
+        }
+        if (c.param < 0 || c.param >= n_sliders)
+            return fail(e, n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ ? DSPFX_ERR_UNSUPPORTED : DSPFX_ERR_INVALID,
+                        "node %d has no `as_input` slider %d", c.node, c.param);
+        if (!n.latch[c.param]) HIPCHK(e, hipMalloc((void **)&n.latch[c.param], (size_t)e->desc.channels * sizeof(float)));
+    }
+    // split like dspfx_process does, offsetting the control signals with the samples
+    const size_t N = e->desc.channels;
+    const size_t rowlen = e->desc.tile_channels ? e->desc.tile_channels : N;
+    if (n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
+    if (e->desc.tile_channels && n_frames > e->min_delay && n_ctl)
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "control ports with n_frames > shortest delay need the frame-major layout");
+    uint32_t sub = std::min(n_frames, e->min_delay);
+    if (e->has_fuzz) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
+    int rc = DSPFX_OK;
+    for (uint32_t f0 = 0; f0 < n_frames && rc == DSPFX_OK; f0 += sub) {
+        const uint32_t nf = std::min(sub, n_frames - f0);
+        const size_t off = (size_t)f0 * rowlen;
+        for (int i = 0; i < n_ctl; ++i) e->nodes[(size_t)ctl[i].node].ctl_now[ctl[i].param] = ctl[i].signal + off;
+        // one sub-block == one dspfx_process call of nf frames on offset pointers (tile stride stays n_frames)
+        e->ctl_tile_frames = n_frames;
+        rc = dspfx_process(e, in + off, side ? side + off : nullptr, out + off, mix ? mix + f0 : nullptr, nf, stream);
+        e->ctl_tile_frames = 0;
+    }
+    for (Node &n : e->nodes)
+        for (int k = 0; k < 3; ++k) n.ctl_now[k] = nullptr;
+    return rc;
 }
 
 extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,

@@ -183,6 +183,19 @@ int dspfx_reset(dspfx_engine *e);
  * block-global over BUF_SIZE, distort.rs:146-172). */
 int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                   uint32_t n_frames, void *stream);
+/* One connected control port (`as_input` slider, dsp-stuff-derive/src/lib.rs:122-161): `param` is
+ * the slider's index in dspfx_node_desc.params (GAIN level 0; DISTORT level 0; OVERDRIVE boost 0,
+ * drive 1, level 2; MIX ratio 0); `signal` is a device buffer in the sample layout.  Per sample the
+ * slider takes lo + (hi-lo)*clamp((x+1)/2, 0, 1) over its reference range; the first value of each
+ * 128-frame block is latched per channel and keeps applying once the port is disconnected
+ * (lib.rs:148-151) until dspfx_set_param overwrites it.  DISTORT/Fuzz does not take a control port. */
+typedef struct dspfx_ctl {
+    int32_t node;
+    int32_t param;
+    const float *signal;
+} dspfx_ctl;
+int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                      uint32_t n_frames, const dspfx_ctl *ctl, int n_ctl, void *stream);
 /* Same with HOST buffers (what a Rust `process(&[f32], &mut [f32])` holds):
  * H2D copy, process, D2H copy, synchronous. */
 int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,

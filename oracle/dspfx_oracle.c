@@ -515,7 +515,13 @@ void orc_node_process(orc_node *n, const float *in_a, const float *in_b,
 
 void orc_chain_run(orc_node **nodes, int n_nodes, int link_flags, const float *in,
                    const float *side, float *out, size_t n_frames, size_t block) {
+    orc_chain_run_ctl(nodes, n_nodes, link_flags, in, side, NULL, out, n_frames, block);
+}
+
+void orc_chain_run_ctl(orc_node **nodes, int n_nodes, int link_flags, const float *in, const float *side,
+                       const float *const *ctl, float *out, size_t n_frames, size_t block) {
     float cur[ORC_BUF_SIZE], port_a[ORC_BUF_SIZE], port_b[ORC_BUF_SIZE], obuf[ORC_BUF_SIZE];
+    float port_c[3][ORC_BUF_SIZE];
     if (block == 0 || block > ORC_BUF_SIZE) block = ORC_BUF_SIZE;
     for (size_t f0 = 0; f0 < n_frames; f0 += block) {
         size_t nf = n_frames - f0 < block ? n_frames - f0 : block;
@@ -539,8 +545,22 @@ void orc_chain_run(orc_node **nodes, int n_nodes, int link_flags, const float *i
                     pb = port_b;
                 }
             }
+            const float *cp[3] = {NULL, NULL, NULL};
+            if (ctl) {
+                for (int j = 0; j < 3; j++) {
+                    const float *sig = ctl[3 * k + j];
+                    if (!sig) continue;
+                    cp[j] = sig + f0;
+                    if (link_flags & 1) { /* a control link is averaged like any other port (node.rs:290-299) */
+                        const float *ins[1] = {sig + f0};
+                        memset(port_c[j], 0, sizeof(float) * nf);
+                        orc_collect_and_average(port_c[j], ins, 1, nf);
+                        cp[j] = port_c[j];
+                    }
+                }
+            }
             memset(obuf, 0, sizeof(float) * nf); /* node.rs:272 */
-            orc_node_process(nodes[k], pa, pb, NULL, obuf, nf);
+            orc_node_process(nodes[k], pa, pb, ctl ? cp : NULL, obuf, nf);
             memcpy(cur, obuf, sizeof(float) * nf); /* node.rs:321-325 fan-out copy */
         }
         memcpy(out + f0, cur, sizeof(float) * nf);

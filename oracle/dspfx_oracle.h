@@ -151,6 +151,12 @@ void orc_node_process(orc_node *n, const float *in_a, const float *in_b,
 void orc_chain_run(orc_node **nodes, int n_nodes, int link_scale, const float *in,
                    const float *side, float *out, size_t n_frames, size_t block);
 
+/* Same with control ports: ctl[3*k + j] is the signal feeding the j-th `as_input` slider port of
+ * node k (field order; NULL = unconnected), n_frames long.  A connected control port is a link like
+ * any other: its value passes collect_and_average when link_flags has bit0. */
+void orc_chain_run_ctl(orc_node **nodes, int n_nodes, int link_flags, const float *in, const float *side,
+                       const float *const *ctl, float *out, size_t n_frames, size_t block);
+
 /* ---- synthetic input --------------------------------------------------- */
 /* x[c,n] = (float)(h>>8) * 2^-23 - 1, h = fmix32(seed ^ c*0x9E3779B9 ^ n*0x85EBCA6B) */
 float orc_noise(uint32_t seed, uint32_t channel, uint32_t n_abs);

@@ -71,6 +71,7 @@ def _bind(L):
     L.orc_slider_input.argtypes = [f32p, f32p, C.c_float, C.c_float, f32p, C.c_size_t]
     L.orc_node_process.argtypes = [vp, f32p, f32p, C.POINTER(f32p), f32p, C.c_size_t]
     L.orc_chain_run.argtypes = [C.POINTER(vp), C.c_int, C.c_int, f32p, f32p, f32p, C.c_size_t, C.c_size_t]
+    L.orc_chain_run_ctl.argtypes = [C.POINTER(vp), C.c_int, C.c_int, f32p, f32p, C.POINTER(f32p), f32p, C.c_size_t, C.c_size_t]
     L.orc_noise.restype = C.c_float
     L.orc_noise.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.orc_run_noise_channels.restype = C.c_int
@@ -141,25 +142,44 @@ def node_from_desc(d: dict, _lib=None) -> Node:
                 d.get("taps_reversed"), _lib=_lib)
 
 
-def chain_run(nodes, x, link_flags=LINK_INTERNAL | LINK_INPUT, side=None, block=BUF_SIZE):
-    """Run one channel through the chain (state is carried in `nodes`)."""
+def chain_run(nodes, x, link_flags=LINK_INTERNAL | LINK_INPUT, side=None, block=BUF_SIZE, ctl=None):
+    """Run one channel through the chain (state is carried in `nodes`).
+    ctl: {(node_index, slider_index): signal} for connected `as_input` control ports."""
     L = nodes[0].L if nodes else lib()
     x = np.ascontiguousarray(x, dtype=np.float32)
     out = np.empty_like(x)
     hs = (C.c_void_p * len(nodes))(*[n.h for n in nodes])
     s = np.ascontiguousarray(side, dtype=np.float32) if side is not None else None
-    L.orc_chain_run(hs, len(nodes), int(link_flags), _f32p(x), _f32p(s), _f32p(out), x.size, block)
+    if ctl:
+        arr = (C.POINTER(C.c_float) * (3 * len(nodes)))()
+        keep = []
+        for (k, j), sig in ctl.items():
+            sig = np.ascontiguousarray(sig, dtype=np.float32)
+            assert sig.size == x.size
+            keep.append(sig)
+            arr[3 * k + j] = _f32p(sig)
+        L.orc_chain_run_ctl(hs, len(nodes), int(link_flags), _f32p(x), _f32p(s), arr, _f32p(out), x.size, block)
+    else:
+        L.orc_chain_run(hs, len(nodes), int(link_flags), _f32p(x), _f32p(s), _f32p(out), x.size, block)
     return out
 
 
-def run_channels(descs, x, link_flags=LINK_INTERNAL | LINK_INPUT, side=None, block=BUF_SIZE):
-    """x: [n_frames][n_channels] frame-major; fresh state per channel."""
+def run_channels(descs, x, link_flags=LINK_INTERNAL | LINK_INPUT, side=None, block=BUF_SIZE, ctl=None, nodes_out=None):
+    """x: [n_frames][n_channels] frame-major; fresh state per channel (or the per-channel node lists
+    in `nodes_out`, which are created on first use and carry state across calls).
+    ctl: {(node, slider): [n_frames][n_channels]}."""
     x = np.asarray(x, dtype=np.float32)
     out = np.empty_like(x)
     for c in range(x.shape[1]):
-        nodes = [node_from_desc(d) for d in descs]
+        if nodes_out is not None:
+            if len(nodes_out) <= c:
+                nodes_out.append([node_from_desc(d) for d in descs])
+            nodes = nodes_out[c]
+        else:
+            nodes = [node_from_desc(d) for d in descs]
         s = side[:, c] if side is not None else None
-        out[:, c] = chain_run(nodes, x[:, c], link_flags, s, block)
+        cc = {k: v[:, c] for k, v in ctl.items()} if ctl else None
+        out[:, c] = chain_run(nodes, x[:, c], link_flags, s, block, cc)
     return out
 
 
