@@ -1,0 +1,157 @@
+"""Parity at BASELINE.json's full sizes (configs 2-5), through checks whose cost does not grow
+with the channel count: the synthetic input is an integer hash of (channel, sample index), so any
+sampled channel can be regenerated and pushed through the oracle without shipping GiBs; plus
+size-independent properties (checksum of the fused mix bus against an independent device-side sum,
+exact linearity under power-of-two scaling, the delay line's impulse response)."""
+import numpy as np
+import pytest
+
+import oracle as O
+from chains import chain3, chain5, fir_taps, ulp_diff
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+SEED = 0x5EED0001
+
+
+@pytest.fixture(scope="module")
+def tc():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def sample_channels(N, W=256):
+    """First/last channel, wave/workgroup/tile edges, and a few in the middle."""
+    c = {0, 1, 63, 64, 127, 128, W - 1, W, 2 * W - 1, N // 2 - 1, N // 2, N - W, N - 65, N - 64, N - 2, N - 1, 12345 % N, 777777 % N}
+    return sorted(x for x in c if 0 <= x < N)
+
+
+def oracle_channels(chain, chans, n_blocks, link_flags=3):
+    descs = [n.oracle_desc() for n in chain]
+    out = np.empty((n_blocks * 128, len(chans)), F)
+    for i, c in enumerate(chans):
+        y, _ = O.run_noise_channels(descs, SEED, c, 1, 0, n_blocks, link_flags=link_flags)
+        out[:, i] = y[:, 0]
+    return out
+
+
+def gather(dspfx, t, chans, n_frames, N, tile):
+    """Pull the sampled channels out of a device block in the engine layout -> [n_frames][len(chans)]."""
+    import torch
+    idx = torch.tensor(chans, device=t.device, dtype=torch.long)
+    if tile:
+        v = t.view(N // tile, n_frames, tile)
+        return v[idx // tile, :, idx % tile].transpose(0, 1).contiguous().cpu().numpy()
+    return t.view(n_frames, N)[:, idx].cpu().numpy()
+
+
+def run_noise_engine(dspfx, tc, chain, N, B, n_calls, tile, chans, want_mix=False):
+    eng = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
+    eng.set_chain(chain)
+    x = tc.empty(B * N, dtype=tc.float32, device="cuda")
+    y = tc.empty_like(x)
+    mix = tc.empty(B, dtype=tc.float32, device="cuda") if want_mix else None
+    got = np.empty((n_calls * B, len(chans)), F)
+    mix_err = 0.0
+    for k in range(n_calls):
+        eng.fill_noise(x, B, k * B, SEED)
+        eng.process(x, out=y, mix=mix, n_frames=B)
+        got[k * B:(k + 1) * B] = gather(dspfx, y, chans, B, N, tile)
+        if want_mix and k % 16 == 0:      # checksum of the fused reduction vs an independent f64 sum on the device
+            v = y.view(N // tile, B, tile) if tile else y.view(B, N)
+            ref = v.double().sum(dim=(0, 2)) if tile else v.double().sum(dim=1)
+            scale = float(ref.abs().max()) + 1.0
+            mix_err = max(mix_err, float((mix.double() - ref).abs().max()) / scale)
+    tc.cuda.synchronize()
+    eng.close()
+    return got, mix_err
+
+
+def test_config2_65536_channels_chain3(dspfx, tc):
+    """BASELINE config 2: 65 536 channels, gain -> biquad -> delay(24000), 200 blocks (> one delay period)."""
+    N, blocks = 1 << 16, 200
+    chans = sample_channels(N)
+    chain = chain3(dspfx)
+    got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 0, chans)
+    ref = oracle_channels(chain, chans, blocks)
+    assert ulp_diff(got, ref).max() <= 1
+    assert np.abs(ref[24000:]).max() > 0      # the feedback path was really exercised
+
+
+@pytest.mark.parametrize("B,tile", [(256, 256), (128, 0)])
+def test_config3_and_5_million_channels_chain5(dspfx, tc, B, tile):
+    """BASELINE config 3 (B=256) / config 5's per-GPU shard (B=128): 1 048 576 channels, 5-node chain,
+    D=24000 (a 94 GiB ring), run past one delay period."""
+    N = 1 << 20
+    n_calls = 25600 // B
+    chans = sample_channels(N)
+    chain = chain5(dspfx)
+    got, mix_err = run_noise_engine(dspfx, tc, chain, N, B, n_calls, tile, chans, want_mix=True)
+    ref = oracle_channels(chain, chans, 25600 // 128)
+    assert ulp_diff(got, ref).max() <= 1
+    assert mix_err < 1e-5, mix_err
+
+
+def test_config4_fir_262144_channels(dspfx, tc):
+    """BASELINE config 4: 262 144 channels x 4096-tap FIR on MFMA, through warm-up into steady state."""
+    N, T, blocks = 1 << 18, 4096, 40
+    chans = sample_channels(N)[::2]
+    chain = [dspfx.Fir(fir_taps(T))]
+    got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 256, chans)
+    ref = oracle_channels(chain, chans, blocks)
+    err = got.astype(np.float64) - ref.astype(np.float64)
+    rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
+    assert rms < 2e-6, rms
+    assert np.abs(err).max() < 3e-5
+
+
+def test_linearity_and_channel_independence_full_size(dspfx, tc):
+    """gain -> biquad -> delay is linear: scaling the input by 2^-3 scales the output exactly
+    (no rounding changes under power-of-two scaling); and a channel's output does not depend on
+    which channels surround it (permuting the input channels permutes the output)."""
+    N, B, calls = 1 << 20, 128, 6
+    chain = [dspfx.Gain(0.8), dspfx.BiQuad(), dspfx.Reverb(delay_samples=256, decay=0.5)]
+    outs = []
+    perm = tc.randperm(N, device="cuda", generator=tc.Generator(device="cuda").manual_seed(1))
+    for mode in ("plain", "scaled", "permuted"):
+        eng = dspfx.Engine(N, B, link_flags=3)
+        eng.set_chain(chain)
+        x = tc.empty((B, N), dtype=tc.float32, device="cuda")
+        y = tc.empty_like(x)
+        acc = []
+        for k in range(calls):
+            eng.fill_noise(x, B, k * B, SEED)
+            if mode == "scaled":
+                x.mul_(0.125)
+            if mode == "permuted":
+                x.copy_(x[:, perm])
+            eng.process(x, out=y, n_frames=B)
+            acc.append(y.clone())
+        outs.append(tc.cat(acc))
+        eng.close()
+    plain, scaled, permuted = outs
+    assert tc.equal(plain * 0.125, scaled)
+    assert tc.equal(plain[:, perm], permuted)
+
+
+def test_delay_impulse_full_size(dspfx, tc):
+    """Every one of 1 048 576 delay lines of 24 000 samples answers an impulse with decay^k at k*D, exactly."""
+    N, B, D = 1 << 20, 128, 24000
+    eng = dspfx.Engine(N, B, link_flags=0, tile_channels=256)
+    eng.set_chain([dspfx.Reverb(delay_samples=D, decay=0.5)])
+    x = tc.zeros(B * N, dtype=tc.float32, device="cuda")
+    y = tc.empty_like(x)
+    n_calls = (2 * D) // B + 2
+    for k in range(n_calls):
+        x.zero_()
+        if k == 0:
+            x.view(N // 256, B, 256)[:, 0, :] = 1.0
+        eng.process(x, out=y, n_frames=B)
+        v = y.view(N // 256, B, 256)
+        expect = tc.zeros(B, dtype=tc.float32, device="cuda")
+        for j in (0, 1, 2):
+            if k * B <= j * D < (k + 1) * B:
+                expect[j * D - k * B] = 0.5 ** j
+        assert tc.equal(v, expect[None, :, None].expand_as(v)), k
+    eng.close()
