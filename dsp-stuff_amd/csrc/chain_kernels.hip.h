@@ -495,16 +495,16 @@ __device__ __forceinline__ void apply_hop(float (&v)[F][CPL], float div, double 
         for (int j = 0; j < CPL; ++j) v[f][j] = link_hop<FAST>(v[f][j], div, rc);
 }
 
-template <int F, int CPL, bool GUARD, bool FAST>
+template <int F, int CPL, bool GUARD, bool FAST, bool LIBM>
 __device__ __forceinline__ void apply_distort_dyn(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
                                                   const Ctx &cx) {
     switch (s.mode) {
     case D_HARD_CLIP: apply_node<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     case D_SOFT_CLIP: apply_node<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-    case D_TANH: apply_node<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_TANH: if constexpr (LIBM) apply_node<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     case D_RECIP_SOFT_CLIP: apply_node<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-    case D_SIN: apply_node<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-    case D_ATAN: apply_node<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SIN: if constexpr (LIBM) apply_node<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_ATAN: if constexpr (LIBM) apply_node<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     case D_SQUARE: apply_node<K_DISTORT, D_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     case D_CHEBYSHEV4: apply_node<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     default: break;
@@ -513,14 +513,14 @@ __device__ __forceinline__ void apply_distort_dyn(const SlotArgs &s, float (&v)[
 
 // One slot: static signature => everything folds at compile time; SIG_DYN => a
 // wave-uniform switch (scalar branches, no divergence).
-template <int SIG, int F, int CPL, bool GUARD, bool FAST>
+template <int SIG, int F, int CPL, bool GUARD, bool FAST, bool MOD = false, bool LIBM = true>
 __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL],
                                          const Ctx &cx) {
     if constexpr (SIG == SIG_NONE) {
         return;
     } else if constexpr (SIG == SIG_DYN) {
         if (s.hop) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
-        if (s.ctl[0] || s.ctl[1] || s.ctl[2] || s.latch_valid) {   // modulated / latched sliders
+        if (MOD && (s.ctl[0] || s.ctl[1] || s.ctl[2] || s.latch_valid)) {   // modulated / latched sliders
             switch (s.kind) {
             case K_GAIN: apply_node_mod<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
             case K_DISTORT: apply_distort_mod_dyn<F, CPL, GUARD, FAST>(s, v, cx); return;
@@ -535,9 +535,9 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         case K_LOW_PASS: apply_node<K_LOW_PASS, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_HIGH_PASS: apply_node<K_HIGH_PASS, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_REVERB: apply_node<K_REVERB, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-        case K_DISTORT: apply_distort_dyn<F, CPL, GUARD, FAST>(s, v, st, cx); break;
-        case K_OVERDRIVE: apply_node<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-        case K_CHEBYSHEV: apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_DISTORT: apply_distort_dyn<F, CPL, GUARD, FAST, LIBM>(s, v, st, cx); break;
+        case K_OVERDRIVE: if constexpr (LIBM) apply_node<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_CHEBYSHEV: if constexpr (LIBM) apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         default: break;
@@ -690,7 +690,9 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // branches); per-node filter state is staged in LDS ([row][lane], conflict-free)
 // for the whole block and touched once per chunk per stateful node.
 // GUARD=true: one-wave tail launch whose out-of-range lanes stay alive with zeros.
-template <int F, bool GUARD, bool FAST>
+// MOD=true additionally evaluates connected / latched `as_input` sliders (control ports); it is a
+// separate instantiation because those paths double the register footprint (239 vs 113 VGPRs).
+template <int F, bool GUARD, bool FAST, bool MOD, bool LIBM>
 __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, bool active, unsigned f0,
                                           int lane, unsigned wave_global) {
     float v[F][1];
@@ -707,7 +709,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
         float st[4][1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) st[k][0] = (k < ns) ? lds[(row + k) * WG + threadIdx.x] : 0.0f;
-        run_slot<SIG_DYN, F, 1, GUARD, FAST>(sl, v, st, cx);
+        run_slot<SIG_DYN, F, 1, GUARD, FAST, MOD, LIBM>(sl, v, st, cx);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
             if (k < ns) lds[(row + k) * WG + threadIdx.x] = st[k][0];
@@ -718,7 +720,9 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
     if (a.mixpart) mixbus_partial<F, 1>(a, v, !GUARD || active, f0, lane, wave_global);
 }
 
-template <int F, bool GUARD>
+// LIBM=false leaves out the f64-libm nodes (Tanh/Sin/Atan modes, overdrive, chebyshev): their register
+// footprint costs every other chain a wave of occupancy; the host picks by chain content.
+template <int F, bool GUARD, bool MOD, bool LIBM>
 __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     extern __shared__ float lds[];   // [state rows][WG]
     const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
@@ -742,13 +746,13 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     }
     unsigned f0 = 0;
     if (a.fast_div) {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true>(a, lds, c, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true>(a, lds, c, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
     } else {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false>(a, lds, c, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false>(a, lds, c, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
     }
     {
         int row = 0;

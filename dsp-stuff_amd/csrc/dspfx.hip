@@ -73,7 +73,7 @@ struct dspfx_engine {
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
-    const Variant *tail = nullptr, *dyn = nullptr;
+    const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr;
     bool has_fuzz = false;
     uint32_t min_delay = 0xffffffffu;
     uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
@@ -234,6 +234,12 @@ bool stage_fast_div(const dspfx_engine *e, const Stage &st) {
     return true;
 }
 
+bool node_needs_libm(const Node &n) {
+    if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV) return true;
+    return n.d.kind == DSPFX_DISTORT &&
+           (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
+}
+
 const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     std::vector<const Variant *> all;
     collect_variants(all);
@@ -242,8 +248,13 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     const Variant *best = nullptr;
     int best_score = -1;
     for (const Variant *v : all) {
-        if (v->guard) continue;
+        if (v->guard || v->mod) continue;
         const bool is_dyn = v->sigs[0] == SIG_DYN;
+        if (is_dyn) {
+            bool need = false;
+            for (int i = 0; i < st.count; ++i) need = need || node_needs_libm(e->nodes[st.first + i]);
+            if (v->libm != need) continue;
+        }
         if (!is_dyn) {
             if (pref.stat == 0) continue;
             if (!st.fast_div) continue;          // static kernels are built with the fast division only
@@ -260,7 +271,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         }
         int score = is_dyn ? 0 : 100;
         // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
-        if (pref.f > 0 ? v->f == pref.f : v->f == 8) score += 10;
+        if (pref.f > 0 ? v->f == pref.f : v->f == (is_dyn ? 16 : 8)) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == ((is_dyn || !e->desc.tile_channels) ? 1 : 2)) score += 5;
         if (score > best_score) {
             best_score = score;
@@ -422,10 +433,13 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 fill_slot(e, st.first + k, a.slot[k]);
                 rows += state_rows(e->nodes[st.first + k]);
             }
-            const Variant *v = st.var;
-            for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the interpreter evaluates them
+            const Variant *v = st.var, *tail = e->tail;
+            for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the MOD interpreter evaluates them
                 const Node &nd = e->nodes[st.first + k];
-                if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) v = e->dyn;
+                if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) {
+                    v = e->dyn_mod;
+                    tail = e->tail_mod;
+                }
             }
             const uint32_t per_wave = 64u * v->cpl;
             const uint32_t n_main = N - N % per_wave;
@@ -447,7 +461,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 a.c_base = n_main;
                 a.n_launch = n_tail;
                 a.wave_base = waves_main;
-                e->tail->launch(a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
+                tail->launch(a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
             }
             HIPCHK(e, hipGetLastError());
             if (deferred) {
@@ -576,8 +590,9 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     std::vector<const Variant *> all;
     collect_variants(all);
     for (const Variant *v : all) {
-        if (v->guard) e->tail = v;
-        if (!v->guard && v->sigs[0] == SIG_DYN && v->f == 8) e->dyn = v;
+        if (v->sigs[0] != SIG_DYN) continue;
+        if (v->guard) (v->mod ? e->tail_mod : e->tail) = v;
+        else if (v->f == 8 && v->libm) (v->mod ? e->dyn_mod : e->dyn) = v;   // fallbacks handle every node kind
     }
     e->mixpart_cols = (size_t)desc->channels / 64 + 8;
     if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess) {

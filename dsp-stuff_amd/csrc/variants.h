@@ -17,6 +17,8 @@ struct Variant {
     int f;
     int cpl;
     bool guard;
+    bool mod;              // interpreter instantiation that evaluates control ports
+    bool libm;             // interpreter instantiation that includes the f64-libm nodes
     void (*launch)(const ChainArgs &, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t);
 };
 
@@ -25,9 +27,9 @@ void launch_static(const ChainArgs &a, unsigned grid, unsigned block, unsigned l
     (void)lds_bytes;
     hipLaunchKernelGGL((chain_kernel<F, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
 }
-template <int F, bool GUARD>
+template <int F, bool GUARD, bool MOD, bool LIBM>
 void launch_dyn(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL((chain_dyn_kernel<F, GUARD>), dim3(grid), dim3(block), lds_bytes, s, a);
+    hipLaunchKernelGGL((chain_dyn_kernel<F, GUARD, MOD, LIBM>), dim3(grid), dim3(block), lds_bytes, s, a);
 }
 
 // each variants_*.hip translation unit exports one of these
@@ -36,8 +38,8 @@ const Variant *variants_static3(int *n);
 const Variant *variants_static5(int *n);
 
 #define DSPFX_STATIC_VARIANT(NAME, NSLOTS, F, CPL, ...) \
-    Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
-#define DSPFX_DYN_VARIANT(NAME, F, GUARD) \
-    Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, &launch_dyn<F, GUARD> }
+    Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, false, true, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
+#define DSPFX_DYN_VARIANT(NAME, F, GUARD, MOD, LIBM) \
+    Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, GUARD, MOD, LIBM> }
 
 }  // namespace dspfx

@@ -8,10 +8,15 @@ static const Variant k_dyn[] = {
     DSPFX_STATIC_VARIANT("copy_f8_c1", 0, 8, 1, NONE8),
     DSPFX_STATIC_VARIANT("copy_f8_c2", 0, 8, 2, NONE8),
     DSPFX_STATIC_VARIANT("copy_f8_c4", 0, 8, 4, NONE8),
-    DSPFX_DYN_VARIANT("dyn_f8", 8, false),
-    DSPFX_DYN_VARIANT("dyn_f4", 4, false),
-    DSPFX_DYN_VARIANT("dyn_f16", 16, false),
-    DSPFX_DYN_VARIANT("dyn_f8_tail", 8, true),
+    DSPFX_DYN_VARIANT("dyn_f8", 8, false, false, false),          // arithmetic nodes only
+    DSPFX_DYN_VARIANT("dyn_f4", 4, false, false, false),
+    DSPFX_DYN_VARIANT("dyn_f16", 16, false, false, false),
+    DSPFX_DYN_VARIANT("dyn_libm_f8", 8, false, false, true),      // + Tanh/Sin/Atan, overdrive, chebyshev
+    DSPFX_DYN_VARIANT("dyn_libm_f4", 4, false, false, true),
+    DSPFX_DYN_VARIANT("dyn_libm_f16", 16, false, false, true),
+    DSPFX_DYN_VARIANT("dyn_f8_tail", 8, true, false, true),
+    DSPFX_DYN_VARIANT("dyn_mod_f8", 8, false, true, true),        // + control ports
+    DSPFX_DYN_VARIANT("dyn_mod_f8_tail", 8, true, true, true),
 };
 const Variant *variants_dyn(int *n) { *n = (int)(sizeof(k_dyn) / sizeof(k_dyn[0])); return k_dyn; }
 }  // namespace dspfx
