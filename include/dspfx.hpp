@@ -1,0 +1,172 @@
+// dspfx.hpp -- C++17 host-side mirror of the reference's operator interface over the C ABI (dspfx.h).
+//
+// The reference is Rust; its toolchain is absent from the build image, so the host layer above the
+// C ABI is written in C++ (and mirrored in Python for the tests).  Names, slider fields, ranges and
+// defaults follow dsp-stuff/src/nodes/*.rs; `GpuChain::process` has the shape of
+// `SimpleNode::process` (dsp-stuff/src/node.rs:135-146): borrowed input slice(s) in, output slice out,
+// node-owned parameters and state.  Errors that the reference turns into panics
+// (node.rs:173,271,280) become dspfx::Error exceptions here; nothing falls back to the CPU.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dspfx.h"
+
+namespace dspfx {
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int st, const std::string &msg) : std::runtime_error("dspfx error " + std::to_string(st) + ": " + msg), status(st) {}
+};
+
+constexpr std::size_t BUF_SIZE = DSPFX_BUF_SIZE;   // node.rs:257
+
+// nodes/distort.rs:18-28
+enum class Mode : int { HardClip = 0, SoftClip, Tanh, RecipSoftClip, Fuzz, Sin, Atan, Square, Chebyshev4 };
+// nodes/fir.rs Mode
+enum class FirMode : int { Balanced = 0, Average = 1 };
+
+// One node of a chain: the reference node's saved fields.
+struct Node {
+    dspfx_node_desc d{};
+    std::vector<double> taps;   // Fir: time-reversed, as fir.rs:163,168 stores them
+};
+
+inline Node make(int kind) {
+    Node n;
+    if (dspfx_node_defaults(kind, &n.d) != DSPFX_OK) throw Error(DSPFX_ERR_INVALID, "unknown node kind");
+    return n;
+}
+// nodes/gain.rs: slider level 0..=10, default 1.0
+inline Node Gain(float level = 1.0f) { Node n = make(DSPFX_GAIN); n.d.params[0] = level; return n; }
+// nodes/biquad.rs:18-41: raw sliders -10..=10, normalised by a0 on the engine (biquad.rs:62-76)
+inline Node BiQuad(float a0 = 1.0f, float a1 = -0.24f, float a2 = 0.0f, float b0 = 0.758f, float b1 = 0.0f, float b2 = 0.0f) {
+    Node n = make(DSPFX_BIQUAD);
+    const float p[6] = {a0, a1, a2, b0, b1, b2};
+    for (int i = 0; i < 6; ++i) n.d.params[i] = p[i];
+    return n;
+}
+inline Node LowPass(float ratio = 0.5f) { Node n = make(DSPFX_LOW_PASS); n.d.params[0] = ratio; return n; }
+inline Node HighPass(float ratio = 0.5f) { Node n = make(DSPFX_HIGH_PASS); n.d.params[0] = ratio; return n; }
+// nodes/reverb.rs: `seconds` goes through reverb.rs:58
+inline Node Reverb(float seconds = 0.5f, float decay = 0.5f, bool page_round = false) {
+    Node n = make(DSPFX_REVERB);
+    n.d.params[0] = decay;
+    n.d.delay_len = dspfx_delay_len(seconds, page_round ? 1 : 0);
+    return n;
+}
+inline Node ReverbSamples(std::uint32_t delay_len, float decay = 0.5f) {
+    Node n = make(DSPFX_REVERB);
+    n.d.params[0] = decay;
+    n.d.delay_len = delay_len;
+    return n;
+}
+// nodes/distort.rs: level 0..=30 default 0 (bypass), mode default SoftClip
+inline Node Distort(float level = 0.0f, Mode mode = Mode::SoftClip) {
+    Node n = make(DSPFX_DISTORT);
+    n.d.params[0] = level;
+    n.d.mode = static_cast<int>(mode);
+    return n;
+}
+inline Node Overdrive(float boost = 0.0f, float drive = 0.0f, float level = 0.0f) {
+    Node n = make(DSPFX_OVERDRIVE);
+    n.d.params[0] = boost; n.d.params[1] = drive; n.d.params[2] = level;
+    return n;
+}
+inline Node Chebyshev(float level_pos = 0.0f, float level_neg = 0.0f) {
+    Node n = make(DSPFX_CHEBYSHEV);
+    n.d.params[0] = level_pos; n.d.params[1] = level_neg;
+    return n;
+}
+// nodes/fir.rs: impulse response h[0..T) in natural order; stored reversed like fir.rs:163,168
+inline Node Fir(const std::vector<double> &impulse_response, FirMode mode = FirMode::Balanced) {
+    Node n = make(DSPFX_FIR);
+    n.taps.assign(impulse_response.rbegin(), impulse_response.rend());
+    n.d.mode = static_cast<int>(mode);
+    return n;
+}
+inline Node Add() { return make(DSPFX_ADD); }
+inline Node Mix(float ratio = 0.5f) { Node n = make(DSPFX_MIX); n.d.params[0] = ratio; return n; }
+
+// N independent mono channels through one chain.
+class Engine {
+  public:
+    Engine(std::uint32_t channels, std::uint32_t max_frames = DSPFX_BUF_SIZE,
+           std::uint32_t link_flags = DSPFX_LINK_INTERNAL | DSPFX_LINK_INPUT, int device = 0,
+           std::uint32_t tile_channels = 0, std::uint64_t channel_offset = 0)
+        : channels_(channels) {
+        dspfx_engine_desc d{DSPFX_ABI_VERSION, device, channels, max_frames, link_flags, tile_channels, channel_offset};
+        const int rc = dspfx_engine_create(&d, &e_);
+        if (rc != DSPFX_OK) throw Error(rc, dspfx_strerror(rc));
+    }
+    ~Engine() { dspfx_engine_destroy(e_); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    Engine(Engine &&o) noexcept : e_(std::exchange(o.e_, nullptr)), channels_(o.channels_) {}
+
+    void set_chain(const std::vector<Node> &nodes) {
+        std::vector<dspfx_node_desc> d;
+        for (const Node &n : nodes) {
+            d.push_back(n.d);
+            if (n.d.kind == DSPFX_FIR) {
+                d.back().taps = n.taps.data();
+                d.back().n_taps = static_cast<std::uint32_t>(n.taps.size());
+            }
+        }
+        chk(dspfx_chain_set(e_, d.data(), static_cast<int>(d.size())));
+    }
+    void set_param(int node, int param, float v) { chk(dspfx_set_param(e_, node, param, v)); }
+    void set_mode(int node, Mode m) { chk(dspfx_set_mode(e_, node, static_cast<int>(m))); }
+    void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }
+    void reset() { chk(dspfx_reset(e_)); }
+    // device buffers, asynchronous on `stream`
+    void process(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr,
+                 float *mix = nullptr, void *stream = nullptr) {
+        chk(dspfx_process(e_, in, side, out, mix, n_frames, stream));
+    }
+    // host buffers ([n_frames][channels]), synchronous
+    void process_host(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr,
+                      float *mix = nullptr) {
+        chk(dspfx_process_host(e_, in, side, out, mix, n_frames));
+    }
+    void mix_finish(float *mix, std::uint32_t n_frames, std::uint64_t n_connected, void *stream = nullptr) {
+        chk(dspfx_mix_finish(e_, mix, n_frames, n_connected, stream));
+    }
+    std::uint32_t channels() const { return channels_; }
+    dspfx_engine *raw() { return e_; }
+
+  private:
+    void chk(int rc) {
+        if (rc != DSPFX_OK) throw Error(rc, dspfx_last_error(e_));
+    }
+    dspfx_engine *e_ = nullptr;
+    std::uint32_t channels_;
+};
+
+// Reference-shaped node: what a `GpuChain: SimpleNode` in the Rust host does per block.
+// process(input, output) takes one 128-frame block per channel bank laid out [frame][channel]
+// (channels == 1 reproduces the reference's mono node exactly); the host's Perform wrapper has
+// already averaged the input pipes (node.rs:290-299), so only the hops BETWEEN the fused nodes are
+// applied here (DSPFX_LINK_INTERNAL).
+class GpuChain {
+  public:
+    GpuChain(std::vector<Node> chain, std::uint32_t channels = 1, int device = 0)
+        : eng_(channels, DSPFX_BUF_SIZE, DSPFX_LINK_INTERNAL, device) {
+        eng_.set_chain(chain);
+    }
+    static const char *title() { return "GPU chain"; }
+    static const char *cfg_name() { return "gpu_chain"; }
+    void process(const float *input, float *output, std::size_t n_frames = BUF_SIZE) {
+        eng_.process_host(input, output, static_cast<std::uint32_t>(n_frames));
+    }
+    Engine &engine() { return eng_; }
+
+  private:
+    Engine eng_;
+};
+
+}  // namespace dspfx

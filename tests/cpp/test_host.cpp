@@ -1,0 +1,79 @@
+// C++ parity test of the host-side mirror (include/dspfx.hpp) against the CPU oracle (oracle/): reads like
+// a test the reference could have had for its nodes.  Exit code 0 = pass.  Built and run by
+// tests/test_cpp_host.py (g++ only: links libdspfx.so and liboracle.so).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/dspfx.hpp"
+#include "../../oracle/dspfx_oracle.h"
+
+static int ulp(float a, float b) {
+    if (a != a && b != b) return 0;
+    int32_t ia, ib;
+    std::memcpy(&ia, &a, 4);
+    std::memcpy(&ib, &b, 4);
+    if (ia < 0) ia = -(ia & 0x7fffffff);
+    if (ib < 0) ib = -(ib & 0x7fffffff);
+    return std::abs(ia - ib);
+}
+
+int main(int argc, char **argv) {
+    const bool expect_no_device = argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0;
+    try {
+        using namespace dspfx;
+        const uint32_t N = 200, blocks = 6;
+        std::vector<Node> chain = {Gain(0.8f), BiQuad(1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f),
+                                   Distort(3.0f, Mode::SoftClip), ReverbSamples(256, 0.5f), HighPass(0.25f)};
+        Engine eng(N, BUF_SIZE, DSPFX_LINK_INTERNAL | DSPFX_LINK_INPUT);
+        if (expect_no_device) { std::printf("FAIL: engine created without a device\n"); return 1; }
+        eng.set_chain(chain);
+        // oracle twins, one per channel
+        std::vector<std::vector<orc_node *>> twins(N);
+        for (uint32_t c = 0; c < N; ++c) {
+            orc_node *g = orc_node_new(ORC_GAIN); orc_node_set_param(g, 0, 0.8f);
+            orc_node *b = orc_node_new(ORC_BIQUAD);
+            const float p[6] = {1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f};
+            for (int i = 0; i < 6; ++i) orc_node_set_param(b, i, p[i]);
+            orc_node *d = orc_node_new(ORC_DISTORT); orc_node_set_param(d, 0, 3.0f); orc_node_set_mode(d, ORC_DIST_SOFT_CLIP);
+            orc_node *r = orc_node_new(ORC_REVERB); orc_node_set_param(r, 0, 0.5f); orc_reverb_set_len(r, 256);
+            orc_node *h = orc_node_new(ORC_HIGH_PASS); orc_node_set_param(h, 0, 0.25f);
+            twins[c] = {g, b, d, r, h};
+        }
+        std::vector<float> x(BUF_SIZE * N), y(BUF_SIZE * N), mix(BUF_SIZE), xc(BUF_SIZE), yc(BUF_SIZE);
+        int worst = 0;
+        double mix_err = 0;
+        for (uint32_t blk = 0; blk < blocks; ++blk) {
+            for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                for (uint32_t c = 0; c < N; ++c) x[f * N + c] = orc_noise(0x5EED0001u, c, blk * BUF_SIZE + f);
+            eng.process_host(x.data(), y.data(), BUF_SIZE, nullptr, mix.data());
+            std::vector<double> msum(BUF_SIZE, 0.0);
+            for (uint32_t c = 0; c < N; ++c) {
+                for (uint32_t f = 0; f < BUF_SIZE; ++f) xc[f] = x[f * N + c];
+                orc_chain_run(twins[c].data(), 5, 3, xc.data(), nullptr, yc.data(), BUF_SIZE, BUF_SIZE);
+                for (uint32_t f = 0; f < BUF_SIZE; ++f) {
+                    worst = std::max(worst, ulp(y[f * N + c], yc[f]));
+                    msum[f] += yc[f];
+                }
+            }
+            for (uint32_t f = 0; f < BUF_SIZE; ++f) mix_err = std::max(mix_err, std::fabs(msum[f] - mix[f]));
+        }
+        // the reference-shaped single-channel node
+        GpuChain node({Gain(2.0f)}, 1);
+        float in1[BUF_SIZE], out1[BUF_SIZE];
+        for (uint32_t f = 0; f < BUF_SIZE; ++f) in1[f] = orc_noise(7, 0, f);
+        node.process(in1, out1);
+        for (uint32_t f = 0; f < BUF_SIZE; ++f)
+            if (out1[f] != in1[f] * 2.0f) { std::printf("FAIL: GpuChain gain\n"); return 1; }
+        // error behaviour: exceptions, not aborts
+        bool threw = false;
+        try { eng.set_chain({ReverbSamples(64)}); } catch (const Error &e) { threw = e.status == DSPFX_ERR_INVALID; }
+        std::printf("max ulp %d, mix err %.3g, invalid chain threw %d\n", worst, mix_err, (int)threw);
+        return (worst <= 1 && mix_err < 1e-3 && threw) ? 0 : 1;
+    } catch (const dspfx::Error &e) {
+        if (expect_no_device && e.status == DSPFX_ERR_NO_DEVICE) { std::printf("ok: %s\n", e.what()); return 0; }
+        std::printf("FAIL: %s\n", e.what());
+        return 1;
+    }
+}
