@@ -384,6 +384,22 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     }
 }
 
+// One delay-ring row (all channels of ring position r) <-> a dense [N] host row.  The ring is
+// [D][N] in a frame-major engine and [N/W][D][W] in a channel-tiled one.
+hipError_t ring_row_copy(const dspfx_engine *e, const Node &n, uint32_t r, void *host, bool to_host) {
+    const size_t N = e->desc.channels;
+    const uint32_t W = e->desc.tile_channels;
+    if (!W) {
+        float *dev = n.state + (size_t)r * N;
+        return to_host ? hipMemcpy(host, dev, N * sizeof(float), hipMemcpyDeviceToHost)
+                       : hipMemcpy(dev, host, N * sizeof(float), hipMemcpyHostToDevice);
+    }
+    float *dev = n.state + (size_t)r * W;
+    const size_t seg = (size_t)W * sizeof(float), pitch = (size_t)n.D * seg;
+    return to_host ? hipMemcpy2D(host, seg, dev, pitch, seg, N / W, hipMemcpyDeviceToHost)
+                   : hipMemcpy2D(dev, pitch, host, seg, seg, N / W, hipMemcpyHostToDevice);
+}
+
 int state_rows(const Node &n) {
     return n.d.kind == DSPFX_BIQUAD ? 4 : ((n.d.kind == DSPFX_LOW_PASS || n.d.kind == DSPFX_HIGH_PASS) ? 1 : 0);
 }
@@ -901,11 +917,16 @@ extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, siz
         const int rc = fir_state_export(n.fir, host_dst);
         return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
     }
-    if (n.d.kind == DSPFX_REVERB) {   // rotate so that row 0 is the oldest sample
+    if (n.d.kind == DSPFX_REVERB) {   // canonical form: [D][N], row 0 = the oldest sample
         const size_t row = (size_t)e->desc.channels * sizeof(float);
-        const size_t head = (size_t)(n.D - n.pos) * row;
-        HIPCHK(e, hipMemcpy(host_dst, (char *)n.state + (size_t)n.pos * row, head, hipMemcpyDeviceToHost));
-        if (n.pos) HIPCHK(e, hipMemcpy((char *)host_dst + head, n.state, (size_t)n.pos * row, hipMemcpyDeviceToHost));
+        if (!e->desc.tile_channels) {   // frame-major: two contiguous pieces
+            const size_t head = (size_t)(n.D - n.pos) * row;
+            HIPCHK(e, hipMemcpy(host_dst, (char *)n.state + (size_t)n.pos * row, head, hipMemcpyDeviceToHost));
+            if (n.pos) HIPCHK(e, hipMemcpy((char *)host_dst + head, n.state, (size_t)n.pos * row, hipMemcpyDeviceToHost));
+        } else {
+            for (uint32_t k = 0; k < n.D; ++k)
+                HIPCHK(e, ring_row_copy(e, n, (n.pos + k) % n.D, (char *)host_dst + (size_t)k * row, true));
+        }
         return DSPFX_OK;
     }
     if (need) HIPCHK(e, hipMemcpy(host_dst, n.state, (size_t)need, hipMemcpyDeviceToHost));
@@ -924,7 +945,13 @@ extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_sr
         const int rc = fir_state_import(n.fir, host_src);
         return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
     }
-    if (need) HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
+    if (n.d.kind == DSPFX_REVERB && e->desc.tile_channels) {
+        const size_t row = (size_t)e->desc.channels * sizeof(float);
+        for (uint32_t k = 0; k < n.D; ++k)
+            HIPCHK(e, ring_row_copy(e, n, k, (void *)((const char *)host_src + (size_t)k * row), false));
+    } else if (need) {
+        HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
+    }
     n.pos = 0;
     return DSPFX_OK;
 }

@@ -401,6 +401,40 @@ def test_state_export_import_continues(dspfx, torch_cuda):
     assert ulp_diff(ring, st_only[256:512]).max() <= 1
 
 
+def test_state_export_is_layout_independent(dspfx, torch_cuda):
+    """Exported state is canonical ([D][N] oldest-first for a delay line) whatever the engine's HBM layout,
+    so it can move between a frame-major and a channel-tiled engine."""
+    N, B = 256, 128
+    ch = chain5(dspfx, delay=384)
+    x = noise_block(N, B * 8)
+    full = run_gpu(dspfx, torch_cuda, ch, x, 3)
+    exports = {}
+    for tile in (0, 64):
+        eng = dspfx.Engine(N, B, tile_channels=tile)
+        eng.set_chain(ch)
+        for b in range(5):      # 640 frames: ring position is mid-ring (640 % 384 = 256)
+            blk = torch_cuda.from_numpy(dspfx.to_layout(x[b * B:(b + 1) * B], tile)).cuda()
+            eng.process(blk, n_frames=B)
+        torch_cuda.cuda.synchronize()
+        exports[tile] = [eng.state_export(i) for i in range(len(ch))]
+    for a, b in zip(exports[0], exports[64]):
+        assert np.array_equal(a, b)
+    # frame-major state into a tiled engine (and back), then continue: same output as the uninterrupted run
+    for src, dst_tile in ((0, 64), (64, 0)):
+        eng = dspfx.Engine(N, B, tile_channels=dst_tile)
+        eng.set_chain(ch)
+        for i, st in enumerate(exports[src]):
+            if len(st):
+                eng.state_import(i, st)
+        out = []
+        for b in range(5, 8):
+            blk = torch_cuda.from_numpy(dspfx.to_layout(x[b * B:(b + 1) * B], dst_tile)).cuda()
+            eng.process(blk, n_frames=B)
+            torch_cuda.cuda.synchronize()
+            out.append(dspfx.from_layout(blk.cpu().numpy(), B, N, dst_tile))
+        assert np.array_equal(np.concatenate(out), full[5 * B:])
+
+
 def test_mix_bus_and_finish(dspfx, torch_cuda):
     N = 4096
     ch = chain5(dspfx, delay=128)
