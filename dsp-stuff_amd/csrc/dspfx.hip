@@ -443,7 +443,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.third_rc = 1.0 / 3.0;
             a.fast_div = st.fast_div ? 1 : 0;
             a.n_slots = st.count;
-            a.side_hop = (side && (e->desc.link_flags & DSPFX_LINK_INTERNAL)) ? 1 : 0;
+            // hop flag of the side input and of control links (both are ordinary links between nodes);
+            // an unconnected side port reads zeros, for which the hop is a no-op
+            a.side_hop = (e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0;
             int rows = 0;
             for (int k = 0; k < st.count; ++k) {
                 fill_slot(e, st.first + k, a.slot[k]);
@@ -795,8 +797,6 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
     const size_t N = e->desc.channels;
     const size_t rowlen = e->desc.tile_channels ? e->desc.tile_channels : N;
     if (n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
-    if (e->desc.tile_channels && n_frames > e->min_delay && n_ctl)
-        return fail(e, DSPFX_ERR_UNSUPPORTED, "control ports with n_frames > shortest delay need the frame-major layout");
     uint32_t sub = std::min(n_frames, e->min_delay);
     if (e->has_fuzz) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
     int rc = DSPFX_OK;

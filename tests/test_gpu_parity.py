@@ -312,6 +312,27 @@ def test_control_ports(dspfx, torch_cuda):
             else:
                 assert np.abs(got - ref).max() <= 2e-6, (lf, np.abs(got - ref).max())
                 assert (ulp_diff(got, ref) > LIBM_COMPOSITE_ULP).mean() < 0.01
+    # no side input, channel-tiled layout, a block longer than the delay line (engine splits it at D):
+    # the control link still gets its collect_and_average hop and its signal is offset with the samples
+    chain = [dspfx.Gain(1.0), dspfx.Reverb(delay_samples=128, decay=0.4), dspfx.Distort(2.0, dspfx.HARD_CLIP)]
+    ctl_c = {(0, 0): cg, (2, 0): cd}
+    Nc = 64
+    xc = np.ascontiguousarray(x[:, :Nc])
+    ctl_c = {k: np.ascontiguousarray(v[:, :Nc]) for k, v in ctl_c.items()}
+    for lf in (3, 0):
+        for tile in (0, 64):
+            eng = dspfx.Engine(Nc, 256, link_flags=lf, tile_channels=tile)
+            eng.set_chain(chain)
+            got = np.empty_like(xc)
+            for b in range(0, B * blocks, 256):
+                sl = slice(b, b + 256)
+                dxx = torch_cuda.from_numpy(dspfx.to_layout(xc[sl], tile)).cuda()
+                dc = {k: torch_cuda.from_numpy(dspfx.to_layout(v[sl], tile)).cuda() for k, v in ctl_c.items()}
+                eng.process(dxx, n_frames=256, ctl=dc)
+                torch_cuda.cuda.synchronize()
+                got[sl] = dspfx.from_layout(dxx.cpu().numpy(), 256, Nc, tile)
+            ref = O.run_channels([n.oracle_desc() for n in chain], xc, lf, ctl=ctl_c)
+            assert ulp_diff(got, ref).max() <= 1, (lf, tile)
     # Fuzz has no control port here; bad slider indices are rejected
     eng = dspfx.Engine(N, B)
     eng.set_chain([dspfx.Distort(3.0, dspfx.FUZZ), dspfx.BiQuad()])
