@@ -271,11 +271,16 @@ class Engine:
             raise DspfxError(rc, self.L.dspfx_last_error(self.h).decode() or self.L.dspfx_strerror(rc).decode())
 
     def close(self):
-        if getattr(self, "h", None) and self.h.value:
-            self.L.dspfx_engine_destroy(self.h)
-            self.h = C.c_void_p()
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            self.L.dspfx_engine_destroy(h)
+            h.value = None
 
-    __del__ = close
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: module globals may already be gone
+            pass
 
     def set_chain(self, nodes: Sequence[NodeSpec]):
         arr = (_NodeDesc * max(1, len(nodes)))()

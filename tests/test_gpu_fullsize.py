@@ -102,7 +102,7 @@ def test_config4_fir_262144_channels(dspfx, tc):
     ref = oracle_channels(chain, chans, blocks)
     err = got.astype(np.float64) - ref.astype(np.float64)
     rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
-    assert rms < 2e-6, rms
+    assert rms < 1e-6, rms
     assert np.abs(err).max() < 3e-5
 
 

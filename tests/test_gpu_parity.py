@@ -15,7 +15,7 @@ F = np.float32
 # routines are within 1 ulp (sinf/atanf/expf) resp. 2 ulp (tanhf) of that (measured)
 LIBM_ULP = {2: 2, 5: 1, 6: 1}   # distort mode -> bar
 LIBM_COMPOSITE_ULP = 4          # overdrive / chebyshev node: libm result feeds further f32 ops
-FIR_RMS_TOL = 2e-6  # relative RMS error of the f32 path vs the f64-accumulating oracle
+FIR_RMS_TOL = 1e-6  # relative RMS error of the f32 MFMA path vs the f64-accumulating oracle (measured 3.2e-7 at T=4096)
 
 
 @pytest.fixture(scope="module")
