@@ -74,6 +74,7 @@ struct ChainArgs {
     unsigned ld;
     unsigned pad_;
     size_t io_tile_stride;   // floats between consecutive channel tiles of in/out/side
+    size_t ntiles;           // channel tiles (1 when frame-major)
     double hop_rc;           // f64 1/hop_div
     double third_rc;         // f64 1/3.0f  (SoftClip's powi(3)/3.0)
     int fast_div;            // every constant divisor of this launch passed the exhaustive check
@@ -85,6 +86,31 @@ struct ChainArgs {
 //   (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
 //   frame-major [B][N]       : w_shift = 31, w_mask = 0x7fffffff, ld = N, tile_stride = 0
 //   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
+// Delay rings are block-major: ring row r (0..D-1) of channel tile t lives at
+//   (((r >> 7) * ntiles + t) * 128 + (r & 127)) * ld + (c & w_mask)
+// i.e. [ceil(D/128)][ntiles][128][W]: the 128 rows a block reads/overwrites are, for ALL tiles together,
+// one or two contiguous N*128*4-byte extents (TLB / DRAM-page friendly at a 94 GiB footprint), and with a
+// single tile (frame-major, W = N) the map degenerates to the plain [D][N].
+#ifndef DSPFX_RING_BLOCKMAJOR
+#define DSPFX_RING_BLOCKMAJOR 1
+#endif
+__host__ __device__ inline size_t ring_row_offset(unsigned r, size_t tile, size_t ntiles, size_t D, size_t ld) {
+#if DSPFX_RING_BLOCKMAJOR
+    (void)D;
+    return (((size_t)(r >> 7) * ntiles + tile) * 128 + (r & 127u)) * ld;
+#else
+    (void)ntiles;
+    return (tile * D + r) * ld;
+#endif
+}
+__host__ __device__ inline size_t ring_rows_allocated(size_t D) {
+#if DSPFX_RING_BLOCKMAJOR
+    return (D + 127) / 128 * 128;
+#else
+    return D;
+#endif
+}
+
 struct Layout {
     unsigned w_shift;
     unsigned w_mask;
@@ -270,6 +296,7 @@ struct Ctx {
     size_t N;
     size_t io_base;  // offset of (frame 0, channel c) in in/out/side
     size_t tile;     // channel tile index
+    size_t ntiles;   // number of channel tiles
     size_t cw;       // channel within its tile
     size_t ld;       // floats between consecutive frames
     unsigned f0;     // first frame of the chunk
@@ -333,7 +360,7 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f) {
             unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
             r = r >= s.D ? r - s.D : r;
-            row[f] = (cx.tile * s.D + r) * cx.ld + cx.cw;   // ring is [tile][D][W] (W == N when frame-major)
+            row[f] = ring_row_offset(r, cx.tile, cx.ntiles, s.D, cx.ld) + cx.cw;
             load_vec<CPL, GUARD, S_RING_LD>(s.state + row[f], tap[f], cx.active);
         }
 #pragma unroll
@@ -654,7 +681,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
     const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
-    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    const Ctx cx{c, a.N, io_base, tile, a.ntiles, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
 #define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
@@ -700,7 +727,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
     const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
-    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
+    const Ctx cx{c, a.N, io_base, tile, a.ntiles, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {

@@ -28,12 +28,14 @@ using namespace dspfx;
 namespace {
 
 enum StageType { ST_FUSED = 0, ST_FUZZ = 1, ST_FIR = 2 };
+constexpr size_t RING_SKEW_BYTES = 0;   // default set from the A/B below
 
 struct Node {
     dspfx_node_desc d{};
     // BIQUAD: normalised coefficients (biquad.rs:62-76)
     float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
-    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N], REVERB ring [D][N], FIR history
+    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N], REVERB ring (+ skew), FIR history
+    float *state_alloc = nullptr;   // allocation base (state = state_alloc + skew for delay rings)
     size_t state_bytes = 0;
     uint32_t D = 0, pos = 0;  // REVERB
     // FIR
@@ -191,8 +193,8 @@ void biquad_regenerate(Node &n) {   // biquad.rs:62-76
 }
 
 void free_node(Node &n) {
-    if (n.state) (void)hipFree(n.state);
-    n.state = nullptr;
+    if (n.state_alloc) (void)hipFree(n.state_alloc);
+    n.state = n.state_alloc = nullptr;
     n.state_bytes = 0;
     fir_free(n.fir);
     for (int k = 0; k < 3; ++k) {
@@ -330,14 +332,26 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     case DSPFX_BIQUAD: bytes = 4 * N * sizeof(float); break;
     case DSPFX_LOW_PASS:
     case DSPFX_HIGH_PASS: bytes = N * sizeof(float); break;
-    case DSPFX_REVERB: bytes = (size_t)n.D * N * sizeof(float); break;
+    case DSPFX_REVERB: bytes = ring_rows_allocated(n.D) * N * sizeof(float); break;
     default: break;
     }
     if (n.state && n.state_bytes != bytes) {
-        (void)hipFree(n.state);
-        n.state = nullptr;
+        (void)hipFree(n.state_alloc);
+        n.state = n.state_alloc = nullptr;
     }
-    if (bytes && !n.state) HIPCHK(e, hipMalloc((void **)&n.state, bytes));
+    if (bytes && !n.state) {
+        // Delay rings start `skew` bytes into their allocation so that a workgroup's ring rows are not
+        // congruent (mod large powers of two) with its input/output tile rows: four streams of one
+        // workgroup on the same HBM bank cost ~10 % (profiles/r01_ab_ring.txt).  DSPFX_RING_SKEW overrides.
+        size_t skew = 0;
+        if (n.d.kind == DSPFX_REVERB) {
+            const char *sk = getenv("DSPFX_RING_SKEW");
+            skew = sk ? (size_t)atol(sk) : (size_t)RING_SKEW_BYTES;
+            skew = skew / 256 * 256;
+        }
+        HIPCHK(e, hipMalloc((void **)&n.state_alloc, bytes + skew));
+        n.state = (float *)((char *)n.state_alloc + skew);
+    }
     n.state_bytes = bytes;
     if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
     n.pos = 0;
@@ -388,16 +402,15 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
 // [D][N] in a frame-major engine and [N/W][D][W] in a channel-tiled one.
 hipError_t ring_row_copy(const dspfx_engine *e, const Node &n, uint32_t r, void *host, bool to_host) {
     const size_t N = e->desc.channels;
-    const uint32_t W = e->desc.tile_channels;
-    if (!W) {
-        float *dev = n.state + (size_t)r * N;
-        return to_host ? hipMemcpy(host, dev, N * sizeof(float), hipMemcpyDeviceToHost)
-                       : hipMemcpy(dev, host, N * sizeof(float), hipMemcpyHostToDevice);
-    }
-    float *dev = n.state + (size_t)r * W;
-    const size_t seg = (size_t)W * sizeof(float), pitch = (size_t)n.D * seg;
-    return to_host ? hipMemcpy2D(host, seg, dev, pitch, seg, N / W, hipMemcpyDeviceToHost)
-                   : hipMemcpy2D(dev, pitch, host, seg, seg, N / W, hipMemcpyHostToDevice);
+    const size_t W = e->desc.tile_channels ? e->desc.tile_channels : N;
+    const size_t ntiles = N / W;
+    float *dev = n.state + ring_row_offset(r, 0, ntiles, n.D, W);
+    const size_t seg = W * sizeof(float);
+    const size_t pitch = (ring_row_offset(r, 1, ntiles, n.D, W) - ring_row_offset(r, 0, ntiles, n.D, W)) * sizeof(float);
+    if (ntiles == 1)
+        return to_host ? hipMemcpy(host, dev, seg, hipMemcpyDeviceToHost) : hipMemcpy(dev, host, seg, hipMemcpyHostToDevice);
+    return to_host ? hipMemcpy2D(host, seg, dev, pitch, seg, ntiles, hipMemcpyDeviceToHost)
+                   : hipMemcpy2D(dev, pitch, host, seg, seg, ntiles, hipMemcpyHostToDevice);
 }
 
 int state_rows(const Node &n) {
@@ -438,6 +451,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.w_mask = lay.w_mask;
             a.ld = lay.ld;
             a.io_tile_stride = lay.tile_stride;
+            a.ntiles = e->desc.tile_channels ? N / e->desc.tile_channels : 1;
             a.hop_div = e->hop_div;
             a.hop_rc = 1.0 / (double)e->hop_div;
             a.third_rc = 1.0 / 3.0;
@@ -919,7 +933,7 @@ extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, siz
     }
     if (n.d.kind == DSPFX_REVERB) {   // canonical form: [D][N], row 0 = the oldest sample
         const size_t row = (size_t)e->desc.channels * sizeof(float);
-        if (!e->desc.tile_channels) {   // frame-major: two contiguous pieces
+        if (!e->desc.tile_channels) {   // frame-major ring is the plain [D][N]: two contiguous pieces
             const size_t head = (size_t)(n.D - n.pos) * row;
             HIPCHK(e, hipMemcpy(host_dst, (char *)n.state + (size_t)n.pos * row, head, hipMemcpyDeviceToHost));
             if (n.pos) HIPCHK(e, hipMemcpy((char *)host_dst + head, n.state, (size_t)n.pos * row, hipMemcpyDeviceToHost));
@@ -1109,6 +1123,11 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
             s += buf;
         }
     }
+    for (size_t i = 0; i < e->nodes.size(); ++i)
+        if (e->nodes[i].state) {
+            snprintf(buf, sizeof buf, "node %zu state @%p (%zu bytes)\n", i, (void *)e->nodes[i].state, e->nodes[i].state_bytes);
+            s += buf;
+        }
     snprintf(dst, cap, "%s", s.c_str());
     return DSPFX_OK;
 }

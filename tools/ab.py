@@ -50,6 +50,10 @@ def main():
         name, _, rest = spec.partition(":")
         kv = dict(x.split("=", 1) for x in rest.split(",") if x)
         pkg = load_pkg(kv.get("lib"), f"{i}")
+        if "skew" in kv:
+            os.environ["DSPFX_RING_SKEW"] = kv["skew"]
+        else:
+            os.environ.pop("DSPFX_RING_SKEW", None)
         if "variant" in kv:
             os.environ["DSPFX_VARIANT"] = kv["variant"].replace(";", ",")
         else:
@@ -60,24 +64,28 @@ def main():
         eng = pkg.Engine(N, B, link_flags=int(kv.get("link", 3)), tile_channels=int(kv.get("tile", 0)))
         eng.set_chain(chain)
         mix = torch.zeros(B, dtype=torch.float32, device=dev) if int(kv.get("mix", 1)) else None
-        arms.append(dict(name=name, eng=eng, mix=mix, ms=[], kern=None, bps=eng.algorithmic_bytes_per_sample(B)))
-        print(f"# {name}: {eng.describe().strip().splitlines()[-1]}", flush=True)
-    x = torch.empty((B, N), dtype=torch.float32, device=dev)
-    y = torch.empty_like(x)
+        yoff = int(kv.get("yoff", 0)) // 4          # output buffer offset in bytes (breaks in/out congruence)
+        ybuf = torch.empty(B * N + yoff, dtype=torch.float32, device=dev)
+        arms.append(dict(name=name, eng=eng, mix=mix, ms=[], kern=None, bps=eng.algorithmic_bytes_per_sample(B),
+                         y=ybuf[yoff:]))
+        desc = eng.describe().strip().splitlines()
+        print(f"# {name}: {[l for l in desc if l.startswith('stage')][-1]}", flush=True)
+        arms[-1]["addr"] = " ".join(l.split("@")[1].split(" ")[0] for l in desc if "state @" in l) + f" y=0x{arms[-1]['y'].data_ptr():x}"
+    x = torch.empty(B * N, dtype=torch.float32, device=dev)
     arms[0]["eng"].fill_noise(x, B, 0)
     stream = torch.cuda.current_stream().cuda_stream
     for a in arms:   # warm up: fill rings, create events
         a["eng"].profile_enable(args.steps + 4)
         a["eng"].profile_enable(0)
         for _ in range(max(8, args.delay // B + 2)):
-            a["eng"].process(x, out=y, mix=a["mix"], n_frames=B, stream=stream)
+            a["eng"].process(x, out=a["y"], mix=a["mix"], n_frames=B, stream=stream)
     torch.cuda.synchronize()
     for r in range(args.rounds):
         order = arms if r % 2 == 0 else arms[::-1]
         for a in order:
             a["eng"].profile_enable(1)
             for _ in range(args.steps):
-                a["eng"].process(x, out=y, mix=a["mix"], n_frames=B, stream=stream)
+                a["eng"].process(x, out=a["y"], mix=a["mix"], n_frames=B, stream=stream)
             torch.cuda.synchronize()
             a["eng"].profile_enable(0)
             ms, n, kern = a["eng"].profile_read()
@@ -88,7 +96,8 @@ def main():
         med, mn = statistics.median(a["ms"]), min(a["ms"])
         gbs = a["bps"] * N * B / (med * 1e-3) / 1e9
         print(f"{a['name']:>14s} {a['kern']:>12s}  median {med:.4f} ms  min {mn:.4f}  max {max(a['ms']):.4f}  "
-              f"{gbs:6.0f} GB/s  vs first {base / med:.3f}x")
+              f"{gbs:6.0f} GB/s  vs first {base / med:.3f}x  {a.get('addr', '')}")
+    print(f"# x=0x{x.data_ptr():x}")
 
 
 if __name__ == "__main__":
