@@ -19,12 +19,15 @@ struct FuzzArgs {
     Layout lay;
 };
 void launch_fuzz(const FuzzArgs &a, hipStream_t s);
-// mix[f] = fixed-order sum of part[f][0..stride)
-void launch_mix_reduce(const float *part, float *mix, unsigned nframes, unsigned stride, hipStream_t s);
+// mix[f] = fixed-order sum over waves of part[wave][f]; part2 = scratch [128][nframes]
+void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s);
 // node.rs:189-191: mix[i] /= div
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s);
 // launches the exhaustive check of the fast constant division; *d_count accumulates mismatches
 int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s);
+// dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)
+void launch_ring_copy(float *ring, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0, unsigned nrows,
+                      int skew, bool to_dense, hipStream_t s);
 // dst[f][c] = noise(seed, c0 + c, n_abs0 + f)
 void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
                   const Layout &lay, hipStream_t s);

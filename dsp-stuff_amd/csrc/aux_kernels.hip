@@ -50,26 +50,31 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
     }
 }
 
-// Deterministic fixed-order sum of the per-wave partials of one frame: every lane sums a fixed
-// strided subset (4 independent accumulators keep the loads in flight), then a fixed LDS tree.
-__global__ void __launch_bounds__(WG) mix_reduce_kernel(const float *part, float *mix, unsigned stride) {
-    __shared__ float sh[WG];
-    const unsigned f = blockIdx.x;
-    const float *row = part + (size_t)f * stride;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
-    unsigned i = threadIdx.x;
-    for (; i + 3 * WG < stride; i += 4 * WG) {
-        const float x0 = row[i], x1 = row[i + WG], x2 = row[i + 2 * WG], x3 = row[i + 3 * WG];
-        a0 = a0 + x0; a1 = a1 + x1; a2 = a2 + x2; a3 = a3 + x3;
+// Mix bus, second stage: part is [waves][nframes] (each wave wrote its own contiguous row).  Stage A: block b
+// sums a fixed slice of waves for every frame (lane = frame: coalesced row reads) into part2[b][frame];
+// stage B: one block sums the slices in fixed order.  Fixed association => run-to-run deterministic.
+constexpr unsigned MIX_SLICES = 128;
+__global__ void __launch_bounds__(WG) mix_reduce_a_kernel(const float *part, float *part2, unsigned waves, unsigned nframes) {
+    const unsigned per = (waves + MIX_SLICES - 1) / MIX_SLICES;
+    const unsigned w0 = blockIdx.x * per, w1 = min(waves, w0 + per);
+    for (unsigned f = threadIdx.x; f < nframes; f += WG) {
+        float a0 = 0.0f, a1 = 0.0f;
+        unsigned w = w0;
+        for (; w + 1 < w1; w += 2) {
+            const float x0 = part[(size_t)w * nframes + f], x1 = part[(size_t)(w + 1) * nframes + f];
+            a0 = a0 + x0;
+            a1 = a1 + x1;
+        }
+        if (w < w1) a0 = a0 + part[(size_t)w * nframes + f];
+        part2[(size_t)blockIdx.x * nframes + f] = a0 + a1;
     }
-    for (; i < stride; i += WG) a0 = a0 + row[i];
-    sh[threadIdx.x] = (a0 + a1) + (a2 + a3);
-    __syncthreads();
-    for (int o = WG / 2; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) sh[threadIdx.x] = sh[threadIdx.x] + sh[threadIdx.x + o];
-        __syncthreads();
+}
+__global__ void __launch_bounds__(WG) mix_reduce_b_kernel(const float *part2, float *mix, unsigned nframes) {
+    for (unsigned f = blockIdx.x * WG + threadIdx.x; f < nframes; f += gridDim.x * WG) {
+        float acc = 0.0f;
+        for (unsigned b = 0; b < MIX_SLICES; ++b) acc = acc + part2[(size_t)b * nframes + f];
+        mix[f] = acc;
     }
-    if (threadIdx.x == 0) mix[f] = sh[0];
 }
 
 __global__ void mix_finish_kernel(float *mix, unsigned n, float div) {
@@ -116,11 +121,35 @@ int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hi
     return (int)hipGetLastError();
 }
 
+__global__ void __launch_bounds__(WG) ring_copy_kernel(float *ring, float *dense, unsigned N, unsigned W, unsigned D,
+                                                       unsigned r0, unsigned nrows, int skew, int to_dense) {
+    const size_t total = (size_t)N * nrows;
+    const size_t ntiles = N / W;
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
+        const unsigned k = (unsigned)(i / N), c = (unsigned)(i % N);
+        unsigned r = r0 + k;
+        r = r >= D ? r - D : r;
+        float *p = ring + ring_row_offset(r, c / W, ntiles, D, W, skew) + (c % W);
+        if (to_dense) dense[i] = *p;
+        else *p = dense[i];
+    }
+}
+void launch_ring_copy(float *ring, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0, unsigned nrows,
+                      int skew, bool to_dense, hipStream_t s) {
+    const size_t total = (size_t)N * nrows;
+    size_t blocks = (total + WG - 1) / WG;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(ring_copy_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, ring, dense, N, W, D, r0, nrows, skew,
+                       to_dense ? 1 : 0);
+}
+
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + WG - 1) / WG), dim3(WG), 0, s, a);
 }
-void launch_mix_reduce(const float *part, float *mix, unsigned nframes, unsigned stride, hipStream_t s) {
-    hipLaunchKernelGGL(mix_reduce_kernel, dim3(nframes), dim3(WG), 0, s, part, mix, stride);
+void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s) {
+    hipLaunchKernelGGL(mix_reduce_a_kernel, dim3(MIX_SLICES), dim3(WG), 0, s, part, part2, waves, nframes);
+    hipLaunchKernelGGL(mix_reduce_b_kernel, dim3((nframes + WG - 1) / WG), dim3(WG), 0, s, part2, mix, nframes);
 }
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s) {
     hipLaunchKernelGGL(mix_finish_kernel, dim3((n + 127) / 128), dim3(128), 0, s, mix, n, div);

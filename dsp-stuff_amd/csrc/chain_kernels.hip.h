@@ -43,7 +43,7 @@ struct SlotArgs {
     unsigned D;
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
-    int pad_;
+    int ring_skew;   // REVERB: rows of each 128-row ring group rotated per tile (ring_row_offset)
     double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
     // control ports (`as_input` sliders, dsp-stuff-derive/src/lib.rs:122-161), slider field order:
     const float *ctl[3];   // connected port: signal in the sample layout, else nullptr
@@ -56,7 +56,7 @@ struct ChainArgs {
     const float *in;
     const float *side;   // port "b" of ADD/MIX, or nullptr
     float *out;
-    float *mixpart;      // [nframes][mix_stride] per-wave partial sums, or nullptr
+    float *mixpart;      // [mix_stride waves][nframes] per-wave partial sums (a wave's row is contiguous), or nullptr
     unsigned N;
     unsigned nframes;
     float hop_div;       // f32(0.0001 + 1.0)  (node.rs:166,179)
@@ -78,7 +78,7 @@ struct ChainArgs {
     double hop_rc;           // f64 1/hop_div
     double third_rc;         // f64 1/3.0f  (SoftClip's powi(3)/3.0)
     int fast_div;            // every constant divisor of this launch passed the exhaustive check
-    int pad2_;
+    int xcd_remap;           // 1: blocks of one XCD (b % 8) cover a contiguous range of channel tiles
     SlotArgs slot[MAX_SLOTS];
 };
 
@@ -94,10 +94,16 @@ struct ChainArgs {
 #ifndef DSPFX_RING_BLOCKMAJOR
 #define DSPFX_RING_BLOCKMAJOR 1
 #endif
-__host__ __device__ inline size_t ring_row_offset(unsigned r, size_t tile, size_t ntiles, size_t D, size_t ld) {
+// `skew` != 0 additionally rotates the rows inside each 128-row group by a tile-dependent amount
+// ((r + 37*tile) & 127): workgroups advance through frames in lockstep, so without it every workgroup on
+// the chip touches the SAME row offset of its tile at any instant and the ring stream's L2-channel pattern
+// can coincide with the output stream's for every workgroup at once (placement-dependent slow mode).
+__host__ __device__ inline size_t ring_row_offset(unsigned r, size_t tile, size_t ntiles, size_t D, size_t ld,
+                                                  int skew = 0) {
 #if DSPFX_RING_BLOCKMAJOR
     (void)D;
-    return (((size_t)(r >> 7) * ntiles + tile) * 128 + (r & 127u)) * ld;
+    const unsigned rr = skew ? ((r + 37u * (unsigned)tile) & 127u) : (r & 127u);
+    return (((size_t)(r >> 7) * ntiles + tile) * 128 + rr) * ld;
 #else
     (void)ntiles;
     return (tile * D + r) * ld;
@@ -360,7 +366,7 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f) {
             unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
             r = r >= s.D ? r - s.D : r;
-            row[f] = ring_row_offset(r, cx.tile, cx.ntiles, s.D, cx.ld) + cx.cw;
+            row[f] = ring_row_offset(r, cx.tile, cx.ntiles, s.D, cx.ld, s.ring_skew) + cx.cw;
             load_vec<CPL, GUARD, S_RING_LD>(s.state + row[f], tap[f], cx.active);
         }
 #pragma unroll
@@ -650,6 +656,20 @@ __device__ __forceinline__ bool mixbus_lane_writes(int lane) {
     return (lane & mask) == 0;
 }
 
+// Block -> work mapping.  The dispatcher places block b on XCD b % 8, so with the identity mapping the
+// workgroups resident on one XCD work on channel tiles 8 apart: a regular 1 MiB stride that can alias
+// onto few of that XCD's L2 channels (measured: TCP_TCR_TCP_STALL_CYCLES x6.4 and +18 % kernel time for
+// unlucky physical placements, profiles/r01_placement.txt).  Remapped, XCD x owns blocks
+// [x*nb/8, (x+1)*nb/8): neighbouring workgroups of an XCD touch neighbouring 128 KiB tiles.
+// Placement only affects speed, never results (every block index is still covered exactly once).
+__device__ __forceinline__ unsigned work_block(int remap) {
+    const unsigned b = blockIdx.x, nb = gridDim.x;
+    if (remap == 2 && (nb & (nb - 1)) == 0) return (b * 0x9E3779B1u) & (nb - 1);   // experiment: scatter (odd multiplier = bijection)
+    if (remap == 3 && (nb & (nb - 1)) == 0) return __brev(b) >> (__clz(nb) + 1);    // experiment: bit reversal
+    if (!remap || (nb & 7u)) return b;
+    return (b & 7u) * (nb >> 3) + (b >> 3);
+}
+
 // ---- the fused chain kernel, statically specialised ---------------------------------
 #define DSPFX_FOR_SLOTS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7)
 
@@ -670,7 +690,7 @@ __device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (
     }
     wave_reduce_scatter<F>(r, lane);
     if (mixbus_lane_writes<F>(lane))
-        a.mixpart[(size_t)(f0 + mixbus_frame_of_lane<F>(lane)) * a.mix_stride + wave_global] = r[0];
+        a.mixpart[(size_t)wave_global * a.nframes + f0 + mixbus_frame_of_lane<F>(lane)] = r[0];
 }
 
 template <int F, int CPL, class SL>
@@ -693,7 +713,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
 template <int F, int CPL, class SL>
 __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
-    const unsigned tid = blockIdx.x * WG + threadIdx.x;
+    const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned wave_global = a.wave_base + (tid >> 6);
     const size_t rel = (size_t)tid * CPL;
@@ -752,7 +772,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
 template <int F, bool GUARD, bool MOD, bool LIBM>
 __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     extern __shared__ float lds[];   // [state rows][WG]
-    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
+    const unsigned tid = (blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x) * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
     const int lane = threadIdx.x & 63;
     const unsigned wave_global = a.wave_base + (tid >> 6);
     const bool active = tid < a.n_launch;

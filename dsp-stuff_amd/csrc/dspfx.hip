@@ -38,6 +38,7 @@ struct Node {
     float *state_alloc = nullptr;   // allocation base (state = state_alloc + skew for delay rings)
     size_t state_bytes = 0;
     uint32_t D = 0, pos = 0;  // REVERB
+    int ring_skew = 0;        // REVERB: per-tile row rotation inside each ring group (ring_row_offset)
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;
@@ -64,6 +65,8 @@ struct dspfx_engine {
     std::string err;
     float hop_div = 1.0f;
     float *mixpart = nullptr;
+    float *mixpart_b = nullptr;   // second-stage scratch [128][max_frames] (one per stream of use: inline / deferred)
+    float *mixpart_b2 = nullptr;
     size_t mixpart_cols = 0;
     // pipelined mix bus (dspfx_process_partials / dspfx_mix_collect): double-buffered partials
     float *mixpart2[2] = {nullptr, nullptr};
@@ -353,6 +356,10 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
         n.state = (float *)((char *)n.state_alloc + skew);
     }
     n.state_bytes = bytes;
+    if (n.d.kind == DSPFX_REVERB) {   // row rotation only makes sense with several tiles; DSPFX_RING_ROWSKEW=0 disables
+        const char *rs = getenv("DSPFX_RING_ROWSKEW");
+        n.ring_skew = (e->desc.tile_channels && DSPFX_RING_BLOCKMAJOR && (rs ? atoi(rs) : 1)) ? 1 : 0;
+    }
     if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
     n.pos = 0;
     if (n.d.kind == DSPFX_FIR) {
@@ -382,6 +389,7 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.state = n.state;
     s.D = n.D;
     s.pos = n.pos;
+    s.ring_skew = n.ring_skew;
     s.hop = node_hop(e, idx);
     s.rc = n.d.kind == DSPFX_DISTORT ? 1.0 / (double)n.d.params[0] : 0.0;
     for (int k = 0; k < 3; ++k) {
@@ -398,19 +406,31 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     }
 }
 
-// One delay-ring row (all channels of ring position r) <-> a dense [N] host row.  The ring is
-// [D][N] in a frame-major engine and [N/W][D][W] in a channel-tiled one.
-hipError_t ring_row_copy(const dspfx_engine *e, const Node &n, uint32_t r, void *host, bool to_host) {
+// Delay-ring rows [r0, r0+nrows) (mod D) <-> dense host rows [nrows][N], through a device bounce buffer and a
+// gather/scatter kernel, so the exported form is canonical whatever the ring's internal layout.
+int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *host, bool to_host) {
     const size_t N = e->desc.channels;
-    const size_t W = e->desc.tile_channels ? e->desc.tile_channels : N;
-    const size_t ntiles = N / W;
-    float *dev = n.state + ring_row_offset(r, 0, ntiles, n.D, W);
-    const size_t seg = W * sizeof(float);
-    const size_t pitch = (ring_row_offset(r, 1, ntiles, n.D, W) - ring_row_offset(r, 0, ntiles, n.D, W)) * sizeof(float);
-    if (ntiles == 1)
-        return to_host ? hipMemcpy(host, dev, seg, hipMemcpyDeviceToHost) : hipMemcpy(dev, host, seg, hipMemcpyHostToDevice);
-    return to_host ? hipMemcpy2D(host, seg, dev, pitch, seg, ntiles, hipMemcpyDeviceToHost)
-                   : hipMemcpy2D(dev, pitch, host, seg, seg, ntiles, hipMemcpyHostToDevice);
+    const uint32_t W = e->desc.tile_channels ? e->desc.tile_channels : (uint32_t)N;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nrows, ((size_t)64 << 20) / (N * sizeof(float))));
+    float *bounce = nullptr;
+    HIPCHK(e, hipMalloc((void **)&bounce, (size_t)chunk * N * sizeof(float)));
+    int rc = DSPFX_OK;
+    for (uint32_t k = 0; k < nrows && rc == DSPFX_OK; k += chunk) {
+        const uint32_t nr = std::min(chunk, nrows - k);
+        const size_t bytes = (size_t)nr * N * sizeof(float);
+        const uint32_t r = (uint32_t)(((uint64_t)r0 + k) % n.D);
+        hipError_t err = hipSuccess;
+        if (!to_host) err = hipMemcpy(bounce, host + (size_t)k * N * sizeof(float), bytes, hipMemcpyHostToDevice);
+        if (err == hipSuccess) {
+            launch_ring_copy(n.state, bounce, (unsigned)N, W, n.D, r, nr, n.ring_skew, to_host, nullptr);
+            err = hipGetLastError();
+        }
+        if (err == hipSuccess) err = hipDeviceSynchronize();
+        if (err == hipSuccess && to_host) err = hipMemcpy(host + (size_t)k * N * sizeof(float), bounce, bytes, hipMemcpyDeviceToHost);
+        if (err != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "ring copy: %s", hipGetErrorString(err));
+    }
+    (void)hipFree(bounce);
+    return rc;
 }
 
 int state_rows(const Node &n) {
@@ -456,6 +476,10 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.hop_rc = 1.0 / (double)e->hop_div;
             a.third_rc = 1.0 / 3.0;
             a.fast_div = st.fast_div ? 1 : 0;
+            {   // DSPFX_XCD_REMAP=0 switches the XCD-contiguous block mapping off (A/B runs); read per launch
+                const char *xr = getenv("DSPFX_XCD_REMAP");
+                a.xcd_remap = xr ? atoi(xr) : 1;
+            }
             a.n_slots = st.count;
             // hop flag of the side input and of control links (both are ordinary links between nodes);
             // an unconnected side port reads zeros, for which the hop is a no-op
@@ -500,7 +524,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 e->part_stride[e->flip] = a.mix_stride;
                 e->part_frames[e->flip] = nframes;
             } else if (a.mixpart) {
-                launch_mix_reduce(e->mixpart, mix, nframes, a.mix_stride, stream);
+                launch_mix_reduce(e->mixpart, e->mixpart_b, mix, nframes, a.mix_stride, stream);
                 HIPCHK(e, hipGetLastError());
             }
         } else if (st.type == ST_FUZZ) {
@@ -627,8 +651,10 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
         else if (v->f == 8 && v->libm) (v->mod ? e->dyn_mod : e->dyn) = v;   // fallbacks handle every node kind
     }
     e->mixpart_cols = (size_t)desc->channels / 64 + 8;
-    if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess) {
-        delete e;
+    if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&e->mixpart_b, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&e->mixpart_b2, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess) {
+        dspfx_engine_destroy(e);
         return DSPFX_ERR_OOM;
     }
     plan(e);
@@ -641,6 +667,8 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     (void)hipSetDevice(e->device);
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
+    if (e->mixpart_b) (void)hipFree(e->mixpart_b);
+    if (e->mixpart_b2) (void)hipFree(e->mixpart_b2);
     for (int i = 0; i < 2; ++i) {
         if (e->mixpart2[i]) (void)hipFree(e->mixpart2[i]);
         if (e->ev_chain[i]) (void)hipEventDestroy(e->ev_chain[i]);
@@ -889,7 +917,7 @@ extern "C" int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames,
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(e, hipStreamWaitEvent(s, e->ev_chain[b], 0));
-    launch_mix_reduce(e->mixpart2[b], mix, n_frames, e->part_stride[b], s);
+    launch_mix_reduce(e->mixpart2[b], e->mixpart_b2, mix, n_frames, e->part_stride[b], s);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipEventRecord(e->ev_red[b], s));
     e->red_pending[b] = true;
@@ -916,6 +944,7 @@ extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
     if (!e || node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;
     const Node &n = e->nodes[(size_t)node];
     if (n.d.kind == DSPFX_FIR) return (int64_t)fir_state_bytes(n.fir);
+    if (n.d.kind == DSPFX_REVERB) return (int64_t)n.D * e->desc.channels * (int64_t)sizeof(float);   // canonical [D][N]
     return (int64_t)n.state_bytes;
 }
 
@@ -931,18 +960,8 @@ extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, siz
         const int rc = fir_state_export(n.fir, host_dst);
         return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
     }
-    if (n.d.kind == DSPFX_REVERB) {   // canonical form: [D][N], row 0 = the oldest sample
-        const size_t row = (size_t)e->desc.channels * sizeof(float);
-        if (!e->desc.tile_channels) {   // frame-major ring is the plain [D][N]: two contiguous pieces
-            const size_t head = (size_t)(n.D - n.pos) * row;
-            HIPCHK(e, hipMemcpy(host_dst, (char *)n.state + (size_t)n.pos * row, head, hipMemcpyDeviceToHost));
-            if (n.pos) HIPCHK(e, hipMemcpy((char *)host_dst + head, n.state, (size_t)n.pos * row, hipMemcpyDeviceToHost));
-        } else {
-            for (uint32_t k = 0; k < n.D; ++k)
-                HIPCHK(e, ring_row_copy(e, n, (n.pos + k) % n.D, (char *)host_dst + (size_t)k * row, true));
-        }
-        return DSPFX_OK;
-    }
+    if (n.d.kind == DSPFX_REVERB)   // canonical form: [D][N], row 0 = the oldest sample
+        return ring_rows_copy(e, n, n.pos, n.D, (char *)host_dst, true);
     if (need) HIPCHK(e, hipMemcpy(host_dst, n.state, (size_t)need, hipMemcpyDeviceToHost));
     return DSPFX_OK;
 }
@@ -959,10 +978,9 @@ extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_sr
         const int rc = fir_state_import(n.fir, host_src);
         return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
     }
-    if (n.d.kind == DSPFX_REVERB && e->desc.tile_channels) {
-        const size_t row = (size_t)e->desc.channels * sizeof(float);
-        for (uint32_t k = 0; k < n.D; ++k)
-            HIPCHK(e, ring_row_copy(e, n, k, (void *)((const char *)host_src + (size_t)k * row), false));
+    if (n.d.kind == DSPFX_REVERB) {
+        const int rc = ring_rows_copy(e, n, 0, n.D, (char *)const_cast<void *>(host_src), false);
+        if (rc) return rc;
     } else if (need) {
         HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
     }
