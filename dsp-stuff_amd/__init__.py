@@ -382,8 +382,8 @@ class Engine:
         self._chk(self.L.dspfx_sync(self.h, C.c_void_p(stream) if stream else None))
 
     def describe(self) -> str:
-        buf = C.create_string_buffer(4096)
-        self._chk(self.L.dspfx_describe(self.h, buf, 4096))
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self.L.dspfx_describe(self.h, buf, 1 << 16))
         return buf.value.decode()
 
     def profile_enable(self, launches: int = 1):

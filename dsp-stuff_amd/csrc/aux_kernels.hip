@@ -121,27 +121,44 @@ int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hi
     return (int)hipGetLastError();
 }
 
-__global__ void __launch_bounds__(WG) ring_copy_kernel(float *ring, float *dense, unsigned N, unsigned W, unsigned D,
-                                                       unsigned r0, unsigned nrows, int skew, int to_dense) {
+__global__ void __launch_bounds__(WG) ring_copy_kernel(float *const *groups, float *dense, unsigned N, unsigned W,
+                                                       unsigned D, unsigned r0, unsigned nrows, int skew, int to_dense) {
     const size_t total = (size_t)N * nrows;
-    const size_t ntiles = N / W;
     for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
         const unsigned k = (unsigned)(i / N), c = (unsigned)(i % N);
         unsigned r = r0 + k;
         r = r >= D ? r - D : r;
-        float *p = ring + ring_row_offset(r, c / W, ntiles, D, W, skew) + (c % W);
+        float *p = groups[r >> 7] + ring_in_group_offset(r, c / W, W, skew) + (c % W);
         if (to_dense) dense[i] = *p;
         else *p = dense[i];
     }
 }
-void launch_ring_copy(float *ring, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0, unsigned nrows,
-                      int skew, bool to_dense, hipStream_t s) {
+void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
+                      unsigned nrows, int skew, bool to_dense, hipStream_t s) {
     const size_t total = (size_t)N * nrows;
     size_t blocks = (total + WG - 1) / WG;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(ring_copy_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, ring, dense, N, W, D, r0, nrows, skew,
+    hipLaunchKernelGGL(ring_copy_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, groups, dense, N, W, D, r0, nrows, skew,
                        to_dense ? 1 : 0);
+}
+
+// Placement probe: nontemporal read-modify-write of a whole group, 8 bytes per lane like the chain kernel.
+__global__ void __launch_bounds__(WG) ring_probe_kernel(float *group, size_t n2, float one) {
+    typedef float v2 __attribute__((ext_vector_type(2)));
+    v2 *p = reinterpret_cast<v2 *>(group);
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
+        v2 t = __builtin_nontemporal_load(p + i);
+        t = t * one;                                   // run-time factor: keeps the load/store pair alive
+        __builtin_nontemporal_store(t, p + i);
+    }
+}
+void launch_ring_probe(float *group, size_t n_floats, hipStream_t s) {
+    const size_t n2 = n_floats / 2;
+    size_t blocks = (n2 + WG - 1) / WG;
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(ring_probe_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, group, n2, 1.0f);
 }
 
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {

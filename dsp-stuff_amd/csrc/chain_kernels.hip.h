@@ -33,17 +33,18 @@ enum : int {
 
 // Per-node kernel arguments (wave-uniform: they live in SGPRs).
 //   BIQUAD : p = {a1,a2,b0,b1,b2} already divided by a0 on the host (biquad.rs:62-76)
-//   REVERB : p[0] = decay; state = ring [D][N]; pos = ring row of the block's first frame
+//   REVERB : p[0] = decay; groups = ring group table; pos = ring row of the block's first frame
 //   others : p = the reference's slider values in field order
 struct SlotArgs {
     int kind;
     int mode;
     float p[6];
     float *state;
+    float *const *groups;   // REVERB: device table of ring group base pointers
     unsigned D;
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
-    int ring_skew;   // REVERB: rows of each 128-row ring group rotated per tile (ring_row_offset)
+    int ring_skew;   // REVERB: rows of each 128-row ring group rotated per tile (ring_in_group_offset)
     double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
     // control ports (`as_input` sliders, dsp-stuff-derive/src/lib.rs:122-161), slider field order:
     const float *ctl[3];   // connected port: signal in the sample layout, else nullptr
@@ -86,35 +87,19 @@ struct ChainArgs {
 //   (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
 //   frame-major [B][N]       : w_shift = 31, w_mask = 0x7fffffff, ld = N, tile_stride = 0
 //   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
-// Delay rings are block-major: ring row r (0..D-1) of channel tile t lives at
-//   (((r >> 7) * ntiles + t) * 128 + (r & 127)) * ld + (c & w_mask)
-// i.e. [ceil(D/128)][ntiles][128][W]: the 128 rows a block reads/overwrites are, for ALL tiles together,
-// one or two contiguous N*128*4-byte extents (TLB / DRAM-page friendly at a 94 GiB footprint), and with a
-// single tile (frame-major, W = N) the map degenerates to the plain [D][N].
-#ifndef DSPFX_RING_BLOCKMAJOR
-#define DSPFX_RING_BLOCKMAJOR 1
-#endif
-// `skew` != 0 additionally rotates the rows inside each 128-row group by a tile-dependent amount
-// ((r + 37*tile) & 127): workgroups advance through frames in lockstep, so without it every workgroup on
-// the chip touches the SAME row offset of its tile at any instant and the ring stream's L2-channel pattern
-// can coincide with the output stream's for every workgroup at once (placement-dependent slow mode).
-__host__ __device__ inline size_t ring_row_offset(unsigned r, size_t tile, size_t ntiles, size_t D, size_t ld,
-                                                  int skew = 0) {
-#if DSPFX_RING_BLOCKMAJOR
-    (void)D;
+// Delay rings are stored as separately allocated GROUPS of 128 rows behind a pointer table:
+// ring row r (0..D-1) of channel tile t, channel-in-tile cw, lives at
+//   groups[r >> 7] + (t * 128 + (r & 127)) * ld + cw            ([ceil(D/128)] x [ntiles][128][W])
+// so the 128 rows a block reads/overwrites are, for ALL tiles together, one or two contiguous
+// N*128*4-byte extents (TLB / DRAM-page friendly at a 94 GiB footprint), and every group can be placed
+// -- and re-placed -- independently: some physical HBM regions stream ~18 % slower for this pattern
+// (profiles/r01_placement.txt), the engine probes each group at setup and re-allocates the slow ones.
+// With a single tile (frame-major, W = N) a group is the plain [128][N].
+constexpr unsigned RING_GROUP_ROWS = 128;
+__host__ __device__ inline size_t ring_in_group_offset(unsigned r, size_t tile, size_t ld, int skew = 0) {
+    // `skew` (experiment, default off: measured harmful) rotates the rows of a group per tile
     const unsigned rr = skew ? ((r + 37u * (unsigned)tile) & 127u) : (r & 127u);
-    return (((size_t)(r >> 7) * ntiles + tile) * 128 + rr) * ld;
-#else
-    (void)ntiles;
-    return (tile * D + r) * ld;
-#endif
-}
-__host__ __device__ inline size_t ring_rows_allocated(size_t D) {
-#if DSPFX_RING_BLOCKMAJOR
-    return (D + 127) / 128 * 128;
-#else
-    return D;
-#endif
+    return (tile * RING_GROUP_ROWS + rr) * ld;
 }
 
 struct Layout {
@@ -361,19 +346,20 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
     } else if constexpr (KIND == K_REVERB) {      // reverb.rs:86-103: y = x + tap*decay; ring <- y
         const float decay = s.p[0];
         float tap[F][CPL];
-        size_t row[F];
+        float *row[F];
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
             r = r >= s.D ? r - s.D : r;
-            row[f] = ring_row_offset(r, cx.tile, cx.ntiles, s.D, cx.ld, s.ring_skew) + cx.cw;
-            load_vec<CPL, GUARD, S_RING_LD>(s.state + row[f], tap[f], cx.active);
+            float *gb = s.groups[r >> 7];                      // wave-uniform: one scalar load
+            row[f] = gb + ring_in_group_offset(r, cx.tile, cx.ld, s.ring_skew) + cx.cw;
+            load_vec<CPL, GUARD, S_RING_LD>(row[f], tap[f], cx.active);
         }
 #pragma unroll
         for (int f = 0; f < F; ++f) {
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap[f][j] * decay;
-            store_vec<CPL, GUARD, S_RING_ST>(s.state + row[f], v[f], cx.active);
+            store_vec<CPL, GUARD, S_RING_ST>(row[f], v[f], cx.active);
         }
     } else if constexpr (KIND == K_DISTORT) {     // distort.rs:176-194 (Fuzz has its own kernel)
         const float level = s.p[0];

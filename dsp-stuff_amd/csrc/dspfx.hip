@@ -28,17 +28,20 @@ using namespace dspfx;
 namespace {
 
 enum StageType { ST_FUSED = 0, ST_FUZZ = 1, ST_FIR = 2 };
-constexpr size_t RING_SKEW_BYTES = 0;   // default set from the A/B below
 
 struct Node {
     dspfx_node_desc d{};
     // BIQUAD: normalised coefficients (biquad.rs:62-76)
     float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
-    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N], REVERB ring (+ skew), FIR history
-    float *state_alloc = nullptr;   // allocation base (state = state_alloc + skew for delay rings)
+    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N]
+    // REVERB: the ring as separately allocated 128-row groups + the device copy of the pointer table
+    std::vector<float *> groups;
+    float **d_groups = nullptr;
+    size_t group_floats = 0;
+    int ring_replaced = 0;    // groups re-allocated by the placement probe
     size_t state_bytes = 0;
     uint32_t D = 0, pos = 0;  // REVERB
-    int ring_skew = 0;        // REVERB: per-tile row rotation inside each ring group (ring_row_offset)
+    int ring_skew = 0;        // REVERB: per-tile row rotation inside each ring group (ring_in_group_offset)
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;
@@ -195,9 +198,18 @@ void biquad_regenerate(Node &n) {   // biquad.rs:62-76
     n.b2 = n.d.params[5] / a0;
 }
 
+void free_ring(Node &n) {
+    for (float *g : n.groups)
+        if (g) (void)hipFree(g);
+    n.groups.clear();
+    if (n.d_groups) (void)hipFree(n.d_groups);
+    n.d_groups = nullptr;
+}
+
 void free_node(Node &n) {
-    if (n.state_alloc) (void)hipFree(n.state_alloc);
-    n.state = n.state_alloc = nullptr;
+    free_ring(n);
+    if (n.state) (void)hipFree(n.state);
+    n.state = nullptr;
     n.state_bytes = 0;
     fir_free(n.fir);
     for (int k = 0; k < 3; ++k) {
@@ -328,6 +340,121 @@ int plan(dspfx_engine *e) {
     return DSPFX_OK;
 }
 
+// Placement tuning of a delay ring (see chain_kernels.hip.h, ring layout).  Some physical HBM regions
+// stream ~18 % slower under the chain kernel's access pattern (every resident workgroup walking its own
+// 128 KiB tile); the effect is stable over time and independent of the in/out buffers, but a plain
+// streaming sweep does not show it (profiles/r01_placement.txt), so the probe IS the delay node's kernel:
+// each candidate group is timed as a one-node REVERB launch over engine-owned scratch in/out.  As many
+// extra candidates as memory allows (at most as many as the ring has groups) are allocated, all are
+// timed, the fastest are kept.  Setup-time only; DSPFX_RING_TUNE=0/1 forces it off/on (default: rings
+// whose groups are >= 64 MiB).
+int tune_ring(dspfx_engine *e, Node &n) {
+    const char *tv = getenv("DSPFX_RING_TUNE");
+    const int mode = tv ? atoi(tv) : -1;
+    const size_t gbytes = n.group_floats * sizeof(float);
+    if (mode == 0 || (mode < 0 && gbytes < ((size_t)64 << 20))) return DSPFX_OK;
+    const uint32_t N = e->desc.channels;
+    if (N < 64 || !e->dyn) return DSPFX_OK;
+    const size_t G = n.groups.size();
+    size_t free_b = 0, total_b = 0;
+    HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
+    const size_t scratch_bytes = 2 * gbytes;                     // in + out blocks of 128 frames
+    const size_t reserve = (size_t)8 << 30;                      // leave room for the caller's buffers
+    size_t extra = 0;
+    if (free_b > scratch_bytes + reserve) extra = std::min(G, (free_b - scratch_bytes - reserve) / gbytes);
+    float *scratch = nullptr, **d_one = nullptr;
+    hipEvent_t a = nullptr, b = nullptr;
+    if (hipMalloc((void **)&scratch, scratch_bytes) != hipSuccess) return DSPFX_OK;   // no room: skip tuning
+    HIPCHK(e, hipMemset(scratch, 0, scratch_bytes));
+    HIPCHK(e, hipMalloc((void **)&d_one, sizeof(float *)));
+    HIPCHK(e, hipEventCreate(&a));
+    HIPCHK(e, hipEventCreate(&b));
+    std::vector<float *> cand = n.groups;
+    for (size_t k = 0; k < extra; ++k) {
+        float *g = nullptr;
+        if (hipMalloc((void **)&g, gbytes) != hipSuccess) break;
+        cand.push_back(g);
+    }
+    ChainArgs ca;
+    memset(&ca, 0, sizeof ca);
+    ca.in = scratch;
+    ca.out = scratch + n.group_floats;
+    ca.N = N;
+    ca.nframes = RING_GROUP_ROWS;
+    if (e->desc.tile_channels) {
+        const uint32_t W = e->desc.tile_channels;
+        ca.w_shift = (unsigned)__builtin_ctz(W);
+        ca.w_mask = W - 1;
+        ca.ld = W;
+        ca.io_tile_stride = (size_t)RING_GROUP_ROWS * W;
+        ca.ntiles = N / W;
+    } else {
+        ca.w_shift = 31;
+        ca.w_mask = 0x7fffffffu;
+        ca.ld = N;
+        ca.ntiles = 1;
+    }
+    ca.hop_div = e->hop_div;
+    ca.hop_rc = 1.0 / (double)e->hop_div;
+    ca.third_rc = 1.0 / 3.0;
+    ca.fast_div = 1;
+    ca.xcd_remap = 1;
+    ca.n_slots = 1;
+    ca.slot[0].kind = DSPFX_REVERB;
+    ca.slot[0].p[0] = 0.5f;
+    ca.slot[0].groups = d_one;
+    ca.slot[0].D = RING_GROUP_ROWS;
+    ca.slot[0].ring_skew = n.ring_skew;
+    const uint32_t n_main = N - N % 64u;
+    ca.n_launch = n_main;
+    const unsigned grid = (n_main + WG - 1) / WG;
+    std::vector<float> t(cand.size(), 0.0f);
+    for (size_t g = 0; g < cand.size(); ++g) {
+        HIPCHK(e, hipMemcpy(d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice));
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {   // rep 0 warms TLB/clocks
+            (void)hipEventRecord(a, nullptr);
+            e->dyn->launch(ca, grid, WG, 0, nullptr);
+            (void)hipEventRecord(b, nullptr);
+            HIPCHK(e, hipEventSynchronize(b));
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, a, b);
+            if (rep) best = std::min(best, ms);
+        }
+        t[g] = best;
+    }
+    if (getenv("DSPFX_RING_TUNE_DEBUG")) {
+        fprintf(stderr, "ring probe ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
+        for (float v : t) fprintf(stderr, " %.3f", v);
+        fprintf(stderr, "\n");
+    }
+    // keep the G fastest candidates (stable: original groups win ties)
+    std::vector<size_t> order(cand.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
+    std::vector<char> keep(cand.size(), 0);
+    for (size_t i = 0; i < G; ++i) keep[order[i]] = 1;
+    std::vector<float *> chosen;
+    int replaced = 0;
+    for (size_t i = 0; i < cand.size(); ++i) {
+        if (keep[i]) {
+            chosen.push_back(cand[i]);
+            if (i >= G) ++replaced;
+        } else {
+            (void)hipFree(cand[i]);
+        }
+    }
+    n.groups = chosen;
+    n.ring_replaced = replaced;
+    (void)hipFree(scratch);
+    (void)hipFree(d_one);
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, gbytes));   // probing wrote into the groups
+    HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
+    return DSPFX_OK;
+}
+
 int alloc_node_state(dspfx_engine *e, Node &n) {
     const size_t N = e->desc.channels;
     size_t bytes = 0;
@@ -335,33 +462,33 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     case DSPFX_BIQUAD: bytes = 4 * N * sizeof(float); break;
     case DSPFX_LOW_PASS:
     case DSPFX_HIGH_PASS: bytes = N * sizeof(float); break;
-    case DSPFX_REVERB: bytes = ring_rows_allocated(n.D) * N * sizeof(float); break;
     default: break;
     }
     if (n.state && n.state_bytes != bytes) {
-        (void)hipFree(n.state_alloc);
-        n.state = n.state_alloc = nullptr;
+        (void)hipFree(n.state);
+        n.state = nullptr;
     }
-    if (bytes && !n.state) {
-        // Delay rings start `skew` bytes into their allocation so that a workgroup's ring rows are not
-        // congruent (mod large powers of two) with its input/output tile rows: four streams of one
-        // workgroup on the same HBM bank cost ~10 % (profiles/r01_ab_ring.txt).  DSPFX_RING_SKEW overrides.
-        size_t skew = 0;
-        if (n.d.kind == DSPFX_REVERB) {
-            const char *sk = getenv("DSPFX_RING_SKEW");
-            skew = sk ? (size_t)atol(sk) : (size_t)RING_SKEW_BYTES;
-            skew = skew / 256 * 256;
-        }
-        HIPCHK(e, hipMalloc((void **)&n.state_alloc, bytes + skew));
-        n.state = (float *)((char *)n.state_alloc + skew);
-    }
+    if (bytes && !n.state) HIPCHK(e, hipMalloc((void **)&n.state, bytes));
     n.state_bytes = bytes;
-    if (n.d.kind == DSPFX_REVERB) {   // row rotation only makes sense with several tiles; DSPFX_RING_ROWSKEW=0 disables
-        const char *rs = getenv("DSPFX_RING_ROWSKEW");
-        n.ring_skew = (e->desc.tile_channels && DSPFX_RING_BLOCKMAJOR && (rs ? atoi(rs) : 1)) ? 1 : 0;
-    }
     if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
     n.pos = 0;
+    if (n.d.kind == DSPFX_REVERB) {   // reverb.rs:55-71: a brand-new zero-filled ring
+        free_ring(n);
+        const size_t ngroups = ((size_t)n.D + RING_GROUP_ROWS - 1) / RING_GROUP_ROWS;
+        n.group_floats = (size_t)RING_GROUP_ROWS * N;
+        n.groups.assign(ngroups, nullptr);
+        for (size_t g = 0; g < ngroups; ++g) {
+            HIPCHK(e, hipMalloc((void **)&n.groups[g], n.group_floats * sizeof(float)));
+            HIPCHK(e, hipMemset(n.groups[g], 0, n.group_floats * sizeof(float)));
+        }
+        HIPCHK(e, hipMalloc((void **)&n.d_groups, ngroups * sizeof(float *)));
+        HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), ngroups * sizeof(float *), hipMemcpyHostToDevice));
+        n.state_bytes = (size_t)n.D * N * sizeof(float);   // canonical (exported) size
+        const char *rs = getenv("DSPFX_RING_ROWSKEW");     // experiment switch, default off (measured harmful)
+        n.ring_skew = (e->desc.tile_channels && rs && atoi(rs)) ? 1 : 0;
+        const int rc = tune_ring(e, n);
+        if (rc) return rc;
+    }
     if (n.d.kind == DSPFX_FIR) {
         const int rc = fir_configure(n.fir, n.taps.data(), (uint32_t)n.taps.size(), n.d.mode, (uint32_t)N,
                                      e->desc.max_frames);
@@ -387,6 +514,7 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.kind = n.d.kind;
     s.mode = n.d.mode;
     s.state = n.state;
+    s.groups = n.d_groups;
     s.D = n.D;
     s.pos = n.pos;
     s.ring_skew = n.ring_skew;
@@ -422,7 +550,7 @@ int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *
         hipError_t err = hipSuccess;
         if (!to_host) err = hipMemcpy(bounce, host + (size_t)k * N * sizeof(float), bytes, hipMemcpyHostToDevice);
         if (err == hipSuccess) {
-            launch_ring_copy(n.state, bounce, (unsigned)N, W, n.D, r, nr, n.ring_skew, to_host, nullptr);
+            launch_ring_copy(n.d_groups, bounce, (unsigned)N, W, n.D, r, nr, n.ring_skew, to_host, nullptr);
             err = hipGetLastError();
         }
         if (err == hipSuccess) err = hipDeviceSynchronize();
@@ -777,7 +905,9 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
     if (!e) return DSPFX_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));
     for (Node &n : e->nodes) {
-        if (n.state) HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
+        if (n.state) HIPCHK(e, hipMemset(n.state, 0, n.d.kind == DSPFX_BIQUAD ? 4 * (size_t)e->desc.channels * sizeof(float)
+                                                                              : (size_t)e->desc.channels * sizeof(float)));
+        for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, n.group_floats * sizeof(float)));
         n.pos = 0;
         if (n.d.kind == DSPFX_FIR) fir_reset(n.fir);
     }
@@ -1142,9 +1272,15 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
         }
     }
     for (size_t i = 0; i < e->nodes.size(); ++i)
-        if (e->nodes[i].state) {
-            snprintf(buf, sizeof buf, "node %zu state @%p (%zu bytes)\n", i, (void *)e->nodes[i].state, e->nodes[i].state_bytes);
+        if (!e->nodes[i].groups.empty()) {
+            snprintf(buf, sizeof buf, "node %zu delay ring: %zu groups x %zu MiB, %d re-placed by the placement probe\n", i,
+                     e->nodes[i].groups.size(), (e->nodes[i].group_floats * sizeof(float)) >> 20, e->nodes[i].ring_replaced);
             s += buf;
+            if (getenv("DSPFX_DESCRIBE_GROUPS"))
+                for (size_t g = 0; g < e->nodes[i].groups.size(); ++g) {
+                    snprintf(buf, sizeof buf, "  group %zu @%p\n", g, (void *)e->nodes[i].groups[g]);
+                    s += buf;
+                }
         }
     snprintf(dst, cap, "%s", s.c_str());
     return DSPFX_OK;

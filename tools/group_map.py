@@ -8,7 +8,7 @@ import torch
 from __graft_entry__ import load_package
 import chains
 pkg = load_package()
-N, B, D = 1 << 20, 128, 24064      # 188 groups exactly (multiple of 128) so step k maps to group k % 188
+N, B, D = 1 << 20, 128, 24064      # 188 groups exactly
 os.environ["DSPFX_VARIANT"] = "static=1,f=8,cpl=2"
 os.environ["DSPFX_RING_ROWSKEW"] = "0"
 dev = torch.device("cuda", 0)
@@ -30,6 +30,15 @@ for k in range(2):
         rows.append(ts)
     for i, ts in enumerate(rows):
         print("engine %d pass %d (out buffer %d): " % (k, i, 0 if i < 2 else 1) + "".join("S" if t > 0.39 else "F" for t in ts) + "  mean %.4f" % (sum(ts) / len(ts)))
+    if os.environ.get("DSPFX_DESCRIBE_GROUPS"):
+        addrs = [int(l.split("@")[1], 16) for l in e.describe().splitlines() if l.strip().startswith("group")]
+        print("   x=0x%x y0=0x%x y1=0x%x" % (x.data_ptr(), ys[0].data_ptr(), ys[1].data_ptr()))
+        runs, prev = [], None
+        for g, (a, t) in enumerate(zip(addrs, rows[0])):
+            m = "S" if t > 0.39 else "F"
+            if m != prev: runs.append([m, g, a, a]); prev = m
+            runs[-1][3] = a
+        for m, g, a0, a1 in runs: print("   %s from group %3d: VA 0x%x .. 0x%x  (GiB %.2f .. %.2f)" % (m, g, a0, a1, a0 / 2**30, a1 / 2**30))
     same = sum((a > 0.39) == (b > 0.39) for a, b in zip(rows[0], rows[1]))
     other = sum((a > 0.39) == (b > 0.39) for a, b in zip(rows[1], rows[2]))
     print("   same groups slow on pass 0 and 1: %d/%d;  pass 1 (buffer 0) vs pass 2 (buffer 1): %d/%d" % (same, G, other, G))

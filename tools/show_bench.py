@@ -1,0 +1,12 @@
+#!/usr/bin/env python3
+"""Pretty-print bench.py JSON lines from stdin."""
+import sys, json
+for l in sys.stdin:
+    l = l.strip()
+    if not l.startswith("{"):
+        continue
+    d = json.loads(l)
+    r = d["roofline"]
+    print("%.4f ms/step  %.3e samples/s  %s kern %.4f ms  %.0f %s frac %.3f  probe %s  %s" % (
+        d["ms_per_step"], d["value"], r["kernel"], r["kernel_ms_avg"], r["achieved"], r["unit"], r["frac"],
+        d["config"].get("placement_probe"), [p for p in d["config"]["plan"] if "ring" in p]))
