@@ -182,6 +182,11 @@ def main():
     eng = pkg.Engine(shard.channels, B, link_flags=args.link_flags, device=local_rank,
                      channel_offset=shard.offset, tile_channels=args.tile)
     eng.set_chain(chain)
+    # the chain kernels get their own high-priority stream: the mix bus' small kernels and the RCCL
+    # all-reduce on the second stream must not delay the next block's launch
+    if os.environ.get("DSPFX_BENCH_HIPRIO", "1") == "1":
+        compute_stream = torch.cuda.Stream(device=dev, priority=-1)
+        torch.cuda.set_stream(compute_stream)
     stream = torch.cuda.current_stream().cuda_stream
 
     # Placement probing.  Some physical HBM regions stream ~18 % slower for this access pattern
