@@ -1,8 +1,9 @@
 // chain_kernels.hip.h -- gfx950 device code for the fused effect chain.
 //
 // One wavefront lane owns CPL adjacent channels; a workgroup of 256 lanes owns
-// 256*CPL adjacent channels.  Samples are frame-major [frame][channel], so every
-// load/store a wave issues is one coalesced burst of 64*CPL consecutive floats.
+// 256*CPL adjacent channels.  In both sample layouts (frame-major [frame][channel] and
+// channel-tiled [channel tile][frame][channel in tile], see Layout) the channels of one frame
+// are contiguous, so every load/store a wave issues is one coalesced burst of 64*CPL floats.
 // The time axis is walked in chunks of F frames held in registers; every node of
 // the chain is applied to the chunk before the next chunk is touched, so samples
 // make exactly one HBM round trip per block (16 B/sample with one delay line).
@@ -63,10 +64,10 @@ struct ChainArgs {
     float hop_div;       // f32(0.0001 + 1.0)  (node.rs:166,179)
     int n_slots;
     int side_hop;
-    unsigned mix_stride; // row length of mixpart = number of waves over all launches
+    unsigned mix_stride; // rows of mixpart = number of waves over all launches of this block
     unsigned c_base;     // first channel of this launch
     unsigned n_launch;   // channels covered by this launch
-    unsigned wave_base;  // mixpart column of this launch's first wave
+    unsigned wave_base;  // mixpart row of this launch's first wave
     // sample layout: channel c, frame f lives at  (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
     //   frame-major [B][N]      : w_shift = 31, w_mask = ~0u>>1, ld = N, tile strides unused
     //   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
@@ -75,7 +76,6 @@ struct ChainArgs {
     unsigned ld;
     unsigned pad_;
     size_t io_tile_stride;   // floats between consecutive channel tiles of in/out/side
-    size_t ntiles;           // channel tiles (1 when frame-major)
     double hop_rc;           // f64 1/hop_div
     double third_rc;         // f64 1/3.0f  (SoftClip's powi(3)/3.0)
     int fast_div;            // every constant divisor of this launch passed the exhaustive check
@@ -122,11 +122,6 @@ constexpr int sig(int kind, int mode = 0, int hop = 0) { return kind | (mode << 
 constexpr int sig_kind(int s) { return s & 0xff; }
 constexpr int sig_mode(int s) { return (s >> 8) & 0xff; }
 constexpr int sig_hop(int s) { return (s >> 16) & 1; }
-
-template <int CPL> struct VecT;
-template <> struct VecT<1> { using type = float; };
-template <> struct VecT<2> { using type = float2; };
-template <> struct VecT<4> { using type = float4; };
 
 // Sample/ring traffic is streamed exactly once per block (reuse distance = a whole
 // delay period), so those loads/stores carry the nontemporal hint: measured 1.13-1.27x
@@ -287,7 +282,6 @@ struct Ctx {
     size_t N;
     size_t io_base;  // offset of (frame 0, channel c) in in/out/side
     size_t tile;     // channel tile index
-    size_t ntiles;   // number of channel tiles
     size_t cw;       // channel within its tile
     size_t ld;       // floats between consecutive frames
     unsigned f0;     // first frame of the chunk
@@ -687,7 +681,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
     const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
-    const Ctx cx{c, a.N, io_base, tile, a.ntiles, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
 #define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
@@ -733,7 +727,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
     const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
-    const Ctx cx{c, a.N, io_base, tile, a.ntiles, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
+    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {

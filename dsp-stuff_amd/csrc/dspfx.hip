@@ -387,12 +387,10 @@ int tune_ring(dspfx_engine *e, Node &n) {
         ca.w_mask = W - 1;
         ca.ld = W;
         ca.io_tile_stride = (size_t)RING_GROUP_ROWS * W;
-        ca.ntiles = N / W;
     } else {
         ca.w_shift = 31;
         ca.w_mask = 0x7fffffffu;
         ca.ld = N;
-        ca.ntiles = 1;
     }
     ca.hop_div = e->hop_div;
     ca.hop_rc = 1.0 / (double)e->hop_div;
@@ -599,7 +597,6 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.w_mask = lay.w_mask;
             a.ld = lay.ld;
             a.io_tile_stride = lay.tile_stride;
-            a.ntiles = e->desc.tile_channels ? N / e->desc.tile_channels : 1;
             a.hop_div = e->hop_div;
             a.hop_rc = 1.0 / (double)e->hop_div;
             a.third_rc = 1.0 / 3.0;
