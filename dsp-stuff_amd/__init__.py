@@ -26,7 +26,8 @@ BUF_SIZE = 128  # dsp-stuff/src/node.rs:257
 ABI_VERSION = 1
 
 # dspfx_kind
-GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX = range(11)
+GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN = range(12)
+SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 # dspfx_distort_mode (nodes/distort.rs:18-28)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
 DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"]
@@ -236,6 +237,12 @@ def Add() -> NodeSpec:
 def Mix(ratio: float = 0.5) -> NodeSpec:
     """nodes/mix.rs: out = b*ratio + a*(1-ratio)"""
     return NodeSpec(MIX, [ratio])
+
+
+def SignalGen(amplitude: float = 0.5, frequency: float = 100.0, mode: int = SIG_SINE) -> NodeSpec:
+    """nodes/signal_gen.rs:41-55: a source -- it has no "in" port, so as a chain node it replaces the
+    signal (put it first).  Sliders amplitude -1..=1 and frequency 0.1..=20000 Hz are both `as_input`."""
+    return NodeSpec(SIGNAL_GEN, [amplitude, frequency], mode=mode)
 
 
 # -------------------------------------------------------------------------- engine

@@ -28,7 +28,7 @@ from typing import List, Tuple
 import numpy as np
 
 from . import (ADD, BIQUAD, CHEBYSHEV, DISTORT, DISTORT_MODES, FIR, FIR_AVERAGE, FIR_BALANCED, GAIN,
-               HIGH_PASS, LOW_PASS, MIX, OVERDRIVE, REVERB, NodeSpec, delay_len)
+               HIGH_PASS, LOW_PASS, MIX, OVERDRIVE, REVERB, SIGNAL_GEN, NodeSpec, delay_len)
 
 
 class DspConfigError(ValueError):
@@ -36,7 +36,8 @@ class DspConfigError(ValueError):
 
 
 _FIR_MODES = {"Balanced": FIR_BALANCED, "Average": FIR_AVERAGE}
-_UNSUPPORTED = {"mux", "demux", "muff", "signal_gen", "envelope", "pitch", "wave_view", "spectrogram"}
+_UNSUPPORTED = {"mux", "demux", "muff", "envelope", "pitch", "wave_view", "spectrogram"}
+SIGNAL_MODES = ["Sine", "Triangle", "Square", "Constant"]   # signal_gen.rs:17-22
 # typename -> (kind, saved slider fields in params order, main input port, as_input control ports)
 _TABLE = {
     "gain": (GAIN, ["level"], "in", ["level"]),
@@ -50,6 +51,7 @@ _TABLE = {
     "fir": (FIR, [], "in", []),
     "add": (ADD, [], "a", []),
     "mix": (MIX, ["ratio"], "a", ["ratio"]),
+    "signal_gen": (SIGNAL_GEN, ["amplitude", "frequency"], None, ["amplitude", "frequency"]),   # a source: no main port
 }
 
 
@@ -66,6 +68,11 @@ def _node_from_cfg(typename: str, cfg: dict, page_round: bool) -> NodeSpec:
         if mode not in DISTORT_MODES:
             raise DspConfigError(f"unknown distort mode {mode!r}")
         return NodeSpec(DISTORT, params, mode=DISTORT_MODES.index(mode))
+    if kind == SIGNAL_GEN:
+        mode = cfg.get("mode", "Sine")
+        if mode not in SIGNAL_MODES:
+            raise DspConfigError(f"unknown signal_gen mode {mode!r}")
+        return NodeSpec(SIGNAL_GEN, params, mode=SIGNAL_MODES.index(mode))
     if kind == FIR:
         mode = cfg.get("mode", "Balanced")
         if mode not in _FIR_MODES:
@@ -92,8 +99,14 @@ def load_dspconfig(text: str, page_round: bool = False) -> Tuple[List[NodeSpec],
             raise DspConfigError(f"unknown node type {n['typename']!r}")
     inputs = [i for i, n in nodes.items() if n["typename"] == "input"]
     outputs = [i for i, n in nodes.items() if n["typename"] == "output"]
+    gens = [i for i, n in nodes.items() if n["typename"] == "signal_gen"]
+    # the chain's source is the input node, or -- in a patch without one -- a signal generator
+    if not inputs and len(gens) == 1:
+        inputs = gens
+    elif gens:
+        raise DspConfigError("a signal_gen node can only be the source of the chain (in place of the input node)")
     if len(inputs) != 1 or len(outputs) != 1:
-        raise DspConfigError("expected exactly one input and one output node")
+        raise DspConfigError("expected exactly one input (or signal_gen) and one output node")
 
     def port_name(node_id, port_id, which):
         for name, pid in nodes[node_id]["cfg"].get(which, {}).items():
@@ -110,6 +123,12 @@ def load_dspconfig(text: str, page_round: bool = False) -> Tuple[List[NodeSpec],
     src = inputs[0]
     chain, order, side_from_input = [], [], False
     cur, seen = src, {src}
+    if nodes[src]["typename"] == "signal_gen":
+        for cp in _TABLE["signal_gen"][3]:
+            if (src, cp) in in_links:
+                raise DspConfigError(f"control port {cp!r} of node {src} is fed by a link (as_input modulation)")
+        chain.append(_node_from_cfg("signal_gen", nodes[src]["cfg"], page_round))
+        order.append(src)
     while True:
         nxt = out_links.get(cur, [])
         if cur == src:   # the input node may also feed port "b" of add/mix nodes (the engine's side input)
@@ -147,7 +166,7 @@ def load_dspconfig(text: str, page_round: bool = False) -> Tuple[List[NodeSpec],
 
 _KIND_TO_TYPENAME = {GAIN: "gain", BIQUAD: "biquad", LOW_PASS: "high_pass",   # LowPass saves as "high_pass" (low_pass.rs:9)
                      HIGH_PASS: "high_pass", REVERB: "reverb", DISTORT: "distort", OVERDRIVE: "overdrive",
-                     CHEBYSHEV: "chebyshev", FIR: "fir", ADD: "add", MIX: "mix"}
+                     CHEBYSHEV: "chebyshev", FIR: "fir", ADD: "add", MIX: "mix", SIGNAL_GEN: "signal_gen"}
 
 
 def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpass_bug: bool = True) -> str:
@@ -162,17 +181,23 @@ def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpa
         return next_id[0] - 1
 
     nodes, links = [], []
-    in_id, in_port = nid(), nid()
-    nodes.append({"id": in_id, "typename": "input", "position": [0.0, 0.0],
-                  "cfg": {"id": in_id, "inputs": {}, "outputs": {"out": in_port}}})
-    prev = (in_id, in_port)
+    if any(n.kind == SIGNAL_GEN for n in chain[1:]):
+        raise DspConfigError("a signal_gen node can only be the first node of a chain")
+    if any(n.kind in (ADD, MIX) for n in chain) and chain and chain[0].kind == SIGNAL_GEN:
+        raise DspConfigError("add/mix take their 'b' port from the input node, which a generator-sourced patch lacks")
+    in_id = in_port = prev = None
+    if not (chain and chain[0].kind == SIGNAL_GEN):
+        in_id, in_port = nid(), nid()
+        nodes.append({"id": in_id, "typename": "input", "position": [0.0, 0.0],
+                      "cfg": {"id": in_id, "inputs": {}, "outputs": {"out": in_port}}})
+        prev = (in_id, in_port)
     for k, n in enumerate(chain):
         tn = _KIND_TO_TYPENAME[n.kind]
         if n.kind == LOW_PASS and not faithful_lowpass_bug:
             tn = "low_pass"
         _, fields, main_port, ctl_ports = _TABLE["low_pass" if n.kind == LOW_PASS else tn]
         node_id = nid()
-        ins = {main_port: nid()}
+        ins = {main_port: nid()} if main_port else {}
         if n.kind in (ADD, MIX):
             ins["b"] = nid()
         for cp in ctl_ports:
@@ -185,12 +210,15 @@ def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpa
             cfg["seconds"] = float(seconds_for_delay(n.delay_len) if seconds_for_delay else np.float32(n.delay_len / 48000.0))
         if n.kind == DISTORT:
             cfg["mode"] = DISTORT_MODES[n.mode]
+        if n.kind == SIGNAL_GEN:
+            cfg["mode"] = SIGNAL_MODES[n.mode]
         if n.kind == FIR:
             cfg["mode"] = "Average" if n.mode == FIR_AVERAGE else "Balanced"
             cfg["file_name"] = None
             cfg["taps"] = [float(t) for t in np.asarray(n.taps_reversed, np.float64)]
         nodes.append({"id": node_id, "typename": tn, "position": [120.0 * (k + 1), 0.0], "cfg": cfg})
-        links.append({"lhs": list(prev), "rhs": [node_id, ins[main_port]]})
+        if main_port:
+            links.append({"lhs": list(prev), "rhs": [node_id, ins[main_port]]})
         if n.kind in (ADD, MIX):
             links.append({"lhs": [in_id, in_port], "rhs": [node_id, ins["b"]]})
         prev = (node_id, outs["out"])

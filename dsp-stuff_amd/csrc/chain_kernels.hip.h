@@ -25,8 +25,9 @@ constexpr int WG = 256;        // workgroup size (4 waves)
 // kinds: numeric values == dspfx_kind in include/dspfx.h
 enum : int {
     K_GAIN = 0, K_BIQUAD = 1, K_LOW_PASS = 2, K_HIGH_PASS = 3, K_REVERB = 4, K_DISTORT = 5,
-    K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10
+    K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10, K_SIGNAL_GEN = 11
 };
+enum : int { G_SINE = 0, G_TRIANGLE = 1, G_SQUARE = 2, G_CONSTANT = 3 };   // signal_gen.rs:17-22
 enum : int {
     D_HARD_CLIP = 0, D_SOFT_CLIP = 1, D_TANH = 2, D_RECIP_SOFT_CLIP = 3, D_FUZZ = 4, D_SIN = 5,
     D_ATAN = 6, D_SQUARE = 7, D_CHEBYSHEV4 = 8
@@ -276,6 +277,22 @@ __device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
     }
 }
 
+// signal_gen.rs:57-104, one sample: `total` is the block-local phase advance, `clock` the phase carried
+// between 128-frame blocks.  Square compares `total` (not the phase) with 0.5, like the reference.
+template <int MODE>
+__device__ __forceinline__ float signal1(float clock, float &total, float frequency, float amplitude) {
+    if constexpr (MODE == G_CONSTANT) {
+        return amplitude;                             // do_const: copies the amplitude block
+    } else {
+        const float TAU = 6.28318530717958647692528676655900577f;
+        const float step = frequency / 48000.0f;
+        total = total + step;
+        if constexpr (MODE == G_SINE) return sin_cr((clock + total) * TAU) * amplitude;
+        else if constexpr (MODE == G_TRIANGLE) return (2.0f * fmodf(clock + total, 1.0f) - 1.0f) * amplitude;
+        else return (total > 0.5f ? 1.0f : -1.0f) * amplitude;
+    }
+}
+
 // ---- per-lane chunk context ------------------------------------------------------
 struct Ctx {
     size_t c;        // first channel of this lane
@@ -373,6 +390,20 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[f][j] = chebyshev1(v[f][j], s.p[0], s.p[1]);
+    } else if constexpr (KIND == K_SIGNAL_GEN) {  // signal_gen.rs:111-128: a source, the input is ignored
+        // st[0] = clock (persisted), st[1] = block-local total; the clock wraps at every 128-frame block end
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = signal1<MODE>(st[0][j], st[1][j], s.p[1], s.p[0]);
+            if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    st[0][j] = fmodf(st[0][j] + st[1][j], 1.0f);   // signal_gen.rs:66-67
+                    st[1][j] = 0.0f;
+                }
+            }
+        }
     } else if constexpr (KIND == K_ADD || KIND == K_MIX) {   // add.rs:29-33, mix.rs:41-46
         const float ratio = s.p[0];
 #pragma unroll
@@ -437,7 +468,7 @@ __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo
 // Nodes with `as_input` sliders, evaluated with per-sample slider values (IEEE division: the
 // divisor is no longer a wave-uniform constant).
 template <int KIND, int MODE, int F, int CPL, bool GUARD, bool FAST>
-__device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][CPL], const Ctx &cx) {
+__device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL], const Ctx &cx) {
     if constexpr (KIND == K_GAIN) {                 // gain.rs:27-37, slider 0..=10
         float lv[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 10.0f, cx, lv);
@@ -463,6 +494,22 @@ __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][
 #pragma unroll
             for (int j = 0; j < CPL; ++j)
                 if (!(lv[f][j] < 0.001f)) v[f][j] = overdrive1(v[f][j], bo[f][j], dr[f][j], lv[f][j]);
+    } else if constexpr (KIND == K_SIGNAL_GEN) {    // signal_gen.rs:111-128, sliders amplitude -1..=1, frequency 0.1..=20000
+        float am[F][CPL], fr[F][CPL];
+        slider_values<F, CPL, GUARD, FAST>(s, 0, -1.0f, 1.0f, cx, am);
+        slider_values<F, CPL, GUARD, FAST>(s, 1, 0.1f, 20000.0f, cx, fr);
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) v[f][j] = signal1<MODE>(st[0][j], st[1][j], fr[f][j], am[f][j]);
+            if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    st[0][j] = fmodf(st[0][j] + st[1][j], 1.0f);
+                    st[1][j] = 0.0f;
+                }
+            }
+        }
     } else if constexpr (KIND == K_MIX) {           // mix.rs:33-46, slider 0..=1
         float ra[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 1.0f, cx, ra);
@@ -486,16 +533,16 @@ __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][
 }
 
 template <int F, int CPL, bool GUARD, bool FAST>
-__device__ __forceinline__ void apply_distort_mod_dyn(const SlotArgs &s, float (&v)[F][CPL], const Ctx &cx) {
+__device__ __forceinline__ void apply_distort_mod_dyn(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL], const Ctx &cx) {
     switch (s.mode) {
-    case D_HARD_CLIP: apply_node_mod<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_SOFT_CLIP: apply_node_mod<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_TANH: apply_node_mod<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_RECIP_SOFT_CLIP: apply_node_mod<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_SIN: apply_node_mod<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_ATAN: apply_node_mod<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_SQUARE: apply_node_mod<K_DISTORT, D_SQUARE, F, CPL, GUARD, FAST>(s, v, cx); break;
-    case D_CHEBYSHEV4: apply_node_mod<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD, FAST>(s, v, cx); break;
+    case D_HARD_CLIP: apply_node_mod<K_DISTORT, D_HARD_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SOFT_CLIP: apply_node_mod<K_DISTORT, D_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_TANH: apply_node_mod<K_DISTORT, D_TANH, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_RECIP_SOFT_CLIP: apply_node_mod<K_DISTORT, D_RECIP_SOFT_CLIP, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SIN: apply_node_mod<K_DISTORT, D_SIN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_ATAN: apply_node_mod<K_DISTORT, D_ATAN, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_SQUARE: apply_node_mod<K_DISTORT, D_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+    case D_CHEBYSHEV4: apply_node_mod<K_DISTORT, D_CHEBYSHEV4, F, CPL, GUARD, FAST>(s, v, st, cx); break;
     default: break;
     }
 }
@@ -535,10 +582,17 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         if (s.hop) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
         if (MOD && (s.ctl[0] || s.ctl[1] || s.ctl[2] || s.latch_valid)) {   // modulated / latched sliders
             switch (s.kind) {
-            case K_GAIN: apply_node_mod<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
-            case K_DISTORT: apply_distort_mod_dyn<F, CPL, GUARD, FAST>(s, v, cx); return;
-            case K_OVERDRIVE: apply_node_mod<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
-            case K_MIX: apply_node_mod<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, cx); return;
+            case K_GAIN: apply_node_mod<K_GAIN, 0, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+            case K_DISTORT: apply_distort_mod_dyn<F, CPL, GUARD, FAST>(s, v, st, cx); return;
+            case K_OVERDRIVE: apply_node_mod<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+            case K_MIX: apply_node_mod<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+            case K_SIGNAL_GEN:
+                switch (s.mode) {
+                case G_SINE: apply_node_mod<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+                case G_TRIANGLE: apply_node_mod<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+                case G_SQUARE: apply_node_mod<K_SIGNAL_GEN, G_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+                default: apply_node_mod<K_SIGNAL_GEN, G_CONSTANT, F, CPL, GUARD, FAST>(s, v, st, cx); return;
+                }
             default: break;
             }
         }
@@ -553,6 +607,16 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         case K_CHEBYSHEV: if constexpr (LIBM) apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_SIGNAL_GEN:
+            if constexpr (LIBM) {
+                switch (s.mode) {
+                case G_SINE: apply_node<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+                case G_TRIANGLE: apply_node<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+                case G_SQUARE: apply_node<K_SIGNAL_GEN, G_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+                default: apply_node<K_SIGNAL_GEN, G_CONSTANT, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+                }
+            }
+            break;
         default: break;
         }
     } else {
@@ -561,23 +625,52 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
     }
 }
 
+// rows of per-channel state a kind keeps in registers / LDS during a launch, and how many of them
+// persist in HBM between launches (SIGNAL_GEN: the clock persists, the block-local total does not)
+__host__ __device__ __forceinline__ constexpr int kind_nstate(int k) {
+    return k == K_BIQUAD ? 4 : (k == K_LOW_PASS || k == K_HIGH_PASS) ? 1 : k == K_SIGNAL_GEN ? 2 : 0;
+}
+__host__ __device__ __forceinline__ constexpr int kind_npersist(int k) { return k == K_SIGNAL_GEN ? 1 : kind_nstate(k); }
 template <int SIG>
 __device__ __forceinline__ int slot_nstate(const SlotArgs &s) {
     if constexpr (SIG == SIG_NONE) return 0;
-    else if constexpr (SIG == SIG_DYN) return s.kind == K_BIQUAD ? 4 : ((s.kind == K_LOW_PASS || s.kind == K_HIGH_PASS) ? 1 : 0);
-    else return sig_kind(SIG) == K_BIQUAD ? 4 : ((sig_kind(SIG) == K_LOW_PASS || sig_kind(SIG) == K_HIGH_PASS) ? 1 : 0);
+    else if constexpr (SIG == SIG_DYN) return kind_nstate(s.kind);
+    else return kind_nstate(sig_kind(SIG));
+}
+template <int SIG>
+__device__ __forceinline__ int slot_npersist(const SlotArgs &s) {
+    if constexpr (SIG == SIG_NONE) return 0;
+    else if constexpr (SIG == SIG_DYN) return kind_npersist(s.kind);
+    else return kind_npersist(sig_kind(SIG));
+}
+// A launch that ends inside a 128-frame block closes the generator's block (the caller's blocks are the
+// reference's blocks): clock = (clock + total) % 1.0
+template <int CPL>
+__device__ __forceinline__ void signal_gen_close_block(const SlotArgs &s, float (&st)[4][CPL], unsigned nframes) {
+    if (s.kind == K_SIGNAL_GEN && s.mode != G_CONSTANT && (nframes & 127u)) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            st[0][j] = fmodf(st[0][j] + st[1][j], 1.0f);
+            st[1][j] = 0.0f;
+        }
+    }
 }
 
 template <int SIG, int CPL, bool GUARD>
 __device__ __forceinline__ void load_state(const SlotArgs &s, float (&st)[4][CPL], size_t c, size_t N, bool active) {
-    const int n = slot_nstate<SIG>(s);
+    const int n = slot_npersist<SIG>(s);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < 4; ++k) {
         if (k < n) load_vec<CPL, GUARD>(s.state + (size_t)k * N + c, st[k], active);
+        else {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) st[k][j] = 0.0f;
+        }
+    }
 }
 template <int SIG, int CPL, bool GUARD>
 __device__ __forceinline__ void store_state(const SlotArgs &s, const float (&st)[4][CPL], size_t c, size_t N, bool active) {
-    const int n = slot_nstate<SIG>(s);
+    const int n = slot_npersist<SIG>(s);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
         if (k < n) store_vec<CPL, GUARD>(s.state + (size_t)k * N + c, st[k], active);
@@ -731,7 +824,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {
-        const SlotArgs &sl = a.slot[s];
+        const SlotArgs sl = a.slot[s];   // a private copy keeps the kernarg table out of scratch
         const int ns = slot_nstate<SIG_DYN>(sl);
         float st[4][1];
 #pragma unroll
@@ -762,10 +855,10 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
         int row = 0;
 #pragma unroll 1
         for (int s = 0; s < a.n_slots; ++s) {
-            const int ns = slot_nstate<SIG_DYN>(a.slot[s]);
+            const int ns = slot_nstate<SIG_DYN>(a.slot[s]), np = slot_npersist<SIG_DYN>(a.slot[s]);
             for (int k = 0; k < ns; ++k) {
-                float t[1];
-                load_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
+                float t[1] = {0.0f};
+                if (k < np) load_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
                 lds[(row + k) * WG + threadIdx.x] = t[0];
             }
             row += ns;
@@ -785,8 +878,13 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
         int row = 0;
 #pragma unroll 1
         for (int s = 0; s < a.n_slots; ++s) {
-            const int ns = slot_nstate<SIG_DYN>(a.slot[s]);
-            for (int k = 0; k < ns; ++k) {
+            const int ns = slot_nstate<SIG_DYN>(a.slot[s]), np = slot_npersist<SIG_DYN>(a.slot[s]);
+            if (a.slot[s].kind == K_SIGNAL_GEN) {
+                float st2[4][1] = {{lds[row * WG + threadIdx.x]}, {lds[(row + 1) * WG + threadIdx.x]}, {0.0f}, {0.0f}};
+                signal_gen_close_block<1>(a.slot[s], st2, a.nframes);
+                lds[row * WG + threadIdx.x] = st2[0][0];
+            }
+            for (int k = 0; k < np; ++k) {
                 float t[1] = {lds[(row + k) * WG + threadIdx.x]};
                 store_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
             }

@@ -84,6 +84,7 @@ struct dspfx_engine {
     const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr;
     bool has_fuzz = false;
     uint32_t min_delay = 0xffffffffu;
+    bool has_siggen = false;   // a SIGNAL_GEN wraps its clock per 128-frame block: sub-launches start on block boundaries
     uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
     float div_v = 0.0f;
     // profiling: event pairs per stage
@@ -252,7 +253,7 @@ bool stage_fast_div(const dspfx_engine *e, const Stage &st) {
 }
 
 bool node_needs_libm(const Node &n) {
-    if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV) return true;
+    if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV || n.d.kind == DSPFX_SIGNAL_GEN) return true;
     return n.d.kind == DSPFX_DISTORT &&
            (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
 }
@@ -301,6 +302,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
 int plan(dspfx_engine *e) {
     e->stages.clear();
     e->has_fuzz = false;
+    e->has_siggen = false;
     e->min_delay = 0xffffffffu;
     const int n = (int)e->nodes.size();
     int i = 0;
@@ -336,6 +338,7 @@ int plan(dspfx_engine *e) {
     for (const Node &nd : e->nodes) {
         if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
         if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
+        if (nd.d.kind == DSPFX_SIGNAL_GEN) e->has_siggen = true;
     }
     return DSPFX_OK;
 }
@@ -459,7 +462,8 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     switch (n.d.kind) {
     case DSPFX_BIQUAD: bytes = 4 * N * sizeof(float); break;
     case DSPFX_LOW_PASS:
-    case DSPFX_HIGH_PASS: bytes = N * sizeof(float); break;
+    case DSPFX_HIGH_PASS:
+    case DSPFX_SIGNAL_GEN: bytes = N * sizeof(float); break;   // z / z / clock
     default: break;
     }
     if (n.state && n.state_bytes != bytes) {
@@ -499,6 +503,8 @@ int validate_node(dspfx_engine *e, const dspfx_node_desc &d) {
     if (d.kind < 0 || d.kind >= DSPFX_N_KINDS) return fail(e, DSPFX_ERR_INVALID, "unknown node kind %d", d.kind);
     if (d.kind == DSPFX_DISTORT && (d.mode < 0 || d.mode > DSPFX_DIST_CHEBYSHEV4))
         return fail(e, DSPFX_ERR_INVALID, "unknown distort mode %d", d.mode);
+    if (d.kind == DSPFX_SIGNAL_GEN && (d.mode < 0 || d.mode > DSPFX_SIG_CONSTANT))
+        return fail(e, DSPFX_ERR_INVALID, "unknown signal generator mode %d", d.mode);
     if (d.kind == DSPFX_REVERB && d.delay_len < DSPFX_BUF_SIZE)
         return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128 (reverb.rs:58 clamps to >= 128)", d.delay_len);
     if (d.kind == DSPFX_FIR && (d.n_taps == 0 || !d.taps))
@@ -559,9 +565,8 @@ int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *
     return rc;
 }
 
-int state_rows(const Node &n) {
-    return n.d.kind == DSPFX_BIQUAD ? 4 : ((n.d.kind == DSPFX_LOW_PASS || n.d.kind == DSPFX_HIGH_PASS) ? 1 : 0);
-}
+// rows of LDS the interpreter keeps per node (kind_nstate in chain_kernels.hip.h)
+int state_rows(const Node &n) { return kind_nstate(n.d.kind); }
 
 // One sub-block (nframes <= every delay length) through all stages.
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
@@ -721,6 +726,7 @@ extern "C" int dspfx_node_defaults(int kind, dspfx_node_desc *d) {
     case DSPFX_REVERB: d->params[0] = 0.5f; d->delay_len = 128; break; // reverb.rs:37, 44-52 (make_buffer)
     case DSPFX_DISTORT: d->mode = DSPFX_DIST_SOFT_CLIP; break;         // distort.rs:46-50
     case DSPFX_MIX: d->params[0] = 0.5f; break;                        // mix.rs:22-28
+    case DSPFX_SIGNAL_GEN: d->params[0] = 0.5f; d->params[1] = 100.0f; break;   // signal_gen.rs:41-49 (mode Sine)
     default: break;
     }
     return DSPFX_OK;
@@ -773,7 +779,8 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     for (const Variant *v : all) {
         if (v->sigs[0] != SIG_DYN) continue;
         if (v->guard) (v->mod ? e->tail_mod : e->tail) = v;
-        else if (v->f == 8 && v->libm) (v->mod ? e->dyn_mod : e->dyn) = v;   // fallbacks handle every node kind
+        else if (v->mod) e->dyn_mod = v;
+        else if (v->f == 8 && v->libm) e->dyn = v;   // fallbacks handle every node kind
     }
     e->mixpart_cols = (size_t)desc->channels / 64 + 8;
     if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess ||
@@ -926,7 +933,7 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
     hipStream_t s = (hipStream_t)stream;
     // a block's delay taps must not depend on the same launch's outputs: split at min delay
     uint32_t sub = std::min(n_frames, e->min_delay);
-    if (e->has_fuzz) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
+    if (e->has_fuzz || e->has_siggen) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
     const size_t N = e->desc.channels;
     for (uint32_t f0 = 0; f0 < n_frames; f0 += sub) {
         const uint32_t nf = std::min(sub, n_frames - f0);
@@ -955,6 +962,7 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
         case DSPFX_DISTORT: n_sliders = n.d.mode == DSPFX_DIST_FUZZ ? 0 : 1; break;
         case DSPFX_OVERDRIVE: n_sliders = 3; break;
         case DSPFX_MIX: n_sliders = 1; break;
+        case DSPFX_SIGNAL_GEN: n_sliders = 2; break;
         default: break;
         }
         if (c.param < 0 || c.param >= n_sliders)
@@ -967,7 +975,7 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
     const size_t rowlen = e->desc.tile_channels ? e->desc.tile_channels : N;
     if (n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
     uint32_t sub = std::min(n_frames, e->min_delay);
-    if (e->has_fuzz) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
+    if (e->has_fuzz || e->has_siggen) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
     int rc = DSPFX_OK;
     for (uint32_t f0 = 0; f0 < n_frames && rc == DSPFX_OK; f0 += sub) {
         const uint32_t nf = std::min(sub, n_frames - f0);
@@ -1227,7 +1235,8 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
         switch (n.d.kind) {
         case DSPFX_BIQUAD: b += 32.0 / n_frames; break;
         case DSPFX_LOW_PASS:
-        case DSPFX_HIGH_PASS: b += 8.0 / n_frames; break;
+        case DSPFX_HIGH_PASS:
+        case DSPFX_SIGNAL_GEN: b += 8.0 / n_frames; break;
         case DSPFX_REVERB: b += 8.0; break;
         case DSPFX_FIR: b += 4.0 + 4.0 * ((double)n.taps.size() - 1.0) / n_frames; break;
         case DSPFX_ADD:
@@ -1242,7 +1251,7 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
 extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
     if (!e || !dst || cap == 0) return DSPFX_ERR_INVALID;
     static const char *kn[] = {"gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "overdrive",
-                               "chebyshev", "fir", "add", "mix"};
+                               "chebyshev", "fir", "add", "mix", "signal_gen"};
     std::string s;
     char buf[256];
     snprintf(buf, sizeof buf, "engine: N=%u max_frames=%u link_flags=%u\n", e->desc.channels, e->desc.max_frames,

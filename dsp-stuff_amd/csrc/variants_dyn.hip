@@ -15,8 +15,8 @@ static const Variant k_dyn[] = {
     DSPFX_DYN_VARIANT("dyn_libm_f4", 4, false, false, true),
     DSPFX_DYN_VARIANT("dyn_libm_f16", 16, false, false, true),
     DSPFX_DYN_VARIANT("dyn_f8_tail", 8, true, false, true),
-    DSPFX_DYN_VARIANT("dyn_mod_f8", 8, false, true, true),        // + control ports
-    DSPFX_DYN_VARIANT("dyn_mod_f8_tail", 8, true, true, true),
+    DSPFX_DYN_VARIANT("dyn_mod_f4", 4, false, true, true),        // + control ports (F=4: no scratch)
+    DSPFX_DYN_VARIANT("dyn_mod_f4_tail", 4, true, true, true),
 };
 const Variant *variants_dyn(int *n) { *n = (int)(sizeof(k_dyn) / sizeof(k_dyn[0])); return k_dyn; }
 }  // namespace dspfx

@@ -67,8 +67,12 @@ typedef enum dspfx_kind {
     DSPFX_FIR = 8,       /* nodes/fir.rs:179-225 */
     DSPFX_ADD = 9,       /* nodes/add.rs:24-34  (port "b" = the side input) */
     DSPFX_MIX = 10,      /* nodes/mix.rs:31-47  (port "b" = the side input) */
-    DSPFX_N_KINDS = 11
+    DSPFX_SIGNAL_GEN = 11, /* nodes/signal_gen.rs:55-129: a SOURCE (no "in" port): replaces the signal */
+    DSPFX_N_KINDS = 12
 } dspfx_kind;
+
+/* nodes/signal_gen.rs:17-22 `enum Mode` */
+typedef enum dspfx_signal_mode { DSPFX_SIG_SINE = 0, DSPFX_SIG_TRIANGLE = 1, DSPFX_SIG_SQUARE = 2, DSPFX_SIG_CONSTANT = 3 } dspfx_signal_mode;
 
 /* nodes/distort.rs:18-28 `enum Mode`, declaration order (repr(u8)) */
 typedef enum dspfx_distort_mode {
@@ -120,6 +124,8 @@ typedef struct dspfx_engine_desc {
  *   FIR        taps/n_taps (time-REVERSED, as fir.rs:163,168 stores them); mode
  *   ADD        -
  *   MIX        params[0]=ratio (0..=1, default .5)                    mix.rs:22-28
+ *   SIGNAL_GEN params[0]=amplitude (-1..=1, default .5), [1]=frequency (0.1..=20000 Hz, default 100); mode
+ *              (dspfx_signal_mode); per-channel phase clock, wrapped at every 128-frame block end  signal_gen.rs:41-55
  * delay_len is explicit because rivulet's capacity rounding is not in the
  * reference tree; dspfx_delay_len() gives both readings.    */
 typedef struct dspfx_node_desc {
@@ -185,7 +191,7 @@ int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *ou
                   uint32_t n_frames, void *stream);
 /* One connected control port (`as_input` slider, dsp-stuff-derive/src/lib.rs:122-161): `param` is
  * the slider's index in dspfx_node_desc.params (GAIN level 0; DISTORT level 0; OVERDRIVE boost 0,
- * drive 1, level 2; MIX ratio 0); `signal` is a device buffer in the sample layout.  Per sample the
+ * drive 1, level 2; MIX ratio 0; SIGNAL_GEN amplitude 0, frequency 1); `signal` is a device buffer in the sample layout.  Per sample the
  * slider takes lo + (hi-lo)*clamp((x+1)/2, 0, 1) over its reference range; the first value of each
  * 128-frame block is latched per channel and keeps applying once the port is disconnected
  * (lib.rs:148-151) until dspfx_set_param overwrites it.  DISTORT/Fuzz does not take a control port. */

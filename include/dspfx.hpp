@@ -91,6 +91,14 @@ inline Node Fir(const std::vector<double> &impulse_response, FirMode mode = FirM
 }
 inline Node Add() { return make(DSPFX_ADD); }
 inline Node Mix(float ratio = 0.5f) { Node n = make(DSPFX_MIX); n.d.params[0] = ratio; return n; }
+// nodes/signal_gen.rs:41-55: a source (no "in" port) -- as a chain node it replaces the signal
+enum class SignalMode : int { Sine = DSPFX_SIG_SINE, Triangle = DSPFX_SIG_TRIANGLE, Square = DSPFX_SIG_SQUARE, Constant = DSPFX_SIG_CONSTANT };
+inline Node SignalGen(float amplitude = 0.5f, float frequency = 100.0f, SignalMode mode = SignalMode::Sine) {
+    Node n = make(DSPFX_SIGNAL_GEN);
+    n.d.params[0] = amplitude; n.d.params[1] = frequency;
+    n.d.mode = static_cast<int>(mode);
+    return n;
+}
 
 // N independent mono channels through one chain.
 class Engine {

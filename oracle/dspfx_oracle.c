@@ -113,6 +113,11 @@ orc_node *orc_node_new(int kind) {
     case ORC_MIX: /* mix.rs:22-28 default 0.5 */
         n->p[0] = 0.5f;
         break;
+    case ORC_SIGNAL_GEN: /* signal_gen.rs:41-55: amplitude 0.5, frequency 100.0, Sine, clock Default (0.0) */
+        n->p[0] = 0.5f;
+        n->p[1] = 100.0f;
+        n->mode = ORC_SIG_SINE;
+        break;
     default:
         break;
     }
@@ -193,6 +198,7 @@ void orc_fir_set_taps(orc_node *n, const double *taps_reversed, uint32_t n_taps)
 void orc_node_reset(orc_node *n) {
     n->bq_x1 = n->bq_x2 = n->bq_y1 = n->bq_y2 = 0.0f;
     n->z = 0.0f;
+    n->clock = 0.0f;
     if (n->ring) memset(n->ring, 0, sizeof(float) * n->ring_len);
     n->ring_pos = 0;
     free(n->dq);
@@ -497,6 +503,29 @@ void orc_node_process(orc_node *n, const float *in_a, const float *in_b,
     case ORC_ADD: { /* add.rs:26-33 */
         const float *b = in_b ? in_b : zeros;
         for (size_t i = 0; i < nf; i++) out[i] = in_a[i] + b[i];
+        break;
+    }
+    case ORC_SIGNAL_GEN: { /* signal_gen.rs:57-129: a source; sliders amplitude -1..=1, frequency 0.1..=20000 */
+        float amplitude[ORC_BUF_SIZE], frequency[ORC_BUF_SIZE];
+        const float TAU = 6.28318530717958647692528676655900577f;
+        orc_slider_input(amplitude, c0, -1.0f, 1.0f, &n->p[0], nf);
+        orc_slider_input(frequency, c1, 0.1f, 20000.0f, &n->p[1], nf);
+        if (n->mode == ORC_SIG_CONSTANT) { /* do_const, 106-108: clock untouched */
+            for (size_t i = 0; i < nf; i++) out[i] = amplitude[i];
+            break;
+        }
+        float clock = n->clock, total = 0.0f;
+        for (size_t i = 0; i < nf; i++) {
+            float step = frequency[i] / 48000.0f;
+            total += step;
+            if (n->mode == ORC_SIG_SINE) /* 64 */
+                out[i] = sinf((clock + total) * TAU) * amplitude[i];
+            else if (n->mode == ORC_SIG_TRIANGLE) /* 80 */
+                out[i] = (2.0f * fmodf(clock + total, 1.0f) - 1.0f) * amplitude[i];
+            else /* Square, 96: compares the block-local `total`, not the phase */
+                out[i] = (total > 0.5f ? 1.0f : -1.0f) * amplitude[i];
+        }
+        n->clock = fmodf(clock + total, 1.0f); /* 66-67 */
         break;
     }
     case ORC_MIX: { /* mix.rs:33-46 */

@@ -50,7 +50,8 @@ enum {
     ORC_FIR = 8,       /* nodes/fir.rs */
     ORC_ADD = 9,       /* nodes/add.rs */
     ORC_MIX = 10,      /* nodes/mix.rs */
-    ORC_N_KINDS = 11
+    ORC_SIGNAL_GEN = 11, /* nodes/signal_gen.rs: a SOURCE (no "in" port); its input is ignored */
+    ORC_N_KINDS = 12
 };
 
 /* nodes/distort.rs:18-28, in declaration order (repr(u8)). */
@@ -65,6 +66,9 @@ enum {
     ORC_DIST_SQUARE = 7,
     ORC_DIST_CHEBYSHEV4 = 8
 };
+
+/* nodes/signal_gen.rs:17-22 Mode */
+enum { ORC_SIG_SINE = 0, ORC_SIG_TRIANGLE = 1, ORC_SIG_SQUARE = 2, ORC_SIG_CONSTANT = 3 };
 
 /* nodes/fir.rs Mode */
 enum { ORC_FIR_BALANCED = 0, ORC_FIR_AVERAGE = 1 };
@@ -82,6 +86,7 @@ enum { ORC_FIR_BALANCED = 0, ORC_FIR_AVERAGE = 1 };
  *   CHEBYSHEV  p[0]=level_pos, p[1]=level_neg
  *   FIR        taps (time-reversed, as stored by fir.rs:163,168), mode
  *   ADD        -              MIX p[0]=ratio
+ *   SIGNAL_GEN p[0]=amplitude, p[1]=frequency, mode; state: clock
  */
 typedef struct orc_node {
     int kind;
@@ -94,6 +99,8 @@ typedef struct orc_node {
     float bq_x1, bq_x2, bq_y1, bq_y2;
     /* one-pole z (low_pass.rs:23 / high_pass.rs:23) */
     float z;
+    /* signal generator phase (signal_gen.rs:52) */
+    float clock;
     /* reverb ring: exactly D samples, FIFO (read oldest, append newest) */
     float *ring;
     uint32_t ring_len, ring_pos;

@@ -206,3 +206,36 @@ def mix(a, b, ratio):
     """mix.rs:41-46"""
     r = F(ratio)
     return ((np.asarray(b, F) * r).astype(F) + (np.asarray(a, F) * F(F(1) - r)).astype(F)).astype(F)
+
+
+class SignalGen:
+    """signal_gen.rs:57-129, one channel.  mode: 0 Sine, 1 Triangle, 2 Square, 3 Constant.
+    float32 sin is taken as the correctly rounded value (numpy's float64 sin, rounded once)."""
+
+    TAU = F(6.283185307179586)
+
+    def __init__(self, amplitude=0.5, frequency=100.0, mode=0):
+        self.amplitude, self.frequency, self.mode = F(amplitude), F(frequency), mode
+        self.clock = F(0.0)
+
+    def process(self, n=BUF_SIZE, amplitude=None, frequency=None):
+        """One block of n frames; amplitude / frequency are optional per-sample (control port) arrays."""
+        amp = np.full(n, self.amplitude, F) if amplitude is None else np.asarray(amplitude, F)
+        frq = np.full(n, self.frequency, F) if frequency is None else np.asarray(frequency, F)
+        if self.mode == 3:
+            return amp.copy()
+        step = (frq / F(48000.0)).astype(F)
+        total = np.empty(n, F)
+        acc = F(0.0)
+        for i in range(n):            # sequential f32 accumulation (signal_gen.rs:65)
+            acc = F(acc + step[i])
+            total[i] = acc
+        ph = (self.clock + total).astype(F)
+        if self.mode == 0:
+            out = (np.sin((ph * self.TAU).astype(F).astype(np.float64)).astype(F) * amp).astype(F)
+        elif self.mode == 1:
+            out = ((F(2.0) * np.fmod(ph, F(1.0)).astype(F) - F(1.0)).astype(F) * amp).astype(F)
+        else:
+            out = (np.where(total > F(0.5), F(1.0), F(-1.0)).astype(F) * amp).astype(F)
+        self.clock = F(np.fmod(F(self.clock + acc), F(1.0)))
+        return out

@@ -74,6 +74,40 @@ def test_roundtrip_and_lowpass_cfg_name_bug(mods):
     assert fixed[1].kind == dspfx.LOW_PASS
 
 
+def test_signal_gen_sourced_patch(mods):
+    """A patch without an input node whose source is a signal generator (signal_gen.rs:29 cfg_name,
+    saved fields amplitude / frequency / mode)."""
+    dspfx, config, _ = mods
+    doc = {
+        "nodes": [
+            {"id": 1, "typename": "signal_gen", "position": [0.0, 0.0],
+             "cfg": {"id": 1, "inputs": {"amplitude": 40, "frequency": 41}, "outputs": {"out": 42},
+                     "amplitude": 0.25, "frequency": 440.0, "mode": "Triangle"}},
+            {"id": 2, "typename": "gain", "position": [100.0, 0.0],
+             "cfg": {"id": 2, "inputs": {"in": 43, "level": 44}, "outputs": {"out": 45}, "level": 2.0}},
+            {"id": 3, "typename": "output", "position": [200.0, 0.0], "cfg": {"id": 3, "inputs": {"in": 46}, "outputs": {}}},
+        ],
+        "links": [{"lhs": [1, 42], "rhs": [2, 43]}, {"lhs": [2, 45], "rhs": [3, 46]}],
+    }
+    chain, info = config.load_dspconfig(json.dumps(doc))
+    assert info["order"] == [1, 2] and [n.kind for n in chain] == [dspfx.SIGNAL_GEN, dspfx.GAIN]
+    assert chain[0].params == [0.25, 440.0] and chain[0].mode == dspfx.SIG_TRIANGLE
+    back, _ = config.load_dspconfig(config.dump_dspconfig(chain))
+    assert [(n.kind, n.params, n.mode) for n in back] == [(n.kind, n.params, n.mode) for n in chain]
+    assert "\"input\"" not in config.dump_dspconfig(chain)
+    # a generator next to an input node, or one whose slider port is fed by a link, is not a linear chain
+    bad = json.loads(json.dumps(doc))
+    bad["nodes"].append({"id": 0, "typename": "input", "position": [0, 0], "cfg": {"id": 0, "inputs": {}, "outputs": {"out": 50}}})
+    with pytest.raises(config.DspConfigError):
+        config.load_dspconfig(json.dumps(bad))
+    bad = json.loads(json.dumps(doc))
+    bad["nodes"][0]["cfg"]["mode"] = "Saw"
+    with pytest.raises(config.DspConfigError):
+        config.load_dspconfig(json.dumps(bad))
+    with pytest.raises(config.DspConfigError):
+        config.dump_dspconfig([dspfx.Gain(1.0), dspfx.SignalGen()])
+
+
 @pytest.mark.parametrize("mutate,msg", [
     (lambda d: d["nodes"].append({"id": 9, "typename": "mux", "position": [0, 0], "cfg": {"id": 9, "inputs": {}, "outputs": {}}}), "outside the accelerated path"),
     (lambda d: d["links"].append({"lhs": [0, 10], "rhs": [3, 14]}), "fans out"),

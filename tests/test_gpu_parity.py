@@ -664,3 +664,133 @@ def test_fir_state_export_import(dspfx, torch_cuda):
         b.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
     torch_cuda.cuda.synchronize()
     assert np.allclose(dy.cpu().numpy()[384:], full[384:], rtol=0, atol=2e-6)
+
+
+# ---- SignalGen: the reference's control source (signal_gen.rs:55-129) ------------------------------
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_signal_gen_modes(dspfx, torch_cuda, mode):
+    """A generator replaces the signal (it has no "in" port); its phase clock wraps at every 128-frame
+    block end.  Triangle / Square / Constant are exact; Sine differs from glibc sinf by <= 1 ulp before
+    the amplitude multiply (<= 2 after)."""
+    N, nf = 100, 128 * 6
+    x = noise_block(N, nf)
+    for freq, amp in ((100.0, 0.5), (12000.0, 1.0), (0.1, -0.3), (19999.0, 0.7), (441.0, -1.0)):
+        chain = [dspfx.SignalGen(amp, freq, mode)]
+        for block, tile in ((128, 0), (256, 0), (384, 0), (128, 64)):
+            n_ch = 128 if tile else N
+            got = run_gpu(dspfx, torch_cuda, chain, x[:, :n_ch] if n_ch <= N else noise_block(n_ch, nf), block=block, tile=tile)
+            ref = O.run_channels([n.oracle_desc() for n in chain], np.zeros((nf, 1), F))[:, :1]
+            assert got.shape[1] == n_ch and np.array_equal(got, np.repeat(got[:, :1], n_ch, axis=1))   # channels are identical
+            d = ulp_diff(got[:, :1], ref)
+            assert d.max() <= (2 if mode == 0 else 0), (mode, freq, block, tile, d.max())
+    # a block that is not a multiple of 128 ends the generator's block with it (the caller's blocks are
+    # the reference's blocks): the oracle is run with the same block length
+    chain = [dspfx.SignalGen(0.9, 777.0, mode)]
+    got = run_gpu(dspfx, torch_cuda, chain, x[:600, :64], block=100)
+    ref = O.run_channels([n.oracle_desc() for n in chain], np.zeros((600, 1), F), block=100)
+    assert ulp_diff(got[:, :1], ref).max() <= (2 if mode == 0 else 0)
+    # ... feeding effects: generator -> gain -> biquad -> delay (block 256 > D: the engine splits on block boundaries)
+    chain = [dspfx.SignalGen(0.8, 1234.5, mode), dspfx.Gain(0.5), dspfx.BiQuad(), dspfx.Reverb(delay_samples=128, decay=0.5),
+             dspfx.Distort(2.0, dspfx.SOFT_CLIP)]
+    for lf in (3, 0):
+        got = run_gpu(dspfx, torch_cuda, chain, x[:, :64], link_flags=lf, block=256)
+        ref = O.run_channels([n.oracle_desc() for n in chain], np.zeros((nf, 1), F), lf)
+        if mode == 0:
+            assert np.abs(got[:, :1] - ref).max() <= 1e-6     # 1-ulp sine differences pass through the filters
+        else:
+            assert ulp_diff(got[:, :1], ref).max() <= 1, (mode, lf)
+
+
+def test_signal_gen_control_ports_and_state(dspfx, torch_cuda):
+    """amplitude / frequency are `as_input` sliders: per-sample modulation + per-channel latch; the clock is
+    per-channel state (export / import / reset)."""
+    N, B, blocks = 96, 128, 6
+    x = noise_block(N, B * blocks)
+    ca = (noise_block(N, B * blocks, seed=31) * F(1.3)).astype(F)
+    cf = (noise_block(N, B * blocks, seed=32) * F(0.02) - F(0.9)).astype(F)     # around 1 kHz, varies per channel
+    ctl_all = {(0, 0): ca, (0, 1): cf}
+    for mode in (0, 1, 2, 3):
+        chain = [dspfx.SignalGen(0.5, 300.0, mode), dspfx.Gain(0.9)]
+        descs = [n.oracle_desc() for n in chain]
+        for lf in (3, 0):
+            eng = dspfx.Engine(N, B, link_flags=lf)
+            eng.set_chain(chain)
+            nodes = []
+            dev = {k: torch_cuda.from_numpy(v).cuda() for k, v in ctl_all.items()}
+            dx = torch_cuda.from_numpy(x).cuda()
+            dy = torch_cuda.empty_like(dx)
+            ref = np.empty_like(x)
+
+            def run(b, ks):
+                sl = slice(b * B, (b + 1) * B)
+                eng.process(dx[sl], out=dy[sl], n_frames=B, ctl={k: dev[k][sl] for k in ks} or None)
+                ref[sl] = O.run_channels(descs, x[sl], lf, ctl={k: ctl_all[k][sl] for k in ks} or None, nodes_out=nodes)
+
+            run(0, [(0, 0), (0, 1)])
+            run(1, [(0, 1)])               # amplitude latched per channel, frequency still modulated
+            run(2, [])                     # both latched: every channel keeps its own frequency
+            eng.set_param(0, 1, 2000.0)    # slider store overwrites the latch
+            for chn in nodes:
+                chn[0].set_param(1, 2000.0)
+            run(3, [])
+            run(4, [(0, 0)])
+            torch_cuda.cuda.synchronize()
+            got = dy.cpu().numpy()[:5 * B]
+            want = ref[:5 * B]
+            if mode == 0:
+                # phases are bit-identical, sinf differs by <= 1 ulp => <= 2 ulp after * amplitude, <= 3 after the gain
+                assert ulp_diff(got, want).max() <= 3, (mode, lf, ulp_diff(got, want).max())
+            else:
+                assert np.array_equal(got, want), (mode, lf)
+            # clock state: canonical [N] f32
+            if mode != 3:
+                clk = eng.state_export(0).view(np.float32)
+                assert clk.shape == (N,)
+                assert np.all((clk >= 0) & (clk < 1)) and len(np.unique(clk)) > N // 2   # per-channel frequencies => per-channel clocks
+                # import into a fresh engine: block 5 continues bit-identically
+                eng2 = dspfx.Engine(N, B, link_flags=lf)
+                eng2.set_chain(chain)
+                eng2.set_param(0, 1, 2000.0)
+                eng2.state_import(0, eng.state_export(0))
+                sl = slice(5 * B, 6 * B)
+                y1, y2 = torch_cuda.empty_like(dx[sl]), torch_cuda.empty_like(dx[sl])
+                # eng holds latched amplitudes; overwrite both sliders on both engines so only the clock matters
+                for e_ in (eng, eng2):
+                    e_.set_param(0, 0, 0.25)
+                    e_.set_param(0, 1, 2000.0)
+                    e_.process(dx[sl], out=y1 if e_ is eng else y2, n_frames=B)
+                torch_cuda.cuda.synchronize()
+                assert torch_cuda.equal(y1, y2)
+                eng.reset()
+                eng2 = dspfx.Engine(N, B, link_flags=lf)
+                eng2.set_chain(chain)
+                for e_ in (eng, eng2):
+                    e_.set_param(0, 0, 0.25)
+                    e_.set_param(0, 1, 2000.0)
+                    e_.process(dx[sl], out=y1 if e_ is eng else y2, n_frames=B)
+                torch_cuda.cuda.synchronize()
+                assert torch_cuda.equal(y1, y2)
+
+
+def test_signal_gen_as_lfo_for_another_chain(dspfx, torch_cuda):
+    """The reference's use of a generator: an LFO patched into a slider port.  Engine A generates the
+    LFO on the GPU, engine B consumes it as the control signal of a gain (tremolo) -- no host round trip."""
+    N, B, blocks = 128, 128, 4
+    x = noise_block(N, B * blocks)
+    lfo_chain = [dspfx.SignalGen(1.0, 750.0, dspfx.SIG_TRIANGLE)]
+    fx_chain = [dspfx.Gain(1.0), dspfx.BiQuad()]
+    a, b = dspfx.Engine(N, B), dspfx.Engine(N, B)
+    a.set_chain(lfo_chain)
+    b.set_chain(fx_chain)
+    dx = torch_cuda.from_numpy(x).cuda()
+    lfo, dy = torch_cuda.empty_like(dx), torch_cuda.empty_like(dx)
+    for k in range(blocks):
+        sl = slice(k * B, (k + 1) * B)
+        a.process(dx[sl], out=lfo[sl], n_frames=B)
+        b.process(dx[sl], out=dy[sl], n_frames=B, ctl={(0, 0): lfo[sl]})
+    torch_cuda.cuda.synchronize()
+    lfo_ref = O.run_channels([n.oracle_desc() for n in lfo_chain], np.zeros((B * blocks, 1), F))
+    assert np.array_equal(lfo.cpu().numpy(), np.repeat(lfo_ref, N, axis=1))
+    ref = O.run_channels([n.oracle_desc() for n in fx_chain], x, ctl={(0, 0): np.repeat(lfo_ref, N, axis=1)})
+    assert ulp_diff(dy.cpu().numpy(), ref).max() <= 1

@@ -274,3 +274,39 @@ def test_noise_generator():
     big = O.noise(0x5EED0001, np.arange(256), np.arange(4096))
     assert -1 <= big.min() and big.max() < 1 and abs(big.mean()) < 5e-3
     assert abs(big.var() - 1 / 3) < 5e-3
+
+
+def test_kat10_signal_gen():
+    # signal_gen.rs:57-129.  12 kHz => step 0.25 exactly, so every phase is exact in f32.
+    tri = O.Node(O.SIGNAL_GEN, [1.0, 12000.0], mode=O.SIG_TRIANGLE).process(np.zeros(8, F))
+    assert np.array_equal(tri, np.array([-0.5, 0, 0.5, -1, -0.5, 0, 0.5, -1], F))   # 2*((k/4)%1)-1
+    sq = O.Node(O.SIGNAL_GEN, [0.5, 12000.0], mode=O.SIG_SQUARE).process(np.zeros(8, F))
+    # Square compares the block-local `total` (not the phase) with 0.5: low for 2 samples, then high for the rest
+    assert np.array_equal(sq, np.array([-0.5, -0.5, 0.5, 0.5, 0.5, 0.5, 0.5, 0.5], F))
+    # Constant copies the amplitude block and ignores the input
+    assert np.array_equal(O.Node(O.SIGNAL_GEN, [-0.25, 440.0], mode=O.SIG_CONSTANT).process(np.ones(5, F)), np.full(5, -0.25, F))
+    # the defaults (signal_gen.rs:41-55): amplitude .5, 100 Hz, Sine
+    n = O.Node(O.SIGNAL_GEN)
+    y = np.concatenate([n.process(np.zeros(128, F)) for _ in range(8)])
+    k = np.arange(1, 1025, dtype=np.float64)
+    assert np.abs(y - 0.5 * np.sin(2 * np.pi * 100.0 * k / 48000.0)).max() < 1e-5
+    # the clock carries the phase between blocks, wrapped to [0,1): block 2 of a triangle continues block 1
+    g, m = O.Node(O.SIGNAL_GEN, [1.0, 1000.0], mode=O.SIG_TRIANGLE), M.SignalGen(1.0, 1000.0, 1)
+    for _ in range(6):
+        assert np.array_equal(g.process(np.zeros(128, F)), m.process())
+    assert 0.0 <= float(m.clock) < 1.0
+    # numpy model == C oracle for every mode, with modulated amplitude and frequency (control ports)
+    rng = np.random.default_rng(21)
+    for mode in range(4):
+        g, m = O.Node(O.SIGNAL_GEN, [0.7, 3000.0], mode=mode), M.SignalGen(0.7, 3000.0, mode)
+        for blk in range(4):
+            a_ctl, f_ctl = rng.uniform(-1.2, 1.2, 128).astype(F), rng.uniform(-1.2, 1.2, 128).astype(F)
+            use = blk % 2 == 1
+            got = g.process(np.zeros(128, F), ctl=[a_ctl, f_ctl] if use else None)
+            if use:
+                m.amplitude, m.frequency = M.slider_input(a_ctl, -1, 1)[0], M.slider_input(f_ctl, 0.1, 20000.0)[0]
+                want = m.process(128, M.slider_input(a_ctl, -1, 1), M.slider_input(f_ctl, 0.1, 20000.0))
+            else:
+                want = m.process()
+            d = np.abs(bits(got).astype(np.int64) - bits(want).astype(np.int64)).max() if mode == 0 else (0 if np.array_equal(got, want) else 99)
+            assert d <= 2, (mode, blk, d)       # glibc sinf is within 1 ulp of the correctly rounded value; x amplitude
