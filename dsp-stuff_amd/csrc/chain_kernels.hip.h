@@ -679,23 +679,52 @@ __device__ __forceinline__ void store_state(const SlotArgs &s, const float (&st)
 // Wave-level reduce-scatter of F per-lane values over the 64 lanes: after it,
 // r[0] of lane l holds the wave total of frame  mixbus_frame_of_lane<F>(l).
 // 2F-2+max(0,6-log2F) adds instead of 6F; fixed order => deterministic.
-// Compile-time recursion keeps every r[] index a constant (registers, no selects chains).
+// Compile-time recursion keeps every r[] index a constant (registers, no select chains).
+// All lane exchanges are VALU operations (no LDS crossbar round trips): gfx950's
+// v_permlane32_swap / v_permlane16_swap exchange the halves of two registers in ONE instruction, which
+// is exactly a reduce-scatter step (lower lanes keep `lo` and receive the partner's `lo`, upper lanes
+// keep `hi` and receive the partner's `hi`); the steps inside a row of 16 use DPP operands
+// (row_ror:8, row_half_mirror, quad_perm) folded into the v_add_f32.
+typedef unsigned int dspfx_u2 __attribute__((ext_vector_type(2)));
+template <int O>
+__device__ __forceinline__ float lane_partner(float x) {
+    // value of the lane paired with this one across lane-index bit O (any pairing across that bit works)
+    constexpr int ctrl = O == 8 ? 0x128      /* row_ror:8          l <-> l^8      */
+                       : O == 4 ? 0x141      /* row_half_mirror    l <-> l^7      */
+                       : O == 2 ? 0x4e       /* quad_perm:[2,3,0,1] l <-> l^2     */
+                                : 0xb1;      /* quad_perm:[1,0,3,2] l <-> l^1     */
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), ctrl, 0xf, 0xf, false));
+}
+template <int O>
+__device__ __forceinline__ float swap_add(float lo, float hi) {
+    // lanes with bit O clear: lo(self) + lo(partner); lanes with bit O set: hi(partner) + hi(self)
+    dspfx_u2 t;
+    if constexpr (O == 32) t = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    else t = __builtin_amdgcn_permlane16_swap(__float_as_uint(lo), __float_as_uint(hi), false, false);
+    return __uint_as_float(t.x) + __uint_as_float(t.y);
+}
 template <int F, int NLIVE, int O>
 __device__ __forceinline__ void rs_stage(float (&r)[F], int lane) {
     if constexpr (O >= 1) {
         if constexpr (NLIVE > 1) {
             constexpr int H = NLIVE / 2;
-            const bool up = (lane & O) != 0;
+            if constexpr (O >= 16) {
 #pragma unroll
-            for (int i = 0; i < H; ++i) {
-                const float lo = r[i], hi = r[H + i];
-                const float keep = up ? hi : lo;
-                const float send = up ? lo : hi;
-                r[i] = keep + __shfl_xor(send, O, 64);
+                for (int i = 0; i < H; ++i) r[i] = swap_add<O>(r[i], r[H + i]);
+            } else {
+                const bool up = (lane & O) != 0;
+#pragma unroll
+                for (int i = 0; i < H; ++i) {
+                    const float lo = r[i], hi = r[H + i];
+                    const float keep = up ? hi : lo;
+                    const float send = up ? lo : hi;
+                    r[i] = keep + lane_partner<O>(send);
+                }
             }
             rs_stage<F, H, O / 2>(r, lane);
         } else {
-            r[0] = r[0] + __shfl_xor(r[0], O, 64);
+            if constexpr (O >= 16) r[0] = swap_add<O>(r[0], r[0]);
+            else r[0] = r[0] + lane_partner<O>(r[0]);
             rs_stage<F, 1, O / 2>(r, lane);
         }
     }
