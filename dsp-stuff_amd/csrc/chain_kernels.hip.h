@@ -28,6 +28,10 @@ enum : int {
     K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10, K_SIGNAL_GEN = 11
 };
 enum : int { G_SINE = 0, G_TRIANGLE = 1, G_SQUARE = 2, G_CONSTANT = 3 };   // signal_gen.rs:17-22
+// Interpreter-only pseudo mode: Square and Constant share one code path, told apart by a per-sample select
+// instead of a branch.  (A separate wave-uniform branch for Constant was dropped by the gfx950 backend in the
+// guarded tail instantiation -- the optimised IR still had it, the ISA did not; caught by the ragged-N test.)
+constexpr int G_SQUARE_OR_CONST = 4;
 enum : int {
     D_HARD_CLIP = 0, D_SOFT_CLIP = 1, D_TANH = 2, D_RECIP_SOFT_CLIP = 3, D_FUZZ = 4, D_SIN = 5,
     D_ATAN = 6, D_SQUARE = 7, D_CHEBYSHEV4 = 8
@@ -123,6 +127,7 @@ constexpr int sig(int kind, int mode = 0, int hop = 0) { return kind | (mode << 
 constexpr int sig_kind(int s) { return s & 0xff; }
 constexpr int sig_mode(int s) { return (s >> 8) & 0xff; }
 constexpr int sig_hop(int s) { return (s >> 16) & 1; }
+template <int KIND> constexpr bool sig_is(int s) { return s >= 0 && sig_kind(s) == KIND; }
 
 // Sample/ring traffic is streamed exactly once per block (reuse distance = a whole
 // delay period), so those loads/stores carry the nontemporal hint: measured 1.13-1.27x
@@ -140,12 +145,18 @@ template <> struct NVecT<4> { typedef float type __attribute__((ext_vector_type(
 constexpr int S_IN = 1, S_RING_LD = 2, S_RING_ST = 4, S_OUT = 8, S_STATE = 0;
 constexpr bool nt_for(int stream) { return (DSPFX_NT & stream) != 0; }
 
+// Every pointer the kernels dereference is hipMalloc'ed device memory: the explicit global address space
+// turns loads through pointers that were themselves loaded (delay-ring group table) from FLAT into GLOBAL
+// instructions.  FLAT operations also count on lgkmcnt, so the scalar loads of the next group pointer used
+// to wait for the previous frame's ring load (measured on the ISA: serialised memory latencies per chunk).
+#define DSPFX_GLOBAL __attribute__((address_space(1)))
 template <int CPL, bool NT>
 __device__ __forceinline__ void load_vec_raw(const float *p, float (&v)[CPL]) {
     using V = typename NVecT<CPL>::type;
+    const DSPFX_GLOBAL V *gp = (const DSPFX_GLOBAL V *)reinterpret_cast<const V *>(p);
     V t;
-    if constexpr (NT) t = __builtin_nontemporal_load(reinterpret_cast<const V *>(p));
-    else t = *reinterpret_cast<const V *>(p);
+    if constexpr (NT) t = __builtin_nontemporal_load(gp);
+    else t = *gp;
     if constexpr (CPL == 1) { v[0] = t; }
     else {
 #pragma unroll
@@ -161,8 +172,9 @@ __device__ __forceinline__ void store_vec_raw(float *p, const float (&v)[CPL]) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) t[j] = v[j];
     }
-    if constexpr (NT) __builtin_nontemporal_store(t, reinterpret_cast<V *>(p));
-    else *reinterpret_cast<V *>(p) = t;
+    DSPFX_GLOBAL V *gp = (DSPFX_GLOBAL V *)reinterpret_cast<V *>(p);
+    if constexpr (NT) __builtin_nontemporal_store(t, gp);
+    else *gp = t;
 }
 
 // GUARD=true is the one-wave tail launch for N % (64*CPL) != 0: out-of-range lanes
@@ -277,6 +289,15 @@ __device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
     }
 }
 
+// ---- feedback delay line (reverb.rs:86-103), split so the tap loads can be issued early ---------
+// The taps of a chunk do not depend on anything the chunk computes (nframes <= D), so a statically
+// specialised kernel issues them together with the sample loads at the top of the chunk instead of after
+// the nodes in front of the delay: one exposed memory latency per chunk instead of two, which is what
+// bounds launches with few channels (one wave per SIMD, nothing else to switch to).
+template <int F, int CPL> struct RingPre {
+    float tap[F][CPL];
+    float *row[F];
+};
 // signal_gen.rs:57-104, one sample: `total` is the block-local phase advance, `clock` the phase carried
 // between 128-frame blocks.  Square compares `total` (not the phase) with 0.5, like the reference.
 template <int MODE>
@@ -289,7 +310,7 @@ __device__ __forceinline__ float signal1(float clock, float &total, float freque
         total = total + step;
         if constexpr (MODE == G_SINE) return sin_cr((clock + total) * TAU) * amplitude;
         else if constexpr (MODE == G_TRIANGLE) return (2.0f * fmodf(clock + total, 1.0f) - 1.0f) * amplitude;
-        else return (total > 0.5f ? 1.0f : -1.0f) * amplitude;
+        else return (total > 0.5f ? 1.0f : -1.0f) * amplitude;   // G_SQUARE, and G_SQUARE_OR_CONST's square half
     }
 }
 
@@ -309,6 +330,28 @@ struct Ctx {
     int side_hop;      // also the hop flag of control links (both are "internal" links)
     bool active;     // false only for padding lanes of the guarded tail launch
 };
+
+template <int F, int CPL, bool GUARD>
+__device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, RingPre<F, CPL> &pre) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
+        r = r >= s.D ? r - s.D : r;
+        float *gb = s.groups[r >> 7];                      // wave-uniform: one scalar load
+        pre.row[f] = gb + ring_in_group_offset(r, cx.tile, cx.ld, s.ring_skew) + cx.cw;
+        load_vec<CPL, GUARD, S_RING_LD>(pre.row[f], pre.tap[f], cx.active);
+    }
+}
+template <int F, int CPL, bool GUARD>
+__device__ __forceinline__ void ring_apply(const SlotArgs &s, float (&v)[F][CPL], const RingPre<F, CPL> &pre, const Ctx &cx) {
+    const float decay = s.p[0];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + pre.tap[f][j] * decay;
+        store_vec<CPL, GUARD, S_RING_ST>(pre.row[f], v[f], cx.active);
+    }
+}
 
 // Apply one node to a chunk v[F][CPL]; st[][] is the node's per-channel state.
 template <int KIND, int MODE, int F, int CPL, bool GUARD, bool FAST>
@@ -355,23 +398,9 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
                 v[f][j] = v[f][j] - z;
             }
     } else if constexpr (KIND == K_REVERB) {      // reverb.rs:86-103: y = x + tap*decay; ring <- y
-        const float decay = s.p[0];
-        float tap[F][CPL];
-        float *row[F];
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
-            r = r >= s.D ? r - s.D : r;
-            float *gb = s.groups[r >> 7];                      // wave-uniform: one scalar load
-            row[f] = gb + ring_in_group_offset(r, cx.tile, cx.ld, s.ring_skew) + cx.cw;
-            load_vec<CPL, GUARD, S_RING_LD>(row[f], tap[f], cx.active);
-        }
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap[f][j] * decay;
-            store_vec<CPL, GUARD, S_RING_ST>(row[f], v[f], cx.active);
-        }
+        RingPre<F, CPL> pre;
+        ring_prefetch<F, CPL, GUARD>(s, cx, pre);
+        ring_apply<F, CPL, GUARD>(s, v, pre, cx);
     } else if constexpr (KIND == K_DISTORT) {     // distort.rs:176-194 (Fuzz has its own kernel)
         const float level = s.p[0];
         if (level < 0.001f) return;               // every mode: `if level < 0.001 { return sample }`
@@ -395,7 +424,17 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
 #pragma unroll
         for (int f = 0; f < F; ++f) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = signal1<MODE>(st[0][j], st[1][j], s.p[1], s.p[0]);
+            for (int j = 0; j < CPL; ++j) {
+                if constexpr (MODE == G_SQUARE_OR_CONST) {
+                    const bool is_const = s.mode == G_CONSTANT;
+                    const float sq = signal1<G_SQUARE>(st[0][j], st[1][j], is_const ? 0.0f : s.p[1], s.p[0]);
+                    v[f][j] = is_const ? s.p[0] : sq;
+                } else {
+                    v[f][j] = signal1<MODE>(st[0][j], st[1][j], s.p[1], s.p[0]);
+                }
+            }
+            // Constant leaves the clock alone (signal_gen.rs:106-108): under G_SQUARE_OR_CONST its total stays 0 and
+            // fmod(clock + 0, 1) == clock for the clock's range [0, 1)
             if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -501,7 +540,15 @@ __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][
 #pragma unroll
         for (int f = 0; f < F; ++f) {
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = signal1<MODE>(st[0][j], st[1][j], fr[f][j], am[f][j]);
+            for (int j = 0; j < CPL; ++j) {
+                if constexpr (MODE == G_SQUARE_OR_CONST) {
+                    const bool is_const = s.mode == G_CONSTANT;
+                    const float sq = signal1<G_SQUARE>(st[0][j], st[1][j], is_const ? 0.0f : fr[f][j], am[f][j]);
+                    v[f][j] = is_const ? am[f][j] : sq;
+                } else {
+                    v[f][j] = signal1<MODE>(st[0][j], st[1][j], fr[f][j], am[f][j]);
+                }
+            }
             if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
 #pragma unroll
                 for (int j = 0; j < CPL; ++j) {
@@ -587,12 +634,10 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
             case K_OVERDRIVE: apply_node_mod<K_OVERDRIVE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); return;
             case K_MIX: apply_node_mod<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); return;
             case K_SIGNAL_GEN:
-                switch (s.mode) {
-                case G_SINE: apply_node_mod<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
-                case G_TRIANGLE: apply_node_mod<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
-                case G_SQUARE: apply_node_mod<K_SIGNAL_GEN, G_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); return;
-                default: apply_node_mod<K_SIGNAL_GEN, G_CONSTANT, F, CPL, GUARD, FAST>(s, v, st, cx); return;
-                }
+                if (s.mode == G_SINE) apply_node_mod<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx);
+                else if (s.mode == G_TRIANGLE) apply_node_mod<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx);
+                else apply_node_mod<K_SIGNAL_GEN, G_SQUARE_OR_CONST, F, CPL, GUARD, FAST>(s, v, st, cx);
+                return;
             default: break;
             }
         }
@@ -609,12 +654,9 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_SIGNAL_GEN:
             if constexpr (LIBM) {
-                switch (s.mode) {
-                case G_SINE: apply_node<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-                case G_TRIANGLE: apply_node<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-                case G_SQUARE: apply_node<K_SIGNAL_GEN, G_SQUARE, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-                default: apply_node<K_SIGNAL_GEN, G_CONSTANT, F, CPL, GUARD, FAST>(s, v, st, cx); break;
-                }
+                if (s.mode == G_SINE) apply_node<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx);
+                else if (s.mode == G_TRIANGLE) apply_node<K_SIGNAL_GEN, G_TRIANGLE, F, CPL, GUARD, FAST>(s, v, st, cx);
+                else apply_node<K_SIGNAL_GEN, G_SQUARE_OR_CONST, F, CPL, GUARD, FAST>(s, v, st, cx);
             }
             break;
         default: break;
@@ -804,7 +846,18 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
     const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
-#define DSPFX_RUN(I) run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);
+    // delay taps first (see RingPre), then the nodes in order
+    RingPre<F, CPL> pre[MAX_SLOTS];
+#define DSPFX_PF(I) if constexpr (sig_is<K_REVERB>(SL::v[I])) ring_prefetch<F, CPL, false>(a.slot[I], cx, pre[I]);
+    DSPFX_FOR_SLOTS(DSPFX_PF)
+#undef DSPFX_PF
+#define DSPFX_RUN(I)                                                                 \
+    if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                      \
+        if constexpr (sig_hop(SL::v[I])) apply_hop<F, CPL, true>(v, cx.hop_div, cx.hop_rc); \
+        ring_apply<F, CPL, false>(a.slot[I], v, pre[I], cx);                         \
+    } else {                                                                         \
+        run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);            \
+    }
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
 #pragma unroll

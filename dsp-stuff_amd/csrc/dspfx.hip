@@ -289,8 +289,13 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         }
         int score = is_dyn ? 0 : 100;
         // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
-        if (pref.f > 0 ? v->f == pref.f : v->f == (is_dyn ? 16 : 8)) score += 10;   // A/B: profiles/r01_ab_dyn.txt
-        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == ((is_dyn || !e->desc.tile_channels) ? 1 : 2)) score += 5;
+        // Few channels (<= 2 waves per SIMD at one channel per lane): nothing hides a wave's memory latency, so
+        // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
+        const bool few = N <= 131072u;
+        const int want_f = is_dyn ? 16 : (few ? 16 : 8);
+        const int want_cpl = (is_dyn || !e->desc.tile_channels || few) ? 1 : 2;
+        if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
+        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
             best_score = score;
             best = v;
@@ -351,6 +356,17 @@ int plan(dspfx_engine *e) {
 // extra candidates as memory allows (at most as many as the ring has groups) are allocated, all are
 // timed, the fastest are kept.  Setup-time only; DSPFX_RING_TUNE=0/1 forces it off/on (default: rings
 // whose groups are >= 64 MiB).
+// Large streamed buffers (delay-ring groups, engine-owned sample buffers).  DSPFX_CONTIG=1 asks the driver for
+// physically contiguous VRAM, which lets the page tables use their largest fragment size (TLB reach).
+hipError_t big_alloc(void **p, size_t bytes) {
+    static const int contig = [] { const char *c = getenv("DSPFX_CONTIG"); return c ? atoi(c) : 0; }();
+    if (contig && bytes >= ((size_t)2 << 20)) {
+        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
+        (void)hipGetLastError();
+    }
+    return hipMalloc(p, bytes);
+}
+
 int tune_ring(dspfx_engine *e, Node &n) {
     const char *tv = getenv("DSPFX_RING_TUNE");
     const int mode = tv ? atoi(tv) : -1;
@@ -375,7 +391,7 @@ int tune_ring(dspfx_engine *e, Node &n) {
     std::vector<float *> cand = n.groups;
     for (size_t k = 0; k < extra; ++k) {
         float *g = nullptr;
-        if (hipMalloc((void **)&g, gbytes) != hipSuccess) break;
+        if (big_alloc((void **)&g, gbytes) != hipSuccess) break;
         cand.push_back(g);
     }
     ChainArgs ca;
@@ -480,7 +496,7 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
         n.group_floats = (size_t)RING_GROUP_ROWS * N;
         n.groups.assign(ngroups, nullptr);
         for (size_t g = 0; g < ngroups; ++g) {
-            HIPCHK(e, hipMalloc((void **)&n.groups[g], n.group_floats * sizeof(float)));
+            HIPCHK(e, big_alloc((void **)&n.groups[g], n.group_floats * sizeof(float)));
             HIPCHK(e, hipMemset(n.groups[g], 0, n.group_floats * sizeof(float)));
         }
         HIPCHK(e, hipMalloc((void **)&n.d_groups, ngroups * sizeof(float *)));

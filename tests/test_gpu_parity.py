@@ -794,3 +794,43 @@ def test_signal_gen_as_lfo_for_another_chain(dspfx, torch_cuda):
     assert np.array_equal(lfo.cpu().numpy(), np.repeat(lfo_ref, N, axis=1))
     ref = O.run_channels([n.oracle_desc() for n in fx_chain], x, ctl={(0, 0): np.repeat(lfo_ref, N, axis=1)})
     assert ulp_diff(dy.cpu().numpy(), ref).max() <= 1
+
+
+def _every_node(dspfx):
+    exact = [dspfx.Gain(0.7), dspfx.BiQuad(), dspfx.LowPass(0.3), dspfx.HighPass(0.3), dspfx.Reverb(delay_samples=128, decay=0.5),
+             dspfx.Add(), dspfx.Mix(0.25)]
+    exact += [dspfx.Distort(3.0, m) for m in (dspfx.HARD_CLIP, dspfx.SOFT_CLIP, dspfx.RECIP_SOFT_CLIP, dspfx.SQUARE, dspfx.CHEBYSHEV4)]
+    exact += [dspfx.SignalGen(0.6, 1500.0, m) for m in (dspfx.SIG_TRIANGLE, dspfx.SIG_SQUARE, dspfx.SIG_CONSTANT)]
+    libm = [dspfx.Distort(3.0, m) for m in (dspfx.TANH, dspfx.SIN, dspfx.ATAN)]
+    libm += [dspfx.Overdrive(5.0, 0.5, 0.8), dspfx.Chebyshev(4.0, 2.0), dspfx.SignalGen(0.6, 1500.0, dspfx.SIG_SINE)]
+    return exact, libm
+
+
+def test_every_node_in_main_tail_and_control_port_kernels(dspfx, torch_cuda):
+    """Each node kind / mode on its own through every interpreter instantiation: the whole-wave launch, the
+    guarded one-wave tail (N % 64 != 0) and -- with a connected control port on a second node -- their
+    control-port versions.  (The per-kind tests above mostly use whole waves; this one found a dropped
+    branch in the guarded kernel's code.)"""
+    N, B, blocks = 100, 128, 3          # 64 channels in the main launch + 36 in the tail
+    x, side = noise_block(N, B * blocks), noise_block(N, B * blocks, seed=9)
+    ctl = (noise_block(N, B * blocks, seed=77) * F(0.5)).astype(F)
+    exact, libm = _every_node(dspfx)
+    for node in exact + libm:
+        bar = 1 if any(node is e for e in exact) else LIBM_COMPOSITE_ULP
+        for with_ctl in (False, True):
+            chain = [node, dspfx.Gain(1.0)] if with_ctl else [node]
+            cports = {(1, 0): ctl} if with_ctl else None
+            eng = dspfx.Engine(N, B, link_flags=3)
+            eng.set_chain(chain)
+            dx, ds = torch_cuda.from_numpy(x).cuda(), torch_cuda.from_numpy(side).cuda()
+            dc = torch_cuda.from_numpy(ctl).cuda()
+            dy = torch_cuda.empty_like(dx)
+            for b in range(blocks):
+                sl = slice(b * B, (b + 1) * B)
+                eng.process(dx[sl], out=dy[sl], side=ds[sl], n_frames=B, ctl={(1, 0): dc[sl]} if with_ctl else None)
+            torch_cuda.cuda.synchronize()
+            ref = O.run_channels([n.oracle_desc() for n in chain], x, 3, side, ctl=cports)
+            d = ulp_diff(dy.cpu().numpy(), ref)
+            # main launch (channels < 64) and tail (>= 64) judged separately so a failure names the kernel
+            assert d[:, :64].max() <= bar, ("main", node.kind, node.mode, with_ctl, d[:, :64].max())
+            assert d[:, 64:].max() <= bar, ("tail", node.kind, node.mode, with_ctl, d[:, 64:].max())

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Pretty-print bench.py JSON lines from stdin."""
-import sys, json
-for l in sys.stdin:
+"""Pretty-print bench.py JSON lines from the files given as arguments, or from stdin."""
+import fileinput, json
+for l in fileinput.input():
     l = l.strip()
     if not l.startswith("{"):
         continue
@@ -9,4 +9,4 @@ for l in sys.stdin:
     r = d["roofline"]
     print("%.4f ms/step  %.3e samples/s  %s kern %.4f ms  %.0f %s frac %.3f  probe %s  %s" % (
         d["ms_per_step"], d["value"], r["kernel"], r["kernel_ms_avg"], r["achieved"], r["unit"], r["frac"],
-        d["config"].get("placement_probe"), [p for p in d["config"]["plan"] if "ring" in p]))
+        (lambda pp: pp and {k: pp[k] for k in ("as_input_ms", "as_output_ms", "output") if k in pp})(d["config"].get("placement_probe")), [p for p in d["config"]["plan"] if "ring" in p]))
