@@ -26,7 +26,7 @@ BUF_SIZE = 128  # dsp-stuff/src/node.rs:257
 ABI_VERSION = 1
 
 # dspfx_kind
-GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN = range(12)
+GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN, ENVELOPE = range(13)
 SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 # dspfx_distort_mode (nodes/distort.rs:18-28)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
@@ -243,6 +243,11 @@ def SignalGen(amplitude: float = 0.5, frequency: float = 100.0, mode: int = SIG_
     """nodes/signal_gen.rs:41-55: a source -- it has no "in" port, so as a chain node it replaces the
     signal (put it first).  Sliders amplitude -1..=1 and frequency 0.1..=20000 Hz are both `as_input`."""
     return NodeSpec(SIGNAL_GEN, [amplitude, frequency], mode=mode)
+
+
+def Envelope(attack: float = 0.0, release: float = 0.0) -> NodeSpec:
+    """nodes/envelope.rs:27-30: peak envelope follower, attack / release in frames (sliders 0..=1000, default 0)."""
+    return NodeSpec(ENVELOPE, [attack, release])
 
 
 # -------------------------------------------------------------------------- engine

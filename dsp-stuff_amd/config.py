@@ -11,7 +11,7 @@ This module turns such a file into the engine's chain descriptor when the graph 
 chain  input -> n0 -> ... -> output  (the shape of every BASELINE config), and writes chains
 back out in the same format.  Graphs the fused engine cannot express raise DspConfigError:
 fan-in/fan-out, control ports fed by links (`as_input` sliders), and node types outside the hot
-path (mux, demux, muff, signal_gen, envelope, pitch, wave_view, spectrogram).
+path (mux, demux, muff, pitch, wave_view, spectrogram).
 
 Reference quirks honoured on purpose:
   * LowPass declares cfg_name = "high_pass" (nodes/low_pass.rs:9), so a LowPass saved by the GUI
@@ -27,7 +27,7 @@ from typing import List, Tuple
 
 import numpy as np
 
-from . import (ADD, BIQUAD, CHEBYSHEV, DISTORT, DISTORT_MODES, FIR, FIR_AVERAGE, FIR_BALANCED, GAIN,
+from . import (ADD, BIQUAD, CHEBYSHEV, DISTORT, DISTORT_MODES, ENVELOPE, FIR, FIR_AVERAGE, FIR_BALANCED, GAIN,
                HIGH_PASS, LOW_PASS, MIX, OVERDRIVE, REVERB, SIGNAL_GEN, NodeSpec, delay_len)
 
 
@@ -36,7 +36,7 @@ class DspConfigError(ValueError):
 
 
 _FIR_MODES = {"Balanced": FIR_BALANCED, "Average": FIR_AVERAGE}
-_UNSUPPORTED = {"mux", "demux", "muff", "envelope", "pitch", "wave_view", "spectrogram"}
+_UNSUPPORTED = {"mux", "demux", "muff", "pitch", "wave_view", "spectrogram"}
 SIGNAL_MODES = ["Sine", "Triangle", "Square", "Constant"]   # signal_gen.rs:17-22
 # typename -> (kind, saved slider fields in params order, main input port, as_input control ports)
 _TABLE = {
@@ -51,6 +51,7 @@ _TABLE = {
     "fir": (FIR, [], "in", []),
     "add": (ADD, [], "a", []),
     "mix": (MIX, ["ratio"], "a", ["ratio"]),
+    "envelope": (ENVELOPE, ["attack", "release"], "in", []),
     "signal_gen": (SIGNAL_GEN, ["amplitude", "frequency"], None, ["amplitude", "frequency"]),   # a source: no main port
 }
 
@@ -166,7 +167,7 @@ def load_dspconfig(text: str, page_round: bool = False) -> Tuple[List[NodeSpec],
 
 _KIND_TO_TYPENAME = {GAIN: "gain", BIQUAD: "biquad", LOW_PASS: "high_pass",   # LowPass saves as "high_pass" (low_pass.rs:9)
                      HIGH_PASS: "high_pass", REVERB: "reverb", DISTORT: "distort", OVERDRIVE: "overdrive",
-                     CHEBYSHEV: "chebyshev", FIR: "fir", ADD: "add", MIX: "mix", SIGNAL_GEN: "signal_gen"}
+                     CHEBYSHEV: "chebyshev", FIR: "fir", ADD: "add", MIX: "mix", SIGNAL_GEN: "signal_gen", ENVELOPE: "envelope"}
 
 
 def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpass_bug: bool = True) -> str:

@@ -25,7 +25,7 @@ constexpr int WG = 256;        // workgroup size (4 waves)
 // kinds: numeric values == dspfx_kind in include/dspfx.h
 enum : int {
     K_GAIN = 0, K_BIQUAD = 1, K_LOW_PASS = 2, K_HIGH_PASS = 3, K_REVERB = 4, K_DISTORT = 5,
-    K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10, K_SIGNAL_GEN = 11
+    K_OVERDRIVE = 6, K_CHEBYSHEV = 7, K_FIR = 8, K_ADD = 9, K_MIX = 10, K_SIGNAL_GEN = 11, K_ENVELOPE = 12
 };
 enum : int { G_SINE = 0, G_TRIANGLE = 1, G_SQUARE = 2, G_CONSTANT = 3 };   // signal_gen.rs:17-22
 // Interpreter-only pseudo mode: Square and Constant share one code path, told apart by a per-sample select
@@ -419,6 +419,21 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[f][j] = chebyshev1(v[f][j], s.p[0], s.p[1]);
+    } else if constexpr (KIND == K_ENVELOPE) {    // envelope.rs:34-52, dasp_envelope Detector::next + dasp_peak full_wave
+        const float ga = s.p[0], gr = s.p[1];     // attack / release gains, computed on the host (powf)
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                const float x = v[f][j];
+                const float d = x < 0.0f ? -x : x;
+                const float l = st[0][j];
+                const float gain = l < d ? ga : gr;
+                const float diff = l + (-d);
+                st[0][j] = d + diff * gain;
+                v[f][j] = st[0][j];
+            }
+        }
     } else if constexpr (KIND == K_SIGNAL_GEN) {  // signal_gen.rs:111-128: a source, the input is ignored
         // st[0] = clock (persisted), st[1] = block-local total; the clock wraps at every 128-frame block end
 #pragma unroll
@@ -652,6 +667,7 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         case K_CHEBYSHEV: if constexpr (LIBM) apply_node<K_CHEBYSHEV, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_ADD: apply_node<K_ADD, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_MIX: apply_node<K_MIX, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
+        case K_ENVELOPE: apply_node<K_ENVELOPE, 0, F, CPL, GUARD, FAST>(s, v, st, cx); break;
         case K_SIGNAL_GEN:
             if constexpr (LIBM) {
                 if (s.mode == G_SINE) apply_node<K_SIGNAL_GEN, G_SINE, F, CPL, GUARD, FAST>(s, v, st, cx);
@@ -670,7 +686,7 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
 // rows of per-channel state a kind keeps in registers / LDS during a launch, and how many of them
 // persist in HBM between launches (SIGNAL_GEN: the clock persists, the block-local total does not)
 __host__ __device__ __forceinline__ constexpr int kind_nstate(int k) {
-    return k == K_BIQUAD ? 4 : (k == K_LOW_PASS || k == K_HIGH_PASS) ? 1 : k == K_SIGNAL_GEN ? 2 : 0;
+    return k == K_BIQUAD ? 4 : (k == K_LOW_PASS || k == K_HIGH_PASS || k == K_ENVELOPE) ? 1 : k == K_SIGNAL_GEN ? 2 : 0;
 }
 __host__ __device__ __forceinline__ constexpr int kind_npersist(int k) { return k == K_SIGNAL_GEN ? 1 : kind_nstate(k); }
 template <int SIG>

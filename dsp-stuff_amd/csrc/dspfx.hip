@@ -479,7 +479,8 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     case DSPFX_BIQUAD: bytes = 4 * N * sizeof(float); break;
     case DSPFX_LOW_PASS:
     case DSPFX_HIGH_PASS:
-    case DSPFX_SIGNAL_GEN: bytes = N * sizeof(float); break;   // z / z / clock
+    case DSPFX_SIGNAL_GEN:
+    case DSPFX_ENVELOPE: bytes = N * sizeof(float); break;   // z / z / clock / env
     default: break;
     }
     if (n.state && n.state_bytes != bytes) {
@@ -548,6 +549,10 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     switch (n.d.kind) {
     case DSPFX_BIQUAD:
         s.p[0] = n.a1; s.p[1] = n.a2; s.p[2] = n.b0; s.p[3] = n.b1; s.p[4] = n.b2;
+        break;
+    case DSPFX_ENVELOPE:   // dasp_envelope calc_gain: the host's powf is the libm the reference calls
+        for (int k = 0; k < 2; ++k)
+            s.p[k] = n.d.params[k] == 0.0f ? 0.0f : powf(2.71828182845904523536028747135266250f, -1.0f / n.d.params[k]);
         break;
     default:
         for (int k = 0; k < 6; ++k) s.p[k] = n.d.params[k];
@@ -1252,7 +1257,8 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
         case DSPFX_BIQUAD: b += 32.0 / n_frames; break;
         case DSPFX_LOW_PASS:
         case DSPFX_HIGH_PASS:
-        case DSPFX_SIGNAL_GEN: b += 8.0 / n_frames; break;
+        case DSPFX_SIGNAL_GEN:
+        case DSPFX_ENVELOPE: b += 8.0 / n_frames; break;
         case DSPFX_REVERB: b += 8.0; break;
         case DSPFX_FIR: b += 4.0 + 4.0 * ((double)n.taps.size() - 1.0) / n_frames; break;
         case DSPFX_ADD:
@@ -1267,7 +1273,7 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
 extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
     if (!e || !dst || cap == 0) return DSPFX_ERR_INVALID;
     static const char *kn[] = {"gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "overdrive",
-                               "chebyshev", "fir", "add", "mix", "signal_gen"};
+                               "chebyshev", "fir", "add", "mix", "signal_gen", "envelope"};
     std::string s;
     char buf[256];
     snprintf(buf, sizeof buf, "engine: N=%u max_frames=%u link_flags=%u\n", e->desc.channels, e->desc.max_frames,

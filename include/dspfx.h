@@ -68,7 +68,8 @@ typedef enum dspfx_kind {
     DSPFX_ADD = 9,       /* nodes/add.rs:24-34  (port "b" = the side input) */
     DSPFX_MIX = 10,      /* nodes/mix.rs:31-47  (port "b" = the side input) */
     DSPFX_SIGNAL_GEN = 11, /* nodes/signal_gen.rs:55-129: a SOURCE (no "in" port): replaces the signal */
-    DSPFX_N_KINDS = 12
+    DSPFX_ENVELOPE = 12, /* nodes/envelope.rs:34-52: dasp_envelope 0.11.0 peak detector (full-wave) */
+    DSPFX_N_KINDS = 13
 } dspfx_kind;
 
 /* nodes/signal_gen.rs:17-22 `enum Mode` */
@@ -126,6 +127,9 @@ typedef struct dspfx_engine_desc {
  *   MIX        params[0]=ratio (0..=1, default .5)                    mix.rs:22-28
  *   SIGNAL_GEN params[0]=amplitude (-1..=1, default .5), [1]=frequency (0.1..=20000 Hz, default 100); mode
  *              (dspfx_signal_mode); per-channel phase clock, wrapped at every 128-frame block end  signal_gen.rs:41-55
+ *   ENVELOPE   params[0]=attack, [1]=release, both in frames (0..=1000, default 0); per-channel envelope
+ *              env = d + (env - d)*g, d = |x|, g = env < d ? e^(-1/attack) : e^(-1/release), g = 0 for 0 frames
+ *              (dasp_envelope 0.11.0 Detector::next, restated as recalled: see oracle/dspfx_oracle.h)  envelope.rs:27-30
  * delay_len is explicit because rivulet's capacity rounding is not in the
  * reference tree; dspfx_delay_len() gives both readings.    */
 typedef struct dspfx_node_desc {

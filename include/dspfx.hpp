@@ -91,6 +91,12 @@ inline Node Fir(const std::vector<double> &impulse_response, FirMode mode = FirM
 }
 inline Node Add() { return make(DSPFX_ADD); }
 inline Node Mix(float ratio = 0.5f) { Node n = make(DSPFX_MIX); n.d.params[0] = ratio; return n; }
+// nodes/envelope.rs:27-30: peak envelope follower, attack / release in frames
+inline Node Envelope(float attack = 0.0f, float release = 0.0f) {
+    Node n = make(DSPFX_ENVELOPE);
+    n.d.params[0] = attack; n.d.params[1] = release;
+    return n;
+}
 // nodes/signal_gen.rs:41-55: a source (no "in" port) -- as a chain node it replaces the signal
 enum class SignalMode : int { Sine = DSPFX_SIG_SINE, Triangle = DSPFX_SIG_TRIANGLE, Square = DSPFX_SIG_SQUARE, Constant = DSPFX_SIG_CONSTANT };
 inline Node SignalGen(float amplitude = 0.5f, float frequency = 100.0f, SignalMode mode = SignalMode::Sine) {

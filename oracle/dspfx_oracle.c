@@ -199,6 +199,7 @@ void orc_node_reset(orc_node *n) {
     n->bq_x1 = n->bq_x2 = n->bq_y1 = n->bq_y2 = 0.0f;
     n->z = 0.0f;
     n->clock = 0.0f;
+    n->env = 0.0f; /* Detector::new: last_env_frame = EQUILIBRIUM */
     if (n->ring) memset(n->ring, 0, sizeof(float) * n->ring_len);
     n->ring_pos = 0;
     free(n->dq);
@@ -526,6 +527,22 @@ void orc_node_process(orc_node *n, const float *in_a, const float *in_b,
                 out[i] = (total > 0.5f ? 1.0f : -1.0f) * amplitude[i];
         }
         n->clock = fmodf(clock + total, 1.0f); /* 66-67 */
+        break;
+    }
+    case ORC_ENVELOPE: { /* envelope.rs:34-52; dasp_envelope 0.11.0 detect/mod.rs (Detector::next), dasp_peak full_wave */
+        /* set_attack_frames / set_release_frames every block (envelope.rs:45-46): calc_gain(n) */
+        float ga = n->p[0] == 0.0f ? 0.0f : powf(2.71828182845904523536028747135266250f, -1.0f / n->p[0]);
+        float gr = n->p[1] == 0.0f ? 0.0f : powf(2.71828182845904523536028747135266250f, -1.0f / n->p[1]);
+        float l = n->env;
+        for (size_t i = 0; i < nf; i++) {
+            float x = in_a[i];
+            float d = x < 0.0f ? -x : x;           /* full_wave: if s < EQUILIBRIUM { -s } else { s } */
+            float gain = l < d ? ga : gr;          /* attack while the envelope is below the rectified sample */
+            float diff = l + (-d);                 /* l.add_amp(-d) */
+            l = d + diff * gain;                   /* d.add_amp(diff.mul_amp(gain)) */
+            out[i] = l;
+        }
+        n->env = l;
         break;
     }
     case ORC_MIX: { /* mix.rs:33-46 */

@@ -20,6 +20,10 @@
  *   - rivulet @b2416e5 circular_buffer (FIFO semantics + initial zero fill only)
  *   - Rust std f32 math on linux-gnu == glibc libm (tanhf/sinf/atanf/expf)
  *   - Rust std VecDeque<f64> growth policy (for Fir's a/b slice split)
+ *   - dasp_envelope 0.11.0 / dasp_peak 0.11.0 (Cargo.lock:1207-1246): Detector::{peak, set_attack_frames,
+ *     set_release_frames, next} with the Peak<FullWave> rectifier, restated from the crate's published source
+ *     AS RECALLED (envelope = d + (last - d) * gain, d = |x|, gain = attack gain while rising else release
+ *     gain, gain(n) = n == 0 ? 0 : powf(e, -1/n)); not verifiable in this container
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (Rust never contracts a*b+c).
  * All citations are relative to /root/reference/.
@@ -51,7 +55,8 @@ enum {
     ORC_ADD = 9,       /* nodes/add.rs */
     ORC_MIX = 10,      /* nodes/mix.rs */
     ORC_SIGNAL_GEN = 11, /* nodes/signal_gen.rs: a SOURCE (no "in" port); its input is ignored */
-    ORC_N_KINDS = 12
+    ORC_ENVELOPE = 12,   /* nodes/envelope.rs over dasp_envelope 0.11.0 Detector<f32, Peak<FullWave>> */
+    ORC_N_KINDS = 13
 };
 
 /* nodes/distort.rs:18-28, in declaration order (repr(u8)). */
@@ -87,6 +92,7 @@ enum { ORC_FIR_BALANCED = 0, ORC_FIR_AVERAGE = 1 };
  *   FIR        taps (time-reversed, as stored by fir.rs:163,168), mode
  *   ADD        -              MIX p[0]=ratio
  *   SIGNAL_GEN p[0]=amplitude, p[1]=frequency, mode; state: clock
+ *   ENVELOPE   p[0]=attack, p[1]=release (both in frames, sliders 0..=1000); state: env
  */
 typedef struct orc_node {
     int kind;
@@ -101,6 +107,8 @@ typedef struct orc_node {
     float z;
     /* signal generator phase (signal_gen.rs:52) */
     float clock;
+    /* envelope follower: Detector::last_env_frame (envelope.rs:25) */
+    float env;
     /* reverb ring: exactly D samples, FIFO (read oldest, append newest) */
     float *ring;
     uint32_t ring_len, ring_pos;

@@ -239,3 +239,35 @@ class SignalGen:
             out = (np.where(total > F(0.5), F(1.0), F(-1.0)).astype(F) * amp).astype(F)
         self.clock = F(np.fmod(F(self.clock + acc), F(1.0)))
         return out
+
+
+class Envelope:
+    """envelope.rs:34-52 over dasp_envelope 0.11.0 Detector<f32, Peak<FullWave>> (restated as recalled, see
+    dspfx_oracle.h): env = d + (env - d) * gain, d = |x|, gain = attack gain while env < d else release gain."""
+
+    E = F(2.718281828459045)
+
+    def __init__(self, attack=0.0, release=0.0):
+        self.attack, self.release = F(attack), F(release)
+        self.env = F(0.0)
+
+    @classmethod
+    def calc_gain(cls, n_frames):
+        n = F(n_frames)
+        if n == F(0):
+            return F(0.0)
+        # powf(e_f32, x): evaluated in float64 and rounded once (glibc powf is within 1 ulp of that)
+        return F(np.power(np.float64(cls.E), np.float64(F(-1.0) / n)))
+
+    def process(self, x):
+        x = np.asarray(x, F)
+        ga, gr = self.calc_gain(self.attack), self.calc_gain(self.release)
+        out = np.empty_like(x)
+        l = self.env
+        for i in range(x.size):
+            d = -x[i] if x[i] < F(0) else x[i]
+            g = ga if l < d else gr
+            l = F(d + F(F(l + (-d)) * g))
+            out[i] = l
+        self.env = l
+        return out

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 BUF_SIZE = 128
 
 # kinds / modes (numeric values shared with include/dspfx.h)
-GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN = range(12)
+GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN, ENVELOPE = range(13)
 SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
 FIR_BALANCED, FIR_AVERAGE = 0, 1

@@ -61,7 +61,7 @@ def test_roundtrip_and_lowpass_cfg_name_bug(mods):
     h = np.array([0.5, -0.25, 0.125])
     chain = [dspfx.Gain(0.8), dspfx.LowPass(0.3), dspfx.Overdrive(5, 0.7, 0.9), dspfx.Chebyshev(4.0, 2.0),
              dspfx.Fir(h, dspfx.FIR_AVERAGE), dspfx.Mix(0.25), dspfx.Add(), dspfx.Distort(2.0, dspfx.TANH),
-             dspfx.Reverb(delay_samples=4800, decay=0.3)]
+             dspfx.Reverb(delay_samples=4800, decay=0.3), dspfx.Envelope(12.0, 480.0)]
     back, info = config.load_dspconfig(config.dump_dspconfig(chain))
     assert info["side_from_input"]
     kinds = [n.kind for n in back]
@@ -70,6 +70,7 @@ def test_roundtrip_and_lowpass_cfg_name_bug(mods):
     assert kinds[:1] + kinds[2:] == [n.kind for n in chain[:1] + chain[2:]]
     assert np.array_equal(back[4].taps_reversed, h[::-1]) and back[4].mode == dspfx.FIR_AVERAGE
     assert back[7].mode == dspfx.TANH and back[8].delay_len == 4800
+    assert back[9].kind == dspfx.ENVELOPE and back[9].params == [12.0, 480.0]
     fixed, _ = config.load_dspconfig(config.dump_dspconfig(chain, faithful_lowpass_bug=False))
     assert fixed[1].kind == dspfx.LOW_PASS
 

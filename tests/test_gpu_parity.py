@@ -801,6 +801,7 @@ def _every_node(dspfx):
              dspfx.Add(), dspfx.Mix(0.25)]
     exact += [dspfx.Distort(3.0, m) for m in (dspfx.HARD_CLIP, dspfx.SOFT_CLIP, dspfx.RECIP_SOFT_CLIP, dspfx.SQUARE, dspfx.CHEBYSHEV4)]
     exact += [dspfx.SignalGen(0.6, 1500.0, m) for m in (dspfx.SIG_TRIANGLE, dspfx.SIG_SQUARE, dspfx.SIG_CONSTANT)]
+    exact += [dspfx.Envelope(), dspfx.Envelope(0.0, 40.0), dspfx.Envelope(12.0, 300.0)]
     libm = [dspfx.Distort(3.0, m) for m in (dspfx.TANH, dspfx.SIN, dspfx.ATAN)]
     libm += [dspfx.Overdrive(5.0, 0.5, 0.8), dspfx.Chebyshev(4.0, 2.0), dspfx.SignalGen(0.6, 1500.0, dspfx.SIG_SINE)]
     return exact, libm
@@ -834,3 +835,53 @@ def test_every_node_in_main_tail_and_control_port_kernels(dspfx, torch_cuda):
             # main launch (channels < 64) and tail (>= 64) judged separately so a failure names the kernel
             assert d[:, :64].max() <= bar, ("main", node.kind, node.mode, with_ctl, d[:, :64].max())
             assert d[:, 64:].max() <= bar, ("tail", node.kind, node.mode, with_ctl, d[:, 64:].max())
+
+
+def test_envelope_follower(dspfx, torch_cuda):
+    """envelope.rs:34-52 (dasp peak detector): gains come from the host's powf like the reference's, the
+    recurrence itself is plain f32 => bit-exact against the oracle, alone and as a stage of a chain, with state
+    carried across blocks, exported / imported and cleared by reset."""
+    N, B, blocks = 200, 128, 5
+    x = noise_block(N, B * blocks)
+    for att, rel in ((0.0, 0.0), (0.0, 64.0), (5.0, 0.0), (48.0, 1000.0), (0.5, 0.25)):
+        chain = [dspfx.Envelope(att, rel)]
+        for lf in (3, 0):
+            got = run_gpu(dspfx, torch_cuda, chain, x, link_flags=lf)
+            assert np.array_equal(got.view(np.uint32), run_oracle(chain, x, lf).view(np.uint32)), (att, rel, lf)
+    chain = [dspfx.BiQuad(), dspfx.Envelope(20.0, 400.0), dspfx.Gain(2.0), dspfx.Reverb(delay_samples=128, decay=0.4)]
+    for block, tile in ((128, 0), (256, 0), (128, 64)):
+        n_ch = 192 if tile else N
+        got = run_gpu(dspfx, torch_cuda, chain, np.ascontiguousarray(x[:, :n_ch]), block=block, tile=tile)
+        assert ulp_diff(got, run_oracle(chain, np.ascontiguousarray(x[:, :n_ch]))).max() <= 1
+    # parameter change between blocks, state export / import, reset
+    eng = dspfx.Engine(N, B)
+    eng.set_chain([dspfx.Envelope(10.0, 200.0)])
+    nodes = []
+    dx = torch_cuda.from_numpy(x).cuda()
+    dy = torch_cuda.empty_like(dx)
+    ref = np.empty_like(x)
+    descs = [dspfx.Envelope(10.0, 200.0).oracle_desc()]
+    for b in range(blocks):
+        sl = slice(b * B, (b + 1) * B)
+        if b == 2:
+            eng.set_param(0, 1, 20.0)
+            for chn in nodes:
+                chn[0].set_param(1, 20.0)
+        eng.process(dx[sl], out=dy[sl], n_frames=B)
+        ref[sl] = O.run_channels(descs, x[sl], 3, nodes_out=nodes)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(dy.cpu().numpy(), ref)
+    env = eng.state_export(0).view(np.float32)
+    assert env.shape == (N,) and np.array_equal(env, ref[-1])            # the state IS the last output
+    eng2 = dspfx.Engine(N, B)
+    eng2.set_chain([dspfx.Envelope(10.0, 20.0)])
+    eng2.state_import(0, eng.state_export(0))
+    y1, y2 = torch_cuda.empty_like(dx[:B]), torch_cuda.empty_like(dx[:B])
+    eng.process(dx[:B], out=y1, n_frames=B)
+    eng2.process(dx[:B], out=y2, n_frames=B)
+    torch_cuda.cuda.synchronize()
+    assert torch_cuda.equal(y1, y2)
+    eng.reset()
+    eng.process(dx[:B], out=y1, n_frames=B)
+    torch_cuda.cuda.synchronize()
+    assert np.array_equal(y1.cpu().numpy(), O.run_channels([dspfx.Envelope(10.0, 20.0).oracle_desc()], x[:B], 3))

@@ -310,3 +310,34 @@ def test_kat10_signal_gen():
                 want = m.process()
             d = np.abs(bits(got).astype(np.int64) - bits(want).astype(np.int64)).max() if mode == 0 else (0 if np.array_equal(got, want) else 99)
             assert d <= 2, (mode, blk, d)       # glibc sinf is within 1 ulp of the correctly rounded value; x amplitude
+
+
+def test_kat11_envelope():
+    # envelope.rs:34-52 over dasp_envelope 0.11.0 (restated as recalled, oracle/dspfx_oracle.h)
+    x = np.array([0.5, -0.25, 0.0, -1.0, 0.125, -0.0], F)
+    # defaults attack = release = 0 frames => both gains 0 => env = d + (l - d) * 0 = |x|
+    y = O.Node(O.ENVELOPE).process(x)
+    assert np.array_equal(y, np.abs(x))
+    # attack 0, release n: rises instantly, decays by e^(-1/n) per frame towards |x|
+    n = 4.0
+    g = F(np.float64(F(2.718281828459045)) ** np.float64(F(-1.0) / F(n)))
+    y = O.Node(O.ENVELOPE, [0.0, n]).process(np.array([1, 0, 0, 0, 0.5, 0], F))
+    want = [F(1.0)]
+    for d in (F(0), F(0), F(0)):
+        want.append(F(d + F(F(want[-1] + (-d)) * g)))
+    want.append(F(F(0.5) + F(F(want[-1] + F(-0.5)) * (g if not want[-1] < F(0.5) else F(0)))))
+    want.append(F(F(0) + F(F(want[-1] + F(-0.0)) * g)))
+    assert np.abs(bits(y).astype(np.int64) - bits(np.array(want, F)).astype(np.int64)).max() <= 1   # powf vs f64 pow
+    assert abs(float(y[3]) - np.exp(-3 / 4)) < 1e-6
+    # attack: approaches a step with time constant n frames; state carries across blocks; reset clears it
+    node, m = O.Node(O.ENVELOPE, [10.0, 100.0]), M.Envelope(10.0, 100.0)
+    rng = np.random.default_rng(5)
+    for _ in range(4):
+        blk = rng.uniform(-1, 1, 128).astype(F)
+        a, b = node.process(blk), m.process(blk)
+        assert np.abs(bits(a).astype(np.int64) - bits(b).astype(np.int64)).max() <= 4    # 1-ulp gain difference, accumulated
+    step = O.Node(O.ENVELOPE, [10.0, 0.0]).process(np.ones(64, F))
+    k = np.arange(1, 65)
+    assert np.abs(step - (1 - np.exp(-k / 10.0))).max() < 1e-5
+    node.reset()
+    assert np.array_equal(node.process(np.zeros(4, F)), np.zeros(4, F))
