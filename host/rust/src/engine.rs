@@ -1,0 +1,182 @@
+//! Safe wrapper over `ffi.rs`: one `Engine` = N independent mono channels through one chain.
+//! Mirrors `include/dspfx.hpp` / `dsp-stuff_amd/__init__.py` (same constructor names as the reference's
+//! nodes, same defaults).  NOT compiled in the build container.
+use super::ffi::*;
+use std::ffi::CStr;
+use std::os::raw::c_int;
+use std::ptr;
+
+#[derive(Debug)]
+pub struct Error {
+    pub status: c_int,
+    pub message: String,
+}
+
+impl std::fmt::Display for Error {
+    fn fmt(&self, f: &mut std::fmt::Formatter<'_>) -> std::fmt::Result {
+        write!(f, "dspfx error {}: {}", self.status, self.message)
+    }
+}
+impl std::error::Error for Error {}
+
+/// One chain node: the descriptor plus the tap storage it may point into.
+#[derive(Clone, Debug)]
+pub struct NodeDesc {
+    pub d: dspfx_node_desc,
+    taps: Vec<f64>, // stored time-reversed, like fir.rs:163,168
+}
+
+impl NodeDesc {
+    fn defaults(kind: c_int) -> Self {
+        let mut d = dspfx_node_desc { kind, mode: 0, params: [0.0; 8], delay_len: 0, n_taps: 0, taps: ptr::null() };
+        let rc = unsafe { dspfx_node_defaults(kind, &mut d) };
+        assert_eq!(rc, DSPFX_OK, "dspfx_node_defaults({kind})");
+        NodeDesc { d, taps: Vec::new() }
+    }
+    fn with(kind: c_int, params: &[f32]) -> Self {
+        let mut n = Self::defaults(kind);
+        n.d.params[..params.len()].copy_from_slice(params);
+        n
+    }
+    /// nodes/gain.rs: level 0..=10, default 1
+    pub fn gain(level: f32) -> Self { Self::with(DSPFX_GAIN, &[level]) }
+    /// nodes/biquad.rs:18-41: raw sliders a0,a1,a2,b0,b1,b2 (normalised by a0 in the engine)
+    pub fn biquad(a0: f32, a1: f32, a2: f32, b0: f32, b1: f32, b2: f32) -> Self { Self::with(DSPFX_BIQUAD, &[a0, a1, a2, b0, b1, b2]) }
+    pub fn low_pass(ratio: f32) -> Self { Self::with(DSPFX_LOW_PASS, &[ratio]) }
+    pub fn high_pass(ratio: f32) -> Self { Self::with(DSPFX_HIGH_PASS, &[ratio]) }
+    /// nodes/reverb.rs: feedback delay; `seconds` goes through reverb.rs:58
+    pub fn reverb(seconds: f32, decay: f32) -> Self {
+        let mut n = Self::with(DSPFX_REVERB, &[decay]);
+        n.d.delay_len = unsafe { dspfx_delay_len(seconds, 0) };
+        n
+    }
+    /// nodes/distort.rs: level 0..=30 (0 = bypass), mode = DSPFX_DIST_*
+    pub fn distort(level: f32, mode: c_int) -> Self {
+        let mut n = Self::with(DSPFX_DISTORT, &[level]);
+        n.d.mode = mode;
+        n
+    }
+    pub fn overdrive(boost: f32, drive: f32, level: f32) -> Self { Self::with(DSPFX_OVERDRIVE, &[boost, drive, level]) }
+    pub fn chebyshev(level_pos: f32, level_neg: f32) -> Self { Self::with(DSPFX_CHEBYSHEV, &[level_pos, level_neg]) }
+    /// nodes/fir.rs: `impulse_response` in natural order h[0..T)
+    pub fn fir(impulse_response: &[f64], mode: c_int) -> Self {
+        let mut n = Self::defaults(DSPFX_FIR);
+        n.taps = impulse_response.iter().rev().copied().collect();
+        n.d.mode = mode;
+        n
+    }
+    pub fn add() -> Self { Self::defaults(DSPFX_ADD) }
+    pub fn mix(ratio: f32) -> Self { Self::with(DSPFX_MIX, &[ratio]) }
+    /// nodes/signal_gen.rs: a source (no "in" port); mode = DSPFX_SIG_*
+    pub fn signal_gen(amplitude: f32, frequency: f32, mode: c_int) -> Self {
+        let mut n = Self::with(DSPFX_SIGNAL_GEN, &[amplitude, frequency]);
+        n.d.mode = mode;
+        n
+    }
+    /// nodes/envelope.rs: attack / release in frames
+    pub fn envelope(attack: f32, release: f32) -> Self { Self::with(DSPFX_ENVELOPE, &[attack, release]) }
+}
+
+pub struct Engine {
+    h: *mut dspfx_engine,
+    channels: u32,
+}
+
+// The engine may be driven by one thread at a time (include/dspfx.h); callers wrap it in a Mutex.
+unsafe impl Send for Engine {}
+
+impl Drop for Engine {
+    fn drop(&mut self) {
+        unsafe { dspfx_engine_destroy(self.h) }
+    }
+}
+
+impl Engine {
+    pub fn new(channels: u32, max_frames: u32, link_flags: u32, device: i32) -> Result<Self, Error> {
+        let desc = dspfx_engine_desc {
+            abi_version: DSPFX_ABI_VERSION, device, channels, max_frames, link_flags, tile_channels: 0, channel_offset: 0,
+        };
+        let mut h = ptr::null_mut();
+        let rc = unsafe { dspfx_engine_create(&desc, &mut h) };
+        if rc != DSPFX_OK {
+            // no CPU fallback: a missing device is an error the caller sees
+            let msg = unsafe { CStr::from_ptr(dspfx_strerror(rc)) }.to_string_lossy().into_owned();
+            return Err(Error { status: rc, message: msg });
+        }
+        Ok(Engine { h, channels })
+    }
+
+    fn check(&self, rc: c_int) -> Result<(), Error> {
+        if rc == DSPFX_OK {
+            return Ok(());
+        }
+        let msg = unsafe { CStr::from_ptr(dspfx_last_error(self.h)) }.to_string_lossy().into_owned();
+        Err(Error { status: rc, message: msg })
+    }
+
+    pub fn channels(&self) -> u32 { self.channels }
+
+    pub fn set_chain(&mut self, chain: &[NodeDesc]) -> Result<(), Error> {
+        let descs: Vec<dspfx_node_desc> = chain
+            .iter()
+            .map(|n| {
+                let mut d = n.d;
+                d.n_taps = n.taps.len() as u32;
+                d.taps = if n.taps.is_empty() { ptr::null() } else { n.taps.as_ptr() };
+                d
+            })
+            .collect();
+        let rc = unsafe { dspfx_chain_set(self.h, descs.as_ptr(), descs.len() as c_int) };
+        self.check(rc)
+    }
+
+    /// A slider store (dsp-stuff-derive/src/lib.rs:487-492) including the reference's
+    /// `after_settings_change` side effects (biquad.rs:62-76: state reset).
+    pub fn set_param(&mut self, node: usize, param: usize, value: f32) -> Result<(), Error> {
+        let rc = unsafe { dspfx_set_param(self.h, node as c_int, param as c_int, value) };
+        self.check(rc)
+    }
+    pub fn set_mode(&mut self, node: usize, mode: c_int) -> Result<(), Error> {
+        let rc = unsafe { dspfx_set_mode(self.h, node as c_int, mode) };
+        self.check(rc)
+    }
+    pub fn set_delay_seconds(&mut self, node: usize, seconds: f32) -> Result<(), Error> {
+        let rc = unsafe { dspfx_set_delay_len(self.h, node as c_int, dspfx_delay_len(seconds, 0)) };
+        self.check(rc)
+    }
+    pub fn reset(&mut self) -> Result<(), Error> {
+        let rc = unsafe { dspfx_reset(self.h) };
+        self.check(rc)
+    }
+
+    /// One block from host slices, frame-major `[n_frames][channels]`; synchronous (H2D, chain, D2H).
+    pub fn process_host(&mut self, input: &[f32], side: Option<&[f32]>, out: &mut [f32], mix: Option<&mut [f32]>,
+                        n_frames: u32) -> Result<(), Error> {
+        let want = n_frames as usize * self.channels as usize;
+        assert!(input.len() == want && out.len() == want, "block must be [n_frames][channels]");
+        if let Some(s) = side {
+            assert_eq!(s.len(), want);
+        }
+        let mix_ptr = match mix {
+            Some(m) => {
+                assert_eq!(m.len(), n_frames as usize);
+                m.as_mut_ptr()
+            }
+            None => ptr::null_mut(),
+        };
+        let rc = unsafe {
+            dspfx_process_host(self.h, input.as_ptr(), side.map_or(ptr::null(), |s| s.as_ptr()), out.as_mut_ptr(), mix_ptr, n_frames)
+        };
+        self.check(rc)
+    }
+
+    pub fn describe(&self) -> String {
+        let mut buf = vec![0u8; 64 << 10];
+        let rc = unsafe { dspfx_describe(self.h, buf.as_mut_ptr() as *mut _, buf.len()) };
+        if rc != DSPFX_OK {
+            return String::new();
+        }
+        let end = buf.iter().position(|&b| b == 0).unwrap_or(buf.len());
+        String::from_utf8_lossy(&buf[..end]).into_owned()
+    }
+}

@@ -1,0 +1,97 @@
+//! `GpuChain`: a reference node (`Node` + `SimpleNode`, dsp-stuff/src/node.rs:104-146) whose `process`
+//! hands the block to libdspfx.  It replaces the k effect nodes of a chain by one node; with
+//! `link_flags = DSPFX_LINK_INTERNAL` the result is what those k nodes produce (the `Perform` wrapper
+//! still applies the hop INTO this node, node.rs:290-299; the engine applies the k-1 hops between the
+//! fused nodes).  NOT compiled in the build container.
+use super::engine::{Engine, NodeDesc};
+use super::ffi::{DSPFX_DIST_SOFT_CLIP, DSPFX_LINK_INTERNAL};
+use crate::{ids::NodeId, node::*};
+use std::sync::Mutex;
+
+#[derive(dsp_stuff_derive::DspNode)]
+#[dsp(
+    input = "in",
+    output = "out",
+    title = "GPU chain",
+    cfg_name = "gpu_chain",
+    description = "biquad > soft clip > delay > biquad > gain, evaluated by libdspfx on an MI355X"
+)]
+pub struct GpuChain {
+    #[dsp(id)]
+    id: NodeId,
+    #[dsp(inputs)]
+    inputs: PortStorage,
+    #[dsp(outputs)]
+    outputs: PortStorage,
+
+    #[dsp(default = "GpuChain::make_engine()")]
+    engine: Mutex<Engine>,
+}
+
+impl GpuChain {
+    fn make_engine() -> Mutex<Engine> {
+        // a missing GPU is fatal, like every other failure on the reference's hot path (node.rs:173,271)
+        let mut e = Engine::new(1, BUF_SIZE as u32, DSPFX_LINK_INTERNAL, 0).expect("libdspfx engine");
+        e.set_chain(&[
+            NodeDesc::biquad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025),
+            NodeDesc::distort(3.0, DSPFX_DIST_SOFT_CLIP),
+            NodeDesc::reverb(0.5, 0.5),
+            NodeDesc::biquad(1.0, -1.98, 0.9801, 0.99, -1.98, 0.99),
+            NodeDesc::gain(0.5),
+        ])
+        .expect("chain");
+        Mutex::new(e)
+    }
+}
+
+impl SimpleNode for GpuChain {
+    fn process(&self, inputs: ProcessInput, mut outputs: ProcessOutput) {
+        let input = inputs.get("in").unwrap(); // already averaged by the Perform wrapper (node.rs:297)
+        let output = outputs.get("out").unwrap();
+        let mut e = self.engine.lock().unwrap();
+        e.process_host(input, None, output, None, input.len() as u32).expect("dspfx_process_host");
+    }
+}
+
+/// The form that uses the GPU: N identical chains evaluated together.  The host gathers the N pipes'
+/// 128-frame blocks into one frame-major `[128][N]` buffer, the engine returns the N outputs and,
+/// optionally, the Output node's mix of all of them (nodes/output.rs:215-249).
+pub struct Bank {
+    engine: Engine,
+    gather: Vec<f32>,
+    scatter: Vec<f32>,
+    mix: Vec<f32>,
+}
+
+impl Bank {
+    pub fn new(channels: u32, chain: &[NodeDesc], link_flags: u32) -> Result<Self, super::engine::Error> {
+        let mut engine = Engine::new(channels, BUF_SIZE as u32, link_flags, 0)?;
+        engine.set_chain(chain)?;
+        let n = channels as usize * BUF_SIZE;
+        Ok(Bank { engine, gather: vec![0.0; n], scatter: vec![0.0; n], mix: vec![0.0; BUF_SIZE] })
+    }
+
+    /// `inputs[c]` / `outputs[c]`: channel c's block (what one pipe of the reference holds).
+    /// Returns the un-normalised mix bus (sum over channels per frame); divide by
+    /// `dspfx_link_divisor(N)` -- or call `dspfx_mix_finish` on the device path -- for the Output hop.
+    pub fn process(&mut self, inputs: &[&[f32]], outputs: &mut [&mut [f32]]) -> Result<&[f32], super::engine::Error> {
+        let n = self.engine.channels() as usize;
+        assert!(inputs.len() == n && outputs.len() == n);
+        let frames = inputs[0].len();
+        assert!(frames <= BUF_SIZE);
+        for (c, ch) in inputs.iter().enumerate() {
+            assert_eq!(ch.len(), frames);
+            for (f, v) in ch.iter().enumerate() {
+                self.gather[f * n + c] = *v;
+            }
+        }
+        let (g, s) = (&self.gather[..frames * n], &mut self.scatter[..frames * n]);
+        self.engine.process_host(g, None, s, Some(&mut self.mix[..frames]), frames as u32)?;
+        for (c, ch) in outputs.iter_mut().enumerate() {
+            for (f, v) in ch.iter_mut().enumerate() {
+                *v = self.scatter[f * n + c];
+            }
+        }
+        Ok(&self.mix[..frames])
+    }
+}

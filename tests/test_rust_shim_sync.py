@@ -1,0 +1,65 @@
+"""host/rust/src/ffi.rs cannot be compiled here (no rustc); this keeps it in step with include/dspfx.h:
+same entry points with the same argument counts, same struct fields in the same order, same constants."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HDR = open(os.path.join(ROOT, "include", "dspfx.h")).read()
+FFI = open(os.path.join(ROOT, "host", "rust", "src", "ffi.rs")).read()
+
+
+def _strip_comments(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return re.sub(r"//[^\n]*", "", text)
+
+
+def _c_protos():
+    body = _strip_comments(HDR)
+    out = {}
+    for m in re.finditer(r"\b(dspfx_\w+)\s*\(([^;{}]*?)\)\s*;", body):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
+    return out
+
+
+def _rust_protos():
+    body = _strip_comments(FFI)
+    out = {}
+    for m in re.finditer(r"pub fn (dspfx_\w+)\s*\(([^)]*)\)", body):
+        args = m.group(2).strip()
+        out[m.group(1)] = 0 if not args else len([a for a in args.split(",") if a.strip()])
+    return out
+
+
+def test_every_entry_point_is_bound_with_the_same_arity(dspfx):
+    c, r = _c_protos(), _rust_protos()
+    assert set(c) == set(dspfx.EXPORTS)                  # the header parse is sound
+    assert set(r) == set(c), (sorted(set(c) - set(r)), sorted(set(r) - set(c)))
+    assert {k: r[k] for k in c} == c
+
+
+def _c_struct_fields(name):
+    m = re.search(r"typedef struct %s\s*\{(.*?)\}\s*%s;" % (name, name), _strip_comments(HDR), re.S)
+    return [re.sub(r"\[.*\]", "", d.strip().split()[-1].lstrip("*")) for d in m.group(1).split(";") if d.strip()]
+
+
+def _rust_struct_fields(name):
+    m = re.search(r"pub struct %s\s*\{(.*?)\}" % name, _strip_comments(FFI), re.S)
+    return [f.strip().split(":")[0].replace("pub ", "").strip() for f in m.group(1).split(",") if f.strip()]
+
+
+def test_repr_c_structs_match():
+    for name in ("dspfx_engine_desc", "dspfx_node_desc", "dspfx_ctl"):
+        assert _rust_struct_fields(name) == _c_struct_fields(name), name
+
+
+def test_constants_match():
+    c = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(DSPFX_[A-Z0-9_]+)\s*=\s*(-?\d+)", _strip_comments(HDR))}
+    c.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DSPFX_[A-Z0-9_]+)\s+(-?\d+)u?\b", HDR)})
+    r = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (DSPFX_[A-Z0-9_]+): \w+ = (-?\d+);", FFI)}
+    assert r, "no constants parsed"
+    for k, v in r.items():
+        assert k in c, k
+        assert c[k] == v, (k, c[k], v)
+    for k in c:                                       # every enum value / flag of the header is mirrored
+        assert k in r, k
