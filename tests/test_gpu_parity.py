@@ -885,3 +885,51 @@ def test_envelope_follower(dspfx, torch_cuda):
     eng.process(dx[:B], out=y1, n_frames=B)
     torch_cuda.cuda.synchronize()
     assert np.array_equal(y1.cpu().numpy(), O.run_channels([dspfx.Envelope(10.0, 20.0).oracle_desc()], x[:B], 3))
+
+
+def _random_exact_node(dspfx, rng):
+    k = rng.integers(0, 9)      # Fuzz is left out: its block-global mean is summed in another order (test_fuzz's bar)
+    if k == 0:
+        return dspfx.Gain(float(rng.uniform(0.1, 2.0)))
+    if k == 1:
+        r, th, a0 = rng.uniform(0.1, 0.95), rng.uniform(0.1, 3.0), rng.uniform(0.5, 2.0)
+        return dspfx.BiQuad(a0, -2 * r * np.cos(th) * a0, r * r * a0, *(rng.uniform(-1, 1, 3) * a0))
+    if k == 2:
+        return dspfx.LowPass(float(rng.uniform(0.0, 1.0)))
+    if k == 3:
+        return dspfx.HighPass(float(rng.uniform(0.0, 1.0)))
+    if k == 4:
+        return dspfx.Reverb(delay_samples=int(rng.integers(128, 700)), decay=float(rng.uniform(0.0, 0.9)))
+    if k == 5:
+        return dspfx.Distort(float(rng.uniform(0.0, 6.0)),
+                             int(rng.choice([dspfx.HARD_CLIP, dspfx.SOFT_CLIP, dspfx.RECIP_SOFT_CLIP, dspfx.SQUARE, dspfx.CHEBYSHEV4])))
+    if k == 6:
+        return dspfx.Add()
+    if k == 7:
+        return dspfx.Mix(float(rng.uniform(0.0, 1.0)))
+    if k == 8:
+        return dspfx.Envelope(float(rng.choice([0.0, 3.0, 50.0])), float(rng.choice([0.0, 7.0, 400.0])))
+    return dspfx.Gain(1.0)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_chains_of_exact_nodes(dspfx, torch_cuda, seed):
+    """Seeded random chains (1..12 nodes of the exact-arithmetic kinds, random parameters, ragged channel
+    counts, both layouts, every link-flag setting, blocks of 128 or 256 frames): the interpreter, its guarded
+    tail, stage splitting (> 8 fused nodes) and the delay sub-block split against the oracle, <= 1 ulp."""
+    rng = np.random.default_rng(1000 + seed)
+    for case in range(3):
+        n_nodes = int(rng.integers(1, 13))
+        chain = [_random_exact_node(dspfx, rng) for _ in range(n_nodes)]
+        tile = int(rng.choice([0, 64]))
+        N = int(rng.choice([64, 128, 320])) if tile else int(rng.choice([1, 63, 100, 129, 273]))
+        block = int(rng.choice([128, 256]))
+        lf = int(rng.choice([0, 1, 3]))
+        nf = 768
+        x, side = noise_block(N, nf, seed=seed * 7 + case), noise_block(N, nf, seed=seed * 7 + case + 100)
+        got = run_gpu(dspfx, torch_cuda, chain, x, link_flags=lf, block=block, side=side, tile=tile)
+        ref = run_oracle(chain, x, lf, side)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), ok), (seed, case)
+        d = ulp_diff(got[ok], ref[ok])
+        assert d.size == 0 or d.max() <= 1, (seed, case, [(n.kind, n.mode) for n in chain], N, block, tile, lf, int(d.max()))
