@@ -32,14 +32,15 @@ SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
 DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"]
 FIR_BALANCED, FIR_AVERAGE = 0, 1
-LINK_INTERNAL, LINK_INPUT = 1, 2
+LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
+MAX_LINKS = 16
 
 # every symbol include/dspfx.h declares
 EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
-    "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_state_size",
+    "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_link_average", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
@@ -104,6 +105,7 @@ def lib():
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_link_average.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, f32p, C.c_uint32, vp]
     L.dspfx_process_ctl.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, C.POINTER(_Ctl), C.c_int, vp]
     L.dspfx_process_partials.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_mix_collect.argtypes = [vp, f32p, C.c_uint32, vp]
@@ -372,6 +374,12 @@ class Engine:
     def mix_finish(self, mix, n_frames: int, n_connected: int, stream: int = 0):
         self._chk(self.L.dspfx_mix_finish(self.h, _ptr(mix), int(n_frames), int(n_connected),
                                           C.c_void_p(stream) if stream else None))
+
+    def link_average(self, srcs, dst, n_frames: int, stream: int = 0):
+        """collect_and_average (node.rs:162-194) of `srcs` (device buffers, link order) into `dst`."""
+        arr = (C.c_void_p * max(1, len(srcs)))(*[_ptr(t).value for t in srcs])
+        self._chk(self.L.dspfx_link_average(self.h, arr, len(srcs), _ptr(dst), int(n_frames),
+                                            C.c_void_p(stream) if stream else None))
 
     def state_export(self, node: int) -> np.ndarray:
         n = int(self.L.dspfx_state_size(self.h, node))

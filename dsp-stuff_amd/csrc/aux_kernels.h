@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/dspfx.h"
+
 #include "chain_kernels.hip.h"
 
 namespace dspfx {
@@ -23,6 +25,16 @@ void launch_fuzz(const FuzzArgs &a, hipStream_t s);
 void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s);
 // node.rs:189-191: mix[i] /= div
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s);
+
+// node.rs:162-194 for a port with several connected pipes: dst = (0 + src0 + src1 + ...) / f32(0.0001 + n)
+struct LinkAvgArgs {
+    const float *src[DSPFX_MAX_LINKS];
+    int n_srcs;
+    float *dst;
+    size_t count;
+    float div;
+};
+void launch_link_average(const LinkAvgArgs &a, hipStream_t s);
 // launches the exhaustive check of the fast constant division; *d_count accumulates mismatches
 int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s);
 // dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)

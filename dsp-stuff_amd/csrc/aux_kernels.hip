@@ -2,6 +2,8 @@
 // Compiled with -ffp-contract=off like every kernel of this library.
 #include "aux_kernels.h"
 
+#include <algorithm>
+
 namespace dspfx {
 
 __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
@@ -80,6 +82,30 @@ __global__ void __launch_bounds__(WG) mix_reduce_b_kernel(const float *part2, fl
 __global__ void mix_finish_kernel(float *mix, unsigned n, float div) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) mix[i] = mix[i] / div;
+}
+
+// collect_and_average over several pipes (node.rs:162-194): the output starts zeroed, every connected pipe is
+// added in link order, then one division by the f32 count 0.0001 + n.  Element-wise, 4 floats per lane.
+__global__ void __launch_bounds__(WG) link_average_kernel(const LinkAvgArgs a) {
+    const size_t n4 = a.count / 4;
+    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n4; i += (size_t)gridDim.x * WG) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = 0; k < a.n_srcs; ++k) {
+            float v[4];
+            load_vec<4, false, S_IN>(a.src[k] + 4 * i, v, true);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = acc[j] + v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] / a.div;
+        store_vec<4, false, S_OUT>(a.dst + 4 * i, acc, true);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < a.count % 4) {   // ragged end
+        const size_t i = n4 * 4 + threadIdx.x;
+        float acc = 0.0f;
+        for (int k = 0; k < a.n_srcs; ++k) acc = acc + a.src[k][i];
+        a.dst[i] = acc / a.div;
+    }
 }
 
 // SURVEY 8d generator; same integer hash as oracle/dspfx_oracle.c:orc_noise
@@ -167,6 +193,11 @@ void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
 void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s) {
     hipLaunchKernelGGL(mix_reduce_a_kernel, dim3(MIX_SLICES), dim3(WG), 0, s, part, part2, waves, nframes);
     hipLaunchKernelGGL(mix_reduce_b_kernel, dim3((nframes + WG - 1) / WG), dim3(WG), 0, s, part2, mix, nframes);
+}
+void launch_link_average(const LinkAvgArgs &a, hipStream_t s) {
+    const size_t n4 = a.count / 4;
+    const unsigned grid = (unsigned)std::min<size_t>(std::max<size_t>(1, (n4 + WG - 1) / WG), 256 * 32);
+    link_average_kernel<<<grid, WG, 0, s>>>(a);
 }
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s) {
     hipLaunchKernelGGL(mix_finish_kernel, dim3((n + 127) / 128), dim3(128), 0, s, mix, n, div);

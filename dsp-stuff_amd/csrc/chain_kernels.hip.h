@@ -327,7 +327,7 @@ struct Ctx {
     double hop_rc;
     double third_rc;
     const float *side;
-    int side_hop;      // also the hop flag of control links (both are "internal" links)
+    int side_hop;      // bit 0: hop on the side input; bit 1: hop on control links (both are "internal" links)
     bool active;     // false only for padding lanes of the guarded tail launch
 };
 
@@ -465,7 +465,7 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
             float b[CPL];
             if (cx.side) {
                 load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
-                if (cx.side_hop) {
+                if (cx.side_hop & 1) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
                 }
@@ -496,7 +496,7 @@ __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 float x = p[f][j];
-                if (cx.side_hop) x = link_hop<FAST>(x, cx.hop_div, cx.hop_rc);   // the control link's collect_and_average
+                if (cx.side_hop & 2) x = link_hop<FAST>(x, cx.hop_div, cx.hop_rc);   // the control link's collect_and_average
                 const float y = (x + 1.0f) / 2.0f;
                 float z = y < 0.0f ? 0.0f : y;          // f32::clamp(0.0, 1.0): NaN stays NaN
                 z = z > 1.0f ? 1.0f : z;
@@ -580,7 +580,7 @@ __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][
             float b[CPL];
             if (cx.side) {
                 load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
-                if (cx.side_hop) {
+                if (cx.side_hop & 1) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
                 }

@@ -634,7 +634,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.n_slots = st.count;
             // hop flag of the side input and of control links (both are ordinary links between nodes);
             // an unconnected side port reads zeros, for which the hop is a no-op
-            a.side_hop = (e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0;
+            a.side_hop = 0;
+            if (e->desc.link_flags & DSPFX_LINK_INTERNAL) a.side_hop = (e->desc.link_flags & DSPFX_LINK_SIDE_RAW) ? 2 : 3;
             int rows = 0;
             for (int k = 0; k < st.count; ++k) {
                 fill_slot(e, st.first + k, a.slot[k]);
@@ -1095,6 +1096,28 @@ extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, 
 }
 
 // -------------------------------------------------------------------- state
+
+extern "C" int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
+                                  void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (!dst || n_srcs < 0 || (n_srcs > 0 && !srcs)) return fail(e, DSPFX_ERR_INVALID, "bad link list");
+    if (n_srcs > DSPFX_MAX_LINKS) return fail(e, DSPFX_ERR_UNSUPPORTED, "more than %d links into one port", DSPFX_MAX_LINKS);
+    if (n_frames == 0) return DSPFX_OK;
+    if (n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
+    for (int k = 0; k < n_srcs; ++k)
+        if (!srcs[k]) return fail(e, DSPFX_ERR_INVALID, "link %d is null", k);
+    HIPCHK(e, hipSetDevice(e->device));
+    LinkAvgArgs a;
+    memset(&a, 0, sizeof a);
+    for (int k = 0; k < n_srcs; ++k) a.src[k] = srcs[k];
+    a.n_srcs = n_srcs;
+    a.dst = dst;
+    a.count = (size_t)n_frames * e->desc.channels;   // element-wise: the same in either layout
+    a.div = dspfx_link_divisor((uint64_t)n_srcs);
+    launch_link_average(a, (hipStream_t)stream);
+    HIPCHK(e, hipGetLastError());
+    return DSPFX_OK;
+}
 
 extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
     if (!e || node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;

@@ -1,0 +1,247 @@
+"""Whole saved graphs (DAGs), not just linear chains: the reference's `DSPConfig` with fan-out, fan-in
+(`collect_and_average` over several pipes, dsp-stuff/src/node.rs:162-194,267-352), Add / Mix fed by two
+different branches, control ports fed by other nodes, generator sources, several links into the Output node.
+
+The graph is cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
+own per-channel state), runs are evaluated in topological order, and the only extra device work is
+`dspfx_link_average` where a port has more than one incoming link.  What a run consumes:
+
+  main port   1 link  -> the producer's buffer, hop applied by the engine (LINK_INPUT)
+              k links -> dspfx_link_average into a scratch buffer, taken raw
+              0 links -> zeros (node.rs:288: the port's buffer stays zeroed)
+  "b" port    same three cases through the engine's side input (LINK_SIDE_RAW for k > 1)
+  slider port 1 link  -> control port of dspfx_process_ctl; more than one link is rejected
+
+Not expressible: cycles (the reference's scheduler would deadlock on them too), mux / demux / pitch / muff and
+the visualiser nodes, slider ports with fan-in.
+"""
+from __future__ import annotations
+
+import json
+from typing import Dict, List, Optional, Tuple
+
+from . import ADD, LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, SIGNAL_GEN, Engine
+from .config import _TABLE, _UNSUPPORTED, DspConfigError, _node_from_cfg
+
+
+class _GNode:
+    __slots__ = ("id", "typename", "cfg", "spec", "main", "side", "ctl", "outs")
+
+    def __init__(self, nid, typename, cfg):
+        self.id, self.typename, self.cfg = nid, typename, cfg
+        self.spec = None
+        self.main: List[int] = []          # producer node ids, link order
+        self.side: List[int] = []
+        self.ctl: Dict[int, List[int]] = {}   # slider index -> producers
+        self.outs: List[Tuple[int, str]] = []  # (consumer id, port name)
+
+
+class Graph:
+    """Parsed DSPConfig: nodes with their incoming links per port, in document order."""
+
+    def __init__(self, text: str, page_round: bool = False):
+        try:
+            doc = json.loads(text)
+            raw_nodes = doc["nodes"]
+            raw_links = [(tuple(map(int, l["lhs"])), tuple(map(int, l["rhs"]))) for l in doc["links"]]
+        except (KeyError, TypeError, ValueError) as e:
+            raise DspConfigError(f"not a DSPConfig document: {e}") from None
+        self.nodes: Dict[int, _GNode] = {}
+        for n in raw_nodes:
+            tn = n["typename"]
+            if tn in _UNSUPPORTED:
+                raise DspConfigError(f"node type {tn!r} is outside the accelerated path")
+            if tn not in _TABLE and tn not in ("input", "output"):
+                raise DspConfigError(f"unknown node type {tn!r}")
+            g = _GNode(int(n["id"]), tn, n["cfg"])
+            if tn in _TABLE:
+                g.spec = _node_from_cfg(tn, n["cfg"], page_round)
+            self.nodes[g.id] = g
+        self.inputs = [i for i, n in self.nodes.items() if n.typename == "input"]
+        self.outputs = [i for i, n in self.nodes.items() if n.typename == "output"]
+        if len(self.inputs) > 1 or len(self.outputs) != 1:
+            raise DspConfigError("expected at most one input node and exactly one output node")
+
+        def port_name(node_id, port_id, which):
+            for name, pid in self.nodes[node_id].cfg.get(which, {}).items():
+                if int(pid) == port_id:
+                    return name
+            raise DspConfigError(f"link refers to unknown {which[:-1]} port {port_id} of node {node_id}")
+
+        for (ln, lp), (rn, rp) in raw_links:
+            if ln not in self.nodes or rn not in self.nodes:
+                raise DspConfigError("link refers to a missing node")
+            port_name(ln, lp, "outputs")
+            pname = port_name(rn, rp, "inputs")
+            dst = self.nodes[rn]
+            self.nodes[ln].outs.append((rn, pname))
+            if dst.typename == "output":
+                dst.main.append(ln)
+                continue
+            _, fields, main_port, ctl_ports = _TABLE[dst.typename]
+            if pname == main_port:
+                dst.main.append(ln)
+            elif pname == "b" and dst.spec.kind in (ADD, MIX):
+                dst.side.append(ln)
+            elif pname in ctl_ports:
+                dst.ctl.setdefault(fields.index(pname), []).append(ln)
+            else:
+                raise DspConfigError(f"node {rn} ({dst.typename}) has no input port {pname!r}")
+        for n in self.nodes.values():
+            for k, src in n.ctl.items():
+                if len(src) > 1:
+                    raise DspConfigError(f"slider port {k} of node {n.id} averages several links")
+        self.order = self._toposort()
+
+    def producers(self, n: _GNode) -> List[int]:
+        return n.main + n.side + [s for v in n.ctl.values() for s in v]
+
+    def _toposort(self) -> List[int]:
+        indeg = {i: len(self.producers(n)) for i, n in self.nodes.items()}
+        ready = [i for i in self.nodes if indeg[i] == 0]          # document order: deterministic
+        order = []
+        while ready:
+            i = ready.pop(0)
+            order.append(i)
+            for j, _ in self.nodes[i].outs:
+                indeg[j] -= 1
+                if indeg[j] == 0:
+                    ready.append(j)
+        if len(order) != len(self.nodes):
+            raise DspConfigError("graph has a cycle")
+        return order
+
+
+class _Run:
+    """A maximal linear run of nodes = one fused engine."""
+
+    def __init__(self, first: _GNode):
+        self.nodes: List[_GNode] = [first]
+        self.engine: Optional[Engine] = None
+        self.out = None
+        self.scratch_main = None
+        self.scratch_side = None
+
+
+def plan_runs(g: Graph):
+    """Cut the graph into maximal linear runs (each becomes one fused engine).  A node joins its producer's run
+    when it is the producer's only consumer and is fed by nothing else on its main port."""
+    run_of: Dict[int, _Run] = {}
+    runs: List[_Run] = []
+    for nid in g.order:
+        n = g.nodes[nid]
+        if n.spec is None:
+            continue
+        prev = g.nodes[n.main[0]] if len(n.main) == 1 else None
+        joinable = (prev is not None and prev.spec is not None and len(prev.outs) == 1
+                    and n.spec.kind != SIGNAL_GEN)
+        if joinable:
+            r = run_of[prev.id]
+            # one side input per engine, shared by every Add/Mix of its chain: two of them may share a run
+            # only when neither has its "b" port connected (both read zeros)
+            mixers = [m for m in r.nodes if m.spec.kind in (ADD, MIX)]
+            clash = n.spec.kind in (ADD, MIX) and mixers and (n.side or any(m.side for m in mixers))
+            if len(r.nodes) < 32 and not clash:
+                r.nodes.append(n)
+                run_of[nid] = r
+                continue
+        r = _Run(n)
+        runs.append(r)
+        run_of[nid] = r
+    return runs, run_of
+
+
+def run_link_flags(r: _Run) -> int:
+    head = r.nodes[0]
+    side_node = next((m for m in r.nodes if m.side), None)
+    flags = LINK_INTERNAL
+    if len(head.main) == 1 and head.spec.kind != SIGNAL_GEN:
+        flags |= LINK_INPUT
+    if side_node is not None and len(side_node.side) > 1:
+        flags |= LINK_SIDE_RAW
+    return flags
+
+
+class GraphEngine:
+    """N independent copies of a saved graph.  `process(x)` takes the Input node's block [n_frames][N] (device
+    tensor, the engine's layout) and returns the Output node's block."""
+
+    def __init__(self, text: str, channels: int, max_frames: int = 128, device: int = 0, tile_channels: int = 0,
+                 page_round: bool = False):
+        import torch
+        self.torch = torch
+        self.g = Graph(text, page_round)
+        self.N, self.B, self.tile = channels, max_frames, tile_channels
+        self.dev = torch.device("cuda", device)
+        self.runs, self.run_of = plan_runs(self.g)
+        for r in self.runs:
+            head = r.nodes[0]
+            side_node = next((m for m in r.nodes if m.side), None)
+            flags = run_link_flags(r)
+            r.engine = Engine(channels, max_frames, link_flags=flags, device=device, tile_channels=tile_channels)
+            r.engine.set_chain([m.spec for m in r.nodes])
+            r.out = self._buf()
+            if len(head.main) > 1:
+                r.scratch_main = self._buf()
+            if side_node is not None and len(side_node.side) > 1:
+                r.scratch_side = self._buf()
+        self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
+        self.final = self._buf()
+        self.util = self.runs[0].engine if self.runs else Engine(channels, max_frames, device=device,
+                                                                  tile_channels=tile_channels)
+
+    def _buf(self):
+        return self.torch.empty(self.B * self.N, dtype=self.torch.float32, device=self.dev)
+
+    def describe(self) -> str:
+        lines = []
+        for k, r in enumerate(self.runs):
+            stage = [l for l in r.engine.describe().splitlines() if l.startswith("stage")]
+            lines.append(f"run {k}: nodes {[m.id for m in r.nodes]}: " + " | ".join(stage))
+        return "\n".join(lines)
+
+    def _source(self, nid: int, x):
+        n = self.g.nodes[nid]
+        if n.typename == "input":
+            return x
+        return self.run_of[nid].out
+
+    def process(self, x, n_frames: Optional[int] = None, stream: int = 0):
+        nf = self.B if n_frames is None else int(n_frames)
+        for nid in self.g.order:
+            n = self.g.nodes[nid]
+            if n.spec is None:
+                continue
+            r = self.run_of[nid]
+            # a run is launched when its LAST node comes up: by then every producer of every node in it has run
+            # (a buffer that feeds a side / slider port, or several consumers, always ends its own run)
+            if r.nodes[-1].id != nid:
+                continue
+            head = r.nodes[0]
+            if len(head.main) == 1:
+                src = self._source(head.main[0], x)
+            elif not head.main:
+                src = self.zeros          # an unconnected port stays zeroed (node.rs:288); generators ignore it
+            else:
+                r.engine.link_average([self._source(s, x) for s in head.main], r.scratch_main, nf, stream)
+                src = r.scratch_main
+            side = None
+            side_node = next((m for m in r.nodes if m.side), None)
+            if side_node is not None:
+                if len(side_node.side) == 1:
+                    side = self._source(side_node.side[0], x)
+                else:
+                    r.engine.link_average([self._source(s, x) for s in side_node.side], r.scratch_side, nf, stream)
+                    side = r.scratch_side
+            ctl = {}
+            for k, m in enumerate(r.nodes):
+                for slider, srcs in m.ctl.items():
+                    ctl[(k, slider)] = self._source(srcs[0], x)
+            r.engine.process(src, out=r.out, side=side, n_frames=nf, stream=stream, ctl=ctl or None)
+        out_node = self.g.nodes[self.g.outputs[0]]
+        self.util.link_average([self._source(s, x) for s in out_node.main], self.final, nf, stream)
+        return self.final
+
+    def close(self):
+        for r in self.runs:
+            r.engine.close()

@@ -56,6 +56,8 @@ pub const DSPFX_ERR_STATE: c_int = -6;
 // link flags
 pub const DSPFX_LINK_INTERNAL: u32 = 1;
 pub const DSPFX_LINK_INPUT: u32 = 2;
+pub const DSPFX_LINK_SIDE_RAW: u32 = 4;
+pub const DSPFX_MAX_LINKS: u32 = 16;
 
 // dspfx_kind
 pub const DSPFX_GAIN: c_int = 0;
@@ -121,6 +123,8 @@ extern "C" {
     pub fn dspfx_process_partials(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_mix_collect(e: *mut dspfx_engine, mix: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_mix_finish(e: *mut dspfx_engine, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
+
+    pub fn dspfx_link_average(e: *mut dspfx_engine, srcs: *const *const f32, n_srcs: c_int, dst: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
 
     pub fn dspfx_state_size(e: *const dspfx_engine, node: c_int) -> i64;
     pub fn dspfx_state_export(e: *mut dspfx_engine, node: c_int, host_dst: *mut c_void, size: usize) -> c_int;

@@ -99,6 +99,11 @@ typedef enum dspfx_fir_mode { DSPFX_FIR_BALANCED = 0, DSPFX_FIR_AVERAGE = 1 } ds
  *             engine is fed by the Input node, nodes/input.rs:213-240).        */
 #define DSPFX_LINK_INTERNAL 1u
 #define DSPFX_LINK_INPUT 2u
+/*   SIDE_RAW: the side input (port "b" of ADD/MIX) is taken as given: it was already averaged
+ *             over several links by dspfx_link_average (graphs with fan-in on that port).  */
+#define DSPFX_LINK_SIDE_RAW 4u
+/* most links into one port that dspfx_link_average accepts */
+#define DSPFX_MAX_LINKS 16
 
 typedef struct dspfx_engine_desc {
     uint32_t abi_version;     /* DSPFX_ABI_VERSION */
@@ -224,6 +229,14 @@ int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stre
 /* Output-node hop of the mix bus (node.rs:189-191): mix[f] /= link_divisor(n_connected),
  * in place on the device; call after the cross-GPU all-reduce with the GLOBAL channel count. */
 int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream);
+
+/* collect_and_average for a port with n_srcs connected pipes (node.rs:162-194), element-wise on whole
+ * blocks: dst = (0 + srcs[0] + srcs[1] + ...) / f32(0.0001 + n_srcs), added in the order given.
+ * n_srcs = 0 gives zeros (an unconnected port); n_srcs = 1 is the plain hop.  Device buffers in the
+ * engine's sample layout; dst may alias one of the sources.  This is the only piece a graph with
+ * fan-in needs besides the chain engines (dsp-stuff_amd/graph.py). */
+int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
+                       void *stream);
 
 /* ---- DSP state (parity tests; the reference never saves it) --- */
 /* Size in bytes of node `node`'s exported state:

@@ -1,0 +1,65 @@
+"""Hand-built DSPConfig documents (the reference's saved-graph JSON, runtime.rs:606-612) for the DAG tests."""
+import json
+
+_PORTS = {   # typename -> (input port names in field order, has output)
+    "input": ([], True), "output": (["in"], False),
+    "gain": (["in", "level"], True), "biquad": (["in"], True), "low_pass": (["in"], True), "high_pass": (["in"], True),
+    "reverb": (["in"], True), "distort": (["in", "level"], True), "overdrive": (["in", "boost", "drive", "level"], True),
+    "chebyshev": (["in"], True), "add": (["a", "b"], True), "mix": (["a", "b", "ratio"], True),
+    "signal_gen": (["amplitude", "frequency"], True), "envelope": (["in"], True),
+}
+
+
+def build(nodes, links):
+    """nodes: [(id, typename, {saved fields})]; links: [(src_id, dst_id, dst_port)] in the order the reference
+    would hold them.  Port ids are assigned here."""
+    next_id = [1000]
+
+    def pid():
+        next_id[0] += 1
+        return next_id[0]
+
+    doc_nodes, ports = [], {}
+    for nid, tn, fields in nodes:
+        ins, has_out = _PORTS[tn]
+        cfg = {"id": nid, "inputs": {p: pid() for p in ins}, "outputs": {"out": pid()} if has_out else {}}
+        cfg.update(fields)
+        ports[nid] = cfg
+        doc_nodes.append({"id": nid, "typename": tn, "position": [0.0, 0.0], "cfg": cfg})
+    doc_links = [{"lhs": [s, ports[s]["outputs"]["out"]], "rhs": [d, ports[d]["inputs"][p]]} for s, d, p in links]
+    return json.dumps({"nodes": doc_nodes, "links": doc_links})
+
+
+BQ = {"a0": 1.0, "a1": -1.2, "a2": 0.5, "b0": 0.3, "b1": 0.2, "b2": 0.1}
+
+
+def diamond():
+    """input -> gain -> (add.a);  input -> biquad -> lowpass -> (add.b);  add -> distort <- gain (2 links);
+    distort and the biquad branch both into the output node."""
+    return build(
+        [(0, "input", {}), (1, "gain", {"level": 0.8}), (2, "biquad", BQ), (3, "high_pass", {"ratio": 0.3}),
+         (4, "add", {}), (5, "distort", {"level": 3.0, "mode": "SoftClip"}), (6, "reverb", {"seconds": 0.004, "decay": 0.4}),
+         (9, "output", {})],
+        [(0, 1, "in"), (0, 2, "in"), (2, 3, "in"), (1, 4, "a"), (3, 4, "b"), (4, 5, "in"), (1, 5, "in"), (5, 6, "in"),
+         (6, 9, "in"), (3, 9, "in")])
+
+
+def lfo_tremolo():
+    """A triangle LFO patched into a gain's level port; the envelope of the input drives a mix ratio."""
+    return build(
+        [(0, "input", {}), (1, "signal_gen", {"amplitude": 0.9, "frequency": 600.0, "mode": "Triangle"}),
+         (2, "gain", {"level": 1.0}), (3, "envelope", {"attack": 4.0, "release": 200.0}), (4, "biquad", BQ),
+         (5, "mix", {"ratio": 0.5}), (9, "output", {})],
+        [(0, 2, "in"), (1, 2, "level"), (0, 3, "in"), (0, 4, "in"), (2, 5, "a"), (4, 5, "b"), (3, 5, "ratio"), (5, 9, "in")])
+
+
+def fan_in_three():
+    """Three branches averaged on one port (k = 3), a mix whose "b" port averages two links, an effect with
+    nothing plugged in, and a generator-only branch."""
+    return build(
+        [(0, "input", {}), (1, "gain", {"level": 0.5}), (2, "low_pass", {"ratio": 0.6}), (3, "high_pass", {"ratio": 0.2}),
+         (4, "distort", {"level": 2.0, "mode": "HardClip"}), (5, "mix", {"ratio": 0.25}),
+         (6, "signal_gen", {"amplitude": 0.3, "frequency": 12000.0, "mode": "Square"}), (7, "gain", {"level": 2.0}),
+         (8, "biquad", BQ), (9, "output", {})],
+        [(0, 1, "in"), (0, 2, "in"), (0, 3, "in"), (1, 4, "in"), (2, 4, "in"), (3, 4, "in"), (4, 5, "a"), (2, 5, "b"),
+         (6, 5, "b"), (6, 7, "in"), (5, 9, "in"), (7, 9, "in"), (8, 9, "in")])

@@ -1,0 +1,53 @@
+"""Saved-graph (DAG) support without a GPU: parsing, the cut into fused runs, and the CPU evaluation the GPU
+tests compare against (checked here against the linear-chain oracle on a graph that IS a chain)."""
+import json
+
+import numpy as np
+
+import graph_eval
+import graphs
+import oracle as O
+
+F = np.float32
+
+
+def test_partition_into_runs(dspfx):
+    from dsp_stuff_amd import graph as G
+    g = G.Graph(graphs.diamond())
+    runs, run_of = G.plan_runs(g)
+    assert sorted(sorted(m.id for m in r.nodes) for r in runs) == [[1], [2, 3], [4], [5, 6]]
+    flags = {tuple(m.id for m in r.nodes): G.run_link_flags(r) for r in runs}
+    assert flags[(1,)] == dspfx.LINK_INTERNAL | dspfx.LINK_INPUT
+    assert flags[(5, 6)] == dspfx.LINK_INTERNAL                      # two links into distort: pre-averaged, taken raw
+    g = G.Graph(graphs.fan_in_three())
+    runs, _ = G.plan_runs(g)
+    flags = {tuple(m.id for m in r.nodes): G.run_link_flags(r) for r in runs}
+    # distort (three links on "in") > mix (two links on "b") fuse: both ports are pre-averaged and taken raw
+    assert flags[(4, 5)] == dspfx.LINK_INTERNAL | dspfx.LINK_SIDE_RAW
+    assert flags[(6,)] == dspfx.LINK_INTERNAL and flags[(8,)] == dspfx.LINK_INTERNAL    # generator / nothing plugged in
+    assert g.order.index(9) == len(g.order) - 1
+
+
+def test_graph_eval_equals_chain_oracle_on_a_chain(dspfx):
+    from dsp_stuff_amd import config, graph as G
+    chain = [dspfx.BiQuad(), dspfx.Distort(3.0, dspfx.SOFT_CLIP), dspfx.Reverb(delay_samples=256, decay=0.5), dspfx.Gain(0.5)]
+    g = G.Graph(config.dump_dspconfig(chain))
+    x = O.noise(3, np.arange(3), np.arange(512))
+    got = graph_eval.run_graph(g, x)
+    # whole-graph semantics = every hop scaled, including the one into the Output node
+    ref = O.run_channels([n.oracle_desc() for n in chain], x, 3)
+    ref = (ref / O.link_divisor(1)).astype(F)
+    assert np.array_equal(got, ref)
+
+
+def test_unplugged_and_fan_in_semantics():
+    from dsp_stuff_amd import graph as G
+    g = G.Graph(graphs.fan_in_three())
+    x = O.noise(5, np.arange(2), np.arange(256))
+    y = graph_eval.run_graph(g, x)
+    assert y.shape == x.shape and np.isfinite(y).all()
+    # node 8 (biquad with nothing plugged in) contributes zeros, but still counts as a connected pipe of the output
+    doc = json.loads(graphs.fan_in_three())
+    doc["links"] = [l for l in doc["links"] if l["lhs"][0] != 8]
+    y2 = graph_eval.run_graph(G.Graph(json.dumps(doc)), x)
+    assert np.allclose(y * O.link_divisor(3), y2 * O.link_divisor(2), rtol=1e-6, atol=1e-7)
