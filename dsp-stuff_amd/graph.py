@@ -12,16 +12,24 @@ own per-channel state), runs are evaluated in topological order, and the only ex
   "b" port    same three cases through the engine's side input (LINK_SIDE_RAW for k > 1)
   slider port 1 link  -> control port of dspfx_process_ctl; more than one link is rejected
 
-Not expressible: cycles (the reference's scheduler would deadlock on them too), mux / demux / pitch / muff and
-the visualiser nodes, slider ports with fan-in.
+Mux / Demux (nodes/mux.rs:42-55, nodes/demux.rs:42-58) are pure routing and cost no kernel of their own: a mux is
+the identity on its selected port (links into the other port are computed but unused, as in the reference), a
+demux is the identity whose unselected output port delivers zeros -- still a connected pipe for whoever averages it.
+
+Not expressible: cycles (the reference's scheduler would deadlock on them too), pitch / muff and the visualiser
+nodes, slider ports with fan-in.
 """
 from __future__ import annotations
 
 import json
 from typing import Dict, List, Optional, Tuple
 
-from . import ADD, LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, SIGNAL_GEN, Engine
-from .config import _TABLE, _UNSUPPORTED, DspConfigError, _node_from_cfg
+from . import ADD, GAIN, LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, SIGNAL_GEN, Engine, NodeSpec
+from .config import _TABLE, DspConfigError, _node_from_cfg
+
+_UNSUPPORTED = {"muff", "pitch", "wave_view", "spectrogram"}
+_ROUTING = {"mux", "demux"}
+ZERO = -1          # pseudo producer: the unselected output port of a demux (a connected pipe that carries zeros)
 
 
 class _GNode:
@@ -51,11 +59,16 @@ class Graph:
             tn = n["typename"]
             if tn in _UNSUPPORTED:
                 raise DspConfigError(f"node type {tn!r} is outside the accelerated path")
-            if tn not in _TABLE and tn not in ("input", "output"):
+            if tn not in _TABLE and tn not in _ROUTING and tn not in ("input", "output"):
                 raise DspConfigError(f"unknown node type {tn!r}")
             g = _GNode(int(n["id"]), tn, n["cfg"])
             if tn in _TABLE:
                 g.spec = _node_from_cfg(tn, n["cfg"], page_round)
+            elif tn in _ROUTING:
+                sel = n["cfg"].get("in_port" if tn == "mux" else "out_port", "A")
+                if sel not in ("A", "B"):
+                    raise DspConfigError(f"{tn} node {g.id}: unknown port selection {sel!r}")
+                g.spec = NodeSpec(GAIN, [1.0])          # x * 1.0f: the copy_from_slice of mux.rs:54 / demux.rs:51,54
             self.nodes[g.id] = g
         self.inputs = [i for i, n in self.nodes.items() if n.typename == "input"]
         self.outputs = [i for i, n in self.nodes.items() if n.typename == "output"]
@@ -71,11 +84,25 @@ class Graph:
         for (ln, lp), (rn, rp) in raw_links:
             if ln not in self.nodes or rn not in self.nodes:
                 raise DspConfigError("link refers to a missing node")
-            port_name(ln, lp, "outputs")
+            oname = port_name(ln, lp, "outputs")
             pname = port_name(rn, rp, "inputs")
             dst = self.nodes[rn]
-            self.nodes[ln].outs.append((rn, pname))
+            src = self.nodes[ln]
+            if src.typename == "demux" and oname != src.cfg.get("out_port", "A").lower():
+                ln = ZERO                               # demux.rs:49-56: the other output keeps its zeroed buffer
+            else:
+                src.outs.append((rn, pname))
             if dst.typename == "output":
+                dst.main.append(ln)
+                continue
+            if dst.typename == "mux":
+                if pname == dst.cfg.get("in_port", "A").lower():
+                    dst.main.append(ln)
+                elif ln != ZERO:
+                    src.outs.pop()                      # mux.rs:47-50: the unselected port is never read
+                    src.outs.append((rn, "unused"))     # ... but it is still a consumer: the producer ends its run
+                continue
+            if dst.typename == "demux":
                 dst.main.append(ln)
                 continue
             _, fields, main_port, ctl_ports = _TABLE[dst.typename]
@@ -94,7 +121,7 @@ class Graph:
         self.order = self._toposort()
 
     def producers(self, n: _GNode) -> List[int]:
-        return n.main + n.side + [s for v in n.ctl.values() for s in v]
+        return [s for s in n.main + n.side + [s for v in n.ctl.values() for s in v] if s != ZERO]
 
     def _toposort(self) -> List[int]:
         indeg = {i: len(self.producers(n)) for i, n in self.nodes.items()}
@@ -103,7 +130,9 @@ class Graph:
         while ready:
             i = ready.pop(0)
             order.append(i)
-            for j, _ in self.nodes[i].outs:
+            for j, port in self.nodes[i].outs:
+                if port == "unused":
+                    continue
                 indeg[j] -= 1
                 if indeg[j] == 0:
                     ready.append(j)
@@ -132,7 +161,7 @@ def plan_runs(g: Graph):
         n = g.nodes[nid]
         if n.spec is None:
             continue
-        prev = g.nodes[n.main[0]] if len(n.main) == 1 else None
+        prev = g.nodes[n.main[0]] if len(n.main) == 1 and n.main[0] != ZERO else None
         joinable = (prev is not None and prev.spec is not None and len(prev.outs) == 1
                     and n.spec.kind != SIGNAL_GEN)
         if joinable:
@@ -201,6 +230,8 @@ class GraphEngine:
         return "\n".join(lines)
 
     def _source(self, nid: int, x):
+        if nid == ZERO:
+            return self.zeros
         n = self.g.nodes[nid]
         if n.typename == "input":
             return x

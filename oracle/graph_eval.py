@@ -34,7 +34,7 @@ def run_graph(graph, x, block=O.BUF_SIZE):
         nodes = {i: O.node_from_desc(n.spec.oracle_desc()) for i, n in graph.nodes.items() if n.spec is not None}
         for f0 in range(0, nf_total, block):
             nf = min(block, nf_total - f0)
-            val = {}
+            val = {-1: np.zeros(nf, np.float32)}       # graph.ZERO: the unselected output of a demux
             for nid in graph.order:
                 n = graph.nodes[nid]
                 if n.typename == "input":

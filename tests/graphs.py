@@ -7,7 +7,9 @@ _PORTS = {   # typename -> (input port names in field order, has output)
     "reverb": (["in"], True), "distort": (["in", "level"], True), "overdrive": (["in", "boost", "drive", "level"], True),
     "chebyshev": (["in"], True), "add": (["a", "b"], True), "mix": (["a", "b", "ratio"], True),
     "signal_gen": (["amplitude", "frequency"], True), "envelope": (["in"], True),
+    "mux": (["a", "b"], True), "demux": (["in"], True),
 }
+_OUTS = {"demux": ["a", "b"]}
 
 
 def build(nodes, links):
@@ -22,11 +24,16 @@ def build(nodes, links):
     doc_nodes, ports = [], {}
     for nid, tn, fields in nodes:
         ins, has_out = _PORTS[tn]
-        cfg = {"id": nid, "inputs": {p: pid() for p in ins}, "outputs": {"out": pid()} if has_out else {}}
+        cfg = {"id": nid, "inputs": {p: pid() for p in ins},
+               "outputs": {o: pid() for o in _OUTS.get(tn, ["out"])} if has_out else {}}
         cfg.update(fields)
         ports[nid] = cfg
         doc_nodes.append({"id": nid, "typename": tn, "position": [0.0, 0.0], "cfg": cfg})
-    doc_links = [{"lhs": [s, ports[s]["outputs"]["out"]], "rhs": [d, ports[d]["inputs"][p]]} for s, d, p in links]
+    doc_links = []
+    for l in links:
+        s, d, p = l[:3]
+        o = l[3] if len(l) > 3 else "out"          # 4th element: the producer's output port (demux: "a" / "b")
+        doc_links.append({"lhs": [s, ports[s]["outputs"][o]], "rhs": [d, ports[d]["inputs"][p]]})
     return json.dumps({"nodes": doc_nodes, "links": doc_links})
 
 
@@ -63,3 +70,14 @@ def fan_in_three():
          (8, "biquad", BQ), (9, "output", {})],
         [(0, 1, "in"), (0, 2, "in"), (0, 3, "in"), (1, 4, "in"), (2, 4, "in"), (3, 4, "in"), (4, 5, "a"), (2, 5, "b"),
          (6, 5, "b"), (6, 7, "in"), (5, 9, "in"), (7, 9, "in"), (8, 9, "in")])
+
+
+def routing(in_port="B", out_port="A"):
+    """mux picks one of two branches; demux sends the signal to one of two effects, both averaged by the output
+    (the unselected one delivers zeros but still counts as a connected pipe)."""
+    return build(
+        [(0, "input", {}), (1, "gain", {"level": 0.5}), (2, "low_pass", {"ratio": 0.4}), (3, "mux", {"in_port": in_port}),
+         (4, "demux", {"out_port": out_port}), (5, "distort", {"level": 2.0, "mode": "HardClip"}), (6, "biquad", BQ),
+         (9, "output", {})],
+        [(0, 1, "in"), (0, 2, "in"), (1, 3, "a"), (2, 3, "b"), (3, 4, "in"), (4, 5, "in", "a"), (4, 6, "in", "b"),
+         (5, 9, "in"), (6, 9, "in")])

@@ -51,3 +51,29 @@ def test_unplugged_and_fan_in_semantics():
     doc["links"] = [l for l in doc["links"] if l["lhs"][0] != 8]
     y2 = graph_eval.run_graph(G.Graph(json.dumps(doc)), x)
     assert np.allclose(y * O.link_divisor(3), y2 * O.link_divisor(2), rtol=1e-6, atol=1e-7)
+
+
+def test_mux_demux_routing_semantics(dspfx):
+    from dsp_stuff_amd import graph as G
+    x = O.noise(9, np.arange(2), np.arange(256))
+    hop = lambda v: (v / O.link_divisor(1)).astype(F)
+    for in_port, out_port in (("A", "A"), ("B", "A"), ("A", "B"), ("B", "B")):
+        g = G.Graph(graphs.routing(in_port, out_port))
+        y = graph_eval.run_graph(g, x)
+        # by hand: branch -> mux (identity after its hop) -> demux (identity after its hop) -> effect -> output average of 2 pipes
+        branch = O.run_channels([(dspfx.Gain(0.5) if in_port == "A" else dspfx.LowPass(0.4)).oracle_desc()], x, 3)
+        routed = hop(hop(branch))
+        eff = dspfx.Distort(2.0, dspfx.HARD_CLIP) if out_port == "A" else dspfx.BiQuad(**graphs.BQ)
+        e = O.run_channels([eff.oracle_desc()], routed, 3)
+        other = O.run_channels([(dspfx.BiQuad(**graphs.BQ) if out_port == "A" else dspfx.Distort(2.0, dspfx.HARD_CLIP)).oracle_desc()],
+                               np.zeros_like(x), 3)
+        pipes = (e, other) if out_port == "A" else (other, e)
+        want = ((F(0) + pipes[0] + pipes[1]) / O.link_divisor(2)).astype(F)
+        assert np.array_equal(y, want), (in_port, out_port)
+        runs, _ = G.plan_runs(g)
+        # the selected branch > mux > demux > the selected effect fuse into one run; the unread branch and the
+        # effect that runs on zeros are runs of their own
+        got = sorted(sorted(m.id for m in r.nodes) for r in runs)
+        branch_id, unread = (1, 2) if in_port == "A" else (2, 1)
+        sel, other_id = (5, 6) if out_port == "A" else (6, 5)
+        assert got == sorted([sorted([branch_id, 3, 4, sel]), [unread], [other_id]]), got

@@ -17,11 +17,12 @@ def G(dspfx):
     return graph
 
 
-@pytest.mark.parametrize("name", ["diamond", "lfo_tremolo", "fan_in_three"])
+@pytest.mark.parametrize("name", ["diamond", "lfo_tremolo", "fan_in_three", "routing", "routing_ab", "routing_ba"])
 @pytest.mark.parametrize("N,tile,B", [(100, 0, 128), (128, 64, 128), (64, 0, 256)])
 def test_graph_matches_reference_semantics(dspfx, G, name, N, tile, B):
     import torch
-    text = getattr(graphs, name)()
+    text = {"routing_ab": lambda: graphs.routing("A", "B"), "routing_ba": lambda: graphs.routing("B", "A")}.get(
+        name, getattr(graphs, name, None))()
     nf = 768
     x = O.noise(0x5EED0001, np.arange(N), np.arange(nf))
     ge = G.GraphEngine(text, N, B, tile_channels=tile)
