@@ -39,7 +39,7 @@ void launch_link_average(const LinkAvgArgs &a, hipStream_t s);
 int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s);
 // dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)
 void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
-                      unsigned nrows, int skew, bool to_dense, hipStream_t s);
+                      unsigned nrows, bool to_dense, hipStream_t s);
 // streams one ring group the way the delay node does (nontemporal load + store of every element):
 // the placement probe times this per group
 void launch_ring_probe(float *group, size_t n_floats, hipStream_t s);

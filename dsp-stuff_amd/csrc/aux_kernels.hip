@@ -148,24 +148,24 @@ int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hi
 }
 
 __global__ void __launch_bounds__(WG) ring_copy_kernel(float *const *groups, float *dense, unsigned N, unsigned W,
-                                                       unsigned D, unsigned r0, unsigned nrows, int skew, int to_dense) {
+                                                       unsigned D, unsigned r0, unsigned nrows, int to_dense) {
     const size_t total = (size_t)N * nrows;
     for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < total; i += (size_t)gridDim.x * WG) {
         const unsigned k = (unsigned)(i / N), c = (unsigned)(i % N);
         unsigned r = r0 + k;
         r = r >= D ? r - D : r;
-        float *p = groups[r >> 7] + ring_in_group_offset(r, c / W, W, skew) + (c % W);
+        float *p = groups[r >> 7] + ring_in_group_offset(r, c / W, W) + (c % W);
         if (to_dense) dense[i] = *p;
         else *p = dense[i];
     }
 }
 void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
-                      unsigned nrows, int skew, bool to_dense, hipStream_t s) {
+                      unsigned nrows, bool to_dense, hipStream_t s) {
     const size_t total = (size_t)N * nrows;
     size_t blocks = (total + WG - 1) / WG;
     if (blocks > 256 * 32) blocks = 256 * 32;
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(ring_copy_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, groups, dense, N, W, D, r0, nrows, skew,
+    hipLaunchKernelGGL(ring_copy_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, groups, dense, N, W, D, r0, nrows,
                        to_dense ? 1 : 0);
 }
 

@@ -50,7 +50,7 @@ struct SlotArgs {
     unsigned D;
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
-    int ring_skew;   // REVERB: rows of each 128-row ring group rotated per tile (ring_in_group_offset)
+    int pad_;
     double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
     // control ports (`as_input` sliders, dsp-stuff-derive/src/lib.rs:122-161), slider field order:
     const float *ctl[3];   // connected port: signal in the sample layout, else nullptr
@@ -101,10 +101,8 @@ struct ChainArgs {
 // (profiles/r01_placement.txt), the engine probes each group at setup and re-allocates the slow ones.
 // With a single tile (frame-major, W = N) a group is the plain [128][N].
 constexpr unsigned RING_GROUP_ROWS = 128;
-__host__ __device__ inline size_t ring_in_group_offset(unsigned r, size_t tile, size_t ld, int skew = 0) {
-    // `skew` (experiment, default off: measured harmful) rotates the rows of a group per tile
-    const unsigned rr = skew ? ((r + 37u * (unsigned)tile) & 127u) : (r & 127u);
-    return (tile * RING_GROUP_ROWS + rr) * ld;
+__host__ __device__ inline size_t ring_in_group_offset(unsigned r, size_t tile, size_t ld) {
+    return (tile * RING_GROUP_ROWS + (r & 127u)) * ld;
 }
 
 struct Layout {
@@ -296,7 +294,7 @@ __device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
 // bounds launches with few channels (one wave per SIMD, nothing else to switch to).
 template <int F, int CPL> struct RingPre {
     float tap[F][CPL];
-    float *row[F];
+    float *row[F];     // wave-uniform row base (scalar registers); the lane adds cx.ring_off
 };
 // signal_gen.rs:57-104, one sample: `total` is the block-local phase advance, `clock` the phase carried
 // between 128-frame blocks.  Square compares `total` (not the phase) with 0.5, like the reference.
@@ -318,9 +316,13 @@ __device__ __forceinline__ float signal1(float clock, float &total, float freque
 struct Ctx {
     size_t c;        // first channel of this lane
     size_t N;
-    size_t io_base;  // offset of (frame 0, channel c) in in/out/side
-    size_t tile;     // channel tile index
-    size_t cw;       // channel within its tile
+    // Addresses are split into a wave-uniform 64-bit part (scalar registers, scalar arithmetic) and a 32-bit
+    // per-lane part that does not depend on the frame, so every sample / ring access is
+    // `global_load/store v, v_off, s[base]`: no 64-bit vector address arithmetic, no VGPR pair per frame.
+    size_t io_base0;   // offset of (frame 0, the wave's first channel) in in/out/side/control buffers   [uniform]
+    unsigned io_off;   // this lane's channel relative to that, in BYTES (see lane_ptr)                    [lane]
+    size_t ring_base0; // (tile0 * 128) * ld + cw0: the wave's first channel inside a ring group, row 0   [uniform]
+    unsigned ring_off; // this lane relative to that                                                      [lane]
     size_t ld;       // floats between consecutive frames
     unsigned f0;     // first frame of the chunk
     float hop_div;
@@ -331,15 +333,48 @@ struct Ctx {
     bool active;     // false only for padding lanes of the guarded tail launch
 };
 
+// Per-wave address bases (see Ctx).  `c` is the lane's first channel; every lane of a wave has c >= c0.
+struct WaveAddr {
+    size_t io_base0, ring_base0;
+    unsigned io_off, ring_off;
+};
+__device__ __forceinline__ WaveAddr wave_addr(const ChainArgs &a, size_t c) {
+    const unsigned c0 = __builtin_amdgcn_readfirstlane((unsigned)c);
+    const size_t tile0 = c0 >> a.w_shift, cw0 = c0 & a.w_mask;
+    const size_t tile = c >> a.w_shift, cw = c & a.w_mask;
+    WaveAddr w;
+    w.io_base0 = tile0 * a.io_tile_stride + cw0;
+    w.ring_base0 = tile0 * RING_GROUP_ROWS * (size_t)a.ld + cw0;
+    w.io_off = (unsigned)((tile * a.io_tile_stride + cw) - w.io_base0) * 4u;
+    w.ring_off = (unsigned)((tile * RING_GROUP_ROWS * (size_t)a.ld + cw) - w.ring_base0) * 4u;
+    return w;
+}
+// uniform base + 32-bit BYTE offset of the lane: the shape the global_load/store "saddr + voffset" form needs
+__device__ __forceinline__ const float *lane_ptr(const float *base, unsigned byte_off) {
+    return (const float *)((const char *)base + byte_off);
+}
+__device__ __forceinline__ float *lane_ptr(float *base, unsigned byte_off) { return (float *)((char *)base + byte_off); }
+
+
+// Pin a wave-uniform pointer into scalar registers (the compiler otherwise may keep it in a VGPR pair per lane).
+__device__ __forceinline__ float *uniform_ptr(float *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (float *)(((unsigned long long)hi << 32) | lo);
+}
 template <int F, int CPL, bool GUARD>
 __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, RingPre<F, CPL> &pre) {
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
         r = r >= s.D ? r - s.D : r;
-        float *gb = s.groups[r >> 7];                      // wave-uniform: one scalar load
-        pre.row[f] = gb + ring_in_group_offset(r, cx.tile, cx.ld, s.ring_skew) + cx.cw;
-        load_vec<CPL, GUARD, S_RING_LD>(pre.row[f], pre.tap[f], cx.active);
+        // the group table is never written by a kernel: read it through the constant address space so the load
+        // is a scalar one whatever stores precede it
+        typedef float *fptr_t;
+        const __attribute__((address_space(4))) fptr_t *tab = (const __attribute__((address_space(4))) fptr_t *)s.groups;
+        float *gb = tab[__builtin_amdgcn_readfirstlane(r >> 7)];
+        pre.row[f] = uniform_ptr(gb + cx.ring_base0 + (size_t)(r & 127u) * cx.ld);
+        load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(pre.row[f], cx.ring_off), pre.tap[f], cx.active);
     }
 }
 template <int F, int CPL, bool GUARD>
@@ -349,7 +384,7 @@ __device__ __forceinline__ void ring_apply(const SlotArgs &s, float (&v)[F][CPL]
     for (int f = 0; f < F; ++f) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + pre.tap[f][j] * decay;
-        store_vec<CPL, GUARD, S_RING_ST>(pre.row[f], v[f], cx.active);
+        store_vec<CPL, GUARD, S_RING_ST>(lane_ptr(pre.row[f], cx.ring_off), v[f], cx.active);
     }
 }
 
@@ -464,7 +499,7 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
         for (int f = 0; f < F; ++f) {
             float b[CPL];
             if (cx.side) {
-                load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
+                load_vec<CPL, GUARD, S_IN>(lane_ptr(cx.side + cx.io_base0 + (size_t)(cx.f0 + f) * cx.ld, cx.io_off), b, cx.active);
                 if (cx.side_hop & 1) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
@@ -492,7 +527,7 @@ __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo
     if (s.ctl[k]) {
 #pragma unroll
         for (int f = 0; f < F; ++f) {
-            load_vec<CPL, GUARD, S_IN>(s.ctl[k] + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, p[f], cx.active);
+            load_vec<CPL, GUARD, S_IN>(lane_ptr(s.ctl[k] + cx.io_base0 + (size_t)(cx.f0 + f) * cx.ld, cx.io_off), p[f], cx.active);
 #pragma unroll
             for (int j = 0; j < CPL; ++j) {
                 float x = p[f][j];
@@ -579,7 +614,7 @@ __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][
         for (int f = 0; f < F; ++f) {
             float b[CPL];
             if (cx.side) {
-                load_vec<CPL, GUARD, S_IN>(cx.side + cx.io_base + (size_t)(cx.f0 + f) * cx.ld, b, cx.active);
+                load_vec<CPL, GUARD, S_IN>(lane_ptr(cx.side + cx.io_base0 + (size_t)(cx.f0 + f) * cx.ld, cx.io_off), b, cx.active);
                 if (cx.side_hop & 1) {
 #pragma unroll
                     for (int j = 0; j < CPL; ++j) b[j] = link_hop<FAST>(b[j], cx.hop_div, cx.hop_rc);
@@ -854,14 +889,12 @@ __device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (
 }
 
 template <int F, int CPL, class SL>
-__device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c,
+__device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c, const WaveAddr &w,
                                             unsigned f0, int lane, unsigned wave_global) {
     float v[F][CPL];
-    const size_t tile = c >> a.w_shift, cw = c & a.w_mask;
-    const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
-    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
     // delay taps first (see RingPre), then the nodes in order
     RingPre<F, CPL> pre[MAX_SLOTS];
 #define DSPFX_PF(I) if constexpr (sig_is<K_REVERB>(SL::v[I])) ring_prefetch<F, CPL, false>(a.slot[I], cx, pre[I]);
@@ -877,7 +910,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<CPL, false, S_OUT>(a.out + io_base + (size_t)(f0 + f) * a.ld, v[f], true);
+    for (int f = 0; f < F; ++f) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
     if (a.mixpart) mixbus_partial<F, CPL>(a, v, true, f0, lane, wave_global);
 }
 
@@ -894,10 +927,11 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 #define DSPFX_LD(I) load_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_LD)
 #undef DSPFX_LD
+    const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL>(a, st, c, f0, lane, wave_global);
+    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL>(a, st, c, w, f0, lane, wave_global);
     if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL>(a, st, c, f0, lane, wave_global);
+        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL>(a, st, c, w, f0, lane, wave_global);
 #define DSPFX_ST(I) store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_ST)
 #undef DSPFX_ST
@@ -911,14 +945,12 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // MOD=true additionally evaluates connected / latched `as_input` sliders (control ports); it is a
 // separate instantiation because those paths double the register footprint (239 vs 113 VGPRs).
 template <int F, bool GUARD, bool FAST, bool MOD, bool LIBM>
-__device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, bool active, unsigned f0,
+__device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, const WaveAddr &w, bool active, unsigned f0,
                                           int lane, unsigned wave_global) {
     float v[F][1];
-    const size_t tile = c >> a.w_shift, cw = c & a.w_mask;
-    const size_t io_base = tile * a.io_tile_stride + cw;
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(a.in + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
-    const Ctx cx{c, a.N, io_base, tile, cw, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
+    for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {
@@ -934,7 +966,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
         row += ns;
     }
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<1, GUARD, S_OUT>(a.out + io_base + (size_t)(f0 + f) * a.ld, v[f], active);
+    for (int f = 0; f < F; ++f) store_vec<1, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
     if (a.mixpart) mixbus_partial<F, 1>(a, v, !GUARD || active, f0, lane, wave_global);
 }
 
@@ -962,15 +994,16 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
             row += ns;
         }
     }
+    const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
     if (a.fast_div) {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
     } else {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false, MOD, LIBM>(a, lds, c, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
     }
     {
         int row = 0;

@@ -41,7 +41,6 @@ struct Node {
     int ring_replaced = 0;    // groups re-allocated by the placement probe
     size_t state_bytes = 0;
     uint32_t D = 0, pos = 0;  // REVERB
-    int ring_skew = 0;        // REVERB: per-tile row rotation inside each ring group (ring_in_group_offset)
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;
@@ -421,7 +420,6 @@ int tune_ring(dspfx_engine *e, Node &n) {
     ca.slot[0].p[0] = 0.5f;
     ca.slot[0].groups = d_one;
     ca.slot[0].D = RING_GROUP_ROWS;
-    ca.slot[0].ring_skew = n.ring_skew;
     const uint32_t n_main = N - N % 64u;
     ca.n_launch = n_main;
     const unsigned grid = (n_main + WG - 1) / WG;
@@ -503,8 +501,6 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
         HIPCHK(e, hipMalloc((void **)&n.d_groups, ngroups * sizeof(float *)));
         HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), ngroups * sizeof(float *), hipMemcpyHostToDevice));
         n.state_bytes = (size_t)n.D * N * sizeof(float);   // canonical (exported) size
-        const char *rs = getenv("DSPFX_RING_ROWSKEW");     // experiment switch, default off (measured harmful)
-        n.ring_skew = (e->desc.tile_channels && rs && atoi(rs)) ? 1 : 0;
         const int rc = tune_ring(e, n);
         if (rc) return rc;
     }
@@ -538,7 +534,6 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.groups = n.d_groups;
     s.D = n.D;
     s.pos = n.pos;
-    s.ring_skew = n.ring_skew;
     s.hop = node_hop(e, idx);
     s.rc = n.d.kind == DSPFX_DISTORT ? 1.0 / (double)n.d.params[0] : 0.0;
     for (int k = 0; k < 3; ++k) {
@@ -575,7 +570,7 @@ int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *
         hipError_t err = hipSuccess;
         if (!to_host) err = hipMemcpy(bounce, host + (size_t)k * N * sizeof(float), bytes, hipMemcpyHostToDevice);
         if (err == hipSuccess) {
-            launch_ring_copy(n.d_groups, bounce, (unsigned)N, W, n.D, r, nr, n.ring_skew, to_host, nullptr);
+            launch_ring_copy(n.d_groups, bounce, (unsigned)N, W, n.D, r, nr, to_host, nullptr);
             err = hipGetLastError();
         }
         if (err == hipSuccess) err = hipDeviceSynchronize();

@@ -50,10 +50,6 @@ def main():
         name, _, rest = spec.partition(":")
         kv = dict(x.split("=", 1) for x in rest.split(",") if x)
         pkg = load_pkg(kv.get("lib"), f"{i}")
-        if "skew" in kv:
-            os.environ["DSPFX_RING_SKEW"] = kv["skew"]
-        else:
-            os.environ.pop("DSPFX_RING_SKEW", None)
         if "variant" in kv:
             os.environ["DSPFX_VARIANT"] = kv["variant"].replace(";", ",")
         else:
