@@ -241,26 +241,33 @@ def main():
         torch.cuda.empty_cache()
     else:
         xs, y = [alloc_buf(i) for i in range(n_in)], alloc_buf()
-    mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(2)] if use_mix else [None, None]
+    mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(4)] if use_mix else [None] * 4
     total_channels = shard.total_channels
-    # Output hop after the cross-GPU all-reduce; the collective of block k overlaps block k+1's kernel
-    # the chain kernels own `stream`; mix collection, its cross-GPU all-reduce and the Output hop run
-    # on a second stream, so block k's mix bus overlaps block k+1's chain kernel
+    # Mix bus.  One GPU: pipelined INSIDE the chain kernel (dspfx_process_mixpipe: block k's launch also finishes
+    # the bus of blocks k-1 / k-2 and applies the Output hop), so the compute stream holds nothing but chain
+    # kernels -- no second stream, no events (measured: the event marker between kernels cost 13 us per step,
+    # profiles/r01_mixpipe.txt).  Several GPUs: per-wave partials are collected on a second stream, all-reduced
+    # over RCCL and divided there, overlapping the next block's chain kernel (parallel.MixBus).
+    # DSPFX_BENCH_MIX = pipe | deferred | inline selects the path for A/B runs.
+    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "deferred" if (use_dist or world > 1) else "pipe")
+    if (use_dist or world > 1) and mix_mode != "deferred":
+        raise SystemExit("multi-GPU runs use the deferred mix bus")
     mix_stream = torch.cuda.Stream(device=dev)
     ms = mix_stream.cuda_stream
     bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms),
                    world=2 if (use_dist and world == 1) else world)   # forced-dist: take the collective path
-
-    inline_mix = os.environ.get("DSPFX_BENCH_INLINE_MIX", "0") == "1"   # A/B switch; deferred (second stream) measured better
+    pipe_fill = [0]
 
     def step(k):
         if not use_mix:
             eng.process(xs[k % n_in], out=y, n_frames=B, stream=stream)
             return
-        m = mixes[k & 1]
-        if inline_mix and world == 1 and not use_dist:
-            # single GPU: second stage + Output hop in stream order right behind the chain kernel (measured
-            # cheaper than overlapping them from a second stream, which disturbs the chain kernel's streaming)
+        m = mixes[k & 3]
+        if mix_mode == "pipe":
+            eng.process_mixpipe(xs[k % n_in], y, m, B, n_connected=total_channels, stream=stream)
+            pipe_fill[0] += 1
+            return
+        if mix_mode == "inline":
             eng.process(xs[k % n_in], out=y, mix=m, n_frames=B, stream=stream)
             eng.mix_finish(m, B, total_channels, stream)
             return
@@ -270,6 +277,11 @@ def main():
             bus.submit(m)
 
     def drain():
+        if use_mix and mix_mode == "pipe":
+            if pipe_fill[0]:
+                eng.mixpipe_flush(mixes[2] if pipe_fill[0] >= 2 else None, mixes[3], n_connected=total_channels, stream=stream)
+                pipe_fill[0] = 0
+            return
         with torch.cuda.stream(mix_stream):
             bus.drain()
 
@@ -362,7 +374,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
-                   "mix_bus": use_mix, "parallelism": f"channel-shard x{world}", "placement_probe": probe_log,
+                   "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}", "placement_probe": probe_log,
                    "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
                    "plan": eng.describe().strip().split("\n")[1:]},
         "roofline": roof,

@@ -25,6 +25,8 @@ void launch_fuzz(const FuzzArgs &a, hipStream_t s);
 void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s);
 // node.rs:189-191: mix[i] /= div
 void launch_mix_finish(float *mix, unsigned n, float div, hipStream_t s);
+void launch_mix_reduce_slices(const float *part, float *part2, unsigned nframes, unsigned waves, hipStream_t s);
+void launch_mix_reduce_final(const float *part2, float *mix, unsigned nframes, hipStream_t s);
 
 // node.rs:162-194 for a port with several connected pipes: dst = (0 + src0 + src1 + ...) / f32(0.0001 + n)
 struct LinkAvgArgs {

@@ -52,31 +52,13 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
     }
 }
 
-// Mix bus, second stage: part is [waves][nframes] (each wave wrote its own contiguous row).  Stage A: block b
-// sums a fixed slice of waves for every frame (lane = frame: coalesced row reads) into part2[b][frame];
-// stage B: one block sums the slices in fixed order.  Fixed association => run-to-run deterministic.
-constexpr unsigned MIX_SLICES = 128;
+// Mix bus, second and third stage as stand-alone kernels (bodies in chain_kernels.hip.h, shared with the
+// in-kernel pipeline).
 __global__ void __launch_bounds__(WG) mix_reduce_a_kernel(const float *part, float *part2, unsigned waves, unsigned nframes) {
-    const unsigned per = (waves + MIX_SLICES - 1) / MIX_SLICES;
-    const unsigned w0 = blockIdx.x * per, w1 = min(waves, w0 + per);
-    for (unsigned f = threadIdx.x; f < nframes; f += WG) {
-        float a0 = 0.0f, a1 = 0.0f;
-        unsigned w = w0;
-        for (; w + 1 < w1; w += 2) {
-            const float x0 = part[(size_t)w * nframes + f], x1 = part[(size_t)(w + 1) * nframes + f];
-            a0 = a0 + x0;
-            a1 = a1 + x1;
-        }
-        if (w < w1) a0 = a0 + part[(size_t)w * nframes + f];
-        part2[(size_t)blockIdx.x * nframes + f] = a0 + a1;
-    }
+    mix_slice_reduce(part, part2, waves, nframes, blockIdx.x, threadIdx.x, WG);
 }
 __global__ void __launch_bounds__(WG) mix_reduce_b_kernel(const float *part2, float *mix, unsigned nframes) {
-    for (unsigned f = blockIdx.x * WG + threadIdx.x; f < nframes; f += gridDim.x * WG) {
-        float acc = 0.0f;
-        for (unsigned b = 0; b < MIX_SLICES; ++b) acc = acc + part2[(size_t)b * nframes + f];
-        mix[f] = acc;
-    }
+    mix_final_reduce(part2, mix, nframes, 0.0f, blockIdx.x * WG + threadIdx.x, gridDim.x * WG);
 }
 
 __global__ void mix_finish_kernel(float *mix, unsigned n, float div) {
@@ -193,6 +175,12 @@ void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
 void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s) {
     hipLaunchKernelGGL(mix_reduce_a_kernel, dim3(MIX_SLICES), dim3(WG), 0, s, part, part2, waves, nframes);
     hipLaunchKernelGGL(mix_reduce_b_kernel, dim3((nframes + WG - 1) / WG), dim3(WG), 0, s, part2, mix, nframes);
+}
+void launch_mix_reduce_final(const float *part2, float *mix, unsigned nframes, hipStream_t s) {
+    hipLaunchKernelGGL(mix_reduce_b_kernel, dim3((nframes + WG - 1) / WG), dim3(WG), 0, s, part2, mix, nframes);
+}
+void launch_mix_reduce_slices(const float *part, float *part2, unsigned nframes, unsigned waves, hipStream_t s) {
+    hipLaunchKernelGGL(mix_reduce_a_kernel, dim3(MIX_SLICES), dim3(WG), 0, s, part, part2, waves, nframes);
 }
 void launch_link_average(const LinkAvgArgs &a, hipStream_t s) {
     const size_t n4 = a.count / 4;

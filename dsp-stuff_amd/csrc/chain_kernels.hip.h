@@ -85,8 +85,54 @@ struct ChainArgs {
     double third_rc;         // f64 1/3.0f  (SoftClip's powi(3)/3.0)
     int fast_div;            // every constant divisor of this launch passed the exhaustive check
     int xcd_remap;           // 1: blocks of one XCD (b % 8) cover a contiguous range of channel tiles
+    // Pipelined mix bus (mixpipe_prologue): the second and third reduction stage of EARLIER blocks ride in this
+    // launch's first workgroups instead of separate kernels on a second stream.
+    int mp_stage;            // bit 0: slice-reduce mp_prev_a into mp_cur_b; bit 1: final-reduce mp_prev_b into mp_mix
+    unsigned mp_rows_a;      // rows (waves) of mp_prev_a
+    const float *mp_prev_a;  // per-wave partials [rows][nframes] of the previous block
+    float *mp_cur_b;         // [MIX_SLICES][nframes] slice sums of the previous block (written here)
+    const float *mp_prev_b;  // slice sums of the block before that (written by the previous launch)
+    float *mp_mix;           // [nframes] mix bus of the block two launches back
+    float mp_div;            // Output-node divisor f32(0.0001 + n), or 0 to leave the sums un-normalised
     SlotArgs slot[MAX_SLOTS];
 };
+
+// ---- mix bus, second and third stage (shared by the stand-alone kernels and the in-kernel pipeline) --------
+// part is [waves][nframes] (each wave wrote its own contiguous row).  Slice stage: slice b sums a fixed range of
+// waves for every frame (lane = frame: coalesced row reads) into part2[b][frame]; final stage: the slices are
+// summed in fixed order.  Fixed association => run-to-run deterministic, and identical in both forms.
+constexpr unsigned MIX_SLICES = 128;
+__device__ __forceinline__ void mix_slice_reduce(const float *part, float *part2, unsigned waves, unsigned nframes,
+                                                 unsigned b, unsigned tid, unsigned nthreads) {
+    const unsigned per = (waves + MIX_SLICES - 1) / MIX_SLICES;
+    const unsigned w0 = b * per, w1 = min(waves, w0 + per);
+    for (unsigned f = tid; f < nframes; f += nthreads) {
+        float a0 = 0.0f, a1 = 0.0f;
+        unsigned w = w0;
+        for (; w + 1 < w1; w += 2) {
+            const float x0 = part[(size_t)w * nframes + f], x1 = part[(size_t)(w + 1) * nframes + f];
+            a0 = a0 + x0;
+            a1 = a1 + x1;
+        }
+        if (w < w1) a0 = a0 + part[(size_t)w * nframes + f];
+        part2[(size_t)b * nframes + f] = a0 + a1;
+    }
+}
+__device__ __forceinline__ void mix_final_reduce(const float *part2, float *mix, unsigned nframes, float div,
+                                                 unsigned tid, unsigned nthreads) {
+    for (unsigned f = tid; f < nframes; f += nthreads) {
+        float acc = 0.0f;
+        for (unsigned b = 0; b < MIX_SLICES; ++b) acc = acc + part2[(size_t)b * nframes + f];
+        mix[f] = div != 0.0f ? acc / div : acc;     // node.rs:189-191 (the Output node's hop)
+    }
+}
+// The first MIX_SLICES workgroups of a launch reduce one slice each of the previous block's partials, the next one
+// finishes the block before that.  Both only read what EARLIER launches on the same stream wrote.
+__device__ __forceinline__ void mixpipe_prologue(const ChainArgs &a) {
+    const unsigned b = blockIdx.x;
+    if ((a.mp_stage & 1) && b < MIX_SLICES) mix_slice_reduce(a.mp_prev_a, a.mp_cur_b, a.mp_rows_a, a.nframes, b, threadIdx.x, blockDim.x);
+    else if ((a.mp_stage & 2) && b == MIX_SLICES) mix_final_reduce(a.mp_prev_b, a.mp_mix, a.nframes, a.mp_div, threadIdx.x, blockDim.x);
+}
 
 // Sample layout shared by every kernel: channel c, frame f lives at
 //   (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
@@ -917,6 +963,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
 template <int F, int CPL, class SL>
 __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
+    if (a.mp_stage) mixpipe_prologue(a);
     const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const unsigned wave_global = a.wave_base + (tid >> 6);
@@ -975,6 +1022,7 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
 template <int F, bool GUARD, bool MOD, bool LIBM>
 __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     extern __shared__ float lds[];   // [state rows][WG]
+    if (a.mp_stage) mixpipe_prologue(a);
     const unsigned tid = (blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x) * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
     const int lane = threadIdx.x & 63;
     const unsigned wave_global = a.wave_base + (tid >> 6);

@@ -77,6 +77,13 @@ struct dspfx_engine {
     int flip = 0;
     uint32_t part_stride[2] = {0, 0}, part_frames[2] = {0, 0};
     float *partials_override = nullptr;   // set while a deferred-mix block is being launched
+    // in-kernel pipelined mix bus (dspfx_process_mixpipe): block k's launch also runs stage 2 of block k-1 and
+    // stage 3 of block k-2.  mp_count = blocks submitted since the last flush.
+    uint64_t mp_count = 0;
+    uint32_t mp_frames = 0, mp_rows[2] = {0, 0};
+    float *mp_mix_now = nullptr;          // where the launch being built delivers block k-2's bus
+    float mp_div_now = 0.0f;
+    bool mp_building = false;
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
@@ -606,7 +613,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         const Stage &st = e->stages[si];
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
-            if (st.count == 0 && !(last && (mix || e->partials_override)) && src == out) continue;   // nothing to do
+            if (st.count == 0 && !(last && (mix || e->partials_override || e->mp_building)) && src == out) continue;   // nothing to do
             ChainArgs a;
             memset(&a, 0, sizeof a);
             a.in = src;
@@ -651,14 +658,39 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
             a.mix_stride = waves_main + (N - n_main + 63) / 64;
             if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
+            const unsigned grid_main = (waves_main * 64 + WG - 1) / WG;
+            if (e->mp_building && last) {   // pipelined mix bus: earlier blocks' reductions ride in this launch
+                const int cur = (int)(e->mp_count & 1), prev = cur ^ 1;
+                a.mixpart = e->mixpart2[cur];
+                if (a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
+                e->mp_rows[cur] = a.mix_stride;
+                const int stage = (e->mp_count >= 1 ? 1 : 0) | (e->mp_count >= 2 ? 2 : 0);
+                float *b_cur = cur ? e->mixpart_b2 : e->mixpart_b, *b_prev = cur ? e->mixpart_b : e->mixpart_b2;
+                if (grid_main > MIX_SLICES) {
+                    a.mp_stage = stage;
+                    a.mp_rows_a = e->mp_rows[prev];
+                    a.mp_prev_a = e->mixpart2[prev];
+                    a.mp_cur_b = b_cur;
+                    a.mp_prev_b = b_prev;
+                    a.mp_mix = e->mp_mix_now;
+                    a.mp_div = e->mp_div_now;
+                } else {                    // too few workgroups to host the prologue: same stages as stand-alone kernels
+                    if (stage & 2) {
+                        launch_mix_reduce_final(b_prev, e->mp_mix_now, nframes, stream);
+                        if (e->mp_div_now != 0.0f) launch_mix_finish(e->mp_mix_now, nframes, e->mp_div_now, stream);
+                    }
+                    if (stage & 1) launch_mix_reduce_slices(e->mixpart2[prev], b_cur, nframes, e->mp_rows[prev], stream);
+                }
+            }
             if (n_main) {
                 a.c_base = 0;
                 a.n_launch = n_main;
                 a.wave_base = 0;
-                const unsigned grid = (waves_main * 64 + WG - 1) / WG;
+                const unsigned grid = grid_main;
                 ProfScope ps(e, si, stream);
                 v->launch(a, grid, WG, (unsigned)(rows * WG * sizeof(float)), stream);
             }
+            a.mp_stage = 0;   // the guarded tail launch never hosts the prologue
             if (N % per_wave) {   // ragged tail: guarded one-wave blocks, lane per channel
                 const uint32_t n_tail = N - n_main;
                 a.c_base = n_main;
@@ -670,7 +702,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             if (deferred) {
                 e->part_stride[e->flip] = a.mix_stride;
                 e->part_frames[e->flip] = nframes;
-            } else if (a.mixpart) {
+            } else if (a.mixpart && !e->mp_building) {
                 launch_mix_reduce(e->mixpart, e->mixpart_b, mix, nframes, a.mix_stride, stream);
                 HIPCHK(e, hipGetLastError());
             }
@@ -932,6 +964,7 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
         n.pos = 0;
         if (n.d.kind == DSPFX_FIR) fir_reset(n.fir);
     }
+    e->mp_count = 0;   // blocks still in the mix pipeline are dropped
     return DSPFX_OK;
 }
 
@@ -1075,6 +1108,71 @@ extern "C" int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames,
     e->red_pending[b] = true;
     e->collect_due = false;
     e->flip ^= 1;
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_process_mixpipe(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                                     uint32_t n_frames, uint64_t n_connected, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (e->collect_due) return fail(e, DSPFX_ERR_STATE, "dspfx_mix_collect must follow dspfx_process_partials");
+    if (n_frames == 0 || n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "bad n_frames %u", n_frames);
+    if (n_frames > e->min_delay)
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "pipelined mix needs n_frames <= shortest delay line (%u)", e->min_delay);
+    if (e->mp_count && n_frames != e->mp_frames)
+        return fail(e, DSPFX_ERR_STATE, "n_frames changed from %u to %u inside the mix pipeline: flush first", e->mp_frames, n_frames);
+    if (e->mp_count >= 2 && !mix) return fail(e, DSPFX_ERR_INVALID, "mix must not be null from the third block on");
+    HIPCHK(e, hipSetDevice(e->device));
+    for (int b = 0; b < 2; ++b)
+        if (!e->mixpart2[b]) {
+            HIPCHK(e, hipMalloc((void **)&e->mixpart2[b], e->mixpart_cols * e->desc.max_frames * sizeof(float)));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_chain[b], hipEventDisableTiming));
+            HIPCHK(e, hipEventCreateWithFlags(&e->ev_red[b], hipEventDisableTiming));
+        }
+    float div = 0.0f;
+    if (n_connected) {
+        if (e->div_n != n_connected || e->div_v == 0.0f) {
+            e->div_v = dspfx_link_divisor(n_connected);
+            e->div_n = n_connected;
+        }
+        div = e->div_v;
+    }
+    e->mp_frames = n_frames;
+    e->mp_mix_now = mix;
+    e->mp_div_now = div;
+    e->mp_building = true;
+    const int rc = dspfx_process(e, in, side, out, nullptr, n_frames, stream);
+    e->mp_building = false;
+    if (rc) return rc;
+    ++e->mp_count;
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_mixpipe_flush(dspfx_engine *e, float *mix_older, float *mix_newer, uint64_t n_connected, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (e->mp_count == 0) return DSPFX_OK;
+    if (!mix_newer || (e->mp_count >= 2 && !mix_older)) return fail(e, DSPFX_ERR_INVALID, "mix buffers must not be null");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nf = e->mp_frames;
+    float div = 0.0f;
+    if (n_connected) {
+        if (e->div_n != n_connected || e->div_v == 0.0f) {
+            e->div_v = dspfx_link_divisor(n_connected);
+            e->div_n = n_connected;
+        }
+        div = e->div_v;
+    }
+    const int last = (int)((e->mp_count - 1) & 1);          // buffers written by the last launch
+    float *b_last = last ? e->mixpart_b2 : e->mixpart_b, *b_other = last ? e->mixpart_b : e->mixpart_b2;
+    if (e->mp_count >= 2) {                                  // block n-2: its slices were reduced by the last launch
+        launch_mix_reduce_final(b_last, mix_older, nf, s);
+        if (div != 0.0f) launch_mix_finish(mix_older, nf, div, s);
+    }
+    launch_mix_reduce_slices(e->mixpart2[last], b_other, nf, e->mp_rows[last], s);   // block n-1: only its partials exist
+    launch_mix_reduce_final(b_other, mix_newer, nf, s);
+    if (div != 0.0f) launch_mix_finish(mix_newer, nf, div, s);
+    HIPCHK(e, hipGetLastError());
+    e->mp_count = 0;
     return DSPFX_OK;
 }
 

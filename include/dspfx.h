@@ -226,6 +226,17 @@ int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, floa
 int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, float *out,
                            uint32_t n_frames, void *stream);
 int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stream);
+/* Mix bus pipelined INSIDE the chain kernel: no second stream, no events, no extra launches.  The launch of
+ * block k also runs, in its first 129 workgroups, the slice reduction of block k-1's partials and the final
+ * reduction (+ the Output hop when n_connected != 0) of block k-2, so `mix` receives the bus of the block
+ * submitted TWO calls earlier (it is not written by the first two calls after a flush / reset; it may be NULL
+ * there).  Same reduction tree as dspfx_process(mix) and dspfx_mix_collect: bit-identical sums.  n_frames must
+ * stay the same between flushes and must not exceed the shortest delay line.
+ * dspfx_mixpipe_flush drains the pipeline with stand-alone kernels: mix_older <- the block before the last one
+ * (may be NULL when only one block is in flight), mix_newer <- the last block. */
+int dspfx_process_mixpipe(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                          uint32_t n_frames, uint64_t n_connected, void *stream);
+int dspfx_mixpipe_flush(dspfx_engine *e, float *mix_older, float *mix_newer, uint64_t n_connected, void *stream);
 /* Output-node hop of the mix bus (node.rs:189-191): mix[f] /= link_divisor(n_connected),
  * in place on the device; call after the cross-GPU all-reduce with the GLOBAL channel count. */
 int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream);

@@ -933,3 +933,53 @@ def test_random_chains_of_exact_nodes(dspfx, torch_cuda, seed):
         assert np.array_equal(np.isfinite(got), ok), (seed, case)
         d = ulp_diff(got[ok], ref[ok])
         assert d.size == 0 or d.max() <= 1, (seed, case, [(n.kind, n.mode) for n in chain], N, block, tile, lf, int(d.max()))
+
+
+@pytest.mark.parametrize("N,tile", [(4096 + 64 * 300 + 37, 0), (65536, 256), (100, 0)])
+def test_mix_bus_pipelined_inside_the_kernel(dspfx, torch_cuda, N, tile):
+    """dspfx_process_mixpipe: block k's launch finishes the mix bus of blocks k-1 / k-2 in its first workgroups.
+    Same reduction tree as the stand-alone kernels => bit-identical to dspfx_process(mix) + dspfx_mix_finish,
+    delivered two calls late; flush drains the last two blocks; the outputs are untouched."""
+    B, blocks = 128, 7
+    chain = chain5(dspfx, 256)
+    x = noise_block(N, B * blocks)
+    ref_eng, eng = dspfx.Engine(N, B, tile_channels=tile), dspfx.Engine(N, B, tile_channels=tile)
+    ref_eng.set_chain(chain)
+    eng.set_chain(chain)
+    for n_conn in (0, N):
+        ref_eng.reset()
+        eng.reset()
+        want_mix, want_out, got_out = [], [], []
+        mixes = [torch_cuda.full((B,), 7.0, device="cuda") for _ in range(blocks)]
+        for k in range(blocks):
+            dx = torch_cuda.from_numpy(dspfx.to_layout(x[k * B:(k + 1) * B], tile)).cuda()
+            y0, y1 = torch_cuda.empty_like(dx), torch_cuda.empty_like(dx)
+            m = torch_cuda.empty(B, device="cuda")
+            ref_eng.process(dx, out=y0, mix=m, n_frames=B)
+            if n_conn:
+                ref_eng.mix_finish(m, B, n_conn)
+            eng.process_mixpipe(dx, y1, mixes[k - 2] if k >= 2 else None, B, n_connected=n_conn)
+            torch_cuda.cuda.synchronize()
+            want_mix.append(m.cpu().numpy())
+            want_out.append(y0.cpu().numpy())
+            got_out.append(y1.cpu().numpy())
+        eng.mixpipe_flush(mixes[blocks - 2], mixes[blocks - 1], n_connected=n_conn)
+        torch_cuda.cuda.synchronize()
+        for k in range(blocks):
+            assert np.array_equal(got_out[k], want_out[k]), (k, "out")
+            assert np.array_equal(mixes[k].cpu().numpy().view(np.uint32), want_mix[k].view(np.uint32)), (N, tile, n_conn, k)
+    # a single block in flight, and changing n_frames without a flush is refused
+    eng.reset()
+    dx = torch_cuda.from_numpy(dspfx.to_layout(x[:B], tile)).cuda()
+    y = torch_cuda.empty_like(dx)
+    m1 = torch_cuda.empty(B, device="cuda")
+    eng.process_mixpipe(dx, y, None, B)
+    eng.mixpipe_flush(None, m1)
+    ref_eng.reset()
+    m0 = torch_cuda.empty(B, device="cuda")
+    ref_eng.process(dx, out=y, mix=m0, n_frames=B)
+    torch_cuda.cuda.synchronize()
+    assert torch_cuda.equal(m0, m1)
+    eng.process_mixpipe(dx, y, None, B)
+    with pytest.raises(dspfx.DspfxError):
+        eng.process_mixpipe(dx, y, None, 64)
