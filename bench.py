@@ -249,25 +249,34 @@ def main():
     # profiles/r01_mixpipe.txt).  Several GPUs: per-wave partials are collected on a second stream, all-reduced
     # over RCCL and divided there, overlapping the next block's chain kernel (parallel.MixBus).
     # DSPFX_BENCH_MIX = pipe | deferred | inline selects the path for A/B runs.
-    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "deferred" if (use_dist or world > 1) else "pipe")
-    if (use_dist or world > 1) and mix_mode != "deferred":
-        raise SystemExit("multi-GPU runs use the deferred mix bus")
+    dist_run = use_dist or world > 1
+    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "pipe")
     mix_stream = torch.cuda.Stream(device=dev)
     ms = mix_stream.cuda_stream
-    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms),
-                   world=2 if (use_dist and world == 1) else world)   # forced-dist: take the collective path
+    # Several GPUs with the in-kernel pipeline: the per-rank sums of BATCH blocks are all-reduced in one RCCL
+    # call on the second stream (one event marker on the compute stream per BATCH blocks instead of per block),
+    # then divided by the global channel count there (parallel.MixBus over a [BATCH * B] buffer).
+    BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
+    bus_world = 2 if (use_dist and world == 1) else world          # forced-dist: take the collective path
+    compute_stream_obj = torch.cuda.current_stream()
+    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
+    pbus = (P.PipelinedMixBus(eng, total_channels, B, compute_stream_obj, mix_stream, bus_world, batch=BATCH, device=dev)
+            if (use_mix and dist_run and mix_mode == "pipe") else None)
     pipe_fill = [0]
 
     def step(k):
         if not use_mix:
             eng.process(xs[k % n_in], out=y, n_frames=B, stream=stream)
             return
+        if pbus is not None:
+            pbus.step(xs[k % n_in], y)
+            return
         m = mixes[k & 3]
         if mix_mode == "pipe":
             eng.process_mixpipe(xs[k % n_in], y, m, B, n_connected=total_channels, stream=stream)
             pipe_fill[0] += 1
             return
-        if mix_mode == "inline":
+        if mix_mode == "inline" and not dist_run:
             eng.process(xs[k % n_in], out=y, mix=m, n_frames=B, stream=stream)
             eng.mix_finish(m, B, total_channels, stream)
             return
@@ -277,6 +286,9 @@ def main():
             bus.submit(m)
 
     def drain():
+        if pbus is not None:
+            pbus.drain()
+            return
         if use_mix and mix_mode == "pipe":
             if pipe_fill[0]:
                 eng.mixpipe_flush(mixes[2] if pipe_fill[0] >= 2 else None, mixes[3], n_connected=total_channels, stream=stream)

@@ -79,3 +79,72 @@ class MixBus:
     def drain(self):
         """Complete the last submitted block (call before reading its mix buffer)."""
         self._complete_pending()
+
+
+class PipelinedMixBus:
+    """Cross-rank mix bus on top of the in-kernel pipeline (`Engine.process_mixpipe`).
+
+    The chain kernels of a rank run back to back on the compute stream; each launch delivers the rank-local,
+    un-normalised bus of the block submitted two calls earlier into a row of a ring buffer.  Every `batch`
+    blocks ONE event marker is put on the compute stream, and the second stream all-reduces the `batch` rows in
+    one RCCL call and applies the Output-node hop with the global channel count (`MixBus` over a
+    [batch * n_frames] buffer).  Three rings decouple the streams: a ring is reused two submits after its own,
+    when its collective and division have long finished (checked with an event query, no stall in steady state).
+    `results()` after `drain()` returns {block index: tensor view} for the blocks still held in the rings.
+    """
+
+    def __init__(self, engine, total_channels: int, n_frames: int, compute_stream, mix_stream, world: int,
+                 batch: int = 8, device=None):
+        import torch
+        self.torch, self.eng = torch, engine
+        self.nf, self.batch = int(n_frames), int(batch)
+        self.cs, self.ms = compute_stream, mix_stream
+        self.rings = [torch.zeros(self.batch * self.nf, dtype=torch.float32, device=device) for _ in range(3)]
+        self.bus = MixBus(total_channels, self.batch * self.nf,
+                          lambda m, nf, n: engine.mix_finish(m, nf, n, mix_stream.cuda_stream), world=world)
+        self.count = 0            # blocks submitted since the last drain
+        self.submitted = 0        # batches handed to the second stream
+        self.events = {}          # batch index -> event recorded on the second stream after its submit
+
+    def _row(self, j):
+        q, r = divmod(j, self.batch)
+        return self.rings[q % 3][r * self.nf:(r + 1) * self.nf]
+
+    def _submit(self, q):
+        torch = self.torch
+        ev = torch.cuda.Event()
+        ev.record(self.cs)
+        self.ms.wait_event(ev)
+        with torch.cuda.stream(self.ms):
+            self.bus.submit(self.rings[q % 3])       # also completes batch q-1 (wait + Output hop)
+            done = torch.cuda.Event()
+            done.record(self.ms)
+        self.events[q] = done
+        self.events.pop(q - 3, None)
+        self.submitted = q + 1
+
+    def step(self, x, out, side=None):
+        j = self.count - 2                           # this call delivers the bus of block j
+        row = None
+        if j >= 0:
+            q, r = divmod(j, self.batch)
+            if r == 0 and (q - 2) in self.events:    # ring q % 3 last held batch q-3, finished by submit q-2
+                if not self.events[q - 2].query():
+                    self.cs.wait_event(self.events[q - 2])
+            row = self._row(j)
+        self.eng.process_mixpipe(x, out, row, self.nf, n_connected=0, side=side, stream=self.cs.cuda_stream)
+        self.count += 1
+        if j >= 0 and (j + 1) % self.batch == 0:
+            self._submit(j // self.batch)
+
+    def drain(self):
+        n = self.count
+        if n:
+            self.eng.mixpipe_flush(self._row(n - 2) if n >= 2 else None, self._row(n - 1), n_connected=0,
+                                   stream=self.cs.cuda_stream)
+            for q in range(self.submitted, (n - 1) // self.batch + 1):    # partly filled rings: unused rows ride along
+                self._submit(q)
+        with self.torch.cuda.stream(self.ms):
+            self.bus.drain()
+        self.count, self.submitted = 0, 0
+        self.events.clear()

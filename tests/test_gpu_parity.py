@@ -983,3 +983,50 @@ def test_mix_bus_pipelined_inside_the_kernel(dspfx, torch_cuda, N, tile):
     eng.process_mixpipe(dx, y, None, B)
     with pytest.raises(dspfx.DspfxError):
         eng.process_mixpipe(dx, y, None, 64)
+
+
+def test_pipelined_mix_bus_with_batched_collective_path(dspfx, torch_cuda):
+    """parallel.PipelinedMixBus (the multi-GPU form of the in-kernel pipeline; world = 1 here, so the RCCL call
+    is skipped but rings, events, batching and drain are the real thing): every block's bus equals
+    dspfx_process(mix) + dspfx_mix_finish bit for bit, including the partly filled last batch."""
+    from dsp_stuff_amd import parallel as P
+    N, B, batch = 4096 * 5, 128, 4
+    chain = chain5(dspfx, 256)
+    ref_eng, eng = dspfx.Engine(N, B), dspfx.Engine(N, B)
+    ref_eng.set_chain(chain)
+    eng.set_chain(chain)
+    cs, ms = torch_cuda.cuda.Stream(), torch_cuda.cuda.Stream()
+    for blocks in (1, 2, 3, 9, 13):                 # 9 and 13 leave 1 row / a ring boundary inside the flush
+        ref_eng.reset()
+        eng.reset()
+        x = noise_block(N, B * blocks, seed=blocks)
+        want = []
+        for k in range(blocks):
+            dx = torch_cuda.from_numpy(x[k * B:(k + 1) * B]).cuda()
+            y = torch_cuda.empty_like(dx)
+            m = torch_cuda.empty(B, device="cuda")
+            ref_eng.process(dx, out=y, mix=m, n_frames=B)
+            ref_eng.mix_finish(m, B, 3 * N)
+            torch_cuda.cuda.synchronize()
+            want.append(m.cpu().numpy())
+        with torch_cuda.cuda.stream(cs):
+            pb = P.PipelinedMixBus(eng, 3 * N, B, cs, ms, world=1, batch=batch, device="cuda")
+            dxs = [torch_cuda.from_numpy(x[k * B:(k + 1) * B]).cuda() for k in range(blocks)]
+            y = torch_cuda.empty_like(dxs[0])
+            torch_cuda.cuda.synchronize()
+            got = {}
+            for k in range(blocks):
+                pb.step(dxs[k], y)
+                # a ring is only reused three batches later: read completed batches before that happens
+                if k >= 2 and (k - 2 + 1) % batch == 0:
+                    torch_cuda.cuda.synchronize()
+                    q = (k - 2) // batch
+                    for j in range(q * batch, (q + 1) * batch):
+                        got[j] = pb._row(j).cpu().numpy().copy()
+            rows = {j: pb._row(j) for j in range(blocks) if j not in got}
+            pb.drain()
+            torch_cuda.cuda.synchronize()
+            for j, r in rows.items():
+                got[j] = r.cpu().numpy().copy()
+        for k in range(blocks):
+            assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (blocks, k)
