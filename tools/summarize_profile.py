@@ -56,3 +56,25 @@ tr[f"cfg5:{N}:{B}"] = {"hbm_bytes_per_launch": total, "source": f"profiles/{rnd}
                        "calibrated on the copy kernel: FETCH_SIZE x2, WRITE_SIZE x1)"}
 json.dump(tr, open(tr_path, "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
+
+# Kernel durations of the timed region only (the --stats average also covers buffer rating and warm-up launches),
+# next to what bench.py itself reported in that traced run: the two must agree.
+import statistics
+rows = [r for r in csv.DictReader(open(os.path.join(src, "trace", "cfg5_kernel_trace.csv")))]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+ch = [r for r in rows if "chain_kernel" in r["Kernel_Name"] and "chain_dyn" not in r["Kernel_Name"]]
+dur = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in ch]
+last = dur[-100:]
+gaps = [(int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) / 1e3 for a, b in zip(ch[-100:], ch[-99:])]
+bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().splitlines()[-1])
+summ = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 200 --no-cpu-baseline",
+        "kernel": ch[0]["Kernel_Name"],
+        "all_launches": {"n": len(dur), "avg_us": sum(dur) / len(dur),
+                         "note": "buffer rating (21 x 192 launches), warm-up (200) and the timed region (100); "
+                                 "ring tuning runs a different kernel"},
+        "timed_region_last_100": {"avg_us": sum(last) / len(last), "median_us": statistics.median(last),
+                                  "gap_median_us": statistics.median(gaps)},
+        "bench_reported_same_run": {"ms_per_step": bench["ms_per_step"], "kernel_ms_avg": bench["roofline"]["kernel_ms_avg"],
+                                    "mix_bus": bench["config"]["mix_bus"]}}
+json.dump(summ, open(os.path.join(dst, f"{rnd}_kernel_trace_summary.json"), "w"), indent=1)
+print(json.dumps(summ["timed_region_last_100"]), json.dumps(summ["bench_reported_same_run"]))
