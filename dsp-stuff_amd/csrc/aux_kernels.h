@@ -42,9 +42,6 @@ int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hi
 // dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)
 void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
                       unsigned nrows, bool to_dense, hipStream_t s);
-// streams one ring group the way the delay node does (nontemporal load + store of every element):
-// the placement probe times this per group
-void launch_ring_probe(float *group, size_t n_floats, hipStream_t s);
 // dst[f][c] = noise(seed, c0 + c, n_abs0 + f)
 void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
                   const Layout &lay, hipStream_t s);

@@ -151,23 +151,6 @@ void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W
                        to_dense ? 1 : 0);
 }
 
-// Placement probe: nontemporal read-modify-write of a whole group, 8 bytes per lane like the chain kernel.
-__global__ void __launch_bounds__(WG) ring_probe_kernel(float *group, size_t n2, float one) {
-    typedef float v2 __attribute__((ext_vector_type(2)));
-    v2 *p = reinterpret_cast<v2 *>(group);
-    for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n2; i += (size_t)gridDim.x * WG) {
-        v2 t = __builtin_nontemporal_load(p + i);
-        t = t * one;                                   // run-time factor: keeps the load/store pair alive
-        __builtin_nontemporal_store(t, p + i);
-    }
-}
-void launch_ring_probe(float *group, size_t n_floats, hipStream_t s) {
-    const size_t n2 = n_floats / 2;
-    size_t blocks = (n2 + WG - 1) / WG;
-    if (blocks > 256 * 8) blocks = 256 * 8;
-    if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(ring_probe_kernel, dim3((unsigned)blocks), dim3(WG), 0, s, group, n2, 1.0f);
-}
 
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + WG - 1) / WG), dim3(WG), 0, s, a);

@@ -905,8 +905,6 @@ __device__ __forceinline__ bool mixbus_lane_writes(int lane) {
 // Placement only affects speed, never results (every block index is still covered exactly once).
 __device__ __forceinline__ unsigned work_block(int remap) {
     const unsigned b = blockIdx.x, nb = gridDim.x;
-    if (remap == 2 && (nb & (nb - 1)) == 0) return (b * 0x9E3779B1u) & (nb - 1);   // experiment: scatter (odd multiplier = bijection)
-    if (remap == 3 && (nb & (nb - 1)) == 0) return __brev(b) >> (__clz(nb) + 1);    // experiment: bit reversal
     if (!remap || (nb & 7u)) return b;
     return (b & 7u) * (nb >> 3) + (b >> 3);
 }
@@ -990,7 +988,7 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // for the whole block and touched once per chunk per stateful node.
 // GUARD=true: one-wave tail launch whose out-of-range lanes stay alive with zeros.
 // MOD=true additionally evaluates connected / latched `as_input` sliders (control ports); it is a
-// separate instantiation because those paths double the register footprint (239 vs 113 VGPRs).
+// separate instantiation because those paths nearly double the register footprint (it runs at F=4).
 template <int F, bool GUARD, bool FAST, bool MOD, bool LIBM>
 __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, const WaveAddr &w, bool active, unsigned f0,
                                           int lane, unsigned wave_global) {
