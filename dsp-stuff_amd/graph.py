@@ -16,8 +16,10 @@ Mux / Demux (nodes/mux.rs:42-55, nodes/demux.rs:42-58) are pure routing and cost
 the identity on its selected port (links into the other port are computed but unused, as in the reference), a
 demux is the identity whose unselected output port delivers zeros -- still a connected pipe for whoever averages it.
 
-Not expressible: cycles (the reference's scheduler would deadlock on them too), pitch / muff and the visualiser
-nodes, slider ports with fan-in.
+The display-only nodes (pitch detector, wave view, spectrogram) produce no signal; they are dropped on import.
+
+Not expressible: cycles (the reference's scheduler would deadlock on them too), muff (GPL crate, source absent),
+slider ports with fan-in.
 """
 from __future__ import annotations
 
@@ -27,7 +29,9 @@ from typing import Dict, List, Optional, Tuple
 from . import ADD, GAIN, LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, SIGNAL_GEN, Engine, NodeSpec
 from .config import _TABLE, DspConfigError, _node_from_cfg
 
-_UNSUPPORTED = {"muff", "pitch", "wave_view", "spectrogram"}
+_UNSUPPORTED = {"muff"}                                # GPL crate, source not in the reference tree
+_SINKS = {"pitch", "wave_view", "spectrogram"}          # display-only: `process` writes no output (pitch.rs:120-146,
+                                                        # wave_view.rs:157-175), so they and the links into them are dropped
 _ROUTING = {"mux", "demux"}
 ZERO = -1          # pseudo producer: the unselected output port of a demux (a connected pipe that carries zeros)
 
@@ -55,8 +59,12 @@ class Graph:
         except (KeyError, TypeError, ValueError) as e:
             raise DspConfigError(f"not a DSPConfig document: {e}") from None
         self.nodes: Dict[int, _GNode] = {}
+        self.dropped: List[int] = []
         for n in raw_nodes:
             tn = n["typename"]
+            if tn in _SINKS:
+                self.dropped.append(int(n["id"]))
+                continue
             if tn in _UNSUPPORTED:
                 raise DspConfigError(f"node type {tn!r} is outside the accelerated path")
             if tn not in _TABLE and tn not in _ROUTING and tn not in ("input", "output"):
@@ -82,6 +90,8 @@ class Graph:
             raise DspConfigError(f"link refers to unknown {which[:-1]} port {port_id} of node {node_id}")
 
         for (ln, lp), (rn, rp) in raw_links:
+            if rn in self.dropped:
+                continue
             if ln not in self.nodes or rn not in self.nodes:
                 raise DspConfigError("link refers to a missing node")
             oname = port_name(ln, lp, "outputs")

@@ -77,3 +77,29 @@ def test_mux_demux_routing_semantics(dspfx):
         branch_id, unread = (1, 2) if in_port == "A" else (2, 1)
         sel, other_id = (5, 6) if out_port == "A" else (6, 5)
         assert got == sorted([sorted([branch_id, 3, 4, sel]), [unread], [other_id]]), got
+
+
+def test_display_only_nodes_are_dropped(dspfx):
+    """pitch / wave_view / spectrogram write no output (pitch.rs:120-146, wave_view.rs:157-175): a graph with
+    them evaluates like the graph without them, and the producer they tap keeps fusing with its only real consumer."""
+    from dsp_stuff_amd import config, graph as G
+    chain = [dspfx.BiQuad(), dspfx.Gain(0.5), dspfx.HighPass(0.2)]
+    doc = json.loads(config.dump_dspconfig(chain))
+    tap = doc["nodes"][1]                                   # the biquad
+    for k, tn in enumerate(("wave_view", "pitch", "spectrogram")):
+        nid, pid = 500 + k, 600 + k
+        doc["nodes"].append({"id": nid, "typename": tn, "position": [0, 0], "cfg": {"id": nid, "inputs": {"in": pid}, "outputs": {}}})
+        doc["links"].append({"lhs": [tap["id"], tap["cfg"]["outputs"]["out"]], "rhs": [nid, pid]})
+    g, plain = G.Graph(json.dumps(doc)), G.Graph(config.dump_dspconfig(chain))
+    assert sorted(g.dropped) == [500, 501, 502] and set(g.nodes) == set(plain.nodes)
+    runs, _ = G.plan_runs(g)
+    assert len(runs) == 1 and len(runs[0].nodes) == 3
+    x = O.noise(4, np.arange(2), np.arange(256))
+    assert np.array_equal(graph_eval.run_graph(g, x), graph_eval.run_graph(plain, x))
+    bad = json.loads(config.dump_dspconfig(chain))
+    bad["nodes"][1]["typename"] = "muff"
+    try:
+        G.Graph(json.dumps(bad))
+        assert False
+    except config.DspConfigError as e:
+        assert "outside the accelerated path" in str(e)
