@@ -40,7 +40,7 @@ EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
-    "dspfx_reset", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
+    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
@@ -105,6 +105,7 @@ def lib():
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_tune_placement.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_mixpipe.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_mixpipe_flush.argtypes = [vp, f32p, f32p, C.c_uint64, vp]
     L.dspfx_link_average.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, f32p, C.c_uint32, vp]
@@ -376,6 +377,11 @@ class Engine:
     def mix_finish(self, mix, n_frames: int, n_connected: int, stream: int = 0):
         self._chk(self.L.dspfx_mix_finish(self.h, _ptr(mix), int(n_frames), int(n_connected),
                                           C.c_void_p(stream) if stream else None))
+
+    def tune_placement(self, x, out, n_frames: int, side=None, stream: int = 0):
+        """Re-tune the delay rings' placement with the real chain kernels on the caller's buffers (resets DSP state)."""
+        self._chk(self.L.dspfx_tune_placement(self.h, _ptr(x), _ptr(side), _ptr(out), int(n_frames),
+                                              C.c_void_p(stream) if stream else None))
 
     def process_mixpipe(self, x, out, mix, n_frames: int, n_connected: int = 0, side=None, stream: int = 0):
         """One block with the mix bus pipelined inside the chain kernel: `mix` receives the bus of the block

@@ -970,6 +970,102 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
 
 // ------------------------------------------------------------- the hot path
 
+// Placement tuning against the caller's own buffers (see include/dspfx.h).  Every candidate 128-row group of every
+// large delay ring is timed with the REAL chain (all stages, the engine's chosen kernels) reading `in` and writing
+// `out`: the node temporarily becomes a 128-row ring made of that one group.  The fastest groups are kept.
+extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
+                                    void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
+    if (n_frames == 0 || n_frames > e->desc.max_frames || n_frames > RING_GROUP_ROWS)
+        return fail(e, DSPFX_ERR_INVALID, "n_frames must be 1..%u here", std::min<uint32_t>(e->desc.max_frames, RING_GROUP_ROWS));
+    if (e->collect_due || e->mp_count) return fail(e, DSPFX_ERR_STATE, "flush the mix pipeline before tuning");
+    HIPCHK(e, hipSetDevice(e->device));
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    HIPCHK(e, hipEventCreate(&ea));
+    HIPCHK(e, hipEventCreate(&eb));
+    int rc = DSPFX_OK;
+    const size_t tile_frames = n_frames;
+    for (Node &n : e->nodes) {
+        if (n.d.kind != DSPFX_REVERB) continue;
+        const size_t gbytes = n.group_floats * sizeof(float);
+        if (gbytes < ((size_t)64 << 20)) continue;
+        const size_t G = n.groups.size();
+        size_t free_b = 0, total_b = 0;
+        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
+        const size_t reserve = (size_t)8 << 30;
+        size_t extra = free_b > reserve ? std::min(G, (free_b - reserve) / gbytes) : 0;
+        std::vector<float *> cand = n.groups;
+        for (size_t k = 0; k < extra; ++k) {
+            float *g = nullptr;
+            if (big_alloc((void **)&g, gbytes) != hipSuccess) break;
+            if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); break; }
+            cand.push_back(g);
+        }
+        // the node as a one-group ring
+        const uint32_t D0 = n.D, pos0 = n.pos, min0 = e->min_delay;
+        float **table0 = n.d_groups;
+        float **d_one = nullptr;
+        HIPCHK(e, hipMalloc((void **)&d_one, sizeof(float *)));
+        n.D = RING_GROUP_ROWS;
+        n.d_groups = d_one;
+        std::vector<float> t(cand.size(), 0.0f);
+        for (size_t g = 0; g < cand.size() && rc == DSPFX_OK; ++g) {
+            HIPCHK(e, hipMemcpyAsync(d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s));
+            float best = 1e30f;
+            for (int rep = 0; rep < 3 && rc == DSPFX_OK; ++rep) {
+                n.pos = 0;
+                (void)hipEventRecord(ea, s);
+                rc = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
+                (void)hipEventRecord(eb, s);
+                if (rc) break;
+                HIPCHK(e, hipEventSynchronize(eb));
+                float ms = 0.0f;
+                (void)hipEventElapsedTime(&ms, ea, eb);
+                if (rep) best = std::min(best, ms);
+            }
+            t[g] = best;
+        }
+        n.D = D0;
+        n.pos = pos0;
+        n.d_groups = table0;
+        e->min_delay = min0;
+        (void)hipFree(d_one);
+        if (rc) {
+            for (size_t i = G; i < cand.size(); ++i) (void)hipFree(cand[i]);
+            break;
+        }
+        if (getenv("DSPFX_RING_TUNE_DEBUG")) {
+            fprintf(stderr, "placement tuning ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
+            for (float v : t) fprintf(stderr, " %.3f", v);
+            fprintf(stderr, "\n");
+        }
+        std::vector<size_t> order(cand.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
+        std::vector<char> keep(cand.size(), 0);
+        for (size_t i = 0; i < G; ++i) keep[order[i]] = 1;
+        std::vector<float *> chosen;
+        int replaced = 0;
+        for (size_t i = 0; i < cand.size(); ++i) {
+            if (keep[i]) {
+                chosen.push_back(cand[i]);
+                if (i >= G) ++replaced;
+            } else {
+                (void)hipFree(cand[i]);
+            }
+        }
+        n.groups = chosen;
+        n.ring_replaced = replaced;
+        HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
+    }
+    (void)hipEventDestroy(ea);
+    (void)hipEventDestroy(eb);
+    if (rc) return rc;
+    return dspfx_reset(e);   // probing ran garbage through the filters and the rings
+}
+
 extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                              uint32_t n_frames, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;

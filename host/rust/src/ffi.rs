@@ -117,6 +117,7 @@ extern "C" {
     pub fn dspfx_set_taps(e: *mut dspfx_engine, node: c_int, taps_reversed: *const f64, n_taps: u32, mode: c_int) -> c_int;
     pub fn dspfx_reset(e: *mut dspfx_engine) -> c_int;
 
+    pub fn dspfx_tune_placement(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_process(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_process_ctl(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, ctl: *const dspfx_ctl, n_ctl: c_int, stream: *mut c_void) -> c_int;
     pub fn dspfx_process_host(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32) -> c_int;

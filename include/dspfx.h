@@ -211,6 +211,15 @@ typedef struct dspfx_ctl {
 } dspfx_ctl;
 int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                       uint32_t n_frames, const dspfx_ctl *ctl, int n_ctl, void *stream);
+/* Placement tuning against the caller's own buffers.  Large delay rings are tables of separately allocated
+ * 128-row groups, and how fast a group streams depends on where it landed physically RELATIVE to the sample
+ * buffers it is streamed with (placement).  dspfx_chain_set already keeps the fastest of up to 2x
+ * candidate groups, judged with scratch buffers; this call repeats that with the real chain kernels reading
+ * `in` and writing `out` -- the buffers the host will keep using -- and keeps the fastest groups again.
+ * Setup-time only (about 0.5 s at 94 GiB); it RESETS all DSP state; n_frames <= 128.  Results never change,
+ * only speed. */
+int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
+                         void *stream);
 /* Same with HOST buffers (what a Rust `process(&[f32], &mut [f32])` holds):
  * H2D copy, process, D2H copy, synchronous. */
 int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,

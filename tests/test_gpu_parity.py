@@ -1030,3 +1030,34 @@ def test_pipelined_mix_bus_with_batched_collective_path(dspfx, torch_cuda):
                 got[j] = r.cpu().numpy().copy()
         for k in range(blocks):
             assert np.array_equal(got[k].view(np.uint32), want[k].view(np.uint32)), (blocks, k)
+
+
+def test_tune_placement_changes_speed_not_results(dspfx, torch_cuda):
+    """dspfx_tune_placement re-times the ring groups with the real chain on the caller's buffers and keeps the
+    fastest; it resets DSP state and must not change a single output bit."""
+    N, B, blocks = 131072, 128, 5            # 64 MiB ring groups: large enough for the tuner to engage
+    chain = chain5(dspfx, 300)               # 3 groups, the last one partly used
+    x = noise_block(N, B * blocks)
+    eng, ref = dspfx.Engine(N, B, tile_channels=256), dspfx.Engine(N, B, tile_channels=256)
+    eng.set_chain(chain)
+    ref.set_chain(chain)
+    dxs = [torch_cuda.from_numpy(dspfx.to_layout(x[k * B:(k + 1) * B], 256)).cuda() for k in range(blocks)]
+    y, y_ref = torch_cuda.empty_like(dxs[0]), torch_cuda.empty_like(dxs[0])
+    eng.process(dxs[0], out=y, n_frames=B)                       # some state, which tuning must wipe
+    eng.tune_placement(dxs[0], y, B)
+    assert "re-placed" in eng.describe()
+    for k in range(blocks):
+        eng.process(dxs[k], out=y, n_frames=B)
+        ref.process(dxs[k], out=y_ref, n_frames=B)
+        torch_cuda.cuda.synchronize()
+        assert torch_cuda.equal(y, y_ref), k
+    with pytest.raises(dspfx.DspfxError):
+        eng.tune_placement(dxs[0], None, B)
+    eng.process_mixpipe(dxs[0], y, None, B)
+    with pytest.raises(dspfx.DspfxError):                       # blocks in the mix pipeline: flush first
+        eng.tune_placement(dxs[0], y, B)
+    # no large ring: a no-op that still resets state
+    small = dspfx.Engine(4096, B)
+    small.set_chain(chain3(dspfx, 256))
+    t = torch_cuda.zeros((B, 4096), device="cuda")
+    small.tune_placement(t, t, B)

@@ -7,6 +7,6 @@ for l in fileinput.input():
         continue
     d = json.loads(l)
     r = d["roofline"]
-    print("%.4f ms/step  %.3e samples/s  %s kern %.4f ms  %.0f %s frac %.3f  probe %s  %s" % (
+    print("%.4f ms/step  %.3e samples/s  %s kern %.4f ms  %.0f %s frac %.3f  tune %s  %s" % (
         d["ms_per_step"], d["value"], r["kernel"], r["kernel_ms_avg"], r["achieved"], r["unit"], r["frac"],
-        (lambda pp: pp and {k: pp[k] for k in ("as_input_ms", "as_output_ms", "output") if k in pp})(d["config"].get("placement_probe")), [p for p in d["config"]["plan"] if "ring" in p]))
+        d["config"].get("placement_tuning"), [p for p in d["config"]["plan"] if "ring" in p]))
