@@ -986,7 +986,7 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
     HIPCHK(e, hipEventCreate(&ea));
     HIPCHK(e, hipEventCreate(&eb));
     int rc = DSPFX_OK;
-    const size_t tile_frames = n_frames;
+    const size_t tile_frames = e->desc.max_frames;   // the buffers are laid out like a full block of the engine
     for (Node &n : e->nodes) {
         if (n.d.kind != DSPFX_REVERB) continue;
         const size_t gbytes = n.group_floats * sizeof(float);

@@ -216,8 +216,8 @@ int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float
  * buffers it is streamed with (placement).  dspfx_chain_set already keeps the fastest of up to 2x
  * candidate groups, judged with scratch buffers; this call repeats that with the real chain kernels reading
  * `in` and writing `out` -- the buffers the host will keep using -- and keeps the fastest groups again.
- * Setup-time only (about 0.5 s at 94 GiB); it RESETS all DSP state; n_frames <= 128.  Results never change,
- * only speed. */
+ * `in` / `out` are laid out like a block of max_frames frames; n_frames <= 128 of it are streamed per probe.
+ * Setup-time only (about 3 s at 94 GiB); it RESETS all DSP state.  Results never change, only speed. */
 int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                          void *stream);
 /* Same with HOST buffers (what a Rust `process(&[f32], &mut [f32])` holds):

@@ -70,8 +70,9 @@ bench = json.loads(open(os.path.join(src, "trace_bench.json")).read().strip().sp
 summ = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 200 --no-cpu-baseline",
         "kernel": ch[0]["Kernel_Name"],
         "all_launches": {"n": len(dur), "avg_us": sum(dur) / len(dur),
-                         "note": "buffer rating (21 x 192 launches), warm-up (200) and the timed region (100); "
-                                 "ring tuning runs a different kernel"},
+                         "note": "placement tuning against the real buffers (candidate groups x 3), two 192-launch probes, "
+                                 "warm-up (200) and the timed region (100); the scratch-buffer ring tuning at set_chain "
+                                 "runs the interpreter kernel"},
         "timed_region_last_100": {"avg_us": sum(last) / len(last), "median_us": statistics.median(last),
                                   "gap_median_us": statistics.median(gaps)},
         "bench_reported_same_run": {"ms_per_step": bench["ms_per_step"], "kernel_ms_avg": bench["roofline"]["kernel_ms_avg"],
