@@ -150,6 +150,10 @@ class Engine {
     void mix_finish(float *mix, std::uint32_t n_frames, std::uint64_t n_connected, void *stream = nullptr) {
         chk(dspfx_mix_finish(e_, mix, n_frames, n_connected, stream));
     }
+    // re-tune the delay rings' placement against the buffers the host will keep using (resets DSP state)
+    void tune_placement(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr, void *stream = nullptr) {
+        chk(dspfx_tune_placement(e_, in, side, out, n_frames, stream));
+    }
     // collect_and_average over several pipes (node.rs:162-194): dst = (0 + srcs...) / f32(0.0001 + n)
     void link_average(const std::vector<const float *> &srcs, float *dst, std::uint32_t n_frames, void *stream = nullptr) {
         chk(dspfx_link_average(e_, srcs.data(), static_cast<int>(srcs.size()), dst, n_frames, stream));
