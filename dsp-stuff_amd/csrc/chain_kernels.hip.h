@@ -408,18 +408,22 @@ __device__ __forceinline__ float *uniform_ptr(float *p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (float *)(((unsigned long long)hi << 32) | lo);
 }
+// wave-uniform base of ring row (pos + f0 + f) for this wave's first channel
+__device__ __forceinline__ float *ring_row(const SlotArgs &s, const Ctx &cx, int f) {
+    unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
+    r = r >= s.D ? r - s.D : r;
+    // the group table is never written by a kernel: read it through the constant address space so the load
+    // is a scalar one whatever stores precede it
+    typedef float *fptr_t;
+    const __attribute__((address_space(4))) fptr_t *tab = (const __attribute__((address_space(4))) fptr_t *)s.groups;
+    float *gb = tab[__builtin_amdgcn_readfirstlane(r >> 7)];
+    return uniform_ptr(gb + cx.ring_base0 + (size_t)(r & 127u) * cx.ld);
+}
 template <int F, int CPL, bool GUARD>
 __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, RingPre<F, CPL> &pre) {
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
-        r = r >= s.D ? r - s.D : r;
-        // the group table is never written by a kernel: read it through the constant address space so the load
-        // is a scalar one whatever stores precede it
-        typedef float *fptr_t;
-        const __attribute__((address_space(4))) fptr_t *tab = (const __attribute__((address_space(4))) fptr_t *)s.groups;
-        float *gb = tab[__builtin_amdgcn_readfirstlane(r >> 7)];
-        pre.row[f] = uniform_ptr(gb + cx.ring_base0 + (size_t)(r & 127u) * cx.ld);
+        pre.row[f] = ring_row(s, cx, f);
         load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(pre.row[f], cx.ring_off), pre.tap[f], cx.active);
     }
 }
@@ -989,53 +993,63 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // GUARD=true: one-wave tail launch whose out-of-range lanes stay alive with zeros.
 // MOD=true additionally evaluates connected / latched `as_input` sliders (control ports); it is a
 // separate instantiation because those paths nearly double the register footprint (it runs at F=4).
-template <int F, bool GUARD, bool FAST, bool MOD, bool LIBM>
+template <int F, int CPL, bool GUARD, bool FAST, bool MOD, bool LIBM>
 __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, const WaveAddr &w, bool active, unsigned f0,
                                           int lane, unsigned wave_global) {
-    float v[F][1];
+    float v[F][CPL];
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<1, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+    for (int f = 0; f < F; ++f) load_vec<CPL, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
+    // (Prefetching the first delay node's taps here, as the static kernels do, was measured: +18 VGPRs cost a wave
+    // of occupancy and the 5-node chain went from 0.4255 to 0.4565 ms.  The interpreter loads them in the node's slot.)
     int row = 0;
 #pragma unroll 1
     for (int s = 0; s < a.n_slots; ++s) {
         const SlotArgs sl = a.slot[s];   // a private copy keeps the kernarg table out of scratch
         const int ns = slot_nstate<SIG_DYN>(sl);
-        float st[4][1];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) st[k][0] = (k < ns) ? lds[(row + k) * WG + threadIdx.x] : 0.0f;
-        run_slot<SIG_DYN, F, 1, GUARD, FAST, MOD, LIBM>(sl, v, st, cx);
+        float st[4][CPL];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < ns) lds[(row + k) * WG + threadIdx.x] = st[k][0];
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) st[k][j] = (k < ns) ? lds[((row + k) * CPL + j) * WG + threadIdx.x] : 0.0f;
+        run_slot<SIG_DYN, F, CPL, GUARD, FAST, MOD, LIBM>(sl, v, st, cx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < ns) {
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) lds[((row + k) * CPL + j) * WG + threadIdx.x] = st[k][j];
+            }
         row += ns;
     }
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<1, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
-    if (a.mixpart) mixbus_partial<F, 1>(a, v, !GUARD || active, f0, lane, wave_global);
+    for (int f = 0; f < F; ++f) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+    if (a.mixpart) mixbus_partial<F, CPL>(a, v, !GUARD || active, f0, lane, wave_global);
 }
 
-// LIBM=false leaves out the f64-libm nodes (Tanh/Sin/Atan modes, overdrive, chebyshev): their register
-// footprint costs every other chain a wave of occupancy; the host picks by chain content.
-template <int F, bool GUARD, bool MOD, bool LIBM>
+// LDS: [state rows][CPL][WG] floats (conflict-free: consecutive lanes, consecutive banks)
+template <int F, int CPL, bool GUARD, bool MOD, bool LIBM>
 __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
-    extern __shared__ float lds[];   // [state rows][WG]
+    extern __shared__ float lds[];
     if (a.mp_stage) mixpipe_prologue(a);
     const unsigned tid = (blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x) * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
     const int lane = threadIdx.x & 63;
     const unsigned wave_global = a.wave_base + (tid >> 6);
-    const bool active = tid < a.n_launch;
+    const size_t rel = (size_t)tid * CPL;
+    const bool active = rel < a.n_launch;
     if (!GUARD && !active) return;                 // whole-wave uniform by construction
-    const size_t c = a.c_base + (active ? tid : 0);
+    const size_t c = a.c_base + (active ? rel : 0);
     {
         int row = 0;
 #pragma unroll 1
         for (int s = 0; s < a.n_slots; ++s) {
             const int ns = slot_nstate<SIG_DYN>(a.slot[s]), np = slot_npersist<SIG_DYN>(a.slot[s]);
             for (int k = 0; k < ns; ++k) {
-                float t[1] = {0.0f};
-                if (k < np) load_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
-                lds[(row + k) * WG + threadIdx.x] = t[0];
+                float t[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) t[j] = 0.0f;
+                if (k < np) load_vec<CPL, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) lds[((row + k) * CPL + j) * WG + threadIdx.x] = t[j];
             }
             row += ns;
         }
@@ -1043,13 +1057,13 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
     if (a.fast_div) {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
     } else {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) dyn_chunk<1, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
     }
     {
         int row = 0;
@@ -1057,13 +1071,23 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
         for (int s = 0; s < a.n_slots; ++s) {
             const int ns = slot_nstate<SIG_DYN>(a.slot[s]), np = slot_npersist<SIG_DYN>(a.slot[s]);
             if (a.slot[s].kind == K_SIGNAL_GEN) {
-                float st2[4][1] = {{lds[row * WG + threadIdx.x]}, {lds[(row + 1) * WG + threadIdx.x]}, {0.0f}, {0.0f}};
-                signal_gen_close_block<1>(a.slot[s], st2, a.nframes);
-                lds[row * WG + threadIdx.x] = st2[0][0];
+                float st2[4][CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) {
+                    st2[0][j] = lds[((row + 0) * CPL + j) * WG + threadIdx.x];
+                    st2[1][j] = lds[((row + 1) * CPL + j) * WG + threadIdx.x];
+                    st2[2][j] = 0.0f;
+                    st2[3][j] = 0.0f;
+                }
+                signal_gen_close_block<CPL>(a.slot[s], st2, a.nframes);
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) lds[((row + 0) * CPL + j) * WG + threadIdx.x] = st2[0][j];
             }
             for (int k = 0; k < np; ++k) {
-                float t[1] = {lds[(row + k) * WG + threadIdx.x]};
-                store_vec<1, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
+                float t[CPL];
+#pragma unroll
+                for (int j = 0; j < CPL; ++j) t[j] = lds[((row + k) * CPL + j) * WG + threadIdx.x];
+                store_vec<CPL, GUARD>(a.slot[s].state + (size_t)k * a.N + c, t, active);
             }
             row += ns;
         }

@@ -290,6 +290,8 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
                 ok = v->sigs[i] == sig(n.d.kind, mode, node_hop(e, st.first + i));
             }
             if (!ok) continue;
+        }
+        if (!is_dyn || v->cpl > 1) {     // the one-channel interpreter is the fallback for every N (the tail launch covers N < 64)
             if (N % (64u * v->cpl) != 0 && N < 64u * v->cpl) continue;
             if (N % v->cpl != 0) continue;   // vector loads need aligned rows
         }
@@ -298,8 +300,10 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         // Few channels (<= 2 waves per SIMD at one channel per lane): nothing hides a wave's memory latency, so
         // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
         const bool few = N <= 131072u;
-        const int want_f = is_dyn ? 16 : (few ? 16 : 8);
-        const int want_cpl = (is_dyn || !e->desc.tile_channels || few) ? 1 : 2;
+        const int want_f = (few && !is_dyn) ? 16 : 8;
+        // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
+        // the 5-node chain, 0.487 -> 0.422 on an 8-node one); the libm-heavy instantiation is VALU-bound either way
+        const int want_cpl = is_dyn ? ((few || v->libm) ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
         if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
@@ -688,7 +692,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 a.wave_base = 0;
                 const unsigned grid = grid_main;
                 ProfScope ps(e, si, stream);
-                v->launch(a, grid, WG, (unsigned)(rows * WG * sizeof(float)), stream);
+                v->launch(a, grid, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream);
             }
             a.mp_stage = 0;   // the guarded tail launch never hosts the prologue
             if (N % per_wave) {   // ragged tail: guarded one-wave blocks, lane per channel
@@ -829,7 +833,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
         if (v->sigs[0] != SIG_DYN) continue;
         if (v->guard) (v->mod ? e->tail_mod : e->tail) = v;
         else if (v->mod) e->dyn_mod = v;
-        else if (v->f == 8 && v->libm) e->dyn = v;   // fallbacks handle every node kind
+        else if (v->f == 8 && v->cpl == 1 && v->libm) e->dyn = v;   // fallbacks handle every node kind
     }
     e->mixpart_cols = (size_t)desc->channels / 64 + 8;
     if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess ||

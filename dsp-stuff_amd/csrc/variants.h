@@ -27,9 +27,9 @@ void launch_static(const ChainArgs &a, unsigned grid, unsigned block, unsigned l
     (void)lds_bytes;
     hipLaunchKernelGGL((chain_kernel<F, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
 }
-template <int F, bool GUARD, bool MOD, bool LIBM>
+template <int F, int CPL, bool GUARD, bool MOD, bool LIBM>
 void launch_dyn(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
-    hipLaunchKernelGGL((chain_dyn_kernel<F, GUARD, MOD, LIBM>), dim3(grid), dim3(block), lds_bytes, s, a);
+    hipLaunchKernelGGL((chain_dyn_kernel<F, CPL, GUARD, MOD, LIBM>), dim3(grid), dim3(block), lds_bytes, s, a);
 }
 
 // each variants_*.hip translation unit exports one of these
@@ -40,6 +40,8 @@ const Variant *variants_static5(int *n);
 #define DSPFX_STATIC_VARIANT(NAME, NSLOTS, F, CPL, ...) \
     Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, false, true, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
 #define DSPFX_DYN_VARIANT(NAME, F, GUARD, MOD, LIBM) \
-    Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, GUARD, MOD, LIBM> }
+    Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, 1, GUARD, MOD, LIBM> }
+#define DSPFX_DYN_VARIANT_C(NAME, F, CPL, LIBM) \
+    Variant { NAME, {SIG_DYN}, 0, F, CPL, false, false, LIBM, &launch_dyn<F, CPL, false, false, LIBM> }
 
 }  // namespace dspfx

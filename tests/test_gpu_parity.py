@@ -373,7 +373,8 @@ def test_chain3_and_chain5_all_variants(dspfx, torch_cuda, monkeypatch):
         for lf in (0, 1, 3):
             ref = run_oracle(ch, x, lf)
             base = None
-            for var in ("static=0,f=8", "static=0,f=4", "static=0,f=16", "static=1,f=8,cpl=1", "static=1,f=8,cpl=2",
+            for var in ("static=0,f=8,cpl=1", "static=0,f=4,cpl=1", "static=0,f=16,cpl=1", "static=0,f=8,cpl=2", "static=0,f=4,cpl=2",
+                        "static=1,f=8,cpl=1", "static=1,f=8,cpl=2", "static=1,f=32,cpl=1",
                         "static=1,f=8,cpl=4", "static=1,f=16,cpl=1", "static=1,f=16,cpl=2", "static=1,f=4,cpl=4"):
                 monkeypatch.setenv("DSPFX_VARIANT", var)
                 y = run_gpu(dspfx, torch_cuda, ch, x, lf)
@@ -1061,3 +1062,36 @@ def test_tune_placement_changes_speed_not_results(dspfx, torch_cuda):
     small.set_chain(chain3(dspfx, 256))
     t = torch_cuda.zeros((B, 4096), device="cuda")
     small.tune_placement(t, t, B)
+
+
+@pytest.mark.parametrize("variant", ["static=0,f=8,cpl=2", "static=0,f=4,cpl=2"])
+def test_two_channel_interpreter_on_every_node_and_random_chains(dspfx, torch_cuda, monkeypatch, variant):
+    """The interpreter's two-channels-per-lane instantiations (the default above 131072 channels) forced at test
+    sizes: every arithmetic node kind on its own, the libm kinds (dyn_libm_f4_c2), and seeded random chains, with a
+    ragged channel count so the one-channel guarded tail runs next to it and the mix bus spans both."""
+    monkeypatch.setenv("DSPFX_VARIANT", variant)
+    N, B, blocks = 128 * 3 + 2 * 17, 128, 3        # 384 channels in the main launch, 34 in the tail
+    x, side = noise_block(N, B * blocks), noise_block(N, B * blocks, seed=9)
+    exact, libm = _every_node(dspfx)
+    for node in exact + libm:
+        bar = 1 if any(node is e for e in exact) else LIBM_COMPOSITE_ULP
+        got, mix = run_gpu(dspfx, torch_cuda, [node], x, side=side, want_mix=True)
+        ref = run_oracle([node], x, 3, side)
+        assert ulp_diff(got, ref).max() <= bar, (variant, node.kind, node.mode)
+        want_mix = ref.astype(np.float64).sum(axis=1)
+        assert np.allclose(mix, want_mix, rtol=1e-4, atol=1e-3 * max(1.0, np.abs(want_mix).max())), (variant, node.kind)
+    eng = dspfx.Engine(N, B)
+    eng.set_chain([dspfx.Gain(0.5), dspfx.BiQuad()])
+    assert "_c2" in eng.describe(), eng.describe()
+    rng = np.random.default_rng(77)
+    for case in range(6):
+        chain = [_random_exact_node(dspfx, rng) for _ in range(int(rng.integers(2, 11)))]
+        tile = int(rng.choice([0, 64]))
+        n_ch = 448 if tile else N
+        xs, ss = np.ascontiguousarray(noise_block(n_ch, B * 4, seed=case)), np.ascontiguousarray(noise_block(n_ch, B * 4, seed=case + 50))
+        lf = int(rng.choice([0, 1, 3]))
+        got = run_gpu(dspfx, torch_cuda, chain, xs, link_flags=lf, side=ss, tile=tile, block=int(rng.choice([128, 256])))
+        ref = run_oracle(chain, xs, lf, ss)
+        ok = np.isfinite(ref)
+        assert np.array_equal(np.isfinite(got), ok)
+        assert ulp_diff(got[ok], ref[ok]).max() <= 1, (variant, case, [(n.kind, n.mode) for n in chain], tile, lf)
