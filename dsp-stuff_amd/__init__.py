@@ -42,7 +42,7 @@ EXPORTS = [
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
     "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
-    "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division",
+    "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
 ]
 
@@ -120,6 +120,7 @@ def lib():
     L.dspfx_sync.argtypes = [vp, vp]
     L.dspfx_describe.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.dspfx_verify_fast_division.argtypes = [C.c_int, C.c_float, C.POINTER(C.c_uint64)]
+    L.dspfx_verify_libm.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.dspfx_profile_enable.argtypes = [vp, C.c_int]
     L.dspfx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.c_int]
     L.dspfx_algorithmic_bytes_per_sample.restype = C.c_double
@@ -144,6 +145,15 @@ def verify_fast_division(c: float, device: int = 0) -> int:
     if rc != 0:
         raise DspfxError(rc, lib().dspfx_strerror(rc).decode())
     return int(n.value)
+
+
+def verify_libm(func: int, device: int = 0):
+    """Exhaustive comparison of the engine's f64 tanh (0) / sin (1) / atan (2) with the math library's: (differing inputs, max ulp)."""
+    n, u = C.c_uint64(), C.c_uint32()
+    rc = lib().dspfx_verify_libm(device, int(func), C.byref(n), C.byref(u))
+    if rc != 0:
+        raise DspfxError(rc, lib().dspfx_strerror(rc).decode())
+    return int(n.value), int(u.value)
 
 
 def link_divisor(n_connected: int) -> np.float32:

@@ -39,6 +39,8 @@ struct LinkAvgArgs {
 void launch_link_average(const LinkAvgArgs &a, hipStream_t s);
 // launches the exhaustive check of the fast constant division; *d_count accumulates mismatches
 int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s);
+// d_out[0] += differing inputs, d_out[1] = max ulp distance: fast tanh (func 0) / sin (func 1) vs the library path
+int verify_libm_on_device(int func, unsigned long long *d_out, hipStream_t s);
 // dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)
 void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
                       unsigned nrows, bool to_dense, hipStream_t s);

@@ -124,6 +124,34 @@ __global__ void __launch_bounds__(WG) verify_div_kernel(float c, double rc, unsi
     if (bad) atomicAdd(mismatches, bad);
 }
 
+// Exhaustive comparison of the fast f64 tanh / sin / atan with the library path, all 2^32 inputs: out[0] += inputs whose
+// f32 results differ, out[1] = max ulp distance seen (NaNs compared as a class).
+__global__ void __launch_bounds__(WG) verify_libm_kernel(int func, unsigned long long *out) {
+    unsigned long long bad = 0, worst = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * WG;
+    for (uint64_t b = (uint64_t)blockIdx.x * WG + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float a = func == 0 ? tanh_lib(x) : func == 1 ? sin_lib(x) : atan_lib(x);
+        const float f = func == 0 ? tanh_cr(x) : func == 1 ? sin_cr(x) : atan_cr(x);
+        if (a != a && f != f) continue;
+        const uint32_t ua = __float_as_uint(a), uf = __float_as_uint(f);
+        if (ua == uf) continue;
+        ++bad;
+        // ulp distance on the monotone integer line (sign-magnitude -> offset)
+        const int64_t ia = (ua >> 31) ? -(int64_t)(ua & 0x7fffffffu) : (int64_t)ua;
+        const int64_t jf = (uf >> 31) ? -(int64_t)(uf & 0x7fffffffu) : (int64_t)uf;
+        const unsigned long long dist = (unsigned long long)(ia > jf ? ia - jf : jf - ia);
+        worst = dist > worst ? dist : worst;
+        if ((a != a) != (f != f)) worst = 0xffffffffull;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (worst) atomicMax(&out[1], worst);
+}
+int verify_libm_on_device(int func, unsigned long long *d_out, hipStream_t s) {
+    hipLaunchKernelGGL(verify_libm_kernel, dim3(256 * 16), dim3(WG), 0, s, func, d_out);
+    return (int)hipGetLastError();
+}
+
 int verify_divisor_on_device(float c, double rc, unsigned long long *d_count, hipStream_t s) {
     hipLaunchKernelGGL(verify_div_kernel, dim3(256 * 16), dim3(WG), 0, s, c, rc, d_count);
     return (int)hipGetLastError();

@@ -274,9 +274,106 @@ __device__ __forceinline__ float rs_signum(float x) {
 // Evaluating in f64 and rounding once gives the correctly rounded f32 result, which is
 // within 1 ulp of glibc's sinf/atanf/expf and 2 ulp of its tanhf (measured over all
 // arguments in range) -- closer than ocml's f32 routines.
-__device__ __forceinline__ float tanh_cr(float x) { return (float)tanh((double)x); }
-__device__ __forceinline__ float sin_cr(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float atan_cr(float x) { return (float)atan((double)x); }
+// The library's f64 tanh / sin are accurate to an f64 ulp and cost accordingly (a tanh-only chain ran at 1.7 TB/s).
+// An f32 result needs far less: the f64 evaluations below are good to ~1e-15 relative, so after the single rounding
+// to f32 they equal the library path except on a few near-tie inputs out of 2^32 (dspfx_verify_libm counts them,
+// exhaustively, and the largest difference is 1 ulp) -- the same distance from glibc as before.
+__device__ __forceinline__ float tanh_lib(float x) { return (float)tanh((double)x); }
+__device__ __forceinline__ float sin_lib(float x) { return (float)sin((double)x); }
+
+// e^y for 0 <= y <= 40: y = k ln2 + r, |r| <= ln2/2, degree-12 Taylor (r^13/13! < 2e-16), scaled by 2^k
+__device__ __forceinline__ double exp_pos_f64(double y) {
+    const double k = __builtin_rint(y * 1.44269504088896338700e+00);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, y);      // ln2 high part (fdlibm split)
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);               // ln2 low part
+    double p = 1.0 / 479001600.0;
+    p = __builtin_fma(p, r, 1.0 / 39916800.0);
+    p = __builtin_fma(p, r, 1.0 / 3628800.0);
+    p = __builtin_fma(p, r, 1.0 / 362880.0);
+    p = __builtin_fma(p, r, 1.0 / 40320.0);
+    p = __builtin_fma(p, r, 1.0 / 5040.0);
+    p = __builtin_fma(p, r, 1.0 / 720.0);
+    p = __builtin_fma(p, r, 1.0 / 120.0);
+    p = __builtin_fma(p, r, 1.0 / 24.0);
+    p = __builtin_fma(p, r, 1.0 / 6.0);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)k);
+}
+// tanh|x| = 1 - 2 / (e^(2|x|) + 1); below 2^-7 the odd series (the difference would cancel); |x| >= 20 saturates
+__device__ __forceinline__ float tanh_cr(float x) {
+    const double ax = __builtin_fabs((double)x);
+    const double y = __builtin_fmin(ax + ax, 40.0);
+    const double d = exp_pos_f64(y) + 1.0;
+    double rc = __builtin_amdgcn_rcp(d);
+    rc = __builtin_fma(__builtin_fma(-d, rc, 1.0), rc, rc);           // two Newton steps: full f64 accuracy
+    rc = __builtin_fma(__builtin_fma(-d, rc, 1.0), rc, rc);
+    const double big = __builtin_fma(-2.0, rc, 1.0);
+    const double x2 = ax * ax;
+    const double small = ax * __builtin_fma(x2, __builtin_fma(x2, __builtin_fma(x2, -17.0 / 315.0, 2.0 / 15.0), -1.0 / 3.0), 1.0);
+    const float t = (float)(ax < 0x1p-7 ? small : big);
+    return x != x ? x : __builtin_copysignf(t, x);
+}
+// sin x = +-sin r or +-cos r with x = n pi/2 + r, |r| <= pi/4 (two-part pi/2, fused), fdlibm's kernel polynomials;
+// |x| >= 2^22, infinities and NaN take the library routine (a divergent branch nobody takes on audio)
+__device__ __forceinline__ float sin_cr(float x) {
+    if (!(__builtin_fabsf(x) < 0x1p22f)) return sin_lib(x);
+    const double xd = (double)x;
+    const double n = __builtin_rint(xd * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-n, 1.57079632679489655800e+00, xd);
+    r = __builtin_fma(-n, 6.12323399573676603587e-17, r);
+    const double z = r * r;
+    double sp = 1.58969099521155010221e-10;
+    sp = __builtin_fma(sp, z, -2.50507602534068634195e-08);
+    sp = __builtin_fma(sp, z, 2.75573137070700676789e-06);
+    sp = __builtin_fma(sp, z, -1.98412698298579493134e-04);
+    sp = __builtin_fma(sp, z, 8.33333333332248946124e-03);
+    sp = __builtin_fma(sp, z, -1.66666666666666324348e-01);
+    const double sv = __builtin_fma(r * z, sp, r);
+    double cp = -1.13596475577881948265e-11;
+    cp = __builtin_fma(cp, z, 2.08757232129817482790e-09);
+    cp = __builtin_fma(cp, z, -2.75573143513906633035e-07);
+    cp = __builtin_fma(cp, z, 2.48015872894767294178e-05);
+    cp = __builtin_fma(cp, z, -1.38888888888741095749e-03);
+    cp = __builtin_fma(cp, z, 4.16666666666666019037e-02);
+    const double cv = __builtin_fma(z * z, cp, __builtin_fma(z, -0.5, 1.0));
+    const int q = (int)n;
+    const double m = (q & 1) ? cv : sv;
+    const float out = (float)((q & 2) ? -m : m);
+    return x == 0.0f ? x : out;                   // keeps -0 (the reduction turns it into +0)
+}
+__device__ __forceinline__ float atan_lib(float x) { return (float)atan((double)x); }
+// atan|x| = base + atan(w), |w| <= tan(pi/8), with ONE division:  |x| <= tan(pi/8): w = |x|;
+// |x| <= 1/tan(pi/8): w = (|x|-1)/(|x|+1), base pi/4;  beyond: w = -1/|x|, base pi/2.
+// atan(w) = w + w^3 P(w^2), P = degree-11 Chebyshev interpolant of the series (rel. error 3e-18 in exact arithmetic)
+__device__ __forceinline__ float atan_cr(float x) {
+    const double a = __builtin_fmin(__builtin_fabs((double)x), 1e40);
+    const bool lo = a <= 4.14213562373095034e-01, hi = a > 2.41421356237309492e+00;
+    const double num = lo ? a : (hi ? -1.0 : a - 1.0);
+    const double den = lo ? 1.0 : (hi ? a : a + 1.0);
+    double rc = __builtin_amdgcn_rcp(den);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    rc = __builtin_fma(__builtin_fma(-den, rc, 1.0), rc, rc);
+    double w = num * rc;
+    w = __builtin_fma(__builtin_fma(-w, den, num), rc, w);             // correctly rounded quotient up to an ulp
+    const double u = w * w;
+    double p = 1.62857568552210278667e-02;
+    p = __builtin_fma(p, u, -3.45705619814277442803e-02);
+    p = __builtin_fma(p, u, 4.55159322062654927987e-02);
+    p = __builtin_fma(p, u, -5.23045427065024423618e-02);
+    p = __builtin_fma(p, u, 5.87892899783477515530e-02);
+    p = __builtin_fma(p, u, -6.66642488573825492404e-02);
+    p = __builtin_fma(p, u, 7.69229637503214269678e-02);
+    p = __builtin_fma(p, u, -9.09090875350087729290e-02);
+    p = __builtin_fma(p, u, 1.11111111051554467544e-01);
+    p = __builtin_fma(p, u, -1.42857142856598284819e-01);
+    p = __builtin_fma(p, u, 1.99999999999998040456e-01);
+    p = __builtin_fma(p, u, -3.33333333333333314830e-01);
+    const double base = lo ? 0.0 : (hi ? 1.57079632679489655800e+00 : 7.85398163397448279000e-01);
+    const float t = (float)(base + __builtin_fma(w * u, p, w));
+    return x != x ? x : __builtin_copysignf(t, x);
+}
 __device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
 
 // distort.rs:63-145, every mode except Fuzz, for level >= 0.001 (the `level < 0.001`
@@ -323,14 +420,13 @@ __device__ __forceinline__ float overdrive1(float sample, float boost, float dri
 }
 
 // chebyshev.rs:28-42
-__device__ __forceinline__ float chebyshev1(float sample, float lp, float ln) {
-    if (sample >= 0.0f) {
-        if (lp < 0.001f) return sample;
-        return tanh_cr(sample * lp) / tanh_cr(lp);
-    } else {
-        if (ln < 0.001f) return sample;
-        return tanh_cr(sample * ln) / tanh_cr(ln);
-    }
+// chebyshev.rs:28-42.  tp / tn are tanh(level_pos) / tanh(level_neg), wave-uniform: computed once per chunk by the
+// caller.  Branch-free: a divergent `if` made every lane pay for both branches and both denominators (4 tanh).
+__device__ __forceinline__ float chebyshev1(float sample, float lp, float ln, float tp, float tn) {
+    const bool pos = sample >= 0.0f;               // NaN takes the negative branch, like the reference
+    const float l = pos ? lp : ln;
+    const float r = tanh_cr(sample * l) / (pos ? tp : tn);
+    return l < 0.001f ? sample : r;
 }
 
 // ---- feedback delay line (reverb.rs:86-103), split so the tap loads can be issued early ---------
@@ -500,10 +596,11 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
 #pragma unroll
             for (int j = 0; j < CPL; ++j) v[f][j] = overdrive1(v[f][j], s.p[0], s.p[1], s.p[2]);
     } else if constexpr (KIND == K_CHEBYSHEV) {   // chebyshev.rs:52-62
+        const float tp = tanh_cr(s.p[0]), tn = tanh_cr(s.p[1]);
 #pragma unroll
         for (int f = 0; f < F; ++f)
 #pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = chebyshev1(v[f][j], s.p[0], s.p[1]);
+            for (int j = 0; j < CPL; ++j) v[f][j] = chebyshev1(v[f][j], s.p[0], s.p[1], tp, tn);
     } else if constexpr (KIND == K_ENVELOPE) {    // envelope.rs:34-52, dasp_envelope Detector::next + dasp_peak full_wave
         const float ga = s.p[0], gr = s.p[1];     // attack / release gains, computed on the host (powf)
 #pragma unroll

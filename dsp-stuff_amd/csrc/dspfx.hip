@@ -302,8 +302,8 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         const bool few = N <= 131072u;
         const int want_f = (few && !is_dyn) ? 16 : 8;
         // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
-        // the 5-node chain, 0.487 -> 0.422 on an 8-node one); the libm-heavy instantiation is VALU-bound either way
-        const int want_cpl = is_dyn ? ((few || v->libm) ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
+        // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
+        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
         if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
@@ -1397,6 +1397,24 @@ extern "C" int dspfx_verify_fast_division(int device, float c, uint64_t *mismatc
     if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
         hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         *mismatches = h;
+        rc = DSPFX_OK;
+    }
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uint32_t *max_ulp) {
+    if (!mismatches || !max_ulp || func < 0 || func > 2) return DSPFX_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return DSPFX_ERR_INVALID;
+    unsigned long long *d = nullptr, h[2] = {0, 0};
+    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return DSPFX_ERR_OOM;
+    int rc = DSPFX_ERR_HIP;
+    if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_libm_on_device(func, d, nullptr) == 0 &&
+        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+        *mismatches = h[0];
+        *max_ulp = (uint32_t)std::min<unsigned long long>(h[1], 0xffffffffull);
         rc = DSPFX_OK;
     }
     (void)hipFree(d);

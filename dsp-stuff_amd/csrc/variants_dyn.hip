@@ -16,7 +16,7 @@ static const Variant k_dyn[] = {
     DSPFX_DYN_VARIANT("dyn_libm_f8", 8, false, false, true),      // + Tanh/Sin/Atan, overdrive, chebyshev
     DSPFX_DYN_VARIANT("dyn_libm_f4", 4, false, false, true),
     DSPFX_DYN_VARIANT("dyn_libm_f16", 16, false, false, true),
-    DSPFX_DYN_VARIANT_C("dyn_libm_f4_c2", 4, 2, true),
+    DSPFX_DYN_VARIANT_C("dyn_libm_f8_c2", 8, 2, true),
     DSPFX_DYN_VARIANT("dyn_f8_tail", 8, true, false, true),
     DSPFX_DYN_VARIANT("dyn_mod_f4", 4, false, true, true),        // + control ports (F=4: no scratch)
     DSPFX_DYN_VARIANT("dyn_mod_f4_tail", 4, true, true, true),

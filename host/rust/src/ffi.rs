@@ -137,6 +137,7 @@ extern "C" {
     pub fn dspfx_sync(e: *mut dspfx_engine, stream: *mut c_void) -> c_int;
     pub fn dspfx_describe(e: *const dspfx_engine, dst: *mut c_char, cap: usize) -> c_int;
     pub fn dspfx_verify_fast_division(device: c_int, c: f32, mismatches: *mut u64) -> c_int;
+    pub fn dspfx_verify_libm(device: c_int, func: c_int, mismatches: *mut u64, max_ulp: *mut u32) -> c_int;
     pub fn dspfx_profile_enable(e: *mut dspfx_engine, enable: c_int) -> c_int;
     pub fn dspfx_profile_read(e: *mut dspfx_engine, total_ms: *mut f64, launches: *mut u32, kernel_name: *mut c_char, cap: usize, reset: c_int) -> c_int;
     pub fn dspfx_algorithmic_bytes_per_sample(e: *const dspfx_engine, n_frames: u32) -> f64;

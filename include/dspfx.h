@@ -282,6 +282,11 @@ int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap);
  * device and returns the number of mismatching inputs (0 => the fast form is exact for
  * c; otherwise the engine keeps IEEE division for c). */
 int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches);
+/* The Tanh / Sin / Atan modes (distort.rs:109,117,125; overdrive.rs:38; chebyshev.rs:34,40; signal_gen.rs:64)
+ * evaluate in f64 and round once.  The engine's own f64 tanh (func 0) / sin (func 1) / atan (func 2) are cheaper than the math library's; this compares the two
+ * over all 2^32 inputs on the device: *mismatches = inputs whose f32 results differ, *max_ulp = the largest
+ * distance among them (a handful of near-tie inputs, 1 ulp). */
+int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uint32_t *max_ulp);
 /* Kernel timing for the roofline report: when enabled, every stage's main kernel
  * launch is bracketed by HIP events on the stream it is launched on.  read()
  * synchronises those events and returns, for the stage with the largest total,

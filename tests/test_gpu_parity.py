@@ -1067,7 +1067,7 @@ def test_tune_placement_changes_speed_not_results(dspfx, torch_cuda):
 @pytest.mark.parametrize("variant", ["static=0,f=8,cpl=2", "static=0,f=4,cpl=2"])
 def test_two_channel_interpreter_on_every_node_and_random_chains(dspfx, torch_cuda, monkeypatch, variant):
     """The interpreter's two-channels-per-lane instantiations (the default above 131072 channels) forced at test
-    sizes: every arithmetic node kind on its own, the libm kinds (dyn_libm_f4_c2), and seeded random chains, with a
+    sizes: every arithmetic node kind on its own, the libm kinds (dyn_libm_f8_c2), and seeded random chains, with a
     ragged channel count so the one-channel guarded tail runs next to it and the mix bus spans both."""
     monkeypatch.setenv("DSPFX_VARIANT", variant)
     N, B, blocks = 128 * 3 + 2 * 17, 128, 3        # 384 channels in the main launch, 34 in the tail
@@ -1095,3 +1095,10 @@ def test_two_channel_interpreter_on_every_node_and_random_chains(dspfx, torch_cu
         ok = np.isfinite(ref)
         assert np.array_equal(np.isfinite(got), ok)
         assert ulp_diff(got[ok], ref[ok]).max() <= 1, (variant, case, [(n.kind, n.mode) for n in chain], tile, lf)
+
+
+def test_fast_f64_tanh_sin_atan_match_the_library_path_exhaustively(dspfx, torch_cuda):
+    """The engine's own f64 tanh / sin / atan against the math library's, all 2^32 inputs, on the device."""
+    for func, name, allowed in ((0, "tanh", 16), (1, "sin", 0), (2, "atan", 0)):
+        n, worst = dspfx.verify_libm(func)
+        assert n <= allowed and worst <= 1, (name, n, worst)

@@ -19,6 +19,9 @@ chain = {
     "eight": lambda: [pkg.Gain(0.9), pkg.BiQuad(*lp), pkg.LowPass(0.3), pkg.Distort(2.0, pkg.HARD_CLIP), pkg.Reverb(delay_samples=D, decay=0.4),
                       pkg.HighPass(0.1), pkg.Envelope(5.0, 300.0), pkg.Gain(1.1)],
     "onepole": lambda: [pkg.LowPass(0.3), pkg.Gain(0.5)],
+    "d_tanh": lambda: [pkg.Distort(3.0, pkg.TANH)], "d_sin": lambda: [pkg.Distort(3.0, pkg.SIN)], "d_atan": lambda: [pkg.Distort(3.0, pkg.ATAN)],
+    "overdrive": lambda: [pkg.Overdrive(5.0, 0.5, 0.8)], "chebyshev": lambda: [pkg.Chebyshev(4.0, 2.0)],
+    "siggen": lambda: [pkg.SignalGen(0.5, 440.0, pkg.SIG_SINE)], "gain": lambda: [pkg.Gain(0.5)],
 }[name]()
 eng = pkg.Engine(N, B, link_flags=3, tile_channels=tile)
 eng.set_chain(chain)
