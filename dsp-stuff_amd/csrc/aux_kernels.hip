@@ -8,47 +8,70 @@ namespace dspfx {
 
 __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
 
-// One lane = one channel; the 128 samples of a reference block stay in registers
-// across the three max-reductions (distort.rs:147-171).  In-place safe.
+// Fuzz (distort.rs:147-171) is block-global: three maxima over the 128 frames of a channel.  A workgroup takes 64
+// channels; wave q holds frames [32q, 32q+32) of each in registers (lane = channel, so every load / store is one
+// 256-byte row segment) and the three maxima are combined across the four waves through LDS.  (One lane holding all
+// 128 frames needed 184 VGPRs = 2 waves per SIMD and ran at 1.5 TB/s.)  In-place safe.
+constexpr int FUZZ_CH = 64, FUZZ_Q = WG / FUZZ_CH, FUZZ_F = 128 / FUZZ_Q;
 __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
-    const size_t c = (size_t)blockIdx.x * WG + threadIdx.x;
-    if (c >= a.N) return;
+    __shared__ unsigned smax[3][FUZZ_Q][FUZZ_CH];
+    const int lane = threadIdx.x & (FUZZ_CH - 1), q = __builtin_amdgcn_readfirstlane(threadIdx.x / FUZZ_CH);
+    const size_t c = (size_t)blockIdx.x * FUZZ_CH + lane;
+    const bool active = c < a.N;
+    const size_t cc = active ? c : 0;
+    // frame-independent per-lane part of the address; the frame part is wave-uniform (scalar)
+    const float *pin = a.in + a.lay.at(0, cc);
+    float *pout = a.out + a.lay.at(0, cc);
+    const size_t ld = a.lay.ld;
+    auto wg_max = [&](int which, unsigned mine) {       // max of the four waves' partial maxima, per channel
+        smax[which][q][lane] = mine;
+        __syncthreads();
+        unsigned m = smax[which][0][lane];
+#pragma unroll
+        for (int k = 1; k < FUZZ_Q; ++k) m = smax[which][k][lane] >= m ? smax[which][k][lane] : m;
+        return m;
+    };
     for (unsigned b0 = 0; b0 < a.nframes; b0 += 128) {
-        float x[128];
-        float lv[1];
-        lv[0] = a.level;
+        float x[FUZZ_F];
+        const unsigned f0 = b0 + q * FUZZ_F;
         unsigned m = 0;
 #pragma unroll
-        for (int f = 0; f < 128; ++f) {
-            float t = a.in[a.lay.at(b0 + f, c)];
+        for (int f = 0; f < FUZZ_F; ++f) {
+            float t = __builtin_nontemporal_load(pin + (size_t)(f0 + f) * ld);
             if (a.hop) t = link_hop<false>(t, a.hop_div, 0.0);
             x[f] = t;
             const unsigned bts = abs_bits(t);      // max_by(total_cmp) over |x| == integer max of the bits
             m = bts >= m ? bts : m;
         }
-        const float mx = __uint_as_float(m);
+        const float mx = __uint_as_float(wg_max(0, m));
+        const double rmx = 1.0 / (double)mx;
         unsigned mzb = 0;
 #pragma unroll
-        for (int f = 0; f < 128; ++f) {
-            const float q = clip1(x[f] * lv[0]) / mx;            // 158
-            const float e = exp_cr(-fabsf(q));                     // q.copysign(-1.0).exp()
-            const float z = -fabsf(1.0f - e);                    // (1.0 - e).copysign(-1.0)
+        for (int f = 0; f < FUZZ_F; ++f) {
+            const float qv = div_lane(clip1(x[f] * a.level), mx, rmx);   // 158
+            const float e = exp_cr(-fabsf(qv));                          // q.copysign(-1.0).exp()
+            const float z = -fabsf(1.0f - e);                            // (1.0 - e).copysign(-1.0)
             x[f] = z;
             const unsigned bts = abs_bits(z);
             mzb = bts >= mzb ? bts : mzb;
         }
-        const float mz = __uint_as_float(mzb);
+        const float mz = __uint_as_float(wg_max(1, mzb));
+        const double rmz = 1.0 / (double)mz;
         unsigned myb = 0;
 #pragma unroll
-        for (int f = 0; f < 128; ++f) {
-            const float y = clip1(x[f] * mx) / mz;               // 167
+        for (int f = 0; f < FUZZ_F; ++f) {
+            const float y = div_lane(clip1(x[f] * mx), mz, rmz);         // 167
             x[f] = y;
             const unsigned bts = abs_bits(y);
             myb = bts >= myb ? bts : myb;
         }
-        const float my = __uint_as_float(myb);
+        const float my = __uint_as_float(wg_max(2, myb));
+        const double rmy = 1.0 / (double)my;
+        if (active) {
 #pragma unroll
-        for (int f = 0; f < 128; ++f) a.out[a.lay.at(b0 + f, c)] = x[f] * mx / my;   // 171
+            for (int f = 0; f < FUZZ_F; ++f) __builtin_nontemporal_store(div_lane(x[f] * mx, my, rmy), pout + (size_t)(f0 + f) * ld);   // 171
+        }
+        __syncthreads();                            // smax is reused by the next 128-frame block
     }
 }
 
@@ -124,15 +147,26 @@ __global__ void __launch_bounds__(WG) verify_div_kernel(float c, double rc, unsi
     if (bad) atomicAdd(mismatches, bad);
 }
 
-// Exhaustive comparison of the fast f64 tanh / sin / atan with the library path, all 2^32 inputs: out[0] += inputs whose
+// Exhaustive comparison of the fast f64 tanh / sin / atan / exp with the library path (func 0..3) and of the
+// per-lane f64 division with IEEE division on 2^32 hashed (numerator, divisor) pairs (func >= 4, the value seeds the hash), all 2^32 inputs: out[0] += inputs whose
 // f32 results differ, out[1] = max ulp distance seen (NaNs compared as a class).
 __global__ void __launch_bounds__(WG) verify_libm_kernel(int func, unsigned long long *out) {
     unsigned long long bad = 0, worst = 0;
     const uint64_t stride = (uint64_t)gridDim.x * WG;
     for (uint64_t b = (uint64_t)blockIdx.x * WG + threadIdx.x; b < (1ull << 32); b += stride) {
         const float x = __uint_as_float((uint32_t)b);
-        const float a = func == 0 ? tanh_lib(x) : func == 1 ? sin_lib(x) : atan_lib(x);
-        const float f = func == 0 ? tanh_cr(x) : func == 1 ? sin_cr(x) : atan_cr(x);
+        float a, f;
+        if (func == 0) { a = tanh_lib(x); f = tanh_cr(x); }
+        else if (func == 1) { a = sin_lib(x); f = sin_cr(x); }
+        else if (func == 2) { a = atan_lib(x); f = atan_cr(x); }
+        else if (func == 3) { a = exp_lib(x); f = exp_cr(x); }
+        else {   // per-lane division: every numerator against a divisor hashed from it (2^32 pairs out of 2^64)
+            uint32_t h = (uint32_t)b * 0x9E3779B9u + (uint32_t)func;
+            h ^= h >> 15; h *= 0x85EBCA6Bu; h ^= h >> 13;
+            const float c = __uint_as_float(h);
+            a = x / c;
+            f = div_lane(x, c, 1.0 / (double)c);
+        }
         if (a != a && f != f) continue;
         const uint32_t ua = __float_as_uint(a), uf = __float_as_uint(f);
         if (ua == uf) continue;
@@ -181,7 +215,7 @@ void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W
 
 
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
-    hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + WG - 1) / WG), dim3(WG), 0, s, a);
+    hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + FUZZ_CH - 1) / FUZZ_CH), dim3(WG), 0, s, a);
 }
 void launch_mix_reduce(const float *part, float *part2, float *mix, unsigned nframes, unsigned waves, hipStream_t s) {
     hipLaunchKernelGGL(mix_reduce_a_kernel, dim3(MIX_SLICES), dim3(WG), 0, s, part, part2, waves, nframes);

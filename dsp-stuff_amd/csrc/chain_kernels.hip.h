@@ -281,8 +281,8 @@ __device__ __forceinline__ float rs_signum(float x) {
 __device__ __forceinline__ float tanh_lib(float x) { return (float)tanh((double)x); }
 __device__ __forceinline__ float sin_lib(float x) { return (float)sin((double)x); }
 
-// e^y for 0 <= y <= 40: y = k ln2 + r, |r| <= ln2/2, degree-12 Taylor (r^13/13! < 2e-16), scaled by 2^k
-__device__ __forceinline__ double exp_pos_f64(double y) {
+// e^y for -160 <= y <= 40: y = k ln2 + r, |r| <= ln2/2, degree-12 Taylor (r^13/13! < 2e-16), scaled by 2^k
+__device__ __forceinline__ double exp_f64(double y) {
     const double k = __builtin_rint(y * 1.44269504088896338700e+00);
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, y);      // ln2 high part (fdlibm split)
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);               // ln2 low part
@@ -305,7 +305,7 @@ __device__ __forceinline__ double exp_pos_f64(double y) {
 __device__ __forceinline__ float tanh_cr(float x) {
     const double ax = __builtin_fabs((double)x);
     const double y = __builtin_fmin(ax + ax, 40.0);
-    const double d = exp_pos_f64(y) + 1.0;
+    const double d = exp_f64(y) + 1.0;
     double rc = __builtin_amdgcn_rcp(d);
     rc = __builtin_fma(__builtin_fma(-d, rc, 1.0), rc, rc);           // two Newton steps: full f64 accuracy
     rc = __builtin_fma(__builtin_fma(-d, rc, 1.0), rc, rc);
@@ -374,7 +374,21 @@ __device__ __forceinline__ float atan_cr(float x) {
     const float t = (float)(base + __builtin_fma(w * u, p, w));
     return x != x ? x : __builtin_copysignf(t, x);
 }
-__device__ __forceinline__ float exp_cr(float x) { return (float)exp((double)x); }
+__device__ __forceinline__ float exp_lib(float x) { return (float)exp((double)x); }
+// e^x rounded once from f64; beyond +-160 / 89 the f32 result is 0 / inf anyway
+__device__ __forceinline__ float exp_cr(float x) {
+    const double y = __builtin_fmax(__builtin_fmin((double)x, 89.0), -160.0);
+    const float r = (float)exp_f64(y);
+    return x != x ? x : r;
+}
+// x / c for a per-lane divisor c with rc = 1.0 / (double)c: the f64 product rounds to the IEEE f32 quotient whenever
+// that quotient is a normal number (no f32 quotient lies within 2^-49 of a rounding boundary unless it is an exact
+// tie, and ties only exist among subnormal results); subnormal results take the IEEE division.
+__device__ __forceinline__ float div_lane(float x, float c, double rc) {
+    float q = (float)((double)x * rc);
+    if (!(__builtin_fabsf(q) >= 0x1p-126f)) q = x / c;
+    return q;
+}
 
 // distort.rs:63-145, every mode except Fuzz, for level >= 0.001 (the `level < 0.001`
 // bypass is wave-uniform while level is a slider value and is tested once per chunk

@@ -1404,7 +1404,7 @@ extern "C" int dspfx_verify_fast_division(int device, float c, uint64_t *mismatc
 }
 
 extern "C" int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uint32_t *max_ulp) {
-    if (!mismatches || !max_ulp || func < 0 || func > 2) return DSPFX_ERR_INVALID;
+    if (!mismatches || !max_ulp || func < 0 || func > 64) return DSPFX_ERR_INVALID;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
     if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return DSPFX_ERR_INVALID;

@@ -285,7 +285,9 @@ int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches);
 /* The Tanh / Sin / Atan modes (distort.rs:109,117,125; overdrive.rs:38; chebyshev.rs:34,40; signal_gen.rs:64)
  * evaluate in f64 and round once.  The engine's own f64 tanh (func 0) / sin (func 1) / atan (func 2) are cheaper than the math library's; this compares the two
  * over all 2^32 inputs on the device: *mismatches = inputs whose f32 results differ, *max_ulp = the largest
- * distance among them (a handful of near-tie inputs, 1 ulp). */
+ * distance among them (a handful of near-tie inputs, 1 ulp).  func 3: the f64 exp of Fuzz (distort.rs:159).
+ * func 4..64: Fuzz's per-lane divisions (distort.rs:158,167,171) as f64 products with an IEEE fallback for
+ * subnormal quotients, against IEEE division on 2^32 (numerator, hashed divisor) pairs; must report 0. */
 int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uint32_t *max_ulp);
 /* Kernel timing for the roofline report: when enabled, every stage's main kernel
  * launch is bracketed by HIP events on the stream it is launched on.  read()

@@ -1099,6 +1099,10 @@ def test_two_channel_interpreter_on_every_node_and_random_chains(dspfx, torch_cu
 
 def test_fast_f64_tanh_sin_atan_match_the_library_path_exhaustively(dspfx, torch_cuda):
     """The engine's own f64 tanh / sin / atan against the math library's, all 2^32 inputs, on the device."""
-    for func, name, allowed in ((0, "tanh", 16), (1, "sin", 0), (2, "atan", 0)):
+    for func, name, allowed in ((0, "tanh", 16), (1, "sin", 0), (2, "atan", 0), (3, "exp", 0)):
         n, worst = dspfx.verify_libm(func)
         assert n <= allowed and worst <= 1, (name, n, worst)
+    # Fuzz's per-lane divisions as f64 products (IEEE fallback for subnormal quotients): identical to IEEE division
+    # on 2^32 (numerator, hashed divisor) pairs per seed
+    for seed in (4, 5):
+        assert dspfx.verify_libm(seed) == (0, 0), seed

@@ -21,6 +21,8 @@ chain = {
     "onepole": lambda: [pkg.LowPass(0.3), pkg.Gain(0.5)],
     "d_tanh": lambda: [pkg.Distort(3.0, pkg.TANH)], "d_sin": lambda: [pkg.Distort(3.0, pkg.SIN)], "d_atan": lambda: [pkg.Distort(3.0, pkg.ATAN)],
     "overdrive": lambda: [pkg.Overdrive(5.0, 0.5, 0.8)], "chebyshev": lambda: [pkg.Chebyshev(4.0, 2.0)],
+    "fuzz": lambda: [pkg.Distort(3.0, pkg.FUZZ)], "fuzz3": lambda: [pkg.BiQuad(*lp), pkg.Distort(3.0, pkg.FUZZ), pkg.Gain(0.5)],
+    "ctl": lambda: [pkg.Gain(1.0), pkg.BiQuad(*lp)],
     "siggen": lambda: [pkg.SignalGen(0.5, 440.0, pkg.SIG_SINE)], "gain": lambda: [pkg.Gain(0.5)],
 }[name]()
 eng = pkg.Engine(N, B, link_flags=3, tile_channels=tile)
