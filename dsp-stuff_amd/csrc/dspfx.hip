@@ -87,7 +87,7 @@ struct dspfx_engine {
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
-    const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr;
+    const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr, *dyn_mod2 = nullptr;
     bool has_fuzz = false;
     uint32_t min_delay = 0xffffffffu;
     bool has_siggen = false;   // a SIGNAL_GEN wraps its clock per 128-frame block: sub-launches start on block boundaries
@@ -651,7 +651,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the MOD interpreter evaluates them
                 const Node &nd = e->nodes[st.first + k];
                 if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) {
-                    v = e->dyn_mod;
+                    // two channels per lane above 131072 channels, like the plain interpreter
+                    v = (e->dyn_mod2 && N > 131072u && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod;
                     tail = e->tail_mod;
                 }
             }
@@ -832,7 +833,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     for (const Variant *v : all) {
         if (v->sigs[0] != SIG_DYN) continue;
         if (v->guard) (v->mod ? e->tail_mod : e->tail) = v;
-        else if (v->mod) e->dyn_mod = v;
+        else if (v->mod) (v->cpl == 2 ? e->dyn_mod2 : e->dyn_mod) = v;
         else if (v->f == 8 && v->cpl == 1 && v->libm) e->dyn = v;   // fallbacks handle every node kind
     }
     e->mixpart_cols = (size_t)desc->channels / 64 + 8;

@@ -43,5 +43,7 @@ const Variant *variants_static5(int *n);
     Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, 1, GUARD, MOD, LIBM> }
 #define DSPFX_DYN_VARIANT_C(NAME, F, CPL, LIBM) \
     Variant { NAME, {SIG_DYN}, 0, F, CPL, false, false, LIBM, &launch_dyn<F, CPL, false, false, LIBM> }
+#define DSPFX_DYN_VARIANT_MOD_C(NAME, F, CPL) \
+    Variant { NAME, {SIG_DYN}, 0, F, CPL, false, true, true, &launch_dyn<F, CPL, false, true, true> }
 
 }  // namespace dspfx

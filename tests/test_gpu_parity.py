@@ -1106,3 +1106,45 @@ def test_fast_f64_tanh_sin_atan_match_the_library_path_exhaustively(dspfx, torch
     # on 2^32 (numerator, hashed divisor) pairs per seed
     for seed in (4, 5):
         assert dspfx.verify_libm(seed) == (0, 0), seed
+
+
+def test_control_ports_two_channel_interpreter_above_131072_channels(dspfx, torch_cuda):
+    """Above 131072 channels a chain with connected control ports runs on the two-channels-per-lane control-port
+    interpreter (dyn_mod_f8_c2).  Channels are independent, so its output must equal, bit for bit, what smaller
+    engines (one channel per lane, validated against the oracle by test_control_ports) produce for channel slices;
+    a few channels are also checked against the oracle directly."""
+    N, B, blocks = 131072 + 1024 + 2, 128, 2          # even, N % 128 == 2: a 2-channel guarded tail rides along
+    chain = [dspfx.Gain(1.0), dspfx.Distort(3.0, dspfx.HARD_CLIP), dspfx.Mix(0.5), dspfx.BiQuad(), dspfx.Overdrive(5.0, 0.5, 0.8)]
+    keys = [(0, 0), (1, 0), (2, 0), (4, 1)]
+
+    def run(c0, n):
+        eng = dspfx.Engine(n, B, channel_offset=c0)
+        eng.set_chain(chain)
+        outs = []
+        for b in range(blocks):
+            x = torch_cuda.empty((B, n), device="cuda")
+            side = torch_cuda.empty_like(x)
+            eng.fill_noise(x, B, b * B, 0x5EED0001)
+            eng.fill_noise(side, B, b * B, 5)
+            ctl = {}
+            for j, k in enumerate(keys):
+                t = torch_cuda.empty_like(x)
+                eng.fill_noise(t, B, b * B, 100 + j)
+                ctl[k] = t
+            y = torch_cuda.empty_like(x)
+            eng.process(x, out=y, side=side, n_frames=B, ctl=ctl)
+            torch_cuda.cuda.synchronize()
+            outs.append(y.cpu().numpy())
+        return np.concatenate(outs)
+
+    big = run(0, N)
+    half = 66048
+    small = np.concatenate([run(0, half), run(half, N - half)], axis=1)
+    assert np.array_equal(big.view(np.uint32), small.view(np.uint32))
+    chans = np.array([0, 1, 127, 128, 70000, N - 3, N - 2, N - 1])
+    nf = B * blocks
+    x = O.noise(0x5EED0001, chans, np.arange(nf))
+    side = O.noise(5, chans, np.arange(nf))
+    ctl = {k: O.noise(100 + j, chans, np.arange(nf)) for j, k in enumerate(keys)}
+    ref = O.run_channels([n.oracle_desc() for n in chain], x, 3, side, ctl=ctl)
+    assert np.abs(big[:, chans] - ref).max() <= 2e-6          # overdrive's atan feeds further f32 ops (test_control_ports' bar)

@@ -29,15 +29,19 @@ eng = pkg.Engine(N, B, link_flags=3, tile_channels=tile)
 eng.set_chain(chain)
 x = torch.empty(B * N, dtype=torch.float32, device="cuda"); y = torch.empty_like(x)
 eng.fill_noise(x, B, 0)
+ctl = None
+if name == "ctl":          # a control port on the gain's level: +4 B/sample
+    cbuf = torch.empty_like(x); eng.fill_noise(cbuf, B, 7)
+    ctl = {(0, 0): cbuf}
 eng.tune_placement(x, y, B)
 def measure(steps=192):
-    for _ in range(200): eng.process(x, out=y, n_frames=B)
+    for _ in range(200): eng.process(x, out=y, n_frames=B, ctl=ctl)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(steps): eng.process(x, out=y, n_frames=B)
+    for _ in range(steps): eng.process(x, out=y, n_frames=B, ctl=ctl)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / steps
 ms = min(measure(), measure())
-bps = eng.algorithmic_bytes_per_sample(B)
+bps = eng.algorithmic_bytes_per_sample(B) + (4 if ctl else 0)
 stage = [l for l in eng.describe().splitlines() if l.startswith("stage")]
 print("%-8s tile %3d  %.4f ms/step  %5.0f GB/s  %s" % (name, tile, ms, bps * N * B / ms / 1e6, " | ".join(s.split(":")[1].split("(")[0].strip() for s in stage)))
