@@ -40,7 +40,7 @@ EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
-    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
+    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
@@ -105,6 +105,8 @@ def lib():
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
+    L.dspfx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
+    L.dspfx_host_free.argtypes = [C.c_void_p]
     L.dspfx_tune_placement.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_mixpipe.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_mixpipe_flush.argtypes = [vp, f32p, f32p, C.c_uint64, vp]
@@ -145,6 +147,30 @@ def verify_fast_division(c: float, device: int = 0) -> int:
     if rc != 0:
         raise DspfxError(rc, lib().dspfx_strerror(rc).decode())
     return int(n.value)
+
+
+class PinnedArray:
+    """A float32 numpy array over page-locked host memory from dspfx_host_alloc (`.array`); freed on close()/GC."""
+
+    def __init__(self, shape):
+        n = int(np.prod(shape))
+        self._p = C.c_void_p()
+        rc = lib().dspfx_host_alloc(n * 4, C.byref(self._p))
+        if rc != 0:
+            raise DspfxError(rc, lib().dspfx_strerror(rc).decode())
+        self.array = np.ctypeslib.as_array((C.c_float * n).from_address(self._p.value)).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.array = None
+            lib().dspfx_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def verify_libm(func: int, device: int = 0):
@@ -373,11 +399,13 @@ class Engine:
         """Pipelined mix bus, part 2 (stream B): wait for the chain kernel, reduce partials -> mix[n_frames]."""
         self._chk(self.L.dspfx_mix_collect(self.h, _ptr(mix), int(n_frames), C.c_void_p(stream) if stream else None))
 
-    def process_host(self, x: np.ndarray, side: Optional[np.ndarray] = None, want_mix: bool = False):
-        """Host path (numpy in / numpy out): H2D, process, D2H."""
+    def process_host(self, x: np.ndarray, side: Optional[np.ndarray] = None, want_mix: bool = False, out=None):
+        """Host path (numpy in / numpy out): H2D, process, D2H.  `out` may be a caller-provided (e.g. pinned) array."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         assert x.ndim == 2 and x.shape[1] == self.channels, x.shape
-        out = np.empty_like(x)
+        if out is None:
+            out = np.empty_like(x)
+        assert out.dtype == np.float32 and out.shape == x.shape and out.flags.c_contiguous
         s = np.ascontiguousarray(side, dtype=np.float32) if side is not None else None
         mix = np.empty(x.shape[0], np.float32) if want_mix else None
         self._chk(self.L.dspfx_process_host(self.h, x.ctypes.data, s.ctypes.data if s is not None else None,

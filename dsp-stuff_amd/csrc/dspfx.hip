@@ -84,6 +84,12 @@ struct dspfx_engine {
     float *mp_mix_now = nullptr;          // where the launch being built delivers block k-2's bus
     float mp_div_now = 0.0f;
     bool mp_building = false;
+    // channel window of the current run_subblock call (pipelined host path): channels [win_c0, win_c0 + win_n), 0 = all;
+    // win_last marks the call that finishes the block (ring positions advance once)
+    uint32_t win_c0 = 0, win_n = 0;
+    bool win_last = true;
+    hipStream_t hs_in = nullptr, hs_out = nullptr, hs_run = nullptr;
+    std::vector<hipEvent_t> hev;
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
@@ -687,7 +693,16 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     if (stage & 1) launch_mix_reduce_slices(e->mixpart2[prev], b_cur, nframes, e->mp_rows[prev], stream);
                 }
             }
-            if (n_main) {
+            if (e->win_n) {   // a channel window (multiples of 1024 channels; the last one runs to N)
+                const uint32_t w0 = e->win_c0, w1 = std::min(n_main, e->win_c0 + e->win_n);
+                if (w1 > w0) {
+                    a.c_base = w0;
+                    a.n_launch = w1 - w0;
+                    a.wave_base = w0 / per_wave;
+                    ProfScope ps(e, si, stream);
+                    v->launch(a, ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream);
+                }
+            } else if (n_main) {
                 a.c_base = 0;
                 a.n_launch = n_main;
                 a.wave_base = 0;
@@ -696,7 +711,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 v->launch(a, grid, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream);
             }
             a.mp_stage = 0;   // the guarded tail launch never hosts the prologue
-            if (N % per_wave) {   // ragged tail: guarded one-wave blocks, lane per channel
+            if (N % per_wave && (!e->win_n || e->win_c0 + e->win_n >= N)) {   // ragged tail: guarded one-wave blocks, lane per channel
                 const uint32_t n_tail = N - n_main;
                 a.c_base = n_main;
                 a.n_launch = n_tail;
@@ -731,6 +746,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         }
         src = out;
     }
+    if (!e->win_last) return DSPFX_OK;   // more channel windows of this block follow
     for (Node &n : e->nodes)   // a connected control port leaves per-channel latched values behind
         for (int k = 0; k < 3; ++k)
             if (n.ctl_now[k]) n.latch_valid |= 1 << k;
@@ -860,6 +876,10 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
         if (e->ev_chain[i]) (void)hipEventDestroy(e->ev_chain[i]);
         if (e->ev_red[i]) (void)hipEventDestroy(e->ev_red[i]);
     }
+    for (hipEvent_t ev : e->hev) (void)hipEventDestroy(ev);
+    if (e->hs_in) (void)hipStreamDestroy(e->hs_in);
+    if (e->hs_out) (void)hipStreamDestroy(e->hs_out);
+    if (e->hs_run) (void)hipStreamDestroy(e->hs_run);
     if (e->h_in) (void)hipFree(e->h_in);
     if (e->h_side) (void)hipFree(e->h_side);
     if (e->h_out) (void)hipFree(e->h_out);
@@ -1142,6 +1162,36 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
     return rc;
 }
 
+extern "C" int dspfx_host_alloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return DSPFX_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        return DSPFX_ERR_OOM;
+    }
+    return DSPFX_OK;
+}
+
+extern "C" int dspfx_host_free(void *p) {
+    if (!p) return DSPFX_OK;
+    return hipHostFree(p) == hipSuccess ? DSPFX_OK : DSPFX_ERR_HIP;
+}
+
+namespace {
+bool is_pinned_host(const void *p) {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof at);
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+}  // namespace
+
 extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                                   uint32_t n_frames) {
     if (!e) return DSPFX_ERR_INVALID;
@@ -1155,6 +1205,53 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
     if (!e->h_out) HIPCHK(e, hipMalloc((void **)&e->h_out, cap));
     if (side && !e->h_side) HIPCHK(e, hipMalloc((void **)&e->h_side, cap));
     if (mix && !e->h_mix) HIPCHK(e, hipMalloc((void **)&e->h_mix, e->desc.max_frames * sizeof(float)));
+    // Pipelined form: the block is cut into channel parts; while part p runs, part p+1 is uploaded and part p-1
+    // downloaded (both directions of the bus busy).  Needs a single fused stage per part (no FIR / Fuzz / mix bus),
+    // the frame-major layout and a block that is not split at a short delay line.
+    bool fused_only = !mix && !e->desc.tile_channels && n_frames <= e->min_delay && !e->has_siggen;
+    for (const Stage &st : e->stages) fused_only = fused_only && st.type == ST_FUSED;
+    const uint32_t N = e->desc.channels;
+    static const uint32_t part = getenv("DSPFX_HOST_PART") ? (uint32_t)atoi(getenv("DSPFX_HOST_PART")) : 65536u;   // channels per part (multiple of 1024); 32k 15.5, 64k 13.7, 128k 14.1, 256k 15.1 ms
+    static const bool pipe_off = getenv("DSPFX_HOST_PIPELINE") && atoi(getenv("DSPFX_HOST_PIPELINE")) == 0;
+    // page-locked buffers only (dspfx_host_alloc): copies from pageable memory are staged by the runtime and do not overlap
+    if (fused_only && !pipe_off && N >= 2 * part && is_pinned_host(in) && is_pinned_host(out) && (!side || is_pinned_host(side))) {
+        if (!e->hs_in) {
+            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_in, hipStreamNonBlocking));
+            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_out, hipStreamNonBlocking));
+            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_run, hipStreamNonBlocking));
+        }
+        const uint32_t n_parts = (N + part - 1) / part;
+        while (e->hev.size() < 2 * (size_t)n_parts) {
+            hipEvent_t ev = nullptr;
+            HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->hev.push_back(ev);
+        }
+        const size_t pitch = (size_t)N * sizeof(float);
+        int rc = DSPFX_OK;
+        for (uint32_t p = 0; p < n_parts && rc == DSPFX_OK; ++p) {
+            const uint32_t c0 = p * part, cn = std::min(part, N - c0);
+            const size_t width = (size_t)cn * sizeof(float);
+            HIPCHK(e, hipMemcpy2DAsync(e->h_in + c0, pitch, in + c0, pitch, width, n_frames, hipMemcpyHostToDevice, e->hs_in));
+            if (side) HIPCHK(e, hipMemcpy2DAsync(e->h_side + c0, pitch, side + c0, pitch, width, n_frames, hipMemcpyHostToDevice, e->hs_in));
+            HIPCHK(e, hipEventRecord(e->hev[2 * p], e->hs_in));
+            HIPCHK(e, hipStreamWaitEvent(e->hs_run, e->hev[2 * p], 0));
+            e->win_c0 = c0;
+            e->win_n = cn;
+            e->win_last = p + 1 == n_parts;
+            rc = run_subblock(e, e->h_in, side ? e->h_side : nullptr, e->h_out, nullptr, n_frames, n_frames, e->hs_run);
+            e->win_c0 = 0;
+            e->win_n = 0;
+            e->win_last = true;
+            if (rc) break;
+            HIPCHK(e, hipEventRecord(e->hev[2 * p + 1], e->hs_run));
+            HIPCHK(e, hipStreamWaitEvent(e->hs_out, e->hev[2 * p + 1], 0));
+            HIPCHK(e, hipMemcpy2DAsync(out + c0, pitch, e->h_out + c0, pitch, width, n_frames, hipMemcpyDeviceToHost, e->hs_out));
+        }
+        (void)hipStreamSynchronize(e->hs_in);
+        (void)hipStreamSynchronize(e->hs_run);
+        HIPCHK(e, hipStreamSynchronize(e->hs_out));
+        return rc;
+    }
     HIPCHK(e, hipMemcpy(e->h_in, in, bytes, hipMemcpyHostToDevice));
     if (side) HIPCHK(e, hipMemcpy(e->h_side, side, bytes, hipMemcpyHostToDevice));
     const int rc = dspfx_process(e, e->h_in, side ? e->h_side : nullptr, e->h_out, mix ? e->h_mix : nullptr,

@@ -220,6 +220,12 @@ int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float
  * Setup-time only (about 3 s at 94 GiB); it RESETS all DSP state.  Results never change, only speed. */
 int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                          void *stream);
+/* Page-locked host memory for the blocks handed to dspfx_process_host.  From ordinary (pageable) buffers the two
+ * copies of a block run one after the other; from these buffers dspfx_process_host cuts the block into channel
+ * parts and overlaps upload, kernel and download (both directions of the bus busy; DESIGN.md, host buffers).  A host
+ * that gathers its pipes into one block anyway should gather into these. */
+int dspfx_host_alloc(size_t bytes, void **out);
+int dspfx_host_free(void *p);
 /* Same with HOST buffers (what a Rust `process(&[f32], &mut [f32])` holds):
  * H2D copy, process, D2H copy, synchronous. */
 int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,

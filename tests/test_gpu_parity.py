@@ -1148,3 +1148,28 @@ def test_control_ports_two_channel_interpreter_above_131072_channels(dspfx, torc
     ctl = {k: O.noise(100 + j, chans, np.arange(nf)) for j, k in enumerate(keys)}
     ref = O.run_channels([n.oracle_desc() for n in chain], x, 3, side, ctl=ctl)
     assert np.abs(big[:, chans] - ref).max() <= 2e-6          # overdrive's atan feeds further f32 ops (test_control_ports' bar)
+
+
+def test_pipelined_host_path_matches_device_path(dspfx, torch_cuda):
+    """From 262144 channels on, dspfx_process_host cuts a block into channel parts and overlaps upload, kernel and
+    download of different parts; results must equal the device path bit for bit (ragged tail, side input, two
+    fused stages, state and ring carried across blocks)."""
+    N, B, blocks = 262144 + 100, 128, 3
+    chain = [dspfx.Gain(0.9), dspfx.BiQuad(), dspfx.Mix(0.3), dspfx.Reverb(delay_samples=256, decay=0.5), dspfx.LowPass(0.2),
+             dspfx.Distort(2.0, dspfx.SOFT_CLIP), dspfx.HighPass(0.1), dspfx.Envelope(3.0, 50.0), dspfx.Gain(1.1), dspfx.Add()]
+    host, dev = dspfx.Engine(N, B), dspfx.Engine(N, B)
+    host.set_chain(chain)
+    dev.set_chain(chain)
+    assert len([l for l in host.describe().splitlines() if l.startswith("stage")]) == 2
+    rng = np.random.default_rng(8)
+    px, ps, py = dspfx.PinnedArray((B, N)), dspfx.PinnedArray((B, N)), dspfx.PinnedArray((B, N))   # page-locked: the pipelined form
+    for b in range(blocks):
+        x = rng.uniform(-1, 1, (B, N)).astype(F)
+        side = rng.uniform(-1, 1, (B, N)).astype(F)
+        px.array[:], ps.array[:] = x, side
+        got = host.process_host(px.array, side=ps.array, out=py.array)
+        dx, ds = torch_cuda.from_numpy(x).cuda(), torch_cuda.from_numpy(side).cuda()
+        dy = torch_cuda.empty_like(dx)
+        dev.process(dx, out=dy, side=ds, n_frames=B)
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(got.view(np.uint32), dy.cpu().numpy().view(np.uint32)), b
