@@ -58,9 +58,35 @@ impl SimpleNode for GpuChain {
 /// optionally, the Output node's mix of all of them (nodes/output.rs:215-249).
 pub struct Bank {
     engine: Engine,
-    gather: Vec<f32>,
-    scatter: Vec<f32>,
+    gather: PinnedBlock,   // page-locked: dspfx_process_host then overlaps upload, kernel and download
+    scatter: PinnedBlock,
     mix: Vec<f32>,
+}
+
+/// `len` f32 of page-locked host memory from `dspfx_host_alloc`.
+struct PinnedBlock {
+    ptr: *mut f32,
+    len: usize,
+}
+unsafe impl Send for PinnedBlock {}
+impl PinnedBlock {
+    fn new(len: usize) -> Result<Self, super::engine::Error> {
+        let mut p: *mut std::os::raw::c_void = std::ptr::null_mut();
+        let rc = unsafe { super::ffi::dspfx_host_alloc(len * std::mem::size_of::<f32>(), &mut p) };
+        if rc != super::ffi::DSPFX_OK {
+            return Err(super::engine::Error { status: rc, message: "dspfx_host_alloc".into() });
+        }
+        let block = PinnedBlock { ptr: p as *mut f32, len };
+        unsafe { std::ptr::write_bytes(block.ptr, 0, len) };
+        Ok(block)
+    }
+    fn as_slice(&self) -> &[f32] { unsafe { std::slice::from_raw_parts(self.ptr, self.len) } }
+    fn as_mut_slice(&mut self) -> &mut [f32] { unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) } }
+}
+impl Drop for PinnedBlock {
+    fn drop(&mut self) {
+        unsafe { super::ffi::dspfx_host_free(self.ptr as *mut _) };
+    }
 }
 
 impl Bank {
@@ -68,7 +94,7 @@ impl Bank {
         let mut engine = Engine::new(channels, BUF_SIZE as u32, link_flags, 0)?;
         engine.set_chain(chain)?;
         let n = channels as usize * BUF_SIZE;
-        Ok(Bank { engine, gather: vec![0.0; n], scatter: vec![0.0; n], mix: vec![0.0; BUF_SIZE] })
+        Ok(Bank { engine, gather: PinnedBlock::new(n)?, scatter: PinnedBlock::new(n)?, mix: vec![0.0; BUF_SIZE] })
     }
 
     /// `inputs[c]` / `outputs[c]`: channel c's block (what one pipe of the reference holds).
@@ -79,17 +105,20 @@ impl Bank {
         assert!(inputs.len() == n && outputs.len() == n);
         let frames = inputs[0].len();
         assert!(frames <= BUF_SIZE);
+        let gather = self.gather.as_mut_slice();
         for (c, ch) in inputs.iter().enumerate() {
             assert_eq!(ch.len(), frames);
             for (f, v) in ch.iter().enumerate() {
-                self.gather[f * n + c] = *v;
+                gather[f * n + c] = *v;
             }
         }
-        let (g, s) = (&self.gather[..frames * n], &mut self.scatter[..frames * n]);
+        let g = &self.gather.as_slice()[..frames * n];
+        let s = &mut self.scatter.as_mut_slice()[..frames * n];
         self.engine.process_host(g, None, s, Some(&mut self.mix[..frames]), frames as u32)?;
+        let scatter = self.scatter.as_slice();
         for (c, ch) in outputs.iter_mut().enumerate() {
             for (f, v) in ch.iter_mut().enumerate() {
-                *v = self.scatter[f * n + c];
+                *v = scatter[f * n + c];
             }
         }
         Ok(&self.mix[..frames])
