@@ -1208,7 +1208,7 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
     // Pipelined form: the block is cut into channel parts; while part p runs, part p+1 is uploaded and part p-1
     // downloaded (both directions of the bus busy).  Needs a single fused stage per part (no FIR / Fuzz / mix bus),
     // the frame-major layout and a block that is not split at a short delay line.
-    bool fused_only = !mix && !e->desc.tile_channels && n_frames <= e->min_delay && !e->has_siggen;
+    bool fused_only = !e->desc.tile_channels && n_frames <= e->min_delay && !e->has_siggen && !e->collect_due && !e->mp_count;
     for (const Stage &st : e->stages) fused_only = fused_only && st.type == ST_FUSED;
     const uint32_t N = e->desc.channels;
     static const uint32_t part = getenv("DSPFX_HOST_PART") ? (uint32_t)atoi(getenv("DSPFX_HOST_PART")) : 65536u;   // channels per part (multiple of 1024); 32k 15.5, 64k 13.7, 128k 14.1, 256k 15.1 ms
@@ -1238,7 +1238,9 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
             e->win_c0 = c0;
             e->win_n = cn;
             e->win_last = p + 1 == n_parts;
+            if (mix) e->partials_override = e->mixpart;   // every part leaves its waves' partial sums; reduced once below
             rc = run_subblock(e, e->h_in, side ? e->h_side : nullptr, e->h_out, nullptr, n_frames, n_frames, e->hs_run);
+            e->partials_override = nullptr;
             e->win_c0 = 0;
             e->win_n = 0;
             e->win_last = true;
@@ -1246,6 +1248,10 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
             HIPCHK(e, hipEventRecord(e->hev[2 * p + 1], e->hs_run));
             HIPCHK(e, hipStreamWaitEvent(e->hs_out, e->hev[2 * p + 1], 0));
             HIPCHK(e, hipMemcpy2DAsync(out + c0, pitch, e->h_out + c0, pitch, width, n_frames, hipMemcpyDeviceToHost, e->hs_out));
+        }
+        if (rc == DSPFX_OK && mix) {
+            launch_mix_reduce(e->mixpart, e->mixpart_b, e->h_mix, n_frames, e->part_stride[e->flip], e->hs_run);
+            HIPCHK(e, hipMemcpyAsync(mix, e->h_mix, n_frames * sizeof(float), hipMemcpyDeviceToHost, e->hs_run));
         }
         (void)hipStreamSynchronize(e->hs_in);
         (void)hipStreamSynchronize(e->hs_run);

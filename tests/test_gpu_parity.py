@@ -1167,9 +1167,11 @@ def test_pipelined_host_path_matches_device_path(dspfx, torch_cuda):
         x = rng.uniform(-1, 1, (B, N)).astype(F)
         side = rng.uniform(-1, 1, (B, N)).astype(F)
         px.array[:], ps.array[:] = x, side
-        got = host.process_host(px.array, side=ps.array, out=py.array)
+        got, got_mix = host.process_host(px.array, side=ps.array, out=py.array, want_mix=True)
         dx, ds = torch_cuda.from_numpy(x).cuda(), torch_cuda.from_numpy(side).cuda()
         dy = torch_cuda.empty_like(dx)
-        dev.process(dx, out=dy, side=ds, n_frames=B)
+        dm = torch_cuda.empty(B, device="cuda")
+        dev.process(dx, out=dy, side=ds, mix=dm, n_frames=B)
         torch_cuda.cuda.synchronize()
         assert np.array_equal(got.view(np.uint32), dy.cpu().numpy().view(np.uint32)), b
+        assert np.array_equal(got_mix.view(np.uint32), dm.cpu().numpy().view(np.uint32)), b   # same partials, same reduction tree
