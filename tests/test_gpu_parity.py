@@ -1175,3 +1175,37 @@ def test_pipelined_host_path_matches_device_path(dspfx, torch_cuda):
         torch_cuda.cuda.synchronize()
         assert np.array_equal(got.view(np.uint32), dy.cpu().numpy().view(np.uint32)), b
         assert np.array_equal(got_mix.view(np.uint32), dm.cpu().numpy().view(np.uint32)), b   # same partials, same reduction tree
+
+
+def test_default_variant_selection_above_131072_channels_matches_small_engines(dspfx, torch_cuda):
+    """Above 131072 channels the engine picks the two-channels-per-lane interpreter by itself.  Channels are
+    independent, so a big engine must reproduce, bit for bit, what two smaller engines (one channel per lane) give for
+    the two halves -- arithmetic chain, libm chain, tiled layout, ragged tail, mix bus."""
+    B, blocks = 128, 2
+    for N, tile, chain in ((131072 + 1024 + 2, 0, [dspfx.Gain(0.9), dspfx.BiQuad(), dspfx.Reverb(delay_samples=200, decay=0.5), dspfx.LowPass(0.3),
+                                                  dspfx.Distort(2.0, dspfx.RECIP_SOFT_CLIP), dspfx.Envelope(2.0, 80.0)]),
+                           (131072 + 2048, 256, [dspfx.BiQuad(), dspfx.Distort(3.0, dspfx.TANH), dspfx.Overdrive(4.0, 0.6, 0.9),
+                                                 dspfx.Chebyshev(3.0, 1.5), dspfx.SignalGen(0.2, 500.0, dspfx.SIG_SINE), dspfx.Gain(0.5)])):
+        def run(c0, n):
+            eng = dspfx.Engine(n, B, channel_offset=c0, tile_channels=tile)
+            eng.set_chain(chain)
+            stage = [l for l in eng.describe().splitlines() if l.startswith("stage")][0]
+            outs, mixes = [], []
+            for b in range(blocks):
+                x = torch_cuda.empty(B * n, device="cuda")
+                eng.fill_noise(x, B, b * B, 0x5EED0001)
+                y = torch_cuda.empty_like(x)
+                m = torch_cuda.empty(B, device="cuda")
+                eng.process(x, out=y, mix=m, n_frames=B)
+                torch_cuda.cuda.synchronize()
+                outs.append(dspfx.from_layout(y.cpu().numpy(), B, n, tile))
+                mixes.append(m.cpu().numpy().astype(np.float64))
+            return np.concatenate(outs), np.concatenate(mixes), stage
+        big, big_mix, stage = run(0, N)
+        assert "_c2" in stage, stage
+        half = 65536 + 512
+        a, am, sa = run(0, half)
+        b, bm, _ = run(half, N - half)
+        assert "_c2" not in sa, sa
+        assert np.array_equal(big.view(np.uint32), np.concatenate([a, b], axis=1).view(np.uint32)), (N, tile)
+        assert np.allclose(big_mix, am + bm, rtol=1e-5, atol=1e-2)
