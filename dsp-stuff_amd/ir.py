@@ -13,6 +13,8 @@ from __future__ import annotations
 
 import struct
 
+import math
+
 import numpy as np
 
 
@@ -72,12 +74,61 @@ def read_wav(path: str):
     return x[:n * ch].reshape(n, ch), rate
 
 
-def load_impulse_response(path: str) -> np.ndarray:
-    """h[0..T) in natural order, f64: channels averaged like fir.rs:140-144; 48 kHz only."""
+def resample_dasp_sinc(samples, source_hz: float, target_hz: float = 48000.0) -> np.ndarray:
+    """fir.rs:153-165: `from_iter(samples).from_hz_to_hz(Sinc::new(Fixed::from([0.0; 16])), rate, 48000).until_exhausted()`.
+
+    dasp 0.11.0 (dasp_signal::interpolate::Converter + dasp_interpolate::sinc::Sinc) is not under /root/reference;
+    this follows its published source AS RECALLED (same caveat as the Envelope node): a 16-frame ring that new
+    source frames enter at the back, an index that climbs to depth 8, a Hann-windowed sinc summed outward from the
+    index with the depth clipped at the ring's ends, the converter stepping `interpolation_value` by
+    source_hz / target_hz and pulling one source frame per whole step.  Sequential f64 arithmetic like the crate."""
+    src = [float(v) for v in np.asarray(samples, np.float64)]
+    ring = [0.0] * 16
+    depth, idx = 8, 0
+    ratio = float(source_hz) / float(target_hz)
+    value, pos, out = 0.0, 0, []
+    pi = math.pi
+    while True:
+        if pos >= len(src) and value >= 1.0:          # Converter::is_exhausted
+            break
+        while value >= 1.0:                            # advance whole source frames
+            nxt = src[pos] if pos < len(src) else 0.0  # FromIterator yields equilibrium once the iterator has ended
+            pos += 1
+            ring.pop(0)
+            ring.append(nxt)
+            if idx < depth:
+                idx += 1
+            value -= 1.0
+        phil, phir = value, 1.0 - value
+        nl, nr = idx, idx + 1
+        rightmost, leftmost = nl + depth, nr - depth
+        if rightmost >= len(ring):
+            max_depth = len(ring) - depth
+        elif leftmost < 0:
+            max_depth = depth + leftmost
+        else:
+            max_depth = depth
+        v = 0.0
+        for n in range(max_depth):
+            a = pi * (phil + n)
+            first = 1.0 if a == 0.0 else math.sin(a) / a
+            second = 0.5 + 0.5 * math.cos(a / depth)
+            v = v + (first * second) * ring[(nl - n) % 16]
+            a = pi * (phir + n)
+            first = 1.0 if a == 0.0 else math.sin(a) / a
+            second = 0.5 + 0.5 * math.cos(a / depth)
+            v = v + (first * second) * ring[(nr + n) % 16]     # ring_buffer::Fixed indexes modulo its length
+        out.append(v)
+        value += ratio
+    return np.asarray(out, np.float64)
+
+
+def load_impulse_response(path: str, resample: bool = True) -> np.ndarray:
+    """h[0..T) in natural order, f64: channels averaged like fir.rs:140-144; a file that is not 48 kHz goes through
+    `resample_dasp_sinc` like fir.rs:153-165 (pass resample=False to refuse it instead)."""
     frames, rate = read_wav(path)
-    if rate != 48000:
-        raise IrError(f"{rate} Hz impulse response: the reference resamples with dasp's 16-tap sinc "
-                      "(fir.rs:153-171), which is not restated here; convert the file to 48 kHz")
+    if rate != 48000 and not resample:
+        raise IrError(f"{rate} Hz impulse response: convert the file to 48 kHz (or allow resampling)")
     if len(frames) == 0:
         raise IrError("empty impulse response")
     ch = frames.shape[1]
@@ -85,4 +136,5 @@ def load_impulse_response(path: str) -> np.ndarray:
     acc = np.zeros(len(frames), np.float64)
     for c in range(ch):
         acc = acc + frames[:, c]
-    return acc / float(ch)
+    mono = acc / float(ch)
+    return mono if rate == 48000 else resample_dasp_sinc(mono, float(rate), 48000.0)

@@ -168,9 +168,32 @@ def test_wav_impulse_response(mods, tmp_path):
     p44 = os.path.join(tmp_path, "ir44.wav")
     _wav(p44, 1, 16, 44100, q)
     with pytest.raises(ir.IrError) as ei:
-        ir.load_impulse_response(p44)
+        ir.load_impulse_response(p44, resample=False)
     assert "48 kHz" in str(ei.value)
+    h44 = ir.load_impulse_response(p44)                                   # fir.rs:153-165: resampled to 48 kHz
+    assert abs(len(h44) - len(q) * 48000 / 44100) <= 3
     bad = os.path.join(tmp_path, "bad.wav")
     open(bad, "wb").write(b"RIFFxxxxWAVE")
     with pytest.raises(ir.IrError):
         ir.load_impulse_response(bad)
+
+
+def test_sinc_resampler_properties(mods):
+    """dasp's 16-tap windowed-sinc converter as restated in ir.py (the crate is not vendored: properties only)."""
+    _, _, ir = mods
+    # the same rate is (nearly) a pure delay: the index settles 8 frames into the 16-frame ring
+    x = np.zeros(64)
+    x[5] = 1.0
+    y = ir.resample_dasp_sinc(x, 48000.0, 48000.0)
+    assert len(y) == len(x) + 1 and np.argmax(np.abs(y)) > 5 and abs(y.max() - 1.0) < 1e-12
+    assert np.abs(np.delete(y, np.argmax(y))).max() < 1e-12
+    # 44.1 kHz -> 48 kHz: length ratio, DC gain ~ 1 once the ring is full, a 1 kHz sine stays a 1 kHz sine
+    n = 2000
+    dc = ir.resample_dasp_sinc(np.ones(n), 44100.0, 48000.0)
+    assert abs(len(dc) - n * 48000 / 44100) <= 3
+    assert np.abs(dc[40:-40] - 1.0).max() < 0.02
+    t = np.arange(n) / 44100.0
+    s = ir.resample_dasp_sinc(np.sin(2 * np.pi * 1000.0 * t), 44100.0, 48000.0)[60:-60]
+    spec = np.abs(np.fft.rfft(s * np.hanning(len(s))))
+    f_peak = np.argmax(spec) * 48000.0 / len(s)
+    assert abs(f_peak - 1000.0) < 48000.0 / len(s) and 0.95 < np.abs(s).max() < 1.05
