@@ -87,6 +87,7 @@ struct ChainArgs {
     int xcd_remap;           // 1: blocks of one XCD (b % 8) cover a contiguous range of channel tiles
     // Pipelined mix bus (mixpipe_prologue): the second and third reduction stage of EARLIER blocks ride in this
     // launch's first workgroups instead of separate kernels on a second stream.
+    int skip_store;          // in-place launch of an empty chain that only feeds the mix bus: nothing to write back
     int mp_stage;            // bit 0: slice-reduce mp_prev_a into mp_cur_b; bit 1: final-reduce mp_prev_b into mp_mix
     unsigned mp_rows_a;      // rows (waves) of mp_prev_a
     const float *mp_prev_a;  // per-wave partials [rows][nframes] of the previous block
@@ -1069,7 +1070,8 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
+    for (int f = 0; f < F; ++f)
+        if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
     if (a.mixpart) mixbus_partial<F, CPL>(a, v, true, f0, lane, wave_global);
 }
 
@@ -1133,7 +1135,8 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
         row += ns;
     }
 #pragma unroll
-    for (int f = 0; f < F; ++f) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+    for (int f = 0; f < F; ++f)
+        if (!a.skip_store) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
     if (a.mixpart) mixbus_partial<F, CPL>(a, v, !GUARD || active, f0, lane, wave_global);
 }
 

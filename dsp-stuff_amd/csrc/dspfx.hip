@@ -644,6 +644,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 a.xcd_remap = xr ? atoi(xr) : 1;
             }
             a.n_slots = st.count;
+            a.skip_store = (st.count == 0 && src == out) ? 1 : 0;   // an empty stage in place exists only for the mix bus
             // hop flag of the side input and of control links (both are ordinary links between nodes);
             // an unconnected side port reads zeros, for which the hop is a no-op
             a.side_hop = 0;

@@ -31,18 +31,27 @@ __device__ __forceinline__ size_t ring_at(uint32_t c, uint32_t row, uint32_t R) 
 }
 
 // ring[(t0 + f) mod R] <- port value of in[f][c]  (fir.rs:193 push_back, after the
-// collect_and_average hop when enabled)
+// collect_and_average hop when enabled).  blockIdx.y = group of 4 frames, x = channels: consecutive lanes take
+// consecutive channels of one frame in both layouts (no 64-bit division per element).
+constexpr uint32_t APPEND_FRAMES = 4;
 __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float *ring, uint32_t N, uint32_t nframes,
                                                          uint32_t row0, uint32_t R, int hop, float hop_div,
                                                          const Layout lay) {
-    const size_t total = (size_t)N * nframes;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const uint32_t f = (uint32_t)(i / N), c = (uint32_t)(i % N);
-        float x = in[lay.at(f, c)];
-        if (hop) x = (0.0f + x) / hop_div;
-        uint32_t r = row0 + f;
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const uint32_t f0 = blockIdx.y * APPEND_FRAMES;
+    float x[APPEND_FRAMES];
+#pragma unroll
+    for (uint32_t k = 0; k < APPEND_FRAMES; ++k)
+        if (f0 + k < nframes) x[k] = __builtin_nontemporal_load(in + lay.at(f0 + k, c));
+#pragma unroll
+    for (uint32_t k = 0; k < APPEND_FRAMES; ++k) {
+        if (f0 + k >= nframes) break;
+        float v = x[k];
+        if (hop) v = (0.0f + v) / hop_div;
+        uint32_t r = row0 + f0 + k;
         r = r >= R ? r - R : r;
-        ring[ring_at(c, r, R)] = x;
+        ring[ring_at(c, r, R)] = v;
     }
 }
 
@@ -262,8 +271,8 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
     }
     const size_t total = (size_t)s.N * nframes;
     const uint32_t row0 = (uint32_t)(s.n_seen % s.R);
-    hipLaunchKernelGGL(fir_append_kernel, dim3(grid_for(total)), dim3(256), 0, stream, in, s.ring, s.N, nframes, row0,
-                       s.R, hop, hop_div, lay);
+    hipLaunchKernelGGL(fir_append_kernel, dim3((s.N + 255) / 256, (nframes + APPEND_FRAMES - 1) / APPEND_FRAMES), dim3(256), 0,
+                       stream, in, s.ring, s.N, nframes, row0, s.R, hop, hop_div, lay);
     // fir.rs:187-190
     const float divisor = s.mode == DSPFX_FIR_AVERAGE ? 1.0f / (float)s.T : 1.0f;
     if (ev_begin) (void)hipEventRecord(ev_begin, stream);
