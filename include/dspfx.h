@@ -17,9 +17,10 @@
  *     and all DSP state (biquad history, one-pole z, delay rings, FIR history)
  *     in HBM -- the same ownership split as node.rs:271-288 vs biquad.rs:43-44,
  *     reverb.rs:40-41, fir.rs:64-65.
- *   - sample layout is frame-major f32: buf[frame * channels + channel]
+ *   - sample layout is frame-major f32 by default: buf[frame * channels + channel]
  *     ("[B][N]"): for every frame the N channels are contiguous, so one
- *     wavefront reads 64 consecutive channels as one coalesced burst.
+ *     wavefront reads 64 consecutive channels as one coalesced burst
+ *     (dspfx_engine_desc.tile_channels selects the channel-tiled form).
  *   - one engine is driven by one thread at a time (like one node task,
  *     runtime.rs:718-728); distinct engines are independent.
  *   - there is NO CPU fallback: without a HIP device every entry point that
@@ -139,7 +140,7 @@ typedef struct dspfx_engine_desc {
  * reference tree; dspfx_delay_len() gives both readings.    */
 typedef struct dspfx_node_desc {
     int32_t kind;        /* dspfx_kind */
-    int32_t mode;        /* dspfx_distort_mode / dspfx_fir_mode */
+    int32_t mode;        /* dspfx_distort_mode / dspfx_fir_mode / dspfx_signal_mode */
     float params[8];
     uint32_t delay_len;  /* REVERB: D >= 128 */
     uint32_t n_taps;     /* FIR */
