@@ -411,6 +411,8 @@ def main():
         except Exception as ex:   # the baseline is reporting only; never lose the GPU line
             line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
                                     "sample": f"failed: {ex}"}
+    else:
+        line["cpu_baseline"] = None      # N > 1, or switched off with --no-cpu-baseline
     print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()

@@ -1,0 +1,45 @@
+"""The committed bench records carry every field of the bench.py contract (one JSON line per run)."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def _records():
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json"))):
+        line = open(path).read().strip().splitlines()[-1]
+        yield path, json.loads(line)
+
+
+def test_committed_bench_lines_follow_the_contract():
+    seen = 0
+    for path, d in _records():
+        seen += 1
+        for k in REQUIRED:
+            assert k in d, (path, k)
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+        assert d["dtype"] == "f32" and d["vs_baseline"] is None
+        assert "workload" in d["config"] and "model" not in d["config"]
+        r = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, (path, k)
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        c = d["cpu_baseline"]
+        if c is not None:
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in c, (path, k)
+            assert c["kind"] in ("port", "reference")
+        assert abs(d["value"] - d["config"]["channels_per_gpu"] * d["n_gpus"] * d["config"]["frames_per_block"]
+                   / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert seen >= 4
+
+
+def test_headline_record_names_the_baseline_metric():
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    d = dict(_records())[os.path.join(ROOT, "profiles", "r01_bench_1gpu.json")]
+    assert d["unit"] == "samples/s" and "samples/sec" in d["metric"]
+    assert d["roofline"]["traffic"] and 0.9 < d["roofline"]["traffic"] / (16.5 * (1 << 20) * 128) < 1.1
+    assert isinstance(base, dict)
