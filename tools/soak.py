@@ -20,9 +20,9 @@ for seed in range(n_seeds):
     elif seed % 3 == 2:
         os.environ["DSPFX_VARIANT"] = "static=0,f=4,cpl=2"
     chain = [T._random_exact_node(dspfx, rng) for _ in range(int(rng.integers(1, 14)))]
-    tile = int(rng.choice([0, 64]))
-    N = int(rng.choice([64, 192, 448])) if tile else int(rng.choice([1, 2, 63, 100, 129, 130, 273, 418]))
-    block = int(rng.choice([128, 256, 384]))
+    tile = int(rng.choice([0, 64, 256]))
+    N = int(rng.choice([1, 3]) * tile) if tile else int(rng.choice([1, 2, 63, 100, 129, 130, 273, 418]))
+    block = int(rng.choice([128, 256, 384, 768]))
     lf = int(rng.choice([0, 1, 3]))
     nf = 768
     x, side = T.noise_block(N, nf, seed=seed), T.noise_block(N, nf, seed=seed + 999)
