@@ -13,9 +13,10 @@
 // relative to /root/reference/): f32, left-to-right, NO fused multiply-add
 // (the translation unit is compiled with -ffp-contract=off), IEEE division.
 #pragma once
+#ifndef __HIPCC_RTC__            // hiprtc (run-time specialisation, see dspfx.hip) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <type_traits>
+#endif
 
 namespace dspfx {
 

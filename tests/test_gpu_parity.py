@@ -1178,7 +1178,8 @@ def test_pipelined_host_path_matches_device_path(dspfx, torch_cuda):
 
 
 def test_default_variant_selection_above_131072_channels_matches_small_engines(dspfx, torch_cuda):
-    """Above 131072 channels the engine picks the two-channels-per-lane interpreter by itself.  Channels are
+    """Above 131072 channels the engine picks a run-time specialised kernel or the two-channels-per-lane interpreter
+    by itself.  Channels are
     independent, so a big engine must reproduce, bit for bit, what two smaller engines (one channel per lane) give for
     the two halves -- arithmetic chain, libm chain, tiled layout, ragged tail, mix bus."""
     B, blocks = 128, 2
@@ -1202,10 +1203,49 @@ def test_default_variant_selection_above_131072_channels_matches_small_engines(d
                 mixes.append(m.cpu().numpy().astype(np.float64))
             return np.concatenate(outs), np.concatenate(mixes), stage
         big, big_mix, stage = run(0, N)
-        assert "_c2" in stage, stage
+        # the arithmetic chain gets a run-time specialised kernel; the one with a generator stays on the interpreter
+        assert ("jit_" in stage) if not tile else ("dyn_libm_f8_c2" in stage), stage
         half = 65536 + 512
         a, am, sa = run(0, half)
         b, bm, _ = run(half, N - half)
-        assert "_c2" not in sa, sa
+        assert "_c2" not in sa and "jit_" not in sa, sa
         assert np.array_equal(big.view(np.uint32), np.concatenate([a, b], axis=1).view(np.uint32)), (N, tile)
         assert np.allclose(big_mix, am + bm, rtol=1e-5, atol=1e-2)
+
+
+def test_runtime_specialised_kernels_match_interpreter_and_oracle(dspfx, torch_cuda, monkeypatch):
+    """DSPFX_JIT=1 forces the hiprtc-instantiated `chain_kernel<F, CPL, SigList<...>>` at test sizes (large engines
+    use it by themselves): every node kind on its own and seeded random chains must give the interpreter's bits and
+    stay within the oracle bars; ragged channel counts, both layouts, mix bus, stage splits."""
+    N, B, blocks = 128 * 3 + 34, 128, 3
+    x, side = noise_block(N, B * blocks), noise_block(N, B * blocks, seed=9)
+    exact, libm = _every_node(dspfx)
+    nodes = [n for n in exact + libm if n.kind != dspfx.SIGNAL_GEN]     # generators stay on the interpreter
+    for node in nodes:
+        bar = 1 if any(node is e for e in exact) else LIBM_COMPOSITE_ULP
+        monkeypatch.setenv("DSPFX_JIT", "0")
+        base, base_mix = run_gpu(dspfx, torch_cuda, [node], x, side=side, want_mix=True)
+        monkeypatch.setenv("DSPFX_JIT", "1")
+        eng = dspfx.Engine(N, B)
+        eng.set_chain([node])
+        assert "jit_" in eng.describe(), eng.describe()
+        got, mix = run_gpu(dspfx, torch_cuda, [node], x, side=side, want_mix=True)
+        assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (node.kind, node.mode)
+        assert np.allclose(mix, base_mix, rtol=1e-5, atol=1e-3)
+        assert ulp_diff(got, run_oracle([node], x, 3, side)).max() <= bar, (node.kind, node.mode)
+    rng = np.random.default_rng(4242)
+    for case in range(8):
+        chain = [_random_exact_node(dspfx, rng) for _ in range(int(rng.integers(2, 13)))]
+        tile = int(rng.choice([0, 64]))
+        n_ch = 448 if tile else int(rng.choice([100, 129, 418]))
+        lf = int(rng.choice([0, 1, 3]))
+        xs, ss = noise_block(n_ch, B * 4, seed=case), noise_block(n_ch, B * 4, seed=case + 50)
+        monkeypatch.setenv("DSPFX_JIT", "1")
+        got = run_gpu(dspfx, torch_cuda, chain, xs, link_flags=lf, side=ss, tile=tile, block=int(rng.choice([128, 256])))
+        monkeypatch.setenv("DSPFX_JIT", "0")
+        base = run_gpu(dspfx, torch_cuda, chain, xs, link_flags=lf, side=ss, tile=tile)
+        ok = np.isfinite(base)
+        assert np.array_equal(got[ok].view(np.uint32), base[ok].view(np.uint32)), (case, [(n.kind, n.mode) for n in chain])
+        ref = run_oracle(chain, xs, lf, ss)
+        assert ulp_diff(got[ok], ref[ok]).max() <= 1, case
+    monkeypatch.delenv("DSPFX_JIT", raising=False)
