@@ -1095,7 +1095,9 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
     for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL>(a, st, c, w, f0, lane, wave_global);
     if constexpr (F > 1)
         for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL>(a, st, c, w, f0, lane, wave_global);
-#define DSPFX_ST(I) store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
+#define DSPFX_ST(I)                                                                              \
+    if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes); \
+    store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_ST)
 #undef DSPFX_ST
 }

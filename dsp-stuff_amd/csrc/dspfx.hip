@@ -416,8 +416,8 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
         for (int i = 0; i < st.count && ok; ++i) {
             const Node &n = e->nodes[st.first + i];
-            ok = n.d.kind != DSPFX_SIGNAL_GEN;      // its block-end bookkeeping lives in the interpreter only
-            sigs[i] = sig(n.d.kind, n.d.kind == DSPFX_DISTORT ? n.d.mode : 0, node_hop(e, st.first + i));
+            const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+            sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
         }
         const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
         if (ok && N >= 64u * (unsigned)cpl)

@@ -1177,7 +1177,7 @@ def test_pipelined_host_path_matches_device_path(dspfx, torch_cuda):
         assert np.array_equal(got_mix.view(np.uint32), dm.cpu().numpy().view(np.uint32)), b   # same partials, same reduction tree
 
 
-def test_default_variant_selection_above_131072_channels_matches_small_engines(dspfx, torch_cuda):
+def test_default_variant_selection_above_131072_channels_matches_small_engines(dspfx, torch_cuda, monkeypatch):
     """Above 131072 channels the engine picks a run-time specialised kernel or the two-channels-per-lane interpreter
     by itself.  Channels are
     independent, so a big engine must reproduce, bit for bit, what two smaller engines (one channel per lane) give for
@@ -1202,8 +1202,11 @@ def test_default_variant_selection_above_131072_channels_matches_small_engines(d
                 outs.append(dspfx.from_layout(y.cpu().numpy(), B, n, tile))
                 mixes.append(m.cpu().numpy().astype(np.float64))
             return np.concatenate(outs), np.concatenate(mixes), stage
+        # frame-major case: the default choice (a run-time specialised kernel); tiled case: specialisation switched
+        # off, so the default interpreter choice (two channels per lane) is what runs
+        if tile:
+            monkeypatch.setenv("DSPFX_JIT", "0")
         big, big_mix, stage = run(0, N)
-        # the arithmetic chain gets a run-time specialised kernel; the one with a generator stays on the interpreter
         assert ("jit_" in stage) if not tile else ("dyn_libm_f8_c2" in stage), stage
         half = 65536 + 512
         a, am, sa = run(0, half)
@@ -1220,7 +1223,7 @@ def test_runtime_specialised_kernels_match_interpreter_and_oracle(dspfx, torch_c
     N, B, blocks = 128 * 3 + 34, 128, 3
     x, side = noise_block(N, B * blocks), noise_block(N, B * blocks, seed=9)
     exact, libm = _every_node(dspfx)
-    nodes = [n for n in exact + libm if n.kind != dspfx.SIGNAL_GEN]     # generators stay on the interpreter
+    nodes = exact + libm
     for node in nodes:
         bar = 1 if any(node is e for e in exact) else LIBM_COMPOSITE_ULP
         monkeypatch.setenv("DSPFX_JIT", "0")
@@ -1233,6 +1236,13 @@ def test_runtime_specialised_kernels_match_interpreter_and_oracle(dspfx, torch_c
         assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), (node.kind, node.mode)
         assert np.allclose(mix, base_mix, rtol=1e-5, atol=1e-3)
         assert ulp_diff(got, run_oracle([node], x, 3, side)).max() <= bar, (node.kind, node.mode)
+    # a generator whose block ends inside a call (100-frame blocks): the specialised kernel closes the block too
+    monkeypatch.setenv("DSPFX_JIT", "1")
+    for mode in (dspfx.SIG_TRIANGLE, dspfx.SIG_SQUARE, dspfx.SIG_CONSTANT):
+        chain = [dspfx.SignalGen(0.9, 777.0, mode), dspfx.Gain(0.5)]
+        got = run_gpu(dspfx, torch_cuda, chain, noise_block(64, 600), block=100)
+        ref = O.run_channels([n.oracle_desc() for n in chain], np.zeros((600, 1), F), block=100)
+        assert np.array_equal(got[:, :1], ref), mode
     rng = np.random.default_rng(4242)
     for case in range(8):
         chain = [_random_exact_node(dspfx, rng) for _ in range(int(rng.integers(2, 13)))]
