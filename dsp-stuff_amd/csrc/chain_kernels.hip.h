@@ -877,7 +877,15 @@ __device__ __forceinline__ void run_slot(const SlotArgs &s, float (&v)[F][CPL], 
         }
     } else {
         if constexpr (sig_hop(SIG)) apply_hop<F, CPL, FAST>(v, cx.hop_div, cx.hop_rc);
-        apply_node<sig_kind(SIG), sig_mode(SIG), F, CPL, GUARD, FAST>(s, v, st, cx);
+        constexpr int K = sig_kind(SIG);
+        constexpr bool has_ports = K == K_GAIN || K == K_DISTORT || K == K_OVERDRIVE || K == K_MIX || K == K_SIGNAL_GEN;
+        if constexpr (MOD && has_ports) {          // specialised kernel with control ports (wave-uniform test)
+            if (s.ctl[0] || s.ctl[1] || s.ctl[2] || s.latch_valid) {
+                apply_node_mod<K, sig_mode(SIG), F, CPL, GUARD, FAST>(s, v, st, cx);
+                return;
+            }
+        }
+        apply_node<K, sig_mode(SIG), F, CPL, GUARD, FAST>(s, v, st, cx);
     }
 }
 
@@ -1049,7 +1057,7 @@ __device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (
         a.mixpart[(size_t)wave_global * a.nframes + f0 + mixbus_frame_of_lane<F>(lane)] = r[0];
 }
 
-template <int F, int CPL, class SL>
+template <int F, int CPL, class SL, bool MOD = false>
 __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c, const WaveAddr &w,
                                             unsigned f0, int lane, unsigned wave_global) {
     float v[F][CPL];
@@ -1066,7 +1074,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
         if constexpr (sig_hop(SL::v[I])) apply_hop<F, CPL, true>(v, cx.hop_div, cx.hop_rc); \
         ring_apply<F, CPL, false>(a.slot[I], v, pre[I], cx);                         \
     } else {                                                                         \
-        run_slot<SL::v[I], F, CPL, false, true>(a.slot[I], v, st[I], cx);            \
+        run_slot<SL::v[I], F, CPL, false, true, MOD>(a.slot[I], v, st[I], cx);       \
     }
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
@@ -1077,7 +1085,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 }
 
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
-template <int F, int CPL, class SL>
+template <int F, int CPL, class SL, bool MOD = false>
 __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
     if (a.mp_stage) mixpipe_prologue(a);
     const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
@@ -1092,9 +1100,9 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 #undef DSPFX_LD
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL>(a, st, c, w, f0, lane, wave_global);
+    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL, MOD>(a, st, c, w, f0, lane, wave_global);
     if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL>(a, st, c, w, f0, lane, wave_global);
+        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL, MOD>(a, st, c, w, f0, lane, wave_global);
 #define DSPFX_ST(I)                                                                              \
     if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes); \
     store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);

@@ -57,6 +57,8 @@ struct Stage {
     StageType type;
     int first, count;
     const Variant *var = nullptr;   // ST_FUSED
+    mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
+    mutable bool var_mod_tried = false;
     bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
 };
 
@@ -297,9 +299,9 @@ std::string csrc_dir() {
     return k == std::string::npos ? "." : p.substr(0, k);
 }
 
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl) {
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod) {
     char key[256];
-    int off = snprintf(key, sizeof key, "d%d_f%d_c%d", device, f, cpl);   // modules belong to the device they were loaded on
+    int off = snprintf(key, sizeof key, "d%d_f%d_c%d%s", device, f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
     for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
     std::lock_guard<std::mutex> lk(g_jit_mu);
     auto it = g_jit.find(key);
@@ -308,7 +310,7 @@ const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, 
     const std::string dir = csrc_dir();
     std::string expr = "dspfx::chain_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
     for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
-    expr += "> >";
+    expr += mod ? ">, true>" : "> >";
     const std::string src = "#include \"chain_kernels.hip.h\"\n";
     hiprtcProgram prog = nullptr;
     if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
@@ -326,7 +328,7 @@ const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, 
                     hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
                     hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
                     k->name = std::string("jit_") + key;
-                    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, false, true, nullptr};
+                    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
                     for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
                     k->var.name = k->name.c_str();
                     res = k;
@@ -357,6 +359,26 @@ int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned
     const JitKernel *k = reinterpret_cast<const JitKernel *>(v);   // `var` is the first member
     void *params[] = {const_cast<ChainArgs *>(&a)};
     return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
+}
+
+// Run-time specialised kernel for a fused stage (nullptr: not wanted / not possible).  mod = with control ports.
+const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N > 131072u);
+    if (!want_jit || st.count < 1 || !st.fast_div) return nullptr;
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
+    if (N < 64u * (unsigned)cpl) return nullptr;
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 8, cpl, mod);
+    return k ? &k->var : nullptr;
 }
 
 const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
@@ -407,22 +429,8 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         }
     }
     // no compiled-in specialisation: instantiate one at run time (large engines, or DSPFX_JIT=1)
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N > 131072u);
-    if (best && best->sigs[0] == SIG_DYN && want_jit && pref.stat != 0 && st.count >= 1 && st.fast_div) {
-        int sigs[MAX_SLOTS];
-        bool ok = true;
-        for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-        for (int i = 0; i < st.count && ok; ++i) {
-            const Node &n = e->nodes[st.first + i];
-            const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-            sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-        }
-        const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
-        if (ok && N >= 64u * (unsigned)cpl)
-            if (const JitKernel *k = jit_get(e->device, sigs, st.count, 8, cpl)) return &k->var;
-    }
+    if (best && best->sigs[0] == SIG_DYN && pref.stat != 0)
+        if (const Variant *j = jit_variant(e, st, false)) return j;
     return best;
 }
 
@@ -764,8 +772,14 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the MOD interpreter evaluates them
                 const Node &nd = e->nodes[st.first + k];
                 if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) {
-                    // two channels per lane above 131072 channels, like the plain interpreter
-                    v = (e->dyn_mod2 && N > 131072u && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod;
+                    // a run-time specialised kernel with control ports when one can be had (compiled on first use),
+                    // else the control-port interpreter: two channels per lane above 131072 channels
+                    if (!st.var_mod_tried) {
+                        st.var_mod_tried = true;
+                        const char *vp = getenv("DSPFX_VARIANT");
+                        if (!(vp && strstr(vp, "static=0"))) st.var_mod = jit_variant(e, st, true);
+                    }
+                    v = st.var_mod ? st.var_mod : ((e->dyn_mod2 && N > 131072u && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod);
                     tail = e->tail_mod;
                 }
             }
