@@ -1108,11 +1108,17 @@ def test_fast_f64_tanh_sin_atan_match_the_library_path_exhaustively(dspfx, torch
         assert dspfx.verify_libm(seed) == (0, 0), seed
 
 
-def test_control_ports_two_channel_interpreter_above_131072_channels(dspfx, torch_cuda):
+@pytest.mark.parametrize("jit", ["0", "default"])
+def test_control_ports_two_channel_interpreter_above_131072_channels(dspfx, torch_cuda, monkeypatch, jit):
     """Above 131072 channels a chain with connected control ports runs on the two-channels-per-lane control-port
     interpreter (dyn_mod_f8_c2).  Channels are independent, so its output must equal, bit for bit, what smaller
     engines (one channel per lane, validated against the oracle by test_control_ports) produce for channel slices;
     a few channels are also checked against the oracle directly."""
+    # jit "0": the control-port interpreter (dyn_mod_f8_c2); "default": the run-time specialised control-port kernel
+    if jit == "0":
+        monkeypatch.setenv("DSPFX_JIT", "0")
+    else:
+        monkeypatch.delenv("DSPFX_JIT", raising=False)
     N, B, blocks = 131072 + 1024 + 2, 128, 2          # even, N % 128 == 2: a 2-channel guarded tail rides along
     chain = [dspfx.Gain(1.0), dspfx.Distort(3.0, dspfx.HARD_CLIP), dspfx.Mix(0.5), dspfx.BiQuad(), dspfx.Overdrive(5.0, 0.5, 0.8)]
     keys = [(0, 0), (1, 0), (2, 0), (4, 1)]
