@@ -14,7 +14,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass, field
-from typing import Optional, Sequence
+from typing import Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -34,13 +34,17 @@ DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin",
 FIR_BALANCED, FIR_AVERAGE = 0, 1
 LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
+GRAPH_MAX_NODES = 8
+ERR_UNSUPPORTED = -5
+GRAPH_INPUT, GRAPH_ZERO = -1, -2
+PORT_MAIN, PORT_SIDE, PORT_SLIDER = 0, 1, 2
 
 # every symbol include/dspfx.h declares
 EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
-    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_state_size",
+    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_graph_set", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
@@ -62,6 +66,10 @@ class _EngineDesc(C.Structure):
 class _NodeDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("mode", C.c_int32), ("params", C.c_float * 8),
                 ("delay_len", C.c_uint32), ("n_taps", C.c_uint32), ("taps", C.POINTER(C.c_double))]
+
+
+class _GraphLink(C.Structure):
+    _fields_ = [("src", C.c_int32), ("dst", C.c_int32), ("port", C.c_int32)]
 
 
 class _Ctl(C.Structure):
@@ -97,6 +105,7 @@ def lib():
     L.dspfx_last_error.argtypes = [vp]
     L.dspfx_chain_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int]
     L.dspfx_chain_len.argtypes = [vp]
+    L.dspfx_graph_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int]
     L.dspfx_set_param.argtypes = [vp, C.c_int, C.c_int, C.c_float]
     L.dspfx_set_mode.argtypes = [vp, C.c_int, C.c_int]
     L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
@@ -349,6 +358,23 @@ class Engine:
                 arr[i].n_taps = len(t)
                 arr[i].taps = t.ctypes.data_as(C.POINTER(C.c_double))
         self._chk(self.L.dspfx_chain_set(self.h, arr, len(nodes)))
+        self.nodes = list(nodes)
+
+    def set_graph(self, nodes: Sequence[NodeSpec], links: Sequence[Tuple[int, int, int]]):
+        """A whole DAG as one generated kernel (include/dspfx.h, dspfx_graph_set).  `nodes` in an order in which every
+        link goes forward; links = (src, dst, port): src a node index, GRAPH_INPUT or GRAPH_ZERO; dst a node index or
+        len(nodes) for the Output node; port PORT_MAIN, PORT_SIDE or PORT_SLIDER + k.  Raises DspfxError with status
+        ERR_UNSUPPORTED when the graph cannot be fused."""
+        arr = (_NodeDesc * max(1, len(nodes)))()
+        for i, n in enumerate(nodes):
+            arr[i].kind, arr[i].mode = n.kind, n.mode
+            for k, v in enumerate(n.params):
+                arr[i].params[k] = float(v)
+            arr[i].delay_len = int(n.delay_len)
+        larr = (_GraphLink * max(1, len(links)))()
+        for i, (s, d, p) in enumerate(links):
+            larr[i].src, larr[i].dst, larr[i].port = int(s), int(d), int(p)
+        self._chk(self.L.dspfx_graph_set(self.h, arr, len(nodes), larr, len(links)))
         self.nodes = list(nodes)
 
     def set_param(self, node: int, param: int, value: float):

@@ -684,6 +684,13 @@ __device__ __forceinline__ void apply_node(const SlotArgs &s, float (&v)[F][CPL]
 // Per-sample value of slider k (dsp-stuff-derive/src/lib.rs:135-153): a connected port maps the
 // signal [-1,1] -> [lo,hi] per sample and latches the first value of every 128-frame block into
 // the slider (per channel here); an unconnected port fills with the slider value.
+// signal [-1, 1] -> slider range [lo, hi] (dsp-stuff-derive/src/lib.rs:139-146)
+__device__ __forceinline__ float slider_map(float x, float lo, float hi) {
+    const float y = (x + 1.0f) / 2.0f;
+    float z = y < 0.0f ? 0.0f : y;          // f32::clamp(0.0, 1.0): NaN stays NaN
+    z = z > 1.0f ? 1.0f : z;
+    return lo + (hi - lo) * z;
+}
 template <int F, int CPL, bool GUARD, bool FAST>
 __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo, float hi, const Ctx &cx,
                                               float (&p)[F][CPL]) {
@@ -695,10 +702,7 @@ __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo
             for (int j = 0; j < CPL; ++j) {
                 float x = p[f][j];
                 if (cx.side_hop & 2) x = link_hop<FAST>(x, cx.hop_div, cx.hop_rc);   // the control link's collect_and_average
-                const float y = (x + 1.0f) / 2.0f;
-                float z = y < 0.0f ? 0.0f : y;          // f32::clamp(0.0, 1.0): NaN stays NaN
-                z = z > 1.0f ? 1.0f : z;
-                p[f][j] = lo + (hi - lo) * z;
+                p[f][j] = slider_map(x, lo, hi);
             }
         }
         if ((cx.f0 & 127u) == 0) store_vec<CPL, GUARD>(s.latch[k] + cx.c, p[0], cx.active);   // lib.rs:148
@@ -718,58 +722,78 @@ __device__ __forceinline__ void slider_values(const SlotArgs &s, int k, float lo
 }
 
 // Nodes with `as_input` sliders, evaluated with per-sample slider values (IEEE division: the
-// divisor is no longer a wave-uniform constant).
+// divisor is no longer a wave-uniform constant).  The `*_mod_core` functions take the slider values as arrays:
+// apply_node_mod fills them from control buffers in memory, the whole-graph kernel (graph_kernel.hip.h) from registers.
+template <int F, int CPL>
+__device__ __forceinline__ void gain_mod_core(float (&v)[F][CPL], const float (&lv)[F][CPL]) {   // gain.rs:27-37
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] * lv[f][j];
+}
+template <int MODE, int F, int CPL>
+__device__ __forceinline__ void distort_mod_core(float (&v)[F][CPL], const float (&lv)[F][CPL]) {   // distort.rs:176-194
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if (!(lv[f][j] < 0.001f)) v[f][j] = distort1<MODE, false>(v[f][j], lv[f][j], 0.0, 0.0);
+}
+template <int F, int CPL>
+__device__ __forceinline__ void overdrive_mod_core(float (&v)[F][CPL], const float (&bo)[F][CPL], const float (&dr)[F][CPL],
+                                                   const float (&lv)[F][CPL]) {   // overdrive.rs:58-72
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+            if (!(lv[f][j] < 0.001f)) v[f][j] = overdrive1(v[f][j], bo[f][j], dr[f][j], lv[f][j]);
+}
+template <int MODE, int F, int CPL>
+__device__ __forceinline__ void siggen_mod_core(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL], const float (&am)[F][CPL],
+                                                const float (&fr)[F][CPL], const Ctx &cx) {   // signal_gen.rs:111-128
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+            if constexpr (MODE == G_SQUARE_OR_CONST) {
+                const bool is_const = s.mode == G_CONSTANT;
+                const float sq = signal1<G_SQUARE>(st[0][j], st[1][j], is_const ? 0.0f : fr[f][j], am[f][j]);
+                v[f][j] = is_const ? am[f][j] : sq;
+            } else {
+                v[f][j] = signal1<MODE>(st[0][j], st[1][j], fr[f][j], am[f][j]);
+            }
+        }
+        if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) {
+                st[0][j] = fmodf(st[0][j] + st[1][j], 1.0f);
+                st[1][j] = 0.0f;
+            }
+        }
+    }
+}
+
 template <int KIND, int MODE, int F, int CPL, bool GUARD, bool FAST>
 __device__ __forceinline__ void apply_node_mod(const SlotArgs &s, float (&v)[F][CPL], float (&st)[4][CPL], const Ctx &cx) {
-    if constexpr (KIND == K_GAIN) {                 // gain.rs:27-37, slider 0..=10
+    if constexpr (KIND == K_GAIN) {                 // slider 0..=10
         float lv[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 10.0f, cx, lv);
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] * lv[f][j];
-    } else if constexpr (KIND == K_DISTORT) {       // distort.rs:176-194, slider 0..=30
+        gain_mod_core<F, CPL>(v, lv);
+    } else if constexpr (KIND == K_DISTORT) {       // slider 0..=30
         float lv[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 30.0f, cx, lv);
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-#pragma unroll
-            for (int j = 0; j < CPL; ++j)
-                if (!(lv[f][j] < 0.001f)) v[f][j] = distort1<MODE, false>(v[f][j], lv[f][j], 0.0, 0.0);
-    } else if constexpr (KIND == K_OVERDRIVE) {     // overdrive.rs:58-72, sliders boost 0..=30, drive 0..=1, level 0..=1
+        distort_mod_core<MODE, F, CPL>(v, lv);
+    } else if constexpr (KIND == K_OVERDRIVE) {     // sliders boost 0..=30, drive 0..=1, level 0..=1
         float bo[F][CPL], dr[F][CPL], lv[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 30.0f, cx, bo);
         slider_values<F, CPL, GUARD, FAST>(s, 1, 0.0f, 1.0f, cx, dr);
         slider_values<F, CPL, GUARD, FAST>(s, 2, 0.0f, 1.0f, cx, lv);
-#pragma unroll
-        for (int f = 0; f < F; ++f)
-#pragma unroll
-            for (int j = 0; j < CPL; ++j)
-                if (!(lv[f][j] < 0.001f)) v[f][j] = overdrive1(v[f][j], bo[f][j], dr[f][j], lv[f][j]);
-    } else if constexpr (KIND == K_SIGNAL_GEN) {    // signal_gen.rs:111-128, sliders amplitude -1..=1, frequency 0.1..=20000
+        overdrive_mod_core<F, CPL>(v, bo, dr, lv);
+    } else if constexpr (KIND == K_SIGNAL_GEN) {    // sliders amplitude -1..=1, frequency 0.1..=20000
         float am[F][CPL], fr[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, -1.0f, 1.0f, cx, am);
         slider_values<F, CPL, GUARD, FAST>(s, 1, 0.1f, 20000.0f, cx, fr);
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) {
-                if constexpr (MODE == G_SQUARE_OR_CONST) {
-                    const bool is_const = s.mode == G_CONSTANT;
-                    const float sq = signal1<G_SQUARE>(st[0][j], st[1][j], is_const ? 0.0f : fr[f][j], am[f][j]);
-                    v[f][j] = is_const ? am[f][j] : sq;
-                } else {
-                    v[f][j] = signal1<MODE>(st[0][j], st[1][j], fr[f][j], am[f][j]);
-                }
-            }
-            if (MODE != G_CONSTANT && ((cx.f0 + f + 1) & 127u) == 0) {
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) {
-                    st[0][j] = fmodf(st[0][j] + st[1][j], 1.0f);
-                    st[1][j] = 0.0f;
-                }
-            }
-        }
+        siggen_mod_core<MODE, F, CPL>(s, v, st, am, fr, cx);
     } else if constexpr (KIND == K_MIX) {           // mix.rs:33-46, slider 0..=1
         float ra[F][CPL];
         slider_values<F, CPL, GUARD, FAST>(s, 0, 0.0f, 1.0f, cx, ra);

@@ -69,6 +69,8 @@ struct dspfx_engine {
     int device = 0;
     std::vector<Node> nodes;
     std::vector<Stage> stages;
+    bool graph_mode = false;                  // dspfx_graph_set: the nodes form a DAG evaluated by one generated kernel
+    std::vector<dspfx_graph_link> wiring;     // its links, in the caller's order
     std::string err;
     float hop_div = 1.0f;
     float *mixpart = nullptr;
@@ -299,19 +301,15 @@ std::string csrc_dir() {
     return k == std::string::npos ? "." : p.substr(0, k);
 }
 
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod) {
-    char key[256];
-    int off = snprintf(key, sizeof key, "d%d_f%d_c%d%s", device, f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
-    for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
+// Compile `src` (which includes headers from this library's directory), load it on the current device and look up the
+// kernel named by `expr`.  Cached per `key` for the life of the process, failures included.
+const JitKernel *jit_compile(const std::string &key, const std::string &src, const std::string &expr, const int (&sigs)[MAX_SLOTS],
+                             int n_slots, int f, int cpl, bool mod) {
     std::lock_guard<std::mutex> lk(g_jit_mu);
     auto it = g_jit.find(key);
     if (it != g_jit.end()) return it->second;
     JitKernel *res = nullptr;
     const std::string dir = csrc_dir();
-    std::string expr = "dspfx::chain_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
-    for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
-    expr += mod ? ">, true>" : "> >";
-    const std::string src = "#include \"chain_kernels.hip.h\"\n";
     hiprtcProgram prog = nullptr;
     if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
         const std::string inc = "-I" + dir;
@@ -327,7 +325,7 @@ const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, 
                 if (hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS &&
                     hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
                     hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
-                    k->name = std::string("jit_") + key;
+                    k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
                     k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
                     for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
                     k->var.name = k->name.c_str();
@@ -348,6 +346,16 @@ const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, 
     }
     g_jit[key] = res;
     return res;
+}
+
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod) {
+    char key[256];
+    int off = snprintf(key, sizeof key, "d%d_f%d_c%d%s", device, f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
+    for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
+    std::string expr = "dspfx::chain_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
+    for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
+    expr += mod ? ">, true>" : "> >";
+    return jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
 }
 
 // A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.
@@ -378,6 +386,125 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
     const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
     if (N < 64u * (unsigned)cpl) return nullptr;
     const JitKernel *k = jit_get(e->device, sigs, st.count, 8, cpl, mod);
+    return k ? &k->var : nullptr;
+}
+
+// ---- a whole graph as one kernel (include/dspfx.h: dspfx_graph_set, csrc/graph_kernel.hip.h) --------------------------
+// Sliders with an `as_input` port, per kind: count and the range a connected signal is mapped to.
+int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]) {
+    switch (d.kind) {
+    case DSPFX_GAIN: lo[0] = 0.0f; hi[0] = 10.0f; return 1;                                    // gain.rs:14
+    case DSPFX_DISTORT: lo[0] = 0.0f; hi[0] = 30.0f; return d.mode == DSPFX_DIST_FUZZ ? 0 : 1;   // distort.rs:37
+    case DSPFX_OVERDRIVE: lo[0] = 0.0f; hi[0] = 30.0f; lo[1] = 0.0f; hi[1] = 1.0f; lo[2] = 0.0f; hi[2] = 1.0f; return 3;
+    case DSPFX_MIX: lo[0] = 0.0f; hi[0] = 1.0f; return 1;                                       // mix.rs:15
+    case DSPFX_SIGNAL_GEN: lo[0] = -1.0f; hi[0] = 1.0f; lo[1] = 0.1f; hi[1] = 20000.0f; return 2;   // signal_gen.rs:31-37
+    default: return 0;
+    }
+}
+std::string hexf(float v) {
+    char b[64];
+    snprintf(b, sizeof b, "%af", (double)v);
+    return b;
+}
+std::string hexd(double v) {
+    char b[64];
+    snprintf(b, sizeof b, "%a", v);
+    return b;
+}
+
+// The generated translation unit: `struct Prog` with the graph's wiring spelled out on register arrays.
+std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[MAX_SLOTS]) {
+    const int n = (int)e->nodes.size();
+    auto port_links = [&](int dst, int port) {
+        std::vector<int> v;
+        for (const dspfx_graph_link &l : e->wiring)
+            if (l.dst == dst && l.port == port) v.push_back(l.src);
+        return v;
+    };
+    std::string body;
+    auto gather = [&](const std::string &dst, const std::vector<int> &srcs, bool declare) {
+        body += "        ";
+        if (declare) body += "float " + dst + "[F][CPL]; ";
+        body += "g_zero<F, CPL>(" + dst + ");";
+        for (int sidx : srcs) {
+            if (sidx == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";
+            else body += " g_acc<F, CPL>(" + dst + ", " + (sidx == DSPFX_GRAPH_INPUT ? std::string("x") : "v" + std::to_string(sidx)) + ");";
+        }
+        if (!srcs.empty()) {
+            const float div = dspfx_link_divisor(srcs.size());
+            body += std::string(" g_div<") + (divisor_is_fast(div) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
+                    hexd(1.0 / (double)div) + ");";
+        }
+        body += "\n";
+    };
+    const std::string FAST = fast ? "true" : "false";
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    bool uses_input = false;
+    for (const dspfx_graph_link &l : e->wiring) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+    for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
+        if (e->nodes[i].d.kind == DSPFX_REVERB)
+            body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(a.slot[" + std::to_string(i) +
+                    "], cx, pre" + std::to_string(i) + ");\n";
+    for (int i = 0; i < n; ++i) {
+        const dspfx_node_desc &d = e->nodes[i].d;
+        const bool has_mode = d.kind == DSPFX_DISTORT || d.kind == DSPFX_SIGNAL_GEN;
+        const int mode = has_mode ? d.mode : 0;
+        sigs[i] = sig(d.kind, mode, 0);
+        const std::string I = std::to_string(i), v = "v" + I, slot = "a.slot[" + I + "]", KM = std::to_string(d.kind) + ", " + std::to_string(mode);
+        body += "        // node " + I + "\n";
+        gather(v, port_links(i, DSPFX_PORT_MAIN), true);
+        float lo[3], hi[3];
+        const int ns = kind_sliders(d, lo, hi);
+        bool any_ctl = false;
+        std::string pn[3];
+        for (int k = 0; k < ns; ++k) any_ctl = any_ctl || !port_links(i, DSPFX_PORT_SLIDER + k).empty();
+        if (any_ctl)
+            for (int k = 0; k < ns; ++k) {
+                pn[k] = "p" + I + "_" + std::to_string(k);
+                const std::vector<int> src = port_links(i, DSPFX_PORT_SLIDER + k);
+                if (src.empty()) {
+                    body += "        float " + pn[k] + "[F][CPL]; g_fill<F, CPL>(" + pn[k] + ", " + slot + ".p[" + std::to_string(k) + "]);\n";
+                } else {
+                    gather(pn[k], src, true);
+                    body += "        g_slider<F, CPL>(" + pn[k] + ", " + hexf(lo[k]) + ", " + hexf(hi[k]) + ");\n";
+                }
+            }
+        if (d.kind == DSPFX_ADD || d.kind == DSPFX_MIX) gather("b" + I, port_links(i, DSPFX_PORT_SIDE), true);
+        body += "        ";
+        if (d.kind == DSPFX_REVERB) body += "ring_apply<F, CPL, false>(" + slot + ", " + v + ", pre" + I + ", cx);";
+        else if (d.kind == DSPFX_ADD) body += "g_add<F, CPL>(" + v + ", b" + I + ");";
+        else if (d.kind == DSPFX_MIX && any_ctl) body += "g_mix_mod<F, CPL>(" + v + ", b" + I + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_MIX) body += "g_mix<F, CPL>(" + v + ", b" + I + ", " + slot + ".p[0]);";
+        else if (d.kind == DSPFX_GAIN && any_ctl) body += "gain_mod_core<F, CPL>(" + v + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_DISTORT && any_ctl) body += "distort_mod_core<" + std::to_string(mode) + ", F, CPL>(" + v + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_OVERDRIVE && any_ctl) body += "overdrive_mod_core<F, CPL>(" + v + ", " + pn[0] + ", " + pn[1] + ", " + pn[2] + ");";
+        else if (d.kind == DSPFX_SIGNAL_GEN && any_ctl)
+            body += "siggen_mod_core<" + std::to_string(mode) + ", F, CPL>(" + slot + ", " + v + ", st[" + I + "], " + pn[0] + ", " + pn[1] + ", cx);";
+        else body += "apply_node<" + KM + ", F, CPL, false, " + FAST + ">(" + slot + ", " + v + ", st[" + I + "], cx);";
+        body += "\n";
+    }
+    body += "        // Output node\n";
+    gather("y", port_links(n, DSPFX_PORT_MAIN), false);
+    std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[MAX_SLOTS] = {";
+    for (int i = 0; i < MAX_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
+    src += std::string("};\n    static constexpr bool uses_input = ") + (uses_input ? "true" : "false") + ";\n";
+    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const ChainArgs &a, const float (&x)[F][CPL], float (&y)[F][CPL],\n"
+           "                                               float (&st)[MAX_SLOTS][4][CPL], const Ctx &cx) {\n";
+    src += body;
+    src += "    }\n};\n}  // namespace dspfx\n";
+    return src;
+}
+
+const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1, f = 8;
+    int sigs[MAX_SLOTS];
+    const std::string src = graph_source(e, st.fast_div, sigs);
+    if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
+    const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
+    const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
+                            std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
+    const JitKernel *k = jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
     return k ? &k->var : nullptr;
 }
 
@@ -464,11 +591,15 @@ int plan(dspfx_engine *e) {
         st.count = 0;
         e->stages.push_back(st);
     }
+    if (e->graph_mode && (e->stages.size() != 1 || e->stages[0].type != ST_FUSED || e->stages[0].count != n))
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph has a node that cannot be fused (FIR, Fuzz) or more than %d nodes", MAX_SLOTS);
     for (Stage &st : e->stages)
         if (st.type == ST_FUSED) {
             st.fast_div = stage_fast_div(e, st);
-            st.var = pick_variant(e, st);
-            if (!st.var) return fail(e, DSPFX_ERR_UNSUPPORTED, "no kernel variant for stage");
+            st.var = e->graph_mode ? graph_variant(e, st) : pick_variant(e, st);
+            if (!st.var)
+                return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
+                                                                    : "no kernel variant for stage");
         }
     for (const Node &nd : e->nodes) {
         if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
@@ -1018,8 +1149,17 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
 
 extern "C" const char *dspfx_last_error(const dspfx_engine *e) { return e ? e->err.c_str() : "null engine"; }
 
+namespace {
+int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
+}
 extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     if (!e) return DSPFX_ERR_INVALID;
+    e->graph_mode = false;
+    e->wiring.clear();
+    return set_nodes(e, nodes, n_nodes);
+}
+namespace {
+int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     if (n_nodes < 0 || n_nodes > DSPFX_MAX_NODES || (n_nodes > 0 && !nodes))
         return fail(e, DSPFX_ERR_INVALID, "chain length %d out of range", n_nodes);
     HIPCHK(e, hipSetDevice(e->device));
@@ -1041,6 +1181,47 @@ extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
         if (rc) return rc;
     }
     return plan(e);
+}
+}  // namespace
+
+extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
+                               int n_links) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (n_nodes < 0 || (n_nodes > 0 && !nodes) || n_links < 0 || (n_links > 0 && !links))
+        return fail(e, DSPFX_ERR_INVALID, "graph: bad node / link arrays");
+    if (n_nodes > DSPFX_GRAPH_MAX_NODES)
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
+    const uint32_t N = e->desc.channels;
+    const uint32_t per_wave = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 128u : 64u;
+    if (N % per_wave) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs channels %% %u == 0", per_wave);
+    std::map<std::pair<int, int>, int> fan_in;
+    for (int i = 0; i < n_links; ++i) {
+        const dspfx_graph_link &l = links[i];
+        if (l.dst < 0 || l.dst > n_nodes || l.src < DSPFX_GRAPH_ZERO || l.src >= l.dst)
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
+        bool ok = l.port == DSPFX_PORT_MAIN;
+        if (l.dst < n_nodes && !ok) {
+            const dspfx_node_desc &d = nodes[l.dst];
+            float lo[3], hi[3];
+            if (l.port == DSPFX_PORT_SIDE) ok = d.kind == DSPFX_ADD || d.kind == DSPFX_MIX;
+            else ok = l.port >= DSPFX_PORT_SLIDER && l.port - DSPFX_PORT_SLIDER < kind_sliders(d, lo, hi);
+        }
+        if (!ok) return fail(e, DSPFX_ERR_INVALID, "graph link %d: node %d has no port %d", i, l.dst, l.port);
+        if (++fan_in[{l.dst, l.port}] > DSPFX_MAX_LINKS)
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: more than %d links into one port", i, DSPFX_MAX_LINKS);
+    }
+    for (int i = 0; i < n_nodes; ++i)
+        if (nodes[i].kind == DSPFX_FIR || (nodes[i].kind == DSPFX_DISTORT && nodes[i].mode == DSPFX_DIST_FUZZ))
+            return fail(e, DSPFX_ERR_UNSUPPORTED, "graph node %d (FIR / Fuzz) has its own kernel and cannot be fused", i);
+    e->graph_mode = true;
+    e->wiring.assign(links, links + n_links);
+    const int rc = set_nodes(e, nodes, n_nodes);
+    if (rc != DSPFX_OK) {   // leave a usable (empty) chain engine behind
+        const std::string msg = e->err;
+        (void)dspfx_chain_set(e, nullptr, 0);
+        e->err = msg;
+    }
+    return rc;
 }
 
 extern "C" int dspfx_chain_len(const dspfx_engine *e) { return e ? (int)e->nodes.size() : DSPFX_ERR_INVALID; }
@@ -1244,6 +1425,7 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
                                  uint32_t n_frames, const dspfx_ctl *ctl, int n_ctl, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
     if (n_ctl < 0 || (n_ctl > 0 && !ctl)) return fail(e, DSPFX_ERR_INVALID, "bad control-port list");
+    if (n_ctl > 0 && e->graph_mode) return fail(e, DSPFX_ERR_INVALID, "a fused graph's control ports are links of the graph");
     HIPCHK(e, hipSetDevice(e->device));
     for (int i = 0; i < n_ctl; ++i) {
         const dspfx_ctl &c = ctl[i];

@@ -1,0 +1,130 @@
+// A whole graph (DAG of at most MAX_SLOTS fusable nodes) as ONE kernel: include/dspfx.h, dspfx_graph_set.
+//
+// The reference evaluates a graph node by node and every link is a pipe through memory (node.rs:267-352).  Here the
+// graph's wiring is compiled into the kernel at run time (hiprtc): the engine generates a `struct Prog` whose `run`
+// evaluates the nodes in the order given, every node output an array of registers, every port's collect_and_average
+// (node.rs:162-194) a few adds and one division on such arrays, and instantiates graph_kernel<F, CPL, Prog>.
+// Per-channel filter state, delay rings, the mix bus and the launch geometry are exactly the chain kernel's
+// (chain_kernels.hip.h); what changes is only where a node's inputs come from.  A block costs one read of the Input
+// node's buffer and one write of the Output node's, whatever the wiring.
+//
+// This header is only ever compiled by hiprtc (it is found next to libdspfx.so, like chain_kernels.hip.h).
+#pragma once
+#include "chain_kernels.hip.h"
+
+namespace dspfx {
+
+// ---- port arithmetic on register arrays ---------------------------------------------------------------
+template <int F, int CPL>
+__device__ __forceinline__ void g_zero(float (&r)[F][CPL]) {      // node.rs:165 / 288: the port's buffer starts zeroed
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = 0.0f;
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_fill(float (&r)[F][CPL], float x) {   // an unconnected slider port: the slider value
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = x;
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_acc(float (&r)[F][CPL], const float (&s)[F][CPL]) {   // node.rs:172-176: buf += pipe
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = r[f][j] + s[f][j];
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_acc_zero(float (&r)[F][CPL]) {   // a connected pipe that carries zeros
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = r[f][j] + 0.0f;
+}
+template <bool FAST, int F, int CPL>
+__device__ __forceinline__ void g_div(float (&r)[F][CPL], float div, double rc) {   // node.rs:189-191: buf /= 0.0001 + k
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = div_c<FAST>(r[f][j], div, rc);
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_slider(float (&p)[F][CPL], float lo, float hi) {   // dsp-stuff-derive/src/lib.rs:139-146
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) p[f][j] = slider_map(p[f][j], lo, hi);
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_add(float (&v)[F][CPL], const float (&b)[F][CPL]) {   // add.rs:29-33
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + b[f][j];
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_mix(float (&v)[F][CPL], const float (&b)[F][CPL], float ratio) {   // mix.rs:41-46
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = (b[f][j] * ratio) + (v[f][j] * (1.0f - ratio));
+}
+template <int F, int CPL>
+__device__ __forceinline__ void g_mix_mod(float (&v)[F][CPL], const float (&b)[F][CPL], const float (&ra)[F][CPL]) {
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) v[f][j] = (b[f][j] * ra[f][j]) + (v[f][j] * (1.0f - ra[f][j]));
+}
+
+// ---- the kernel ---------------------------------------------------------------------------------------
+// PROG (generated):  static constexpr int sigs[MAX_SLOTS]   node signatures (state rows to load / store)
+//                    static constexpr bool uses_input       false: no link leaves the Input node, `in` is not read
+//                    template <int F, int CPL> static void run(a, x, y, st, cx)   x = Input block, y = Output block
+template <int F, int CPL, class PROG>
+__device__ __forceinline__ void graph_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c, const WaveAddr &w,
+                                            unsigned f0, int lane, unsigned wave_global) {
+    float x[F][CPL], y[F][CPL];
+    if constexpr (PROG::uses_input) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), x[f], true);
+    } else {
+        g_zero<F, CPL>(x);
+    }
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, nullptr, 0, true};
+    PROG::template run<F, CPL>(a, x, y, st, cx);
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+        store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), y[f], true);
+    if (a.mixpart) mixbus_partial<F, CPL>(a, y, true, f0, lane, wave_global);
+}
+
+// Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves), like chain_kernel.
+template <int F, int CPL, class PROG>
+__global__ void __launch_bounds__(WG) graph_kernel(const ChainArgs a) {
+    if (a.mp_stage) mixpipe_prologue(a);
+    const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const size_t rel = (size_t)tid * CPL;
+    if (rel >= a.n_launch) return;                 // whole-wave uniform by construction
+    const size_t c = a.c_base + rel;
+    float st[MAX_SLOTS][4][CPL];
+#define DSPFX_LD(I) load_state<PROG::sigs[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
+    DSPFX_FOR_SLOTS(DSPFX_LD)
+#undef DSPFX_LD
+    const WaveAddr w = wave_addr(a, c);
+    unsigned f0 = 0;
+    for (; f0 + F <= a.nframes; f0 += F) graph_chunk<F, CPL, PROG>(a, st, c, w, f0, lane, wave_global);
+    if constexpr (F > 1)
+        for (; f0 < a.nframes; ++f0) graph_chunk<1, CPL, PROG>(a, st, c, w, f0, lane, wave_global);
+#define DSPFX_ST(I)                                                                              \
+    if constexpr (sig_is<K_SIGNAL_GEN>(PROG::sigs[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes); \
+    store_state<PROG::sigs[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
+    DSPFX_FOR_SLOTS(DSPFX_ST)
+#undef DSPFX_ST
+}
+
+}  // namespace dspfx

@@ -2,7 +2,11 @@
 (`collect_and_average` over several pipes, dsp-stuff/src/node.rs:162-194,267-352), Add / Mix fed by two
 different branches, control ports fed by other nodes, generator sources, several links into the Output node.
 
-The graph is cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
+A graph of at most 8 fusable nodes becomes ONE kernel generated for its wiring (`dspfx_graph_set`, csrc/graph_kernel.hip.h):
+node outputs stay in registers and a block costs one read of the Input node's buffer and one write of the Output node's.
+
+Anything else (more nodes, a FIR or Fuzz node, a channel count that is not a multiple of 128, no run-time compiler) is
+cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
 own per-channel state), runs are evaluated in topological order, and the only extra device work is
 `dspfx_link_average` where a port has more than one incoming link.  What a run consumes:
 
@@ -26,7 +30,8 @@ from __future__ import annotations
 import json
 from typing import Dict, List, Optional, Tuple
 
-from . import ADD, GAIN, LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, SIGNAL_GEN, Engine, NodeSpec
+from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_MAX_NODES, GRAPH_ZERO, LINK_INPUT, LINK_INTERNAL,
+               LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine, NodeSpec)
 from .config import _TABLE, DspConfigError, _node_from_cfg
 
 _UNSUPPORTED = {"muff"}                                # GPL crate, source not in the reference tree
@@ -201,17 +206,66 @@ def run_link_flags(r: _Run) -> int:
     return flags
 
 
+def fused_plan(g: Graph):
+    """The graph as `dspfx_graph_set` takes it: (node specs in topological order, links), or None when it cannot
+    be one kernel (too many nodes, a FIR or Fuzz node)."""
+    order = [nid for nid in g.order if g.nodes[nid].spec is not None]
+    if len(order) > GRAPH_MAX_NODES:
+        return None
+    for nid in order:
+        sp = g.nodes[nid].spec
+        if sp.kind == FIR or (sp.kind == DISTORT and sp.mode == FUZZ):
+            return None
+    idx = {nid: i for i, nid in enumerate(order)}
+
+    def src(s):
+        if s == ZERO:
+            return GRAPH_ZERO
+        return GRAPH_INPUT if g.nodes[s].typename == "input" else idx[s]
+
+    links = []
+    for nid in order:
+        n = g.nodes[nid]
+        links += [(src(s), idx[nid], PORT_MAIN) for s in n.main]
+        links += [(src(s), idx[nid], PORT_SIDE) for s in n.side]
+        for k, srcs in sorted(n.ctl.items()):
+            links += [(src(s), idx[nid], PORT_SLIDER + k) for s in srcs]
+    links += [(src(s), len(order), PORT_MAIN) for s in g.nodes[g.outputs[0]].main]
+    return [g.nodes[nid].spec for nid in order], links
+
+
 class GraphEngine:
     """N independent copies of a saved graph.  `process(x)` takes the Input node's block [n_frames][N] (device
-    tensor, the engine's layout) and returns the Output node's block."""
+    tensor, the engine's layout) and returns the Output node's block.
+    fused: None = one generated kernel for the whole graph when it can be had, else run by run; True = insist on
+    the one kernel; False = always run by run."""
 
     def __init__(self, text: str, channels: int, max_frames: int = 128, device: int = 0, tile_channels: int = 0,
-                 page_round: bool = False):
+                 page_round: bool = False, fused: Optional[bool] = None):
         import torch
         self.torch = torch
         self.g = Graph(text, page_round)
         self.N, self.B, self.tile = channels, max_frames, tile_channels
         self.dev = torch.device("cuda", device)
+        self.fused: Optional[Engine] = None
+        self.runs, self.run_of = [], {}
+        self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
+        self.final = self._buf()
+        plan = fused_plan(self.g) if fused is not False else None
+        if plan is not None:
+            eng = Engine(channels, max_frames, device=device, tile_channels=tile_channels)
+            try:
+                eng.set_graph(*plan)
+                self.fused = eng
+            except DspfxError as e:
+                eng.close()
+                if fused or e.status != ERR_UNSUPPORTED:
+                    raise
+        elif fused:
+            raise DspConfigError("this graph cannot be fused into one kernel")
+        if self.fused is not None:
+            self.util = self.fused
+            return
         self.runs, self.run_of = plan_runs(self.g)
         for r in self.runs:
             head = r.nodes[0]
@@ -224,8 +278,6 @@ class GraphEngine:
                 r.scratch_main = self._buf()
             if side_node is not None and len(side_node.side) > 1:
                 r.scratch_side = self._buf()
-        self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
-        self.final = self._buf()
         self.util = self.runs[0].engine if self.runs else Engine(channels, max_frames, device=device,
                                                                   tile_channels=tile_channels)
 
@@ -233,6 +285,8 @@ class GraphEngine:
         return self.torch.empty(self.B * self.N, dtype=self.torch.float32, device=self.dev)
 
     def describe(self) -> str:
+        if self.fused is not None:
+            return "one kernel: " + " | ".join(l for l in self.fused.describe().splitlines() if l.startswith("stage"))
         lines = []
         for k, r in enumerate(self.runs):
             stage = [l for l in r.engine.describe().splitlines() if l.startswith("stage")]
@@ -249,6 +303,9 @@ class GraphEngine:
 
     def process(self, x, n_frames: Optional[int] = None, stream: int = 0):
         nf = self.B if n_frames is None else int(n_frames)
+        if self.fused is not None:
+            self.fused.process(self.zeros if x is None else x, out=self.final, n_frames=nf, stream=stream)
+            return self.final
         for nid in self.g.order:
             n = self.g.nodes[nid]
             if n.spec is None:
@@ -284,5 +341,7 @@ class GraphEngine:
         return self.final
 
     def close(self):
+        if self.fused is not None:
+            self.fused.close()
         for r in self.runs:
             r.engine.close()

@@ -40,6 +40,15 @@ pub struct dspfx_ctl {
     pub signal: *const f32,
 }
 
+/// One link of a graph given to `dspfx_graph_set` (include/dspfx.h).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct dspfx_graph_link {
+    pub src: i32,
+    pub dst: i32,
+    pub port: i32,
+}
+
 pub const DSPFX_ABI_VERSION: u32 = 1;
 pub const DSPFX_BUF_SIZE: u32 = 128; // dsp-stuff/src/node.rs:257
 pub const DSPFX_MAX_NODES: u32 = 32;
@@ -58,6 +67,12 @@ pub const DSPFX_LINK_INTERNAL: u32 = 1;
 pub const DSPFX_LINK_INPUT: u32 = 2;
 pub const DSPFX_LINK_SIDE_RAW: u32 = 4;
 pub const DSPFX_MAX_LINKS: u32 = 16;
+pub const DSPFX_GRAPH_MAX_NODES: u32 = 8;
+pub const DSPFX_GRAPH_INPUT: i32 = -1;
+pub const DSPFX_GRAPH_ZERO: i32 = -2;
+pub const DSPFX_PORT_MAIN: i32 = 0;
+pub const DSPFX_PORT_SIDE: i32 = 1;
+pub const DSPFX_PORT_SLIDER: i32 = 2;
 
 // dspfx_kind
 pub const DSPFX_GAIN: c_int = 0;
@@ -129,6 +144,7 @@ extern "C" {
 
     pub fn dspfx_process_mixpipe(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_mixpipe_flush(e: *mut dspfx_engine, mix_older: *mut f32, mix_newer: *mut f32, n_connected: u64, stream: *mut c_void) -> c_int;
+    pub fn dspfx_graph_set(e: *mut dspfx_engine, nodes: *const dspfx_node_desc, n_nodes: c_int, links: *const dspfx_graph_link, n_links: c_int) -> c_int;
     pub fn dspfx_link_average(e: *mut dspfx_engine, srcs: *const *const f32, n_srcs: c_int, dst: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
 
     pub fn dspfx_state_size(e: *const dspfx_engine, node: c_int) -> i64;

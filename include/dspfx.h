@@ -265,6 +265,39 @@ int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_
 int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
                        void *stream);
 
+/* ---- a whole graph in one kernel ------------------------------------------------------------------
+ * The reference evaluates a saved graph (DSPConfig) node by node, every link a pipe through memory
+ * (node.rs:267-352).  For a DAG of at most DSPFX_GRAPH_MAX_NODES fusable nodes (every kind except FIR and
+ * Distort/Fuzz) the engine instead compiles ONE kernel for the graph at run time: node outputs live in
+ * registers, every port's collect_and_average (node.rs:162-194) is arithmetic on them, and a block costs one
+ * read of the Input node's buffer and one write of the Output node's, whatever the wiring.
+ *
+ * `nodes` are given in an order in which every link goes forward (src < dst).  A link connects the output of
+ * node `src` (or DSPFX_GRAPH_INPUT: the block passed as `in`; or DSPFX_GRAPH_ZERO: a connected pipe that
+ * carries zeros, the unselected output of a demux) to port `port` of node `dst` (dst == n_nodes: the Output
+ * node, whose only port is MAIN; its value is the block written to `out`).  A port with k links averages
+ * them in the order given, (0 + x1 + ... + xk) / f32(0.0001 + k); a port without links reads zeros (main,
+ * "b") or keeps its slider value (slider ports).  Ports: DSPFX_PORT_MAIN, DSPFX_PORT_SIDE (port "b" of
+ * ADD / MIX), DSPFX_PORT_SLIDER + k (the `as_input` port of slider k, dsp-stuff-derive/src/lib.rs:135-153).
+ * The engine's link_flags do not apply (every hop is explicit), `side` of the process calls is ignored and
+ * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 128 == 0.
+ * DSPFX_ERR_UNSUPPORTED: the graph cannot be fused (too many nodes, a FIR / Fuzz node, channel count) or the
+ * run-time compiler is unavailable: evaluate it run by run instead (dsp-stuff_amd/graph.py does).
+ * dspfx_chain_set returns the engine to chain mode. */
+#define DSPFX_GRAPH_MAX_NODES 8
+#define DSPFX_GRAPH_INPUT (-1)
+#define DSPFX_GRAPH_ZERO (-2)
+#define DSPFX_PORT_MAIN 0
+#define DSPFX_PORT_SIDE 1
+#define DSPFX_PORT_SLIDER 2
+typedef struct dspfx_graph_link {
+    int32_t src;    /* producing node index, DSPFX_GRAPH_INPUT or DSPFX_GRAPH_ZERO */
+    int32_t dst;    /* consuming node index, or n_nodes for the Output node */
+    int32_t port;   /* DSPFX_PORT_* of the consumer */
+} dspfx_graph_link;
+int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
+                    int n_links);
+
 /* ---- DSP state (parity tests; the reference never saves it) --- */
 /* Size in bytes of node `node`'s exported state:
  *   BIQUAD 4*N f32 [x1|x2|y1|y2][N]; LOW/HIGH_PASS N f32; REVERB D*N f32

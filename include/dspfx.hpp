@@ -133,6 +133,12 @@ class Engine {
         }
         chk(dspfx_chain_set(e_, d.data(), static_cast<int>(d.size())));
     }
+    // a whole DAG as one generated kernel (dspfx.h, dspfx_graph_set); Error::status == DSPFX_ERR_UNSUPPORTED when it cannot be fused
+    void set_graph(const std::vector<Node> &nodes, const std::vector<dspfx_graph_link> &links) {
+        std::vector<dspfx_node_desc> d;
+        for (const Node &n : nodes) d.push_back(n.d);
+        chk(dspfx_graph_set(e_, d.data(), static_cast<int>(d.size()), links.data(), static_cast<int>(links.size())));
+    }
     void set_param(int node, int param, float v) { chk(dspfx_set_param(e_, node, param, v)); }
     void set_mode(int node, Mode m) { chk(dspfx_set_mode(e_, node, static_cast<int>(m))); }
     void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }

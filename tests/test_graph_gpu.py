@@ -17,15 +17,26 @@ def G(dspfx):
     return graph
 
 
-@pytest.mark.parametrize("name", ["diamond", "lfo_tremolo", "fan_in_three", "routing", "routing_ab", "routing_ba"])
-@pytest.mark.parametrize("N,tile,B", [(100, 0, 128), (128, 64, 128), (64, 0, 256)])
-def test_graph_matches_reference_semantics(dspfx, G, name, N, tile, B):
-    import torch
-    text = {"routing_ab": lambda: graphs.routing("A", "B"), "routing_ba": lambda: graphs.routing("B", "A")}.get(
+NAMES = ["diamond", "lfo_tremolo", "fan_in_three", "routing", "routing_ab", "routing_ba"]
+
+
+def graph_text(name):
+    return {"routing_ab": lambda: graphs.routing("A", "B"), "routing_ba": lambda: graphs.routing("B", "A")}.get(
         name, getattr(graphs, name, None))()
+
+
+@pytest.mark.parametrize("fused", [None, False])
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("N,tile,B", [(100, 0, 128), (128, 64, 128), (64, 0, 256)])
+def test_graph_matches_reference_semantics(dspfx, G, name, N, tile, B, fused):
+    """fused=None: the whole graph as one generated kernel (N = 100 is not a whole number of waves and falls back to
+    run-by-run evaluation); fused=False: always run by run."""
+    import torch
+    text = graph_text(name)
     nf = 768
     x = O.noise(0x5EED0001, np.arange(N), np.arange(nf))
-    ge = G.GraphEngine(text, N, B, tile_channels=tile)
+    ge = G.GraphEngine(text, N, B, tile_channels=tile, fused=fused)
+    assert (ge.fused is not None) == (fused is None and N % 64 == 0), ge.describe()
     got = np.empty_like(x)
     for f0 in range(0, nf, B):
         dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
@@ -38,8 +49,59 @@ def test_graph_matches_reference_semantics(dspfx, G, name, N, tile, B):
     ge.close()
 
 
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("N,tile", [(132096, 256), (4096, 0)])
+def test_one_kernel_graph_equals_run_by_run(dspfx, G, name, N, tile):
+    """The generated whole-graph kernel and the run-by-run evaluation perform the same f32 operations in the same
+    order: bit-identical outputs, block after block (two channels per lane above 131072 tiled channels)."""
+    import torch
+    B, blocks = 128, 4
+    a = G.GraphEngine(graph_text(name), N, B, tile_channels=tile, fused=True)
+    b = G.GraphEngine(graph_text(name), N, B, tile_channels=tile, fused=False)
+    assert "jit_graph" in a.describe(), a.describe()
+    if N > 131072:
+        assert "_c2" in a.describe(), a.describe()
+    for k in range(blocks):
+        x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+        a.util.fill_noise(x, B, k * B, 0x5EED0002)
+        ya = a.process(x, B).clone()
+        yb = b.process(x, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), (name, N, tile, k)
+    a.close()
+    b.close()
+
+
+def test_graph_set_rejections(dspfx):
+    E = dspfx
+    eng = E.Engine(128, 128)
+    gain = E.NodeSpec(E.GAIN, [0.5])
+    with pytest.raises(E.DspfxError) as ei:      # a link must go forward
+        eng.set_graph([gain, gain], [(1, 0, E.PORT_MAIN)])
+    assert ei.value.status == -1
+    with pytest.raises(E.DspfxError) as ei:      # GAIN has one slider port and no "b" port
+        eng.set_graph([gain], [(E.GRAPH_INPUT, 0, E.PORT_SIDE)])
+    assert ei.value.status == -1
+    with pytest.raises(E.DspfxError) as ei:
+        eng.set_graph([gain], [(E.GRAPH_INPUT, 0, E.PORT_SLIDER + 1)])
+    assert ei.value.status == -1
+    with pytest.raises(E.DspfxError) as ei:      # Fuzz has its own kernel
+        eng.set_graph([E.NodeSpec(E.DISTORT, [2.0], mode=E.FUZZ)], [(E.GRAPH_INPUT, 0, E.PORT_MAIN)])
+    assert ei.value.status == E.ERR_UNSUPPORTED
+    with pytest.raises(E.DspfxError) as ei:
+        eng.set_graph([gain] * 9, [])
+    assert ei.value.status == E.ERR_UNSUPPORTED
+    eng.close()
+    odd = E.Engine(100, 128)
+    with pytest.raises(E.DspfxError) as ei:      # whole waves only
+        odd.set_graph([gain], [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (0, 1, E.PORT_MAIN)])
+    assert ei.value.status == E.ERR_UNSUPPORTED
+    odd.set_chain([gain])                        # the engine is still a usable chain engine
+    odd.close()
+
+
 def test_graph_partition_and_rejections(dspfx, G):
-    g = G.GraphEngine(graphs.diamond(), 64)
+    g = G.GraphEngine(graphs.diamond(), 64, fused=False)
     runs = sorted(sorted(m.id for m in r.nodes) for r in g.runs)
     # gain (fan-out 2) and high_pass (fan-out 2) end their runs; biquad > high_pass fuse; add starts a run
     # (two different producers), distort has fan-in, distort > reverb fuse

@@ -49,13 +49,13 @@ def _rust_struct_fields(name):
 
 
 def test_repr_c_structs_match():
-    for name in ("dspfx_engine_desc", "dspfx_node_desc", "dspfx_ctl"):
+    for name in ("dspfx_engine_desc", "dspfx_node_desc", "dspfx_ctl", "dspfx_graph_link"):
         assert _rust_struct_fields(name) == _c_struct_fields(name), name
 
 
 def test_constants_match():
     c = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(DSPFX_[A-Z0-9_]+)\s*=\s*(-?\d+)", _strip_comments(HDR))}
-    c.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DSPFX_[A-Z0-9_]+)\s+(-?\d+)u?\b", HDR)})
+    c.update({m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(DSPFX_[A-Z0-9_]+)\s+\(?(-?\d+)\)?u?\b", HDR)})
     r = {m.group(1): int(m.group(2)) for m in re.finditer(r"pub const (DSPFX_[A-Z0-9_]+): \w+ = (-?\d+);", FFI)}
     assert r, "no constants parsed"
     for k, v in r.items():

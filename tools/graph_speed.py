@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Step time of a whole saved graph (DAG) on GraphEngine: tests/graphs.py documents at 1 048 576 channels."""
-import os, sys, time
+"""Step time of a whole saved graph (DAG) on GraphEngine: tests/graphs.py documents at 1 048 576 channels, as one
+generated kernel (dspfx_graph_set) and evaluated run by run.   usage: graph_speed.py [name] [channels]"""
+import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
@@ -11,16 +12,20 @@ import graphs
 N, B = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20, 128
 name = sys.argv[1] if len(sys.argv) > 1 else "diamond"
 text = getattr(graphs, name)()
-ge = G.GraphEngine(text, N, B, tile_channels=256)
 x = torch.empty(B * N, dtype=torch.float32, device="cuda")
-ge.util.fill_noise(x, B, 0)
-for _ in range(20): ge.process(x, B)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-steps = 100
-t0 = time.perf_counter(); e0.record()
-for _ in range(steps): ge.process(x, B)
-e1.record(); torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / steps
-print("%s: %d runs, %.4f ms/block (host submit %.3f ms), %.3e samples/s" % (name, len(ge.runs), ms, (time.perf_counter() - t0) * 1e3 / steps, N * B / ms * 1e3))
-print(ge.describe())
+for fused in (True, False):
+    ge = G.GraphEngine(text, N, B, tile_channels=256, fused=fused)
+    ge.util.fill_noise(x, B, 0)
+    if ge.fused is not None:
+        ge.fused.tune_placement(x, ge.final, B)
+    for _ in range(20): ge.process(x, B)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    steps = 100
+    e0.record()
+    for _ in range(steps): ge.process(x, B)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    print("%s %s: %.4f ms/block, %.3e samples/s, %.0f GB/s of in+out" % (name, "one kernel " if fused else "run by run", ms, N * B / ms * 1e3, 8 * N * B / ms / 1e6))
+    print(ge.describe())
+    ge.close()
