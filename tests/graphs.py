@@ -81,3 +81,63 @@ def routing(in_port="B", out_port="A"):
          (9, "output", {})],
         [(0, 1, "in"), (0, 2, "in"), (1, 3, "a"), (2, 3, "b"), (3, 4, "in"), (4, 5, "in", "a"), (4, 6, "in", "b"),
          (5, 9, "in"), (6, 9, "in")])
+
+
+def random_dag(seed, n_nodes=8, libm=False):
+    """A random DAG of `n_nodes` effect nodes between an input (id 0) and an output (id 99): every port draws 0-3
+    links from earlier nodes (fan-in, fan-out and unplugged ports all occur), slider ports at most one.
+    libm=False keeps to the kinds whose arithmetic is exact f32 (no tanh / sin / exp), so the oracle comparison
+    needs no tolerance beyond the hop's."""
+    import random
+    rnd = random.Random(seed)
+    exact_modes = ["HardClip", "SoftClip", "RecipSoftClip", "Square", "Chebyshev4"]
+    pool = ["gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "add", "mix", "envelope", "signal_gen", "gain", "mix"]
+    if libm:
+        pool += ["overdrive", "chebyshev", "distort_libm", "signal_sine"]
+    nodes, links = [(0, "input", {})], []
+    for nid in range(1, n_nodes + 1):
+        tn = rnd.choice(pool)
+        if tn == "gain":
+            f = {"level": rnd.choice([0.5, 0.8, 1.0, 1.25])}
+        elif tn == "biquad":
+            f = dict(BQ)
+        elif tn in ("low_pass", "high_pass"):
+            f = {"ratio": rnd.choice([0.2, 0.5, 0.7])}
+        elif tn == "reverb":
+            f = {"seconds": rnd.choice([0.003, 0.004, 0.01]), "decay": rnd.choice([0.3, 0.5])}
+        elif tn == "distort":
+            f = {"level": rnd.choice([0.0, 1.5, 3.0, 7.0]), "mode": rnd.choice(exact_modes)}
+        elif tn == "distort_libm":
+            tn, f = "distort", {"level": rnd.choice([1.5, 3.0]), "mode": rnd.choice(["Tanh", "Sin", "Atan"])}
+        elif tn == "mix":
+            f = {"ratio": rnd.choice([0.0, 0.25, 0.5, 1.0])}
+        elif tn == "envelope":
+            f = {"attack": rnd.choice([0.0, 4.0, 50.0]), "release": rnd.choice([0.0, 100.0, 400.0])}
+        elif tn == "signal_gen":
+            f = {"amplitude": rnd.choice([0.3, 0.9, -0.5]), "frequency": rnd.choice([50.0, 440.0, 9000.0]),
+                 "mode": rnd.choice(["Triangle", "Square", "Constant"])}
+        elif tn == "signal_sine":
+            tn, f = "signal_gen", {"amplitude": 0.7, "frequency": rnd.choice([220.0, 3000.0]), "mode": "Sine"}
+        elif tn == "overdrive":
+            f = {"boost": rnd.choice([2.0, 10.0]), "drive": rnd.choice([0.3, 0.8]), "level": rnd.choice([0.0, 0.5, 1.0])}
+        elif tn == "chebyshev":
+            f = {"level_pos": rnd.choice([0.5, 2.0]), "level_neg": rnd.choice([0.7, 3.0])}
+        else:
+            f = {}
+        nodes.append((nid, tn, f))
+        ins = _PORTS.get(tn, (["in"], True))[0]
+        earlier = list(range(0, nid))
+        for k, port in enumerate(ins):
+            is_signal_port = port in ("in", "a", "b")
+            if is_signal_port:
+                n_links = rnd.choice([0, 1, 1, 1, 2, 3]) if tn != "signal_gen" else 0
+            else:
+                n_links = rnd.choice([0, 0, 1])
+            for s in rnd.sample(earlier, min(n_links, len(earlier))):
+                links.append((s, nid, port))
+    nodes.append((99, "output", {}))
+    for s in rnd.sample(range(1, n_nodes + 1), rnd.choice([1, 2, 3])):
+        links.append((s, 99, "in"))
+    if not any(l[1] == 99 and l[0] == n_nodes for l in links):
+        links.append((n_nodes, 99, "in"))       # the last node always reaches the output
+    return build(nodes, links)

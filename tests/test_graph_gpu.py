@@ -72,6 +72,48 @@ def test_one_kernel_graph_equals_run_by_run(dspfx, G, name, N, tile):
     b.close()
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_dag_matches_reference_semantics(dspfx, G, seed):
+    """Random 8-node DAGs (fan-in up to 3 on every port, fan-out, unplugged ports, slider ports fed by nodes) of the
+    exact-arithmetic kinds, as one generated kernel, against the node-by-node evaluation of the oracle."""
+    import torch
+    N, B, nf = 64, 128, 512
+    tile = 64 if seed % 2 else 0
+    text = graphs.random_dag(seed, 8)
+    x = O.noise(0x5EED0003 + seed, np.arange(N), np.arange(nf))
+    ge = G.GraphEngine(text, N, B, tile_channels=tile, fused=True)
+    got = np.empty_like(x)
+    for f0 in range(0, nf, B):
+        y = ge.process(torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda(), B)
+        torch.cuda.synchronize()
+        got[f0:f0 + B] = dspfx.from_layout(y.cpu().numpy(), B, N, tile)
+    ref = graph_eval.run_graph(ge.g, x)
+    assert np.isfinite(ref).all()
+    d = ulp_diff(got, ref)
+    assert d.max() <= 1, (seed, int(d.max()), text)
+    ge.close()
+
+
+@pytest.mark.parametrize("seed", range(100, 116))
+def test_random_dag_one_kernel_equals_run_by_run(dspfx, G, seed):
+    """Random DAGs of every fusable kind (libm nodes included): the generated kernel and the run-by-run evaluation
+    are bit-identical."""
+    import torch
+    N, B = 4096, 128
+    text = graphs.random_dag(seed, 8, libm=True)
+    a = G.GraphEngine(text, N, B, fused=True)
+    b = G.GraphEngine(text, N, B, fused=False)
+    for k in range(4):
+        x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+        a.util.fill_noise(x, B, k * B, 0x5EED0004 + seed)
+        ya = a.process(x, B).clone()
+        yb = b.process(x, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), (seed, k, text)
+    a.close()
+    b.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
