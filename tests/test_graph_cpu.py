@@ -103,3 +103,27 @@ def test_display_only_nodes_are_dropped(dspfx):
         assert False
     except config.DspConfigError as e:
         assert "outside the accelerated path" in str(e)
+
+
+def test_fused_plan_is_the_graph_in_link_order(dspfx):
+    """What `dspfx_graph_set` receives: nodes in topological order, every link forward, each port's links in the
+    document's order (the order collect_and_average adds them in)."""
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    specs, links = G.fused_plan(G.Graph(graphs.diamond()))
+    assert [s.kind for s in specs] == [E.GAIN, E.BIQUAD, E.HIGH_PASS, E.ADD, E.DISTORT, E.REVERB]
+    assert links == [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (E.GRAPH_INPUT, 1, E.PORT_MAIN), (1, 2, E.PORT_MAIN),
+                     (0, 3, E.PORT_MAIN), (2, 3, E.PORT_SIDE), (3, 4, E.PORT_MAIN), (0, 4, E.PORT_MAIN),
+                     (4, 5, E.PORT_MAIN), (5, 6, E.PORT_MAIN), (2, 6, E.PORT_MAIN)]
+    specs, links = G.fused_plan(G.Graph(graphs.lfo_tremolo()))
+    assert (0, 3, E.PORT_SLIDER + 0) in links and (1, 4, E.PORT_SLIDER + 0) in links   # LFO -> gain.level, envelope -> mix.ratio
+    specs, links = G.fused_plan(G.Graph(graphs.routing("B", "A")))
+    assert any(s == E.GRAPH_ZERO for s, _, _ in links)          # the demux's unselected output: a connected pipe of zeros
+    for seed in range(30):
+        g = G.Graph(graphs.random_dag(seed, 8, libm=bool(seed % 2)))
+        specs, links = G.fused_plan(g)
+        assert len(specs) == 8 and all(s < d for s, d, _ in links) and all(0 <= d <= 8 for _, d, _ in links)
+    assert G.fused_plan(G.Graph(graphs.random_dag(1, 9))) is None            # more nodes than one kernel holds
+    fuzz = json.loads(graphs.diamond())
+    next(n for n in fuzz["nodes"] if n["id"] == 5)["cfg"]["mode"] = "Fuzz"
+    assert G.fused_plan(G.Graph(json.dumps(fuzz))) is None                   # Fuzz is block-global: its own kernel
