@@ -114,6 +114,52 @@ def test_random_dag_one_kernel_equals_run_by_run(dspfx, G, seed):
     b.close()
 
 
+def test_graph_engine_mix_bus_host_path_and_parameter_changes(dspfx, G):
+    """A graph engine is an engine: the mix bus, the host-buffer path and slider / mode changes work as on a chain."""
+    import json
+    import torch
+    E = dspfx
+    N, B = 2048, 128
+    doc = graphs.diamond()
+    specs, links = G.fused_plan(G.Graph(doc))
+    eng = E.Engine(N, B)
+    eng.set_graph(specs, links)
+    x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+    eng.fill_noise(x, B, 0, 0x5EED0005)
+    y = torch.empty_like(x)
+    mix = torch.empty(B, dtype=torch.float32, device="cuda")
+    eng.process(x, out=y, mix=mix, n_frames=B)
+    torch.cuda.synchronize()
+    yh = y.cpu().numpy().reshape(B, N)
+    assert np.allclose(mix.cpu().numpy(), yh.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-3)
+    # host-buffer path of a second engine: same block, same bits
+    eng2 = E.Engine(N, B)
+    eng2.set_graph(specs, links)
+    out_h = eng2.process_host(x.cpu().numpy().reshape(B, N))
+    assert np.array_equal(out_h.view(np.uint32), yh.view(np.uint32))
+    eng2.close()
+    # slider and mode changes on the fused graph == the same graph saved with those settings
+    eng.set_param(0, 0, 0.25)                   # gain.level
+    eng.set_mode(4, E.HARD_CLIP)                # distort: SoftClip -> HardClip (a different generated kernel)
+    eng.reset()
+    mod = json.loads(doc)
+    next(n for n in mod["nodes"] if n["id"] == 1)["cfg"]["level"] = 0.25
+    next(n for n in mod["nodes"] if n["id"] == 5)["cfg"]["mode"] = "HardClip"
+    ref = G.GraphEngine(json.dumps(mod), N, B, fused=False)
+    for k in range(3):
+        eng.fill_noise(x, B, k * B, 0x5EED0006)
+        eng.process(x, out=y, n_frames=B)
+        yr = ref.process(x, B)
+        torch.cuda.synchronize()
+        assert torch.equal(y.view(torch.int32), yr.view(torch.int32)), k
+    with pytest.raises(E.DspfxError):           # control ports of a fused graph are links, not call arguments
+        eng.process(x, out=y, n_frames=B, ctl={(0, 0): x})
+    eng.set_chain([E.Gain(0.5)])                # back to a chain engine
+    assert "jit_graph" not in eng.describe()
+    ref.close()
+    eng.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
