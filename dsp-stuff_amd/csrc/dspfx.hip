@@ -13,6 +13,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,7 @@
 #include "aux_kernels.h"
 #include "fir_kernels.h"
 #include "variants.h"
+#include "graph_kernel.hip.h"   // GraphArgs
 
 using namespace dspfx;
 
@@ -365,6 +367,8 @@ int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned
         return 0;
     }
     const JitKernel *k = reinterpret_cast<const JitKernel *>(v);   // `var` is the first member
+    // a graph kernel takes GraphArgs: run_subblock's ChainArgs is the first member of one, so the same address serves
+    static_assert(offsetof(GraphArgs, c) == 0, "GraphArgs must begin with its ChainArgs");
     void *params[] = {const_cast<ChainArgs *>(&a)};
     return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
 }
@@ -413,7 +417,7 @@ std::string hexd(double v) {
 }
 
 // The generated translation unit: `struct Prog` with the graph's wiring spelled out on register arrays.
-std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[MAX_SLOTS]) {
+std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[GRAPH_SLOTS]) {
     const int n = (int)e->nodes.size();
     auto port_links = [&](int dst, int port) {
         std::vector<int> v;
@@ -438,19 +442,19 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[MAX_SLOTS
         body += "\n";
     };
     const std::string FAST = fast ? "true" : "false";
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
     bool uses_input = false;
     for (const dspfx_graph_link &l : e->wiring) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
     for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
         if (e->nodes[i].d.kind == DSPFX_REVERB)
-            body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(a.slot[" + std::to_string(i) +
-                    "], cx, pre" + std::to_string(i) + ");\n";
+            body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(gslot<" + std::to_string(i) +
+                    ">(g), cx, pre" + std::to_string(i) + ");\n";
     for (int i = 0; i < n; ++i) {
         const dspfx_node_desc &d = e->nodes[i].d;
         const bool has_mode = d.kind == DSPFX_DISTORT || d.kind == DSPFX_SIGNAL_GEN;
         const int mode = has_mode ? d.mode : 0;
         sigs[i] = sig(d.kind, mode, 0);
-        const std::string I = std::to_string(i), v = "v" + I, slot = "a.slot[" + I + "]", KM = std::to_string(d.kind) + ", " + std::to_string(mode);
+        const std::string I = std::to_string(i), v = "v" + I, slot = "gslot<" + I + ">(g)", KM = std::to_string(d.kind) + ", " + std::to_string(mode);
         body += "        // node " + I + "\n";
         gather(v, port_links(i, DSPFX_PORT_MAIN), true);
         float lo[3], hi[3];
@@ -485,11 +489,11 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[MAX_SLOTS
     }
     body += "        // Output node\n";
     gather("y", port_links(n, DSPFX_PORT_MAIN), false);
-    std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[MAX_SLOTS] = {";
-    for (int i = 0; i < MAX_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
+    std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[GRAPH_SLOTS] = {";
+    for (int i = 0; i < GRAPH_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < GRAPH_SLOTS ? ", " : "");
     src += std::string("};\n    static constexpr bool uses_input = ") + (uses_input ? "true" : "false") + ";\n";
-    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const ChainArgs &a, const float (&x)[F][CPL], float (&y)[F][CPL],\n"
-           "                                               float (&st)[MAX_SLOTS][4][CPL], const Ctx &cx) {\n";
+    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], float (&y)[F][CPL],\n"
+           "                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
     src += body;
     src += "    }\n};\n}  // namespace dspfx\n";
     return src;
@@ -497,9 +501,11 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[MAX_SLOTS
 
 const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     const uint32_t N = e->desc.channels;
-    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1, f = 8;
-    int sigs[MAX_SLOTS];
-    const std::string src = graph_source(e, st.fast_div, sigs);
+    // two channels per lane as the chain kernels do, unless the graph is large: twice the registers per live value
+    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0 && st.count <= MAX_SLOTS) ? 2 : 1, f = 8;
+    int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
+    const std::string src = graph_source(e, st.fast_div, gsigs);
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
     if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
     const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
     const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
@@ -573,7 +579,7 @@ int plan(dspfx_engine *e) {
         if (fusable(e->nodes[i])) {
             st.type = ST_FUSED;
             st.first = i;
-            while (i < n && fusable(e->nodes[i]) && i - st.first < MAX_SLOTS) ++i;
+            while (i < n && fusable(e->nodes[i]) && i - st.first < (e->graph_mode ? GRAPH_SLOTS : MAX_SLOTS)) ++i;
             st.count = i - st.first;
         } else {
             st.type = e->nodes[i].d.kind == DSPFX_FIR ? ST_FIR : ST_FUZZ;
@@ -592,7 +598,7 @@ int plan(dspfx_engine *e) {
         e->stages.push_back(st);
     }
     if (e->graph_mode && (e->stages.size() != 1 || e->stages[0].type != ST_FUSED || e->stages[0].count != n))
-        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph has a node that cannot be fused (FIR, Fuzz) or more than %d nodes", MAX_SLOTS);
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph has a node that cannot be fused (FIR, Fuzz) or more than %d nodes", GRAPH_SLOTS);
     for (Stage &st : e->stages)
         if (st.type == ST_FUSED) {
             st.fast_div = stage_fast_div(e, st);
@@ -869,8 +875,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
             if (st.count == 0 && !(last && (mix || e->partials_override || e->mp_building)) && src == out) continue;   // nothing to do
-            ChainArgs a;
-            memset(&a, 0, sizeof a);
+            GraphArgs ga;                   // a graph kernel reads the slots beyond ChainArgs from it
+            memset(&ga, 0, sizeof ga);
+            ChainArgs &a = ga.c;
             a.in = src;
             a.side = side;
             a.out = out;
@@ -896,7 +903,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             if (e->desc.link_flags & DSPFX_LINK_INTERNAL) a.side_hop = (e->desc.link_flags & DSPFX_LINK_SIDE_RAW) ? 2 : 3;
             int rows = 0;
             for (int k = 0; k < st.count; ++k) {
-                fill_slot(e, st.first + k, a.slot[k]);
+                fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS]);
                 rows += state_rows(e->nodes[st.first + k]);
             }
             const Variant *v = st.var, *tail = e->tail;
@@ -1192,7 +1199,7 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     if (n_nodes > DSPFX_GRAPH_MAX_NODES)
         return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
     const uint32_t N = e->desc.channels;
-    const uint32_t per_wave = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 128u : 64u;
+    const uint32_t per_wave = (e->desc.tile_channels && N > 131072u && N % 2u == 0 && n_nodes <= MAX_SLOTS) ? 128u : 64u;
     if (N % per_wave) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs channels %% %u == 0", per_wave);
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {

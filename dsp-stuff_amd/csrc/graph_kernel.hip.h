@@ -1,4 +1,4 @@
-// A whole graph (DAG of at most MAX_SLOTS fusable nodes) as ONE kernel: include/dspfx.h, dspfx_graph_set.
+// A whole graph (DAG of at most GRAPH_SLOTS fusable nodes) as ONE kernel: include/dspfx.h, dspfx_graph_set.
 //
 // The reference evaluates a graph node by node and every link is a pipe through memory (node.rs:267-352).  Here the
 // graph's wiring is compiled into the kernel at run time (hiprtc): the engine generates a `struct Prog` whose `run`
@@ -8,11 +8,26 @@
 // (chain_kernels.hip.h); what changes is only where a node's inputs come from.  A block costs one read of the Input
 // node's buffer and one write of the Output node's, whatever the wiring.
 //
-// This header is only ever compiled by hiprtc (it is found next to libdspfx.so, like chain_kernels.hip.h).
+// The kernel is only ever instantiated by hiprtc (this header is found next to libdspfx.so, like
+// chain_kernels.hip.h); the engine includes it for GraphArgs, and graph_kernel_check.hip keeps it compiling.
 #pragma once
 #include "chain_kernels.hip.h"
 
 namespace dspfx {
+
+// A graph may hold twice the nodes of a fused chain stage: the chain kernels' argument block stays as it is and
+// the graph kernel's appends the slots beyond it.
+constexpr int GRAPH_SLOTS = 16;
+struct GraphArgs {
+    ChainArgs c;                              // first: the engine builds a ChainArgs and launches either kind of kernel
+    SlotArgs more[GRAPH_SLOTS - MAX_SLOTS];   // slots MAX_SLOTS .. GRAPH_SLOTS-1
+};
+template <int I>
+__host__ __device__ __forceinline__ const SlotArgs &gslot(const GraphArgs &g) {
+    if constexpr (I < MAX_SLOTS) return g.c.slot[I];
+    else return g.more[I - MAX_SLOTS];
+}
+#define DSPFX_FOR_GSLOTS(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15)
 
 // ---- port arithmetic on register arrays ---------------------------------------------------------------
 template <int F, int CPL>
@@ -80,12 +95,13 @@ __device__ __forceinline__ void g_mix_mod(float (&v)[F][CPL], const float (&b)[F
 }
 
 // ---- the kernel ---------------------------------------------------------------------------------------
-// PROG (generated):  static constexpr int sigs[MAX_SLOTS]   node signatures (state rows to load / store)
-//                    static constexpr bool uses_input       false: no link leaves the Input node, `in` is not read
-//                    template <int F, int CPL> static void run(a, x, y, st, cx)   x = Input block, y = Output block
+// PROG (generated):  static constexpr int sigs[GRAPH_SLOTS]  node signatures (state rows to load / store)
+//                    static constexpr bool uses_input        false: no link leaves the Input node, `in` is not read
+//                    template <int F, int CPL> static void run(g, x, y, st, cx)   x = Input block, y = Output block
 template <int F, int CPL, class PROG>
-__device__ __forceinline__ void graph_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c, const WaveAddr &w,
+__device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAPH_SLOTS][4][CPL], size_t c, const WaveAddr &w,
                                             unsigned f0, int lane, unsigned wave_global) {
+    const ChainArgs &a = g.c;
     float x[F][CPL], y[F][CPL];
     if constexpr (PROG::uses_input) {
 #pragma unroll
@@ -94,7 +110,7 @@ __device__ __forceinline__ void graph_chunk(const ChainArgs &a, float (&st)[MAX_
         g_zero<F, CPL>(x);
     }
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, nullptr, 0, true};
-    PROG::template run<F, CPL>(a, x, y, st, cx);
+    PROG::template run<F, CPL>(g, x, y, st, cx);
 #pragma unroll
     for (int f = 0; f < F; ++f)
         store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), y[f], true);
@@ -103,7 +119,8 @@ __device__ __forceinline__ void graph_chunk(const ChainArgs &a, float (&st)[MAX_
 
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves), like chain_kernel.
 template <int F, int CPL, class PROG>
-__global__ void __launch_bounds__(WG) graph_kernel(const ChainArgs a) {
+__global__ void __launch_bounds__(WG) graph_kernel(const GraphArgs g) {
+    const ChainArgs &a = g.c;
     if (a.mp_stage) mixpipe_prologue(a);
     const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -111,19 +128,19 @@ __global__ void __launch_bounds__(WG) graph_kernel(const ChainArgs a) {
     const size_t rel = (size_t)tid * CPL;
     if (rel >= a.n_launch) return;                 // whole-wave uniform by construction
     const size_t c = a.c_base + rel;
-    float st[MAX_SLOTS][4][CPL];
-#define DSPFX_LD(I) load_state<PROG::sigs[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
-    DSPFX_FOR_SLOTS(DSPFX_LD)
+    float st[GRAPH_SLOTS][4][CPL];
+#define DSPFX_LD(I) load_state<PROG::sigs[I], CPL, false>(gslot<I>(g), st[I], c, a.N, true);
+    DSPFX_FOR_GSLOTS(DSPFX_LD)
 #undef DSPFX_LD
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) graph_chunk<F, CPL, PROG>(a, st, c, w, f0, lane, wave_global);
+    for (; f0 + F <= a.nframes; f0 += F) graph_chunk<F, CPL, PROG>(g, st, c, w, f0, lane, wave_global);
     if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) graph_chunk<1, CPL, PROG>(a, st, c, w, f0, lane, wave_global);
+        for (; f0 < a.nframes; ++f0) graph_chunk<1, CPL, PROG>(g, st, c, w, f0, lane, wave_global);
 #define DSPFX_ST(I)                                                                              \
-    if constexpr (sig_is<K_SIGNAL_GEN>(PROG::sigs[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes); \
-    store_state<PROG::sigs[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
-    DSPFX_FOR_SLOTS(DSPFX_ST)
+    if constexpr (sig_is<K_SIGNAL_GEN>(PROG::sigs[I])) signal_gen_close_block<CPL>(gslot<I>(g), st[I], a.nframes); \
+    store_state<PROG::sigs[I], CPL, false>(gslot<I>(g), st[I], c, a.N, true);
+    DSPFX_FOR_GSLOTS(DSPFX_ST)
 #undef DSPFX_ST
 }
 

@@ -6,25 +6,26 @@
 
 namespace dspfx {
 struct CheckProg {
-    static constexpr int sigs[MAX_SLOTS] = {sig(K_GAIN), sig(K_REVERB), sig(K_MIX), sig(K_SIGNAL_GEN, G_SINE), sig(K_OVERDRIVE),
-                                            sig(K_BIQUAD), sig(K_DISTORT, D_TANH), sig(K_ADD)};
+    static constexpr int sigs[GRAPH_SLOTS] = {sig(K_GAIN), sig(K_REVERB), sig(K_MIX), sig(K_SIGNAL_GEN, G_SINE), sig(K_OVERDRIVE),
+                                              sig(K_BIQUAD), sig(K_DISTORT, D_TANH), sig(K_ADD), sig(K_LOW_PASS), SIG_NONE, SIG_NONE,
+                                              SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE};
     static constexpr bool uses_input = true;
     template <int F, int CPL>
-    static __device__ __forceinline__ void run(const ChainArgs &a, const float (&x)[F][CPL], float (&y)[F][CPL],
-                                               float (&st)[MAX_SLOTS][4][CPL], const Ctx &cx) {
-        RingPre<F, CPL> pre1; ring_prefetch<F, CPL, false>(a.slot[1], cx, pre1);
+    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], float (&y)[F][CPL],
+                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {
+        RingPre<F, CPL> pre1; ring_prefetch<F, CPL, false>(gslot<1>(g), cx, pre1);
         // node 0: one link from the Input node
         float v0[F][CPL]; g_zero<F, CPL>(v0); g_acc<F, CPL>(v0, x); g_div<true, F, CPL>(v0, 0x1.0006p+0f, 0x1.fff2p-1);
-        apply_node<K_GAIN, 0, F, CPL, false, true>(a.slot[0], v0, st[0], cx);
+        apply_node<K_GAIN, 0, F, CPL, false, true>(gslot<0>(g), v0, st[0], cx);
         // node 1: fan-in of a node and a pipe of zeros, IEEE division
         float v1[F][CPL]; g_zero<F, CPL>(v1); g_acc<F, CPL>(v1, v0); g_acc_zero<F, CPL>(v1); g_div<false, F, CPL>(v1, 0x1.00034p+1f, 0x1.fff98p-2);
-        ring_apply<F, CPL, false>(a.slot[1], v1, pre1, cx);
+        ring_apply<F, CPL, false>(gslot<1>(g), v1, pre1, cx);
         // node 3: a generator whose frequency slider is fed by node 1
         float v3[F][CPL]; g_zero<F, CPL>(v3);
-        float p3_0[F][CPL]; g_fill<F, CPL>(p3_0, a.slot[3].p[0]);
+        float p3_0[F][CPL]; g_fill<F, CPL>(p3_0, gslot<3>(g).p[0]);
         float p3_1[F][CPL]; g_zero<F, CPL>(p3_1); g_acc<F, CPL>(p3_1, v1); g_div<true, F, CPL>(p3_1, 0x1.0006p+0f, 0x1.fff2p-1);
         g_slider<F, CPL>(p3_1, 0x1.99999ap-4f, 0x1.388p+14f);
-        siggen_mod_core<G_SINE, F, CPL>(a.slot[3], v3, st[3], p3_0, p3_1, cx);
+        siggen_mod_core<G_SINE, F, CPL>(gslot<3>(g), v3, st[3], p3_0, p3_1, cx);
         // node 2: Mix with its ratio slider and "b" port connected
         float v2[F][CPL]; g_zero<F, CPL>(v2); g_acc<F, CPL>(v2, v0); g_div<true, F, CPL>(v2, 0x1.0006p+0f, 0x1.fff2p-1);
         float p2_0[F][CPL]; g_zero<F, CPL>(p2_0); g_acc<F, CPL>(p2_0, v3); g_div<true, F, CPL>(p2_0, 0x1.0006p+0f, 0x1.fff2p-1);
@@ -33,13 +34,13 @@ struct CheckProg {
         g_mix_mod<F, CPL>(v2, b2, p2_0);
         // node 4: one of three sliders connected
         float v4[F][CPL]; g_zero<F, CPL>(v4); g_acc<F, CPL>(v4, v2); g_div<true, F, CPL>(v4, 0x1.0006p+0f, 0x1.fff2p-1);
-        float p4_0[F][CPL]; g_fill<F, CPL>(p4_0, a.slot[4].p[0]);
-        float p4_1[F][CPL]; g_fill<F, CPL>(p4_1, a.slot[4].p[1]);
+        float p4_0[F][CPL]; g_fill<F, CPL>(p4_0, gslot<4>(g).p[0]);
+        float p4_1[F][CPL]; g_fill<F, CPL>(p4_1, gslot<4>(g).p[1]);
         float p4_2[F][CPL]; g_zero<F, CPL>(p4_2); g_acc<F, CPL>(p4_2, v3); g_div<true, F, CPL>(p4_2, 0x1.0006p+0f, 0x1.fff2p-1);
         g_slider<F, CPL>(p4_2, 0x0p+0f, 0x1p+0f);
         overdrive_mod_core<F, CPL>(v4, p4_0, p4_1, p4_2);
         float v5[F][CPL]; g_zero<F, CPL>(v5); g_acc<F, CPL>(v5, v4); g_div<true, F, CPL>(v5, 0x1.0006p+0f, 0x1.fff2p-1);
-        apply_node<K_BIQUAD, 0, F, CPL, false, true>(a.slot[5], v5, st[5], cx);
+        apply_node<K_BIQUAD, 0, F, CPL, false, true>(gslot<5>(g), v5, st[5], cx);
         float v6[F][CPL]; g_zero<F, CPL>(v6); g_acc<F, CPL>(v6, v5); g_div<true, F, CPL>(v6, 0x1.0006p+0f, 0x1.fff2p-1);
         float p6_0[F][CPL]; g_zero<F, CPL>(p6_0); g_acc<F, CPL>(p6_0, v3); g_div<true, F, CPL>(p6_0, 0x1.0006p+0f, 0x1.fff2p-1);
         g_slider<F, CPL>(p6_0, 0x0p+0f, 0x1.ep+4f);
@@ -49,11 +50,14 @@ struct CheckProg {
         float b7[F][CPL]; g_zero<F, CPL>(b7);
         g_add<F, CPL>(v7, b7);
         gain_mod_core<F, CPL>(v7, p2_0);
-        g_mix<F, CPL>(v7, b2, a.slot[2].p[0]);
+        g_mix<F, CPL>(v7, b2, gslot<2>(g).p[0]);
+        // node 8: a slot beyond the chain kernels' argument block
+        float v8[F][CPL]; g_zero<F, CPL>(v8); g_acc<F, CPL>(v8, v7); g_div<true, F, CPL>(v8, 0x1.0006p+0f, 0x1.fff2p-1);
+        apply_node<K_LOW_PASS, 0, F, CPL, false, true>(gslot<8>(g), v8, st[8], cx);
         // Output node: two links
-        g_zero<F, CPL>(y); g_acc<F, CPL>(y, v7); g_acc<F, CPL>(y, v2); g_div<true, F, CPL>(y, 0x1.00034p+1f, 0x1.fff98p-2);
+        g_zero<F, CPL>(y); g_acc<F, CPL>(y, v8); g_acc<F, CPL>(y, v2); g_div<true, F, CPL>(y, 0x1.00034p+1f, 0x1.fff98p-2);
     }
 };
-template __global__ void graph_kernel<8, 2, CheckProg>(const ChainArgs);
-template __global__ void graph_kernel<8, 1, CheckProg>(const ChainArgs);
+template __global__ void graph_kernel<8, 2, CheckProg>(const GraphArgs);
+template __global__ void graph_kernel<8, 1, CheckProg>(const GraphArgs);
 }  // namespace dspfx

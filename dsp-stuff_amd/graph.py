@@ -2,7 +2,7 @@
 (`collect_and_average` over several pipes, dsp-stuff/src/node.rs:162-194,267-352), Add / Mix fed by two
 different branches, control ports fed by other nodes, generator sources, several links into the Output node.
 
-A graph of at most 8 fusable nodes becomes ONE kernel generated for its wiring (`dspfx_graph_set`, csrc/graph_kernel.hip.h):
+A graph of at most 16 fusable nodes becomes ONE kernel generated for its wiring (`dspfx_graph_set`, csrc/graph_kernel.hip.h):
 node outputs stay in registers and a block costs one read of the Input node's buffer and one write of the Output node's.
 
 Anything else (more nodes, a FIR or Fuzz node, a channel count that is not a multiple of 128, no run-time compiler) is

@@ -67,7 +67,7 @@ pub const DSPFX_LINK_INTERNAL: u32 = 1;
 pub const DSPFX_LINK_INPUT: u32 = 2;
 pub const DSPFX_LINK_SIDE_RAW: u32 = 4;
 pub const DSPFX_MAX_LINKS: u32 = 16;
-pub const DSPFX_GRAPH_MAX_NODES: u32 = 8;
+pub const DSPFX_GRAPH_MAX_NODES: u32 = 16;
 pub const DSPFX_GRAPH_INPUT: i32 = -1;
 pub const DSPFX_GRAPH_ZERO: i32 = -2;
 pub const DSPFX_PORT_MAIN: i32 = 0;

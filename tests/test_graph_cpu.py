@@ -120,10 +120,11 @@ def test_fused_plan_is_the_graph_in_link_order(dspfx):
     specs, links = G.fused_plan(G.Graph(graphs.routing("B", "A")))
     assert any(s == E.GRAPH_ZERO for s, _, _ in links)          # the demux's unselected output: a connected pipe of zeros
     for seed in range(30):
-        g = G.Graph(graphs.random_dag(seed, 8, libm=bool(seed % 2)))
+        n = 8 if seed < 20 else 16
+        g = G.Graph(graphs.random_dag(seed, n, libm=bool(seed % 2)))
         specs, links = G.fused_plan(g)
-        assert len(specs) == 8 and all(s < d for s, d, _ in links) and all(0 <= d <= 8 for _, d, _ in links)
-    assert G.fused_plan(G.Graph(graphs.random_dag(1, 9))) is None            # more nodes than one kernel holds
+        assert len(specs) == n and all(s < d for s, d, _ in links) and all(0 <= d <= n for _, d, _ in links)
+    assert G.fused_plan(G.Graph(graphs.random_dag(1, 17))) is None            # more nodes than one kernel holds
     fuzz = json.loads(graphs.diamond())
     next(n for n in fuzz["nodes"] if n["id"] == 5)["cfg"]["mode"] = "Fuzz"
     assert G.fused_plan(G.Graph(json.dumps(fuzz))) is None                   # Fuzz is block-global: its own kernel
