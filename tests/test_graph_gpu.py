@@ -115,6 +115,26 @@ def test_random_dag_one_kernel_equals_run_by_run(dspfx, G, seed):
     b.close()
 
 
+@pytest.mark.parametrize("name", ["diamond", "lfo_tremolo", "fan_in_three"])
+@pytest.mark.parametrize("nf", [100, 37, 1])
+def test_one_kernel_graph_short_blocks(dspfx, G, name, nf):
+    """Blocks that are not a multiple of the kernel's 8-frame chunk (the single-frame tail loop) and shorter than the
+    reference's 128: still bit-identical to the run-by-run evaluation, block after block."""
+    import torch
+    N, B = 1024, 128
+    a = G.GraphEngine(graph_text(name), N, B, fused=True)
+    b = G.GraphEngine(graph_text(name), N, B, fused=False)
+    x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+    for k in range(5):
+        a.util.fill_noise(x, nf, k * nf, 0x5EED0007)
+        ya = a.process(x, nf).clone()
+        yb = b.process(x, nf)
+        torch.cuda.synchronize()
+        assert torch.equal(ya[:nf * N].view(torch.int32), yb[:nf * N].view(torch.int32)), (name, nf, k)
+    a.close()
+    b.close()
+
+
 def test_graph_engine_mix_bus_host_path_and_parameter_changes(dspfx, G):
     """A graph engine is an engine: the mix bus, the host-buffer path and slider / mode changes work as on a chain."""
     import json
