@@ -66,6 +66,22 @@ int main(int argc, char **argv) {
         node.process(in1, out1);
         for (uint32_t f = 0; f < BUF_SIZE; ++f)
             if (out1[f] != in1[f] * 2.0f) { std::printf("FAIL: GpuChain gain\n"); return 1; }
+        // a chain handed over as a graph (every link explicit, the Output node's hop included) is the chain engine's
+        // block divided once more by f32(0.0001 + 1): same bits, from C++
+        const uint32_t NG = 256;
+        std::vector<Node> short_chain = {Gain(0.8f), BiQuad(1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f), HighPass(0.25f)};
+        Engine as_chain(NG, BUF_SIZE, DSPFX_LINK_INTERNAL | DSPFX_LINK_INPUT), as_graph(NG, BUF_SIZE, 0);
+        as_chain.set_chain(short_chain);
+        as_graph.set_graph(short_chain, {{DSPFX_GRAPH_INPUT, 0, DSPFX_PORT_MAIN}, {0, 1, DSPFX_PORT_MAIN}, {1, 2, DSPFX_PORT_MAIN},
+                                         {2, 3, DSPFX_PORT_MAIN}});
+        std::vector<float> xg(BUF_SIZE * NG), yc2(BUF_SIZE * NG), yg(BUF_SIZE * NG);
+        for (uint32_t f = 0; f < BUF_SIZE; ++f)
+            for (uint32_t c = 0; c < NG; ++c) xg[f * NG + c] = orc_noise(0x5EED0009u, c, f);
+        as_chain.process_host(xg.data(), yc2.data(), BUF_SIZE);
+        as_graph.process_host(xg.data(), yg.data(), BUF_SIZE);
+        const float hop = dspfx_link_divisor(1);
+        for (size_t i = 0; i < yg.size(); ++i)
+            if (ulp(yg[i], (0.0f + yc2[i]) / hop) != 0) { std::printf("FAIL: graph-as-chain at %zu\n", i); return 1; }
         // error behaviour: exceptions, not aborts
         bool threw = false;
         try { eng.set_chain({ReverbSamples(64)}); } catch (const Error &e) { threw = e.status == DSPFX_ERR_INVALID; }
