@@ -568,6 +568,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
 }
 
 int plan(dspfx_engine *e) {
+    HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
     e->stages.clear();
     e->has_fuzz = false;
     e->has_siggen = false;

@@ -181,6 +181,35 @@ def test_graph_engine_mix_bus_host_path_and_parameter_changes(dspfx, G):
     eng.close()
 
 
+def test_long_chain_as_one_graph_kernel(dspfx):
+    """A 12-node chain is two launches for dspfx_chain_set (8 + 4 nodes) and one for dspfx_graph_set; the results
+    differ only by the Output node's hop, which the graph form includes."""
+    import torch
+    E = dspfx
+    N, B = 2048, 128
+    chain = [E.Gain(0.9), E.BiQuad(1.0, -1.2, 0.5, 0.3, 0.2, 0.1), E.Distort(3.0, E.SOFT_CLIP), E.LowPass(0.3),
+             E.Reverb(delay_samples=256, decay=0.4), E.HighPass(0.2), E.Gain(1.1), E.Distort(2.0, E.HARD_CLIP),
+             E.BiQuad(1.0, -0.5, 0.2, 0.4, 0.1, 0.0), E.Envelope(4.0, 100.0), E.Reverb(delay_samples=384, decay=0.3), E.Gain(0.7)]
+    a = E.Engine(N, B, link_flags=E.LINK_INTERNAL | E.LINK_INPUT)
+    a.set_chain(chain)
+    assert a.describe().count("stage") >= 2
+    g = E.Engine(N, B)
+    g.set_graph(chain, [(E.GRAPH_INPUT, 0, E.PORT_MAIN)] + [(i, i + 1, E.PORT_MAIN) for i in range(len(chain))])
+    assert g.describe().count("fused kernel") == 1 and "jit_graph" in g.describe()
+    x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+    ya, yg = torch.empty_like(x), torch.empty_like(x)
+    hop = np.float32(O.link_divisor(1))
+    for k in range(4):
+        a.fill_noise(x, B, k * B, 0x5EED0008)
+        a.process(x, out=ya, n_frames=B)
+        g.process(x, out=yg, n_frames=B)
+        torch.cuda.synchronize()
+        want = ((np.float32(0.0) + ya.cpu().numpy()) / hop).astype(np.float32)
+        assert np.array_equal(yg.cpu().numpy().view(np.uint32), want.view(np.uint32)), k
+    a.close()
+    g.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
