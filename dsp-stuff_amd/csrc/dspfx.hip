@@ -291,6 +291,7 @@ struct JitKernel {
     hipModule_t module = nullptr;
     hipFunction_t fn = nullptr;
     std::string name;
+    int vgprs = 0;          // registers per lane the compiler allocated (occupancy: 512 / vgprs waves per SIMD)
 };
 std::mutex g_jit_mu;
 std::map<std::string, JitKernel *> g_jit;     // key -> kernel (nullptr = tried and failed)
@@ -328,6 +329,10 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
                     hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
                     hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
                     k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
+                    if (hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn) != hipSuccess) {
+                        (void)hipGetLastError();
+                        k->vgprs = 0;
+                    }
                     k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
                     for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
                     k->var.name = k->name.c_str();
@@ -501,16 +506,30 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[GRAPH_SLO
 
 const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     const uint32_t N = e->desc.channels;
-    // two channels per lane as the chain kernels do, unless the graph is large: twice the registers per live value
-    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0 && st.count <= MAX_SLOTS) ? 2 : 1, f = 8;
+    const int f = 8;
     int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
     const std::string src = graph_source(e, st.fast_div, gsigs);
     for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
     if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
-    const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
-    const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
-                            std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
-    const JitKernel *k = jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
+    auto build = [&](int cpl) {
+        const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
+        const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
+                                std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
+        return jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
+    };
+    // Two channels per lane as the chain kernels do (large tiled engines), as long as the graph's live values fit:
+    // every node output still needed is F x CPL registers, and past 128 VGPRs the lost occupancy costs more than
+    // the wider accesses gain (profiles/r01_graph_one_kernel.txt).  DSPFX_VARIANT="cpl=1|2" forces either (A/B runs).
+    const Pref pref = read_pref();
+    const bool can2 = N % 128u == 0;
+    if (pref.cpl == 2 && can2) { const JitKernel *k = build(2); return k ? &k->var : nullptr; }
+    if (pref.cpl == 1) { const JitKernel *k = build(1); return k ? &k->var : nullptr; }
+    const JitKernel *k = nullptr;
+    if (e->desc.tile_channels && N > 131072u && can2) {
+        k = build(2);
+        if (k && k->vgprs <= 128) return &k->var;
+    }
+    k = build(1);
     return k ? &k->var : nullptr;
 }
 
@@ -1200,8 +1219,7 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     if (n_nodes > DSPFX_GRAPH_MAX_NODES)
         return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
     const uint32_t N = e->desc.channels;
-    const uint32_t per_wave = (e->desc.tile_channels && N > 131072u && N % 2u == 0 && n_nodes <= MAX_SLOTS) ? 128u : 64u;
-    if (N % per_wave) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs channels %% %u == 0", per_wave);
+    if (N % 64u) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs whole waves: channels %% 64 == 0");
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {
         const dspfx_graph_link &l = links[i];
@@ -1933,9 +1951,14 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
     for (size_t i = 0; i < e->stages.size(); ++i) {
         const Stage &st = e->stages[i];
         if (st.type == ST_FUSED) {
-            snprintf(buf, sizeof buf, "stage %zu: fused kernel %s (F=%d, CPL=%d):", i, st.var ? st.var->name : "?",
+            snprintf(buf, sizeof buf, "stage %zu: fused kernel %s (F=%d, CPL=%d", i, st.var ? st.var->name : "?",
                      st.var ? st.var->f : 0, st.var ? st.var->cpl : 0);
             s += buf;
+            if (st.var && !st.var->launch) {   // compiled at run time: say what the compiler allocated
+                snprintf(buf, sizeof buf, ", %d VGPRs", reinterpret_cast<const JitKernel *>(st.var)->vgprs);
+                s += buf;
+            }
+            s += "):";
             for (int k = 0; k < st.count; ++k) {
                 s += " ";
                 s += kn[e->nodes[(size_t)(st.first + k)].d.kind];

@@ -5,7 +5,7 @@ different branches, control ports fed by other nodes, generator sources, several
 A graph of at most 16 fusable nodes becomes ONE kernel generated for its wiring (`dspfx_graph_set`, csrc/graph_kernel.hip.h):
 node outputs stay in registers and a block costs one read of the Input node's buffer and one write of the Output node's.
 
-Anything else (more nodes, a FIR or Fuzz node, a channel count that is not a multiple of 128, no run-time compiler) is
+Anything else (more nodes, a FIR or Fuzz node, a channel count that is not a multiple of 64, no run-time compiler) is
 cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
 own per-channel state), runs are evaluated in topological order, and the only extra device work is
 `dspfx_link_average` where a port has more than one incoming link.  What a run consumes:

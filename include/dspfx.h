@@ -280,7 +280,7 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * "b") or keeps its slider value (slider ports).  Ports: DSPFX_PORT_MAIN, DSPFX_PORT_SIDE (port "b" of
  * ADD / MIX), DSPFX_PORT_SLIDER + k (the `as_input` port of slider k, dsp-stuff-derive/src/lib.rs:135-153).
  * The engine's link_flags do not apply (every hop is explicit), `side` of the process calls is ignored and
- * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 128 == 0.
+ * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 64 == 0 (whole waves).
  * DSPFX_ERR_UNSUPPORTED: the graph cannot be fused (too many nodes, a FIR / Fuzz node, channel count) or the
  * run-time compiler is unavailable: evaluate it run by run instead (dsp-stuff_amd/graph.py does).
  * dspfx_chain_set returns the engine to chain mode.  (A plain chain of 9..16 fusable nodes, which dspfx_chain_set
