@@ -72,6 +72,7 @@ struct dspfx_engine {
     std::vector<Node> nodes;
     std::vector<Stage> stages;
     bool graph_mode = false;                  // dspfx_graph_set: the nodes form a DAG evaluated by one generated kernel
+    bool no_long = false;                     // chain mode: do not fuse more than MAX_SLOTS nodes into one (graph) kernel
     std::vector<dspfx_graph_link> wiring;     // its links, in the caller's order
     std::string err;
     float hop_div = 1.0f;
@@ -421,23 +422,34 @@ std::string hexd(double v) {
     return b;
 }
 
-// The generated translation unit: `struct Prog` with the graph's wiring spelled out on register arrays.
-std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[GRAPH_SLOTS]) {
-    const int n = (int)e->nodes.size();
+// One link of the program being generated; node indices are local to the stage.  raw: the only link into its port and
+// taken as it is -- a hop of a chain engine whose DSPFX_LINK_* flag is off.
+struct GLink {
+    int src, dst, port;
+    bool raw;
+};
+
+// The generated translation unit: `struct Prog` with the wiring of nodes [first, first + n) spelled out on register arrays.
+std::string graph_source(const dspfx_engine *e, int first, int n, const std::vector<GLink> &links, bool fast, int (&sigs)[GRAPH_SLOTS]) {
     auto port_links = [&](int dst, int port) {
-        std::vector<int> v;
-        for (const dspfx_graph_link &l : e->wiring)
-            if (l.dst == dst && l.port == port) v.push_back(l.src);
+        std::vector<GLink> v;
+        for (const GLink &l : links)
+            if (l.dst == dst && l.port == port) v.push_back(l);
         return v;
     };
     std::string body;
-    auto gather = [&](const std::string &dst, const std::vector<int> &srcs, bool declare) {
+    auto gather = [&](const std::string &dst, const std::vector<GLink> &srcs, bool declare) {
+        auto name = [](int sidx) { return sidx == DSPFX_GRAPH_INPUT ? std::string("x") : "v" + std::to_string(sidx); };
         body += "        ";
         if (declare) body += "float " + dst + "[F][CPL]; ";
+        if (srcs.size() == 1 && srcs[0].raw) {
+            body += "g_copy<F, CPL>(" + dst + ", " + name(srcs[0].src) + ");\n";
+            return;
+        }
         body += "g_zero<F, CPL>(" + dst + ");";
-        for (int sidx : srcs) {
-            if (sidx == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";
-            else body += " g_acc<F, CPL>(" + dst + ", " + (sidx == DSPFX_GRAPH_INPUT ? std::string("x") : "v" + std::to_string(sidx)) + ");";
+        for (const GLink &l : srcs) {
+            if (l.src == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";
+            else body += " g_acc<F, CPL>(" + dst + ", " + name(l.src) + ");";
         }
         if (!srcs.empty()) {
             const float div = dspfx_link_divisor(srcs.size());
@@ -449,13 +461,13 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[GRAPH_SLO
     const std::string FAST = fast ? "true" : "false";
     for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
     bool uses_input = false;
-    for (const dspfx_graph_link &l : e->wiring) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+    for (const GLink &l : links) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
     for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
-        if (e->nodes[i].d.kind == DSPFX_REVERB)
+        if (e->nodes[(size_t)(first + i)].d.kind == DSPFX_REVERB)
             body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(gslot<" + std::to_string(i) +
                     ">(g), cx, pre" + std::to_string(i) + ");\n";
     for (int i = 0; i < n; ++i) {
-        const dspfx_node_desc &d = e->nodes[i].d;
+        const dspfx_node_desc &d = e->nodes[(size_t)(first + i)].d;
         const bool has_mode = d.kind == DSPFX_DISTORT || d.kind == DSPFX_SIGNAL_GEN;
         const int mode = has_mode ? d.mode : 0;
         sigs[i] = sig(d.kind, mode, 0);
@@ -470,7 +482,7 @@ std::string graph_source(const dspfx_engine *e, bool fast, int (&sigs)[GRAPH_SLO
         if (any_ctl)
             for (int k = 0; k < ns; ++k) {
                 pn[k] = "p" + I + "_" + std::to_string(k);
-                const std::vector<int> src = port_links(i, DSPFX_PORT_SLIDER + k);
+                const std::vector<GLink> src = port_links(i, DSPFX_PORT_SLIDER + k);
                 if (src.empty()) {
                     body += "        float " + pn[k] + "[F][CPL]; g_fill<F, CPL>(" + pn[k] + ", " + slot + ".p[" + std::to_string(k) + "]);\n";
                 } else {
@@ -508,7 +520,15 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     const uint32_t N = e->desc.channels;
     const int f = 8;
     int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
-    const std::string src = graph_source(e, st.fast_div, gsigs);
+    std::vector<GLink> links;
+    if (e->graph_mode) {
+        for (const dspfx_graph_link &l : e->wiring) links.push_back(GLink{l.src, l.dst, l.port, false});
+    } else {   // a long stage of a chain engine: node after node, hops as the engine's link flags say, no Output hop
+        for (int i = 0; i < st.count; ++i)
+            links.push_back(GLink{i == 0 ? DSPFX_GRAPH_INPUT : i - 1, i, DSPFX_PORT_MAIN, node_hop(e, st.first + i) == 0});
+        links.push_back(GLink{st.count - 1, st.count, DSPFX_PORT_MAIN, true});
+    }
+    const std::string src = graph_source(e, st.first, st.count, links, st.fast_div, gsigs);
     for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
     if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
     auto build = [&](int cpl) {
@@ -586,6 +606,19 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     return best;
 }
 
+// Chain engines: may a fusable run of more than MAX_SLOTS nodes become one generated kernel?  The conditions of the
+// run-time specialised chain kernels (jit_variant), whole waves only, and not after control ports were used (those are
+// evaluated by the chain kernels).
+bool long_stage_wanted(const dspfx_engine *e) {
+    if (e->no_long) return false;
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    if (!(jit_mode == 1 || (jit_mode != 0 && N > 131072u))) return false;
+    if (read_pref().stat == 0) return false;
+    return N % 64u == 0;
+}
+
 int plan(dspfx_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
     e->stages.clear();
@@ -599,7 +632,21 @@ int plan(dspfx_engine *e) {
         if (fusable(e->nodes[i])) {
             st.type = ST_FUSED;
             st.first = i;
-            while (i < n && fusable(e->nodes[i]) && i - st.first < (e->graph_mode ? GRAPH_SLOTS : MAX_SLOTS)) ++i;
+            int limit = e->graph_mode ? GRAPH_SLOTS : MAX_SLOTS;
+            if (!e->graph_mode && long_stage_wanted(e)) {
+                // A fusable run longer than one chain launch holds: up to GRAPH_SLOTS of its nodes become one generated
+                // kernel (the chain as a graph) instead of two chain launches with a round trip through memory in
+                // between (12 nodes: 0.575 -> 0.429 ms).  Add / Mix read the engine's side input from memory, which
+                // that kernel does not do: a run with one of them is cut as before.
+                int j = i;
+                bool mixers = false;
+                while (j < n && fusable(e->nodes[j]) && j - i < GRAPH_SLOTS) {
+                    mixers = mixers || e->nodes[j].d.kind == DSPFX_ADD || e->nodes[j].d.kind == DSPFX_MIX;
+                    ++j;
+                }
+                if (j - i > MAX_SLOTS && !mixers) limit = GRAPH_SLOTS;
+            }
+            while (i < n && fusable(e->nodes[i]) && i - st.first < limit) ++i;
             st.count = i - st.first;
         } else {
             st.type = e->nodes[i].d.kind == DSPFX_FIR ? ST_FIR : ST_FUZZ;
@@ -622,7 +669,11 @@ int plan(dspfx_engine *e) {
     for (Stage &st : e->stages)
         if (st.type == ST_FUSED) {
             st.fast_div = stage_fast_div(e, st);
-            st.var = e->graph_mode ? graph_variant(e, st) : pick_variant(e, st);
+            st.var = (e->graph_mode || st.count > MAX_SLOTS) ? graph_variant(e, st) : pick_variant(e, st);
+            if (!st.var && !e->graph_mode && st.count > MAX_SLOTS) {   // no run-time compiler: cut the run as usual
+                e->no_long = true;
+                return plan(e);
+            }
             if (!st.var)
                 return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
                                                                     : "no kernel variant for stage");
@@ -1183,6 +1234,7 @@ extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     if (!e) return DSPFX_ERR_INVALID;
     e->graph_mode = false;
     e->wiring.clear();
+    e->no_long = false;
     return set_nodes(e, nodes, n_nodes);
 }
 namespace {
@@ -1453,6 +1505,15 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
     if (n_ctl < 0 || (n_ctl > 0 && !ctl)) return fail(e, DSPFX_ERR_INVALID, "bad control-port list");
     if (n_ctl > 0 && e->graph_mode) return fail(e, DSPFX_ERR_INVALID, "a fused graph's control ports are links of the graph");
     HIPCHK(e, hipSetDevice(e->device));
+    if (n_ctl > 0 && !e->no_long) {   // control ports are evaluated by the chain kernels: cut long stages back to their size
+        bool has_long = false;
+        for (const Stage &st : e->stages) has_long = has_long || (st.type == ST_FUSED && st.count > MAX_SLOTS);
+        if (has_long) {
+            e->no_long = true;
+            const int rc = plan(e);
+            if (rc) return rc;
+        }
+    }
     for (int i = 0; i < n_ctl; ++i) {
         const dspfx_ctl &c = ctl[i];
         if (c.node < 0 || c.node >= (int)e->nodes.size() || !c.signal)

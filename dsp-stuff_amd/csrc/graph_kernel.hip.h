@@ -45,6 +45,13 @@ __device__ __forceinline__ void g_fill(float (&r)[F][CPL], float x) {   // an un
         for (int j = 0; j < CPL; ++j) r[f][j] = x;
 }
 template <int F, int CPL>
+__device__ __forceinline__ void g_copy(float (&r)[F][CPL], const float (&s)[F][CPL]) {   // a chain hop that is switched off
+#pragma unroll
+    for (int f = 0; f < F; ++f)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) r[f][j] = s[f][j];
+}
+template <int F, int CPL>
 __device__ __forceinline__ void g_acc(float (&r)[F][CPL], const float (&s)[F][CPL]) {   // node.rs:172-176: buf += pipe
 #pragma unroll
     for (int f = 0; f < F; ++f)

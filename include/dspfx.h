@@ -283,8 +283,8 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 64 == 0 (whole waves).
  * DSPFX_ERR_UNSUPPORTED: the graph cannot be fused (too many nodes, a FIR / Fuzz node, channel count) or the
  * run-time compiler is unavailable: evaluate it run by run instead (dsp-stuff_amd/graph.py does).
- * dspfx_chain_set returns the engine to chain mode.  (A plain chain of 9..16 fusable nodes, which dspfx_chain_set
- * runs as two kernels, may be handed over as a graph too and then runs as one.) */
+ * dspfx_chain_set returns the engine to chain mode.  (dspfx_chain_set itself uses the same generated kernel for a
+ * run of 9..16 fusable nodes without Add / Mix on engines above 131072 channels: one launch instead of two.) */
 #define DSPFX_GRAPH_MAX_NODES 16
 #define DSPFX_GRAPH_INPUT (-1)
 #define DSPFX_GRAPH_ZERO (-2)

@@ -1265,3 +1265,51 @@ def test_runtime_specialised_kernels_match_interpreter_and_oracle(dspfx, torch_c
         ref = run_oracle(chain, xs, lf, ss)
         assert ulp_diff(got[ok], ref[ok]).max() <= 1, case
     monkeypatch.delenv("DSPFX_JIT", raising=False)
+
+
+@pytest.mark.parametrize("lf", [0, 1, 3])
+def test_long_chain_runs_as_one_generated_kernel(dspfx, torch_cuda, monkeypatch, lf):
+    """A fusable run of 9..16 nodes on a large engine (DSPFX_JIT=1 stands in for > 131072 channels) is ONE generated
+    kernel (the chain as a graph, hops per the engine's link flags) instead of two chain launches: same bits as the
+    two-launch form, within the oracle's bar; a run with an Add / Mix (side input from memory) is cut as before; once
+    control ports are used the engine goes back to chain launches."""
+    torch = torch_cuda
+    E = dspfx
+    N, B, blocks = 192, 128, 4
+    chain = [E.Gain(0.9), E.BiQuad(1.0, -1.2, 0.5, 0.3, 0.2, 0.1), E.Distort(3.0, E.SOFT_CLIP), E.LowPass(0.3),
+             E.Reverb(delay_samples=256, decay=0.4), E.HighPass(0.2), E.Gain(1.1), E.Distort(2.0, E.HARD_CLIP),
+             E.BiQuad(1.0, -0.5, 0.2, 0.4, 0.1, 0.0), E.Envelope(4.0, 100.0), E.Reverb(delay_samples=160, decay=0.3), E.Gain(0.7)]
+    x = noise_block(N, B * blocks, seed=0x5EED000A)
+    monkeypatch.setenv("DSPFX_JIT", "0")
+    two = run_gpu(E, torch, chain, x, link_flags=lf)
+    monkeypatch.setenv("DSPFX_JIT", "1")
+    eng = E.Engine(N, B, link_flags=lf)
+    eng.set_chain(chain)
+    d = eng.describe()
+    assert d.count("fused kernel") == 1 and "jit_graph" in d, d
+    one, mix = run_gpu(E, torch, chain, x, link_flags=lf, want_mix=True)
+    assert np.array_equal(one.view(np.uint32), two.view(np.uint32))
+    assert np.allclose(mix, one.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-3)
+    assert ulp_diff(one, run_oracle(chain, x, lf)).max() <= 1
+    # control ports: evaluated by the chain kernels -> the engine re-plans into chain launches, state carried over
+    ctl_sig = noise_block(N, B * blocks, seed=0x5EED000B)
+    ref_eng = E.Engine(N, B, link_flags=lf)
+    monkeypatch.setenv("DSPFX_JIT", "0")
+    ref_eng.set_chain(chain)
+    for k in range(blocks):
+        dx = torch.from_numpy(x[k * B:(k + 1) * B]).cuda()
+        dc = torch.from_numpy(ctl_sig[k * B:(k + 1) * B]).cuda()
+        ctl = {(0, 0): dc} if k >= 2 else None
+        ya = eng.process(dx, out=torch.empty_like(dx), n_frames=B, ctl=ctl)
+        yb = ref_eng.process(dx, out=torch.empty_like(dx), n_frames=B, ctl=ctl)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), k
+    assert eng.describe().count("fused kernel") == 2, eng.describe()
+    eng.close()
+    ref_eng.close()
+    # an Add in the run reads the side input from memory: two chain launches as before
+    monkeypatch.setenv("DSPFX_JIT", "1")
+    eng = E.Engine(N, B, link_flags=lf)
+    eng.set_chain(chain[:6] + [E.Add()] + chain[6:])
+    assert eng.describe().count("fused kernel") == 2 and "jit_graph" not in eng.describe(), eng.describe()
+    eng.close()

@@ -181,7 +181,7 @@ def test_graph_engine_mix_bus_host_path_and_parameter_changes(dspfx, G):
     eng.close()
 
 
-def test_long_chain_as_one_graph_kernel(dspfx):
+def test_long_chain_as_one_graph_kernel(dspfx, monkeypatch):
     """A 12-node chain is two launches for dspfx_chain_set (8 + 4 nodes) and one for dspfx_graph_set; the results
     differ only by the Output node's hop, which the graph form includes."""
     import torch
@@ -190,6 +190,7 @@ def test_long_chain_as_one_graph_kernel(dspfx):
     chain = [E.Gain(0.9), E.BiQuad(1.0, -1.2, 0.5, 0.3, 0.2, 0.1), E.Distort(3.0, E.SOFT_CLIP), E.LowPass(0.3),
              E.Reverb(delay_samples=256, decay=0.4), E.HighPass(0.2), E.Gain(1.1), E.Distort(2.0, E.HARD_CLIP),
              E.BiQuad(1.0, -0.5, 0.2, 0.4, 0.1, 0.0), E.Envelope(4.0, 100.0), E.Reverb(delay_samples=384, decay=0.3), E.Gain(0.7)]
+    monkeypatch.setenv("DSPFX_JIT", "0")       # the chain engine proper: interpreter, 8 + 4 nodes
     a = E.Engine(N, B, link_flags=E.LINK_INTERNAL | E.LINK_INPUT)
     a.set_chain(chain)
     assert a.describe().count("stage") >= 2
