@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""A 12-node chain at 1 048 576 channels: dspfx_chain_set (two launches of 8 + 4 nodes) against the same chain handed
-over as a graph (dspfx_graph_set: one generated kernel)."""
+"""A 12-node chain at 1 048 576 channels through dspfx_chain_set and handed over as a graph (dspfx_graph_set).  Large
+engines compile the run as one generated kernel either way; DSPFX_VARIANT=static=0 shows the chain engine's two-launch
+form (8 + 4 nodes, interpreter), which is what profiles/r01_graph_one_kernel.txt compares against."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
