@@ -130,6 +130,18 @@ impl Engine {
         self.check(rc)
     }
 
+    /// A whole saved graph (`DSPConfig`: runtime.rs:560-612) as ONE generated kernel: `nodes` in an order in which
+    /// every link goes forward, `links` as (producer, consumer, port) with `DSPFX_GRAPH_INPUT` / `DSPFX_GRAPH_ZERO`
+    /// producers and consumer == nodes.len() for the Output node.  `Err` with status `DSPFX_ERR_UNSUPPORTED` when
+    /// the graph cannot be fused (FIR / Fuzz node, more than `DSPFX_GRAPH_MAX_NODES` nodes): evaluate it run by run.
+    pub fn set_graph(&mut self, nodes: &[NodeDesc], links: &[dspfx_graph_link]) -> Result<(), Error> {
+        let descs: Vec<dspfx_node_desc> = nodes.iter().map(|n| n.d).collect();
+        let rc = unsafe {
+            dspfx_graph_set(self.h, descs.as_ptr(), descs.len() as c_int, links.as_ptr(), links.len() as c_int)
+        };
+        self.check(rc)
+    }
+
     /// A slider store (dsp-stuff-derive/src/lib.rs:487-492) including the reference's
     /// `after_settings_change` side effects (biquad.rs:62-76: state reset).
     pub fn set_param(&mut self, node: usize, param: usize, value: f32) -> Result<(), Error> {
