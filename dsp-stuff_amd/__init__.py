@@ -44,7 +44,7 @@ EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
     "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
-    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_graph_set", "dspfx_state_size",
+    "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_graph_set", "dspfx_graph_source", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
@@ -106,6 +106,7 @@ def lib():
     L.dspfx_chain_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int]
     L.dspfx_chain_len.argtypes = [vp]
     L.dspfx_graph_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int]
+    L.dspfx_graph_source.argtypes = [C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int, C.c_char_p, C.c_size_t]
     L.dspfx_set_param.argtypes = [vp, C.c_int, C.c_int, C.c_float]
     L.dspfx_set_mode.argtypes = [vp, C.c_int, C.c_int]
     L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
@@ -360,11 +361,8 @@ class Engine:
         self._chk(self.L.dspfx_chain_set(self.h, arr, len(nodes)))
         self.nodes = list(nodes)
 
-    def set_graph(self, nodes: Sequence[NodeSpec], links: Sequence[Tuple[int, int, int]]):
-        """A whole DAG as one generated kernel (include/dspfx.h, dspfx_graph_set).  `nodes` in an order in which every
-        link goes forward; links = (src, dst, port): src a node index, GRAPH_INPUT or GRAPH_ZERO; dst a node index or
-        len(nodes) for the Output node; port PORT_MAIN, PORT_SIDE or PORT_SLIDER + k.  Raises DspfxError with status
-        ERR_UNSUPPORTED when the graph cannot be fused."""
+    @staticmethod
+    def _graph_arrays(nodes, links):
         arr = (_NodeDesc * max(1, len(nodes)))()
         for i, n in enumerate(nodes):
             arr[i].kind, arr[i].mode = n.kind, n.mode
@@ -374,6 +372,14 @@ class Engine:
         larr = (_GraphLink * max(1, len(links)))()
         for i, (s, d, p) in enumerate(links):
             larr[i].src, larr[i].dst, larr[i].port = int(s), int(d), int(p)
+        return arr, larr
+
+    def set_graph(self, nodes: Sequence[NodeSpec], links: Sequence[Tuple[int, int, int]]):
+        """A whole DAG as one generated kernel (include/dspfx.h, dspfx_graph_set).  `nodes` in an order in which every
+        link goes forward; links = (src, dst, port): src a node index, GRAPH_INPUT or GRAPH_ZERO; dst a node index or
+        len(nodes) for the Output node; port PORT_MAIN, PORT_SIDE or PORT_SLIDER + k.  Raises DspfxError with status
+        ERR_UNSUPPORTED when the graph cannot be fused."""
+        arr, larr = self._graph_arrays(nodes, links)
         self._chk(self.L.dspfx_graph_set(self.h, arr, len(nodes), larr, len(links)))
         self.nodes = list(nodes)
 
@@ -501,3 +507,14 @@ class Engine:
 
     def algorithmic_bytes_per_sample(self, n_frames: int) -> float:
         return float(self.L.dspfx_algorithmic_bytes_per_sample(self.h, int(n_frames)))
+
+
+def graph_source(nodes: Sequence[NodeSpec], links: Sequence[Tuple[int, int, int]]) -> str:
+    """The translation unit `Engine.set_graph` would compile for this graph (needs no device)."""
+    L = lib()
+    arr, larr = Engine._graph_arrays(nodes, links)
+    buf = C.create_string_buffer(1 << 18)
+    rc = L.dspfx_graph_source(arr, len(nodes), larr, len(links), buf, len(buf))
+    if rc != 0:
+        raise DspfxError(rc, L.dspfx_strerror(rc).decode())
+    return buf.value.decode()

@@ -1263,15 +1263,17 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
 }
 }  // namespace
 
-extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
-                               int n_links) {
-    if (!e) return DSPFX_ERR_INVALID;
+namespace {
+// Shape checks shared by dspfx_graph_set and dspfx_graph_source (e may be null).
+int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links) {
     if (n_nodes < 0 || (n_nodes > 0 && !nodes) || n_links < 0 || (n_links > 0 && !links))
         return fail(e, DSPFX_ERR_INVALID, "graph: bad node / link arrays");
     if (n_nodes > DSPFX_GRAPH_MAX_NODES)
         return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
-    const uint32_t N = e->desc.channels;
-    if (N % 64u) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs whole waves: channels %% 64 == 0");
+    for (int i = 0; i < n_nodes; ++i) {
+        const int rc = validate_node(e, nodes[i]);
+        if (rc) return rc;
+    }
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {
         const dspfx_graph_link &l = links[i];
@@ -1291,6 +1293,17 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     for (int i = 0; i < n_nodes; ++i)
         if (nodes[i].kind == DSPFX_FIR || (nodes[i].kind == DSPFX_DISTORT && nodes[i].mode == DSPFX_DIST_FUZZ))
             return fail(e, DSPFX_ERR_UNSUPPORTED, "graph node %d (FIR / Fuzz) has its own kernel and cannot be fused", i);
+    return DSPFX_OK;
+}
+}  // namespace
+
+extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
+                               int n_links) {
+    if (!e) return DSPFX_ERR_INVALID;
+    const uint32_t N = e->desc.channels;
+    if (N % 64u) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs whole waves: channels %% 64 == 0");
+    const int vrc = validate_graph(e, nodes, n_nodes, links, n_links);
+    if (vrc) return vrc;
     e->graph_mode = true;
     e->wiring.assign(links, links + n_links);
     const int rc = set_nodes(e, nodes, n_nodes);
@@ -1300,6 +1313,30 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
         e->err = msg;
     }
     return rc;
+}
+
+extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links,
+                                  char *dst, size_t cap) {
+    if (!dst || cap == 0) return DSPFX_ERR_INVALID;
+    const int vrc = validate_graph(nullptr, nodes, n_nodes, links, n_links);
+    if (vrc) return vrc;
+    dspfx_engine tmp;                       // never touches a device: only the node descriptors are read
+    tmp.nodes.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) {
+        tmp.nodes[(size_t)i].d = nodes[i];
+        tmp.nodes[(size_t)i].d.taps = nullptr;
+    }
+    std::vector<GLink> gl;
+    for (int i = 0; i < n_links; ++i) gl.push_back(GLink{links[i].src, links[i].dst, links[i].port, false});
+    Stage st{};
+    st.type = ST_FUSED;
+    st.first = 0;
+    st.count = n_nodes;
+    int sigs[GRAPH_SLOTS];
+    const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st), sigs);
+    if (src.size() + 1 > cap) return DSPFX_ERR_INVALID;
+    memcpy(dst, src.c_str(), src.size() + 1);
+    return DSPFX_OK;
 }
 
 extern "C" int dspfx_chain_len(const dspfx_engine *e) { return e ? (int)e->nodes.size() : DSPFX_ERR_INVALID; }

@@ -145,6 +145,7 @@ extern "C" {
     pub fn dspfx_process_mixpipe(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_mixpipe_flush(e: *mut dspfx_engine, mix_older: *mut f32, mix_newer: *mut f32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_graph_set(e: *mut dspfx_engine, nodes: *const dspfx_node_desc, n_nodes: c_int, links: *const dspfx_graph_link, n_links: c_int) -> c_int;
+    pub fn dspfx_graph_source(nodes: *const dspfx_node_desc, n_nodes: c_int, links: *const dspfx_graph_link, n_links: c_int, dst: *mut c_char, cap: usize) -> c_int;
     pub fn dspfx_link_average(e: *mut dspfx_engine, srcs: *const *const f32, n_srcs: c_int, dst: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
 
     pub fn dspfx_state_size(e: *const dspfx_engine, node: c_int) -> i64;

@@ -298,6 +298,12 @@ typedef struct dspfx_graph_link {
 } dspfx_graph_link;
 int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
                     int n_links);
+/* The translation unit dspfx_graph_set would compile for this graph (the generated `struct Prog`; it includes
+ * csrc/graph_kernel.hip.h), NUL-terminated into dst[cap].  Needs no engine and no device: for inspection and for
+ * checking the generator where there is no GPU (without one every division is written in its IEEE form, since the
+ * exact-division check runs on the device).  DSPFX_ERR_INVALID: bad graph or cap too small. */
+int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links,
+                       char *dst, size_t cap);
 
 /* ---- DSP state (parity tests; the reference never saves it) --- */
 /* Size in bytes of node `node`'s exported state:

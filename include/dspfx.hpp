@@ -9,6 +9,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -104,6 +105,18 @@ inline Node SignalGen(float amplitude = 0.5f, float frequency = 100.0f, SignalMo
     n.d.params[0] = amplitude; n.d.params[1] = frequency;
     n.d.mode = static_cast<int>(mode);
     return n;
+}
+
+// The translation unit Engine::set_graph would compile for this graph (dspfx.h: dspfx_graph_source); needs no device.
+inline std::string graph_source(const std::vector<Node> &nodes, const std::vector<dspfx_graph_link> &links) {
+    std::vector<dspfx_node_desc> d;
+    for (const Node &n : nodes) d.push_back(n.d);
+    std::string out(std::size_t{1} << 18, '\0');
+    const int rc = dspfx_graph_source(d.data(), static_cast<int>(d.size()), links.data(), static_cast<int>(links.size()),
+                                      out.data(), out.size());
+    if (rc != DSPFX_OK) throw Error(rc, dspfx_strerror(rc));
+    out.resize(std::strlen(out.c_str()));
+    return out;
 }
 
 // N independent mono channels through one chain.

@@ -82,6 +82,10 @@ int main(int argc, char **argv) {
         const float hop = dspfx_link_divisor(1);
         for (size_t i = 0; i < yg.size(); ++i)
             if (ulp(yg[i], (0.0f + yc2[i]) / hop) != 0) { std::printf("FAIL: graph-as-chain at %zu\n", i); return 1; }
+        if (graph_source(short_chain, {{DSPFX_GRAPH_INPUT, 0, DSPFX_PORT_MAIN}, {0, 3, DSPFX_PORT_MAIN}}).find("struct Prog") == std::string::npos) {
+            std::printf("FAIL: graph_source\n");
+            return 1;
+        }
         // error behaviour: exceptions, not aborts
         bool threw = false;
         try { eng.set_chain({ReverbSamples(64)}); } catch (const Error &e) { threw = e.status == DSPFX_ERR_INVALID; }

@@ -3,6 +3,7 @@ tests compare against (checked here against the linear-chain oracle on a graph t
 import json
 
 import numpy as np
+import pytest
 
 import graph_eval
 import graphs
@@ -128,3 +129,38 @@ def test_fused_plan_is_the_graph_in_link_order(dspfx):
     fuzz = json.loads(graphs.diamond())
     next(n for n in fuzz["nodes"] if n["id"] == 5)["cfg"]["mode"] = "Fuzz"
     assert G.fused_plan(G.Graph(json.dumps(fuzz))) is None                   # Fuzz is block-global: its own kernel
+
+
+def _compile_generated(dspfx, specs, links, tmp_path, tag):
+    """hipcc the translation unit the engine would hand to hiprtc, with the kernel instantiated both ways."""
+    import os
+    import subprocess
+    src = dspfx.graph_source(specs, links)
+    assert "struct Prog" in src and '#include "graph_kernel.hip.h"' in src
+    f = tmp_path / f"{tag}.hip"
+    f.write_text(src + "template __global__ void dspfx::graph_kernel<8, 2, dspfx::Prog>(const dspfx::GraphArgs);\n"
+                       "template __global__ void dspfx::graph_kernel<8, 1, dspfx::Prog>(const dspfx::GraphArgs);\n")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "dsp-stuff_amd", "csrc")
+    r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O1", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", f"-I{csrc}",
+                        "-c", str(f), "-o", str(tmp_path / f"{tag}.o")], capture_output=True, text=True)
+    assert r.returncode == 0, src + "\n" + r.stderr
+    return src
+
+
+def test_generated_graph_kernels_compile_without_a_gpu(dspfx, tmp_path):
+    """The code generator behind dspfx_graph_set, exercised where there is no device: every port form it emits
+    (fan-in with the divisor spelled out, pipes of zeros, "b" ports, slider ports fed by nodes, unplugged ports,
+    generators, delay-tap prefetch, a slot beyond the chain argument block) must be valid against graph_kernel.hip.h."""
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    src = _compile_generated(E, *G.fused_plan(G.Graph(graphs.diamond())), tmp_path, "diamond")
+    assert "g_acc<F, CPL>(v3, v0)" in src and "g_add<F, CPL>(v3, b3)" in src           # Add: main <- gain, "b" <- high_pass
+    assert "ring_prefetch<F, CPL, false>(gslot<5>(g)" in src and src.count("g_div<") == 8   # one division per connected port
+    assert "0x1.00034" in src                                                           # f32(0.0001 + 2): two links into a port
+    src = _compile_generated(E, *G.fused_plan(G.Graph(graphs.lfo_tremolo())), tmp_path, "lfo")
+    assert "gain_mod_core<F, CPL>(v3, p3_0)" in src and "g_mix_mod<F, CPL>(v4, b4, p4_0)" in src
+    src = _compile_generated(E, *G.fused_plan(G.Graph(graphs.routing("B", "A"))), tmp_path, "routing")
+    assert "g_acc_zero<F, CPL>" in src
+    _compile_generated(E, *G.fused_plan(G.Graph(graphs.random_dag(116, 16, libm=True))), tmp_path, "random16")
+    with pytest.raises(E.DspfxError):
+        E.graph_source([E.Gain(1.0)], [(0, 0, E.PORT_MAIN)])                           # a link must go forward
