@@ -155,3 +155,30 @@ def test_delay_impulse_full_size(dspfx, tc):
                 expect[j * D - k * B] = 0.5 ** j
         assert tc.equal(v, expect[None, :, None].expand_as(v)), k
     eng.close()
+
+
+@pytest.mark.parametrize("name", ["diamond", "lfo_tremolo", "fan_in_three"])
+def test_whole_graph_kernel_million_channels(dspfx, tc, name):
+    """A saved DAG at 1 048 576 tiled channels as ONE generated kernel: sampled channels against the node-by-node
+    oracle evaluation (<= 1 ulp), and the whole block bit-identical to the run-by-run evaluation of the same graph."""
+    import graph_eval
+    import graphs
+    from dsp_stuff_amd import graph as G
+    N, B, tile, blocks = 1 << 20, 128, 256, 6
+    chans = sample_channels(N, tile)
+    text = getattr(graphs, name)()
+    one = G.GraphEngine(text, N, B, tile_channels=tile, fused=True)
+    runs = G.GraphEngine(text, N, B, tile_channels=tile, fused=False)
+    x = tc.empty(B * N, dtype=tc.float32, device="cuda")
+    got = np.empty((blocks * B, len(chans)), F)
+    for k in range(blocks):
+        one.util.fill_noise(x, B, k * B, SEED)
+        ya = one.process(x, B)
+        yb = runs.process(x, B)
+        assert tc.equal(ya.view(tc.int32), yb.view(tc.int32)), (name, k)
+        got[k * B:(k + 1) * B] = gather(dspfx, ya, chans, B, N, tile)
+    xs = O.noise(SEED, np.array(chans), np.arange(blocks * B))
+    ref = graph_eval.run_graph(one.g, xs)
+    assert ulp_diff(got, ref).max() <= 1
+    one.close()
+    runs.close()
