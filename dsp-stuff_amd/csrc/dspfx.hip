@@ -2033,7 +2033,12 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
         default: break;
         }
     }
-    if (side) b += 4.0;
+    if (side && !e->graph_mode) b += 4.0;   // a fused graph's "b" ports are fed from registers
+    if (e->graph_mode) {                    // ... and a graph without an Input link never reads `in`
+        bool uses_input = false;
+        for (const dspfx_graph_link &l : e->wiring) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+        if (!uses_input) b -= 4.0;
+    }
     return b;
 }
 
