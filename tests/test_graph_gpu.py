@@ -154,7 +154,7 @@ def test_graph_engine_mix_bus_host_path_and_parameter_changes(dspfx, G):
     yh = y.cpu().numpy().reshape(B, N)
     assert np.allclose(mix.cpu().numpy(), yh.astype(np.float64).sum(axis=1), rtol=1e-5, atol=1e-3)
     # algorithmic traffic of the graph kernel: one read + one write + the delay node's tap and store + filter state
-    assert abs(eng.bytes_per_sample(B) - (8 + 8 + (32 + 8) / B)) < 1e-9          # biquad 32/B, high_pass 8/B; "b" ports cost nothing
+    assert abs(eng.algorithmic_bytes_per_sample(B) - (8 + 8 + (32 + 8) / B)) < 1e-9          # biquad 32/B, high_pass 8/B; "b" ports cost nothing
     # host-buffer path of a second engine: same block, same bits
     eng2 = E.Engine(N, B)
     eng2.set_graph(specs, links)
