@@ -5,8 +5,11 @@ different branches, control ports fed by other nodes, generator sources, several
 A graph of at most 16 fusable nodes becomes ONE kernel generated for its wiring (`dspfx_graph_set`, csrc/graph_kernel.hip.h):
 node outputs stay in registers and a block costs one read of the Input node's buffer and one write of the Output node's.
 
-Anything else (more nodes, a FIR or Fuzz node, a channel count that is not a multiple of 64, no run-time compiler) is
-cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
+A graph whose FIR / Fuzz nodes (kernels of their own) are passed by all the signal -- an amp chain into a cabinet
+impulse response into a reverb -- is cut at those nodes and every segment between them is one such kernel (`series_plan`).
+
+Anything else (more nodes, a link that bypasses a FIR or Fuzz node, a channel count that is not a multiple of 64, no
+run-time compiler) is cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
 own per-channel state), runs are evaluated in topological order, and the only extra device work is
 `dspfx_link_average` where a port has more than one incoming link.  What a run consumes:
 
@@ -234,6 +237,89 @@ def fused_plan(g: Graph):
     return [g.nodes[nid].spec for nid in order], links
 
 
+def _unfusable(sp) -> bool:
+    return sp.kind == FIR or (sp.kind == DISTORT and sp.mode == FUZZ)
+
+
+def series_plan(g: Graph):
+    """A graph with FIR / Fuzz nodes (their own kernels) that ALL the signal passes through -- an amp chain into a
+    cabinet impulse response into a reverb -- cut at those nodes: [("graph", specs, links), ("node", spec), ("graph", ...), ...],
+    alternating, every "graph" segment a single-input single-output sub-DAG for `dspfx_graph_set` whose Output is the
+    averaged main port of the node that follows it.  None when some link bypasses such a node, when one of them has a
+    connected slider port, or when a segment is too large."""
+    order = [nid for nid in g.order if g.nodes[nid].spec is not None]
+    cuts = [nid for nid in order if _unfusable(g.nodes[nid].spec)]
+    if not cuts:
+        return None
+    out_id = g.outputs[0]
+    anc: Dict[int, frozenset] = {}          # cut nodes among a node's strict ancestors
+    fed: Dict[int, bool] = {}               # downstream of the Input node
+    for nid in g.order:
+        a, f = set(), False
+        for p in g.producers(g.nodes[nid]):
+            a |= anc[p]
+            if p in cuts:
+                a.add(p)
+            f = f or fed[p] or g.nodes[p].typename == "input"
+        anc[nid], fed[nid] = frozenset(a), f
+    cuts.sort(key=lambda c: len(anc[c]))
+    for i, c in enumerate(cuts):                       # the cut nodes must follow one another
+        if anc[c] != frozenset(cuts[:i]) or g.nodes[c].ctl or g.nodes[c].side:
+            return None
+    k = len(cuts)
+    level: Dict[int, int] = {}                         # segment a node's INPUT ports belong to
+    for nid in g.order:
+        if nid in cuts:
+            level[nid] = cuts.index(nid)
+        elif fed[nid] or anc[nid] or g.nodes[nid].typename == "input":
+            if anc[nid] != frozenset(cuts[:len(anc[nid])]):
+                return None
+            level[nid] = len(anc[nid])
+    if level.get(out_id) != k:
+        return None                                    # the Output does not depend on every such node
+    for nid in reversed(g.order):                      # sources fed by nothing (generators, unplugged effects): where they are used
+        if nid in level:
+            continue
+        users = {level[c] for c, port in g.nodes[nid].outs if port != "unused"}
+        if len(users) > 1:
+            return None
+        level[nid] = users.pop() if users else k
+
+    def out_level(p):                                  # segment a node's OUTPUT lives in
+        return level[p] + 1 if p in cuts else level[p]
+
+    for nid in g.order:
+        for p in g.producers(g.nodes[nid]):
+            if out_level(p) != level[nid]:
+                return None                            # a link that bypasses a FIR / Fuzz node
+    steps = []
+    for j in range(k + 1):
+        seg = [nid for nid in order if nid not in cuts and level[nid] == j]
+        if len(seg) > GRAPH_MAX_NODES:
+            return None
+        idx = {nid: i for i, nid in enumerate(seg)}
+        seg_in = cuts[j - 1] if j else (g.inputs[0] if g.inputs else None)
+
+        def src(s):
+            if s == ZERO:
+                return GRAPH_ZERO
+            return GRAPH_INPUT if s == seg_in else idx[s]
+
+        links = []
+        for nid in seg:
+            n = g.nodes[nid]
+            links += [(src(s), idx[nid], PORT_MAIN) for s in n.main]
+            links += [(src(s), idx[nid], PORT_SIDE) for s in n.side]
+            for kk, srcs in sorted(n.ctl.items()):
+                links += [(src(s), idx[nid], PORT_SLIDER + kk) for s in srcs]
+        sink = g.nodes[cuts[j]] if j < k else g.nodes[out_id]
+        links += [(src(s), len(seg), PORT_MAIN) for s in sink.main]
+        steps.append(("graph", [g.nodes[nid].spec for nid in seg], links))
+        if j < k:
+            steps.append(("node", g.nodes[cuts[j]].spec))
+    return steps
+
+
 class GraphEngine:
     """N independent copies of a saved graph.  `process(x)` takes the Input node's block [n_frames][N] (device
     tensor, the engine's layout) and returns the Output node's block.
@@ -248,6 +334,7 @@ class GraphEngine:
         self.N, self.B, self.tile = channels, max_frames, tile_channels
         self.dev = torch.device("cuda", device)
         self.fused: Optional[Engine] = None
+        self.series = []
         self.runs, self.run_of = [], {}
         self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
         self.final = self._buf()
@@ -265,6 +352,27 @@ class GraphEngine:
             raise DspConfigError("this graph cannot be fused into one kernel")
         if self.fused is not None:
             self.util = self.fused
+            return
+        # FIR / Fuzz nodes in series with fusable sub-graphs: one generated kernel per segment
+        self.series = []                   # [(engine, out buffer)]
+        steps = series_plan(self.g) if fused is None else None
+        if steps is not None:
+            try:
+                for kind, *what in steps:
+                    eng = Engine(channels, max_frames, link_flags=0, device=device, tile_channels=tile_channels)
+                    self.series.append((eng, self._buf()))
+                    if kind == "graph":
+                        eng.set_graph(*what)
+                    else:
+                        eng.set_chain(what)          # the hop into it is the previous segment's Output average
+            except DspfxError as e:
+                for eng, _ in self.series:
+                    eng.close()
+                self.series = []
+                if e.status != ERR_UNSUPPORTED:
+                    raise
+        if self.series:
+            self.util = self.series[0][0]
             return
         self.runs, self.run_of = plan_runs(self.g)
         for r in self.runs:
@@ -287,6 +395,9 @@ class GraphEngine:
     def describe(self) -> str:
         if self.fused is not None:
             return "one kernel: " + " | ".join(l for l in self.fused.describe().splitlines() if l.startswith("stage"))
+        if self.series:
+            return "\n".join(f"segment {k}: " + " | ".join(l for l in eng.describe().splitlines() if l.startswith("stage"))
+                             for k, (eng, _) in enumerate(self.series))
         lines = []
         for k, r in enumerate(self.runs):
             stage = [l for l in r.engine.describe().splitlines() if l.startswith("stage")]
@@ -306,6 +417,12 @@ class GraphEngine:
         if self.fused is not None:
             self.fused.process(self.zeros if x is None else x, out=self.final, n_frames=nf, stream=stream)
             return self.final
+        if self.series:
+            buf = self.zeros if x is None else x
+            for eng, out in self.series:
+                eng.process(buf, out=out, n_frames=nf, stream=stream)
+                buf = out
+            return buf
         for nid in self.g.order:
             n = self.g.nodes[nid]
             if n.spec is None:
@@ -343,5 +460,7 @@ class GraphEngine:
     def close(self):
         if self.fused is not None:
             self.fused.close()
+        for eng, _ in self.series:
+            eng.close()
         for r in self.runs:
             r.engine.close()

@@ -7,7 +7,7 @@ _PORTS = {   # typename -> (input port names in field order, has output)
     "reverb": (["in"], True), "distort": (["in", "level"], True), "overdrive": (["in", "boost", "drive", "level"], True),
     "chebyshev": (["in"], True), "add": (["a", "b"], True), "mix": (["a", "b", "ratio"], True),
     "signal_gen": (["amplitude", "frequency"], True), "envelope": (["in"], True),
-    "mux": (["a", "b"], True), "demux": (["in"], True),
+    "mux": (["a", "b"], True), "demux": (["in"], True), "fir": (["in"], True),
 }
 _OUTS = {"demux": ["a", "b"]}
 
@@ -140,4 +140,23 @@ def random_dag(seed, n_nodes=8, libm=False):
         links.append((s, 99, "in"))
     if not any(l[1] == 99 and l[0] == n_nodes for l in links):
         links.append((n_nodes, 99, "in"))       # the last node always reaches the output
+    return build(nodes, links)
+
+
+def cab_rig(taps=64, bypass=False, cut="fir"):
+    """The shape of a guitar rig: drive stage with a parallel clean path -> cabinet impulse response (FIR) -> Fuzz-free
+    tail with a delay mixed against the dry signal.  All the signal passes through the FIR node, so the graph is two
+    fusable segments around it.  bypass=True adds a link around the FIR node (then it is not); cut="fuzz" puts a
+    Distort/Fuzz node (block-global, also a kernel of its own) in the FIR node's place."""
+    import math
+    h = [math.exp(-6.0 * j / taps) * (1.0 if j % 3 else -0.7) / 4.0 for j in range(taps)]
+    nodes = [(0, "input", {}), (1, "gain", {"level": 1.5}), (2, "distort", {"level": 4.0, "mode": "SoftClip"}),
+             (3, "biquad", BQ), (4, "add", {}),
+             (5, "fir", {"taps": h[::-1], "mode": "Balanced"}) if cut == "fir" else (5, "distort", {"level": 5.0, "mode": "Fuzz"}),
+             (6, "reverb", {"seconds": 0.005, "decay": 0.4}), (7, "mix", {"ratio": 0.3}), (8, "high_pass", {"ratio": 0.1}),
+             (9, "output", {})]
+    links = [(0, 1, "in"), (1, 2, "in"), (1, 3, "in"), (2, 4, "a"), (3, 4, "b"), (4, 5, "in"), (2, 5, "in"),
+             (5, 6, "in"), (5, 7, "a"), (6, 7, "b"), (7, 8, "in"), (8, 9, "in")]
+    if bypass:
+        links.append((4, 7, "a"))
     return build(nodes, links)

@@ -164,3 +164,21 @@ def test_generated_graph_kernels_compile_without_a_gpu(dspfx, tmp_path):
     _compile_generated(E, *G.fused_plan(G.Graph(graphs.random_dag(116, 16, libm=True))), tmp_path, "random16")
     with pytest.raises(E.DspfxError):
         E.graph_source([E.Gain(1.0)], [(0, 0, E.PORT_MAIN)])                           # a link must go forward
+
+
+def test_series_plan_cuts_at_the_nodes_all_signal_passes(dspfx):
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    g = G.Graph(graphs.cab_rig())
+    assert G.fused_plan(g) is None                                   # a FIR node is its own kernel
+    steps = G.series_plan(g)
+    assert [s[0] for s in steps] == ["graph", "node", "graph"]
+    specs, links = steps[0][1], steps[0][2]
+    assert [s.kind for s in specs] == [E.GAIN, E.DISTORT, E.BIQUAD, E.ADD]
+    assert links[-2:] == [(3, 4, E.PORT_MAIN), (1, 4, E.PORT_MAIN)]  # the FIR node's two incoming links = the segment's Output
+    assert steps[1][1].kind == E.FIR
+    specs, links = steps[2][1], steps[2][2]
+    assert [s.kind for s in specs] == [E.REVERB, E.MIX, E.HIGH_PASS]
+    assert links[:3] == [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (E.GRAPH_INPUT, 1, E.PORT_MAIN), (0, 1, E.PORT_SIDE)]
+    assert G.series_plan(G.Graph(graphs.cab_rig(bypass=True))) is None   # a link around the FIR node
+    assert G.series_plan(G.Graph(graphs.diamond())) is None              # nothing to cut at

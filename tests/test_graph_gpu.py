@@ -213,6 +213,47 @@ def test_long_chain_as_one_graph_kernel(dspfx, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("N,tile", [(128, 0), (256, 64)])
+def test_graph_with_a_fir_node_in_series(dspfx, G, N, tile):
+    """An amp stage, a cabinet impulse response (FIR: its own MFMA kernel) and a delay tail: the graph is cut at the FIR
+    node and each side is one generated kernel.  Bit-identical to the run-by-run evaluation (same FIR kernel, same
+    inputs); against the oracle within the FIR path's tolerance.  A link around the FIR node makes it run by run."""
+    import torch
+    B, nf = 128, 768
+    text = graphs.cab_rig()
+    x = O.noise(0x5EED000C, np.arange(N), np.arange(nf))
+    a = G.GraphEngine(text, N, B, tile_channels=tile)
+    b = G.GraphEngine(text, N, B, tile_channels=tile, fused=False)
+    assert len(a.series) == 3 and a.describe().count("jit_graph") == 2 and "fir kernel" in a.describe(), a.describe()
+    got = np.empty_like(x)
+    for f0 in range(0, nf, B):
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
+        ya = a.process(dx, B).clone()
+        yb = b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), f0
+        got[f0:f0 + B] = dspfx.from_layout(ya.cpu().numpy(), B, N, tile)
+    ref = graph_eval.run_graph(a.g, x)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    a.close()
+    b.close()
+    c = G.GraphEngine(graphs.cab_rig(bypass=True), N, B, tile_channels=tile)
+    assert not c.series and c.fused is None and len(c.runs) > 1
+    c.close()
+    # the same rig around a Fuzz node (block-global over 128 frames: its own kernel too)
+    a = G.GraphEngine(graphs.cab_rig(cut="fuzz"), N, B, tile_channels=tile)
+    b = G.GraphEngine(graphs.cab_rig(cut="fuzz"), N, B, tile_channels=tile, fused=False)
+    assert len(a.series) == 3 and "fuzz kernel" in a.describe(), a.describe()
+    for f0 in range(0, nf, B):
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
+        ya = a.process(dx, B).clone()
+        yb = b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), f0
+    a.close()
+    b.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
