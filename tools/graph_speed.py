@@ -11,9 +11,9 @@ from dsp_stuff_amd import graph as G
 import graphs
 N, B = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20, 128
 name = sys.argv[1] if len(sys.argv) > 1 else "diamond"
-text = graphs.random_dag(*map(int, name.split(":")[1:]), libm=True) if name.startswith("random:") else getattr(graphs, name)()   # random:<seed>:<nodes>
+text = graphs.cab_rig(4096) if name == "cab_rig" else graphs.random_dag(*map(int, name.split(":")[1:]), libm=True) if name.startswith("random:") else getattr(graphs, name)()   # random:<seed>:<nodes>
 x = torch.empty(B * N, dtype=torch.float32, device="cuda")
-for fused in (True, False):
+for fused in (None, False):
     ge = G.GraphEngine(text, N, B, tile_channels=256, fused=fused)
     ge.util.fill_noise(x, B, 0)
     if ge.fused is not None:
@@ -26,6 +26,6 @@ for fused in (True, False):
     for _ in range(steps): ge.process(x, B)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
-    print("%s %s: %.4f ms/block, %.3e samples/s, %.0f GB/s of in+out" % (name, "one kernel " if fused else "run by run", ms, N * B / ms * 1e3, 8 * N * B / ms / 1e6))
+    print("%s %s: %.4f ms/block, %.3e samples/s, %.0f GB/s of in+out" % (name, "run by run" if fused is False else ("one kernel " if ge.fused is not None else "segments   "), ms, N * B / ms * 1e3, 8 * N * B / ms / 1e6))
     print(ge.describe())
     ge.close()
