@@ -38,6 +38,7 @@ GRAPH_MAX_NODES = 16
 ERR_UNSUPPORTED = -5
 GRAPH_INPUT, GRAPH_ZERO = -1, -2
 PORT_MAIN, PORT_SIDE, PORT_SLIDER = 0, 1, 2
+PORT_RAW = 256
 
 # every symbol include/dspfx.h declares
 EXPORTS = [

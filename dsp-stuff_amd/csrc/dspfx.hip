@@ -522,7 +522,7 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
     std::vector<GLink> links;
     if (e->graph_mode) {
-        for (const dspfx_graph_link &l : e->wiring) links.push_back(GLink{l.src, l.dst, l.port, false});
+        for (const dspfx_graph_link &l : e->wiring) links.push_back(GLink{l.src, l.dst, l.port & ~DSPFX_PORT_RAW, (l.port & DSPFX_PORT_RAW) != 0});
     } else {   // a long stage of a chain engine: node after node, hops as the engine's link flags say, no Output hop
         for (int i = 0; i < st.count; ++i)
             links.push_back(GLink{i == 0 ? DSPFX_GRAPH_INPUT : i - 1, i, DSPFX_PORT_MAIN, node_hop(e, st.first + i) == 0});
@@ -1279,17 +1279,21 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
         const dspfx_graph_link &l = links[i];
         if (l.dst < 0 || l.dst > n_nodes || l.src < DSPFX_GRAPH_ZERO || l.src >= l.dst)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
-        bool ok = l.port == DSPFX_PORT_MAIN;
+        const int port = l.port & ~DSPFX_PORT_RAW;
+        bool ok = port == DSPFX_PORT_MAIN;
         if (l.dst < n_nodes && !ok) {
             const dspfx_node_desc &d = nodes[l.dst];
             float lo[3], hi[3];
-            if (l.port == DSPFX_PORT_SIDE) ok = d.kind == DSPFX_ADD || d.kind == DSPFX_MIX;
-            else ok = l.port >= DSPFX_PORT_SLIDER && l.port - DSPFX_PORT_SLIDER < kind_sliders(d, lo, hi);
+            if (port == DSPFX_PORT_SIDE) ok = d.kind == DSPFX_ADD || d.kind == DSPFX_MIX;
+            else ok = port >= DSPFX_PORT_SLIDER && port - DSPFX_PORT_SLIDER < kind_sliders(d, lo, hi);
         }
         if (!ok) return fail(e, DSPFX_ERR_INVALID, "graph link %d: node %d has no port %d", i, l.dst, l.port);
-        if (++fan_in[{l.dst, l.port}] > DSPFX_MAX_LINKS)
+        if (++fan_in[{l.dst, port}] > DSPFX_MAX_LINKS)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: more than %d links into one port", i, DSPFX_MAX_LINKS);
     }
+    for (int i = 0; i < n_links; ++i)   // a RAW link is its port's only link, and it carries a signal
+        if ((links[i].port & DSPFX_PORT_RAW) && (fan_in[{links[i].dst, links[i].port & ~DSPFX_PORT_RAW}] != 1 || links[i].src == DSPFX_GRAPH_ZERO))
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: a RAW link must be the only link into its port", i);
     for (int i = 0; i < n_nodes; ++i)
         if (nodes[i].kind == DSPFX_FIR || (nodes[i].kind == DSPFX_DISTORT && nodes[i].mode == DSPFX_DIST_FUZZ))
             return fail(e, DSPFX_ERR_UNSUPPORTED, "graph node %d (FIR / Fuzz) has its own kernel and cannot be fused", i);
@@ -1327,7 +1331,8 @@ extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, con
         tmp.nodes[(size_t)i].d.taps = nullptr;
     }
     std::vector<GLink> gl;
-    for (int i = 0; i < n_links; ++i) gl.push_back(GLink{links[i].src, links[i].dst, links[i].port, false});
+    for (int i = 0; i < n_links; ++i)
+        gl.push_back(GLink{links[i].src, links[i].dst, links[i].port & ~DSPFX_PORT_RAW, (links[i].port & DSPFX_PORT_RAW) != 0});
     Stage st{};
     st.type = ST_FUSED;
     st.first = 0;

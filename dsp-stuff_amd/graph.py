@@ -34,7 +34,7 @@ import json
 from typing import Dict, List, Optional, Tuple
 
 from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_MAX_NODES, GRAPH_ZERO, LINK_INPUT, LINK_INTERNAL,
-               LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine, NodeSpec)
+               LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_RAW, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine, NodeSpec)
 from .config import _TABLE, DspConfigError, _node_from_cfg
 
 _UNSUPPORTED = {"muff"}                                # GPL crate, source not in the reference tree
@@ -241,83 +241,117 @@ def _unfusable(sp) -> bool:
     return sp.kind == FIR or (sp.kind == DISTORT and sp.mode == FUZZ)
 
 
-def series_plan(g: Graph):
-    """A graph with FIR / Fuzz nodes (their own kernels) that ALL the signal passes through -- an amp chain into a
-    cabinet impulse response into a reverb -- cut at those nodes: [("graph", specs, links), ("node", spec), ("graph", ...), ...],
-    alternating, every "graph" segment a single-input single-output sub-DAG for `dspfx_graph_set` whose Output is the
-    averaged main port of the node that follows it.  None when some link bypasses such a node, when one of them has a
-    connected slider port, or when a segment is too large."""
-    order = [nid for nid in g.order if g.nodes[nid].spec is not None]
-    cuts = [nid for nid in order if _unfusable(g.nodes[nid].spec)]
-    if not cuts:
-        return None
+def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
+    """A graph too large for one kernel, or with FIR / Fuzz nodes (kernels of their own), as a SERIES of engines:
+    [("graph", specs, links), ("node", spec), ("graph", ...), ...].  Two kinds of boundary:
+
+      * in front of a FIR / Fuzz node that all the live signal goes into -- an amp chain into a cabinet impulse
+        response into a reverb: the segment's Output is that node's averaged main port, the node follows, the next
+        segment's Input is the node's output;
+      * where a segment would exceed `max_nodes`, at a point of the evaluation order that ONE signal crosses: the
+        segment's Output link hands that signal over as it is (PORT_RAW), the next segment's Input is that buffer.
+
+    Every segment is a single-input single-output sub-DAG for `dspfx_graph_set`.  None when no such cutting exists
+    (some link bypasses a FIR / Fuzz node, one of them has a connected slider port, a stretch of more than
+    `max_nodes` nodes has no single-signal crossing)."""
+    nodes = [nid for nid in g.order if g.nodes[nid].spec is not None]
     out_id = g.outputs[0]
-    anc: Dict[int, frozenset] = {}          # cut nodes among a node's strict ancestors
-    fed: Dict[int, bool] = {}               # downstream of the Input node
+    in_id = g.inputs[0] if g.inputs else None
+    fed = {}
     for nid in g.order:
-        a, f = set(), False
-        for p in g.producers(g.nodes[nid]):
-            a |= anc[p]
-            if p in cuts:
-                a.add(p)
-            f = f or fed[p] or g.nodes[p].typename == "input"
-        anc[nid], fed[nid] = frozenset(a), f
-    cuts.sort(key=lambda c: len(anc[c]))
-    for i, c in enumerate(cuts):                       # the cut nodes must follow one another
-        if anc[c] != frozenset(cuts[:i]) or g.nodes[c].ctl or g.nodes[c].side:
-            return None
-    k = len(cuts)
-    level: Dict[int, int] = {}                         # segment a node's INPUT ports belong to
-    for nid in g.order:
-        if nid in cuts:
-            level[nid] = cuts.index(nid)
-        elif fed[nid] or anc[nid] or g.nodes[nid].typename == "input":
-            if anc[nid] != frozenset(cuts[:len(anc[nid])]):
-                return None
-            level[nid] = len(anc[nid])
-    if level.get(out_id) != k:
-        return None                                    # the Output does not depend on every such node
-    for nid in reversed(g.order):                      # sources fed by nothing (generators, unplugged effects): where they are used
-        if nid in level:
-            continue
-        users = {level[c] for c, port in g.nodes[nid].outs if port != "unused"}
-        if len(users) > 1:
-            return None
-        level[nid] = users.pop() if users else k
+        fed[nid] = g.nodes[nid].typename == "input" or any(fed[p] for p in g.producers(g.nodes[nid]))
+    # sources fed by nothing (generators, unplugged effects) are evaluated as late as possible: right before their
+    # first consumer, so that they do not keep a signal alive across the points where the graph could be cut
+    order, placed = [], set()
 
-    def out_level(p):                                  # segment a node's OUTPUT lives in
-        return level[p] + 1 if p in cuts else level[p]
-
-    for nid in g.order:
+    def place(nid):
+        if nid in placed:
+            return
         for p in g.producers(g.nodes[nid]):
-            if out_level(p) != level[nid]:
-                return None                            # a link that bypasses a FIR / Fuzz node
+            if g.nodes[p].spec is not None and not fed[p]:
+                place(p)
+        placed.add(nid)
+        order.append(nid)
+
+    for nid in nodes:
+        if fed[nid]:
+            place(nid)
+    for nid in nodes:
+        place(nid)
+    pos = {nid: i for i, nid in enumerate(order)}
+    pos[out_id] = len(order)
+    users: Dict[int, List[int]] = {}                   # value (node id / input id) -> positions that read it
+    for nid in order + [out_id]:
+        for p in g.producers(g.nodes[nid]):
+            users.setdefault(p, []).append(pos[nid])
+
+    def live_after(values, p):
+        """those of `values` still read at position p or later"""
+        return [v for v in values if any(u >= p for u in users.get(v, []))]
+
     steps = []
-    for j in range(k + 1):
-        seg = [nid for nid in order if nid not in cuts and level[nid] == j]
-        if len(seg) > GRAPH_MAX_NODES:
-            return None
-        idx = {nid: i for i, nid in enumerate(seg)}
-        seg_in = cuts[j - 1] if j else (g.inputs[0] if g.inputs else None)
+    start, cur_in = 0, in_id
 
-        def src(s):
-            if s == ZERO:
+    def emit(lo, hi, sink_links, raw):
+        seg = order[lo:hi]
+        idx = {nid: i for i, nid in enumerate(seg)}
+
+        def src(sv):
+            if sv == ZERO:
                 return GRAPH_ZERO
-            return GRAPH_INPUT if s == seg_in else idx[s]
+            if sv == cur_in:
+                return GRAPH_INPUT
+            return idx[sv]                             # KeyError = a signal from further back: caught below
 
         links = []
         for nid in seg:
             n = g.nodes[nid]
-            links += [(src(s), idx[nid], PORT_MAIN) for s in n.main]
-            links += [(src(s), idx[nid], PORT_SIDE) for s in n.side]
+            links += [(src(sv), idx[nid], PORT_MAIN) for sv in n.main]
+            links += [(src(sv), idx[nid], PORT_SIDE) for sv in n.side]
             for kk, srcs in sorted(n.ctl.items()):
-                links += [(src(s), idx[nid], PORT_SLIDER + kk) for s in srcs]
-        sink = g.nodes[cuts[j]] if j < k else g.nodes[out_id]
-        links += [(src(s), len(seg), PORT_MAIN) for s in sink.main]
+                links += [(src(sv), idx[nid], PORT_SLIDER + kk) for sv in srcs]
+        links += [(src(sv), len(seg), PORT_MAIN | (PORT_RAW if raw else 0)) for sv in sink_links]
         steps.append(("graph", [g.nodes[nid].spec for nid in seg], links))
-        if j < k:
-            steps.append(("node", g.nodes[cuts[j]].spec))
+
+    try:
+        i = start
+        while i <= len(order):
+            at_end = i == len(order)
+            cut_node = (not at_end) and _unfusable(g.nodes[order[i]].spec)
+            if at_end or cut_node:
+                # the stretch [start, i) must fit: cut it at single-signal crossings while it does not
+                while i - start > max_nodes:
+                    best = None
+                    for p in range(start + 1, min(start + max_nodes, i - 1) + 1):
+                        live = live_after([cur_in] + order[start:p], p)
+                        if len(live) == 1 and live[0] != cur_in:
+                            best = (p, live[0])
+                    if best is None:
+                        return None
+                    emit(start, best[0], [best[1]], True)
+                    start, cur_in = best
+                if at_end:
+                    emit(start, i, g.nodes[out_id].main, False)
+                    break
+                u = g.nodes[order[i]]
+                if u.ctl or u.side:
+                    return None
+                # everything alive here must be read by this node's main port and by nothing later
+                if any(v not in u.main or any(x > i for x in users.get(v, []))
+                       for v in live_after([cur_in] + order[start:i], i)):
+                    return None
+                emit(start, i, u.main, False)
+                steps.append(("node", u.spec))
+                start, cur_in = i + 1, order[i]
+            i += 1
+    except KeyError:
+        return None                                    # a link from before the previous boundary: no series form
     return steps
+
+
+def series_plan(g: Graph):
+    """`segment_plan` for graphs that need it: None for a graph that is one kernel anyway."""
+    return None if fused_plan(g) is not None else segment_plan(g)
 
 
 class GraphEngine:

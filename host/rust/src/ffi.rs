@@ -73,6 +73,7 @@ pub const DSPFX_GRAPH_ZERO: i32 = -2;
 pub const DSPFX_PORT_MAIN: i32 = 0;
 pub const DSPFX_PORT_SIDE: i32 = 1;
 pub const DSPFX_PORT_SLIDER: i32 = 2;
+pub const DSPFX_PORT_RAW: i32 = 256;
 
 // dspfx_kind
 pub const DSPFX_GAIN: c_int = 0;

@@ -291,6 +291,10 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
 #define DSPFX_PORT_MAIN 0
 #define DSPFX_PORT_SIDE 1
 #define DSPFX_PORT_SLIDER 2
+/* OR into `port`: the port's only link, taken as it is (no averaging, no division).  For cutting a large graph into
+ * consecutive kernels at a point where a single signal crosses: the first kernel's Output link is RAW, the next
+ * engine reads that buffer as its Input (dsp-stuff_amd/graph.py, segment_plan). */
+#define DSPFX_PORT_RAW 256
 typedef struct dspfx_graph_link {
     int32_t src;    /* producing node index, DSPFX_GRAPH_INPUT or DSPFX_GRAPH_ZERO */
     int32_t dst;    /* consuming node index, or n_nodes for the Output node */

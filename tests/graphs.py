@@ -160,3 +160,61 @@ def cab_rig(taps=64, bypass=False, cut="fir"):
     if bypass:
         links.append((4, 7, "a"))
     return build(nodes, links)
+
+
+def long_rig(seed, n_blocks=10, fir_at=None):
+    """A pedalboard longer than one kernel holds: `n_blocks` stages in series, each a small sub-graph with one way in and
+    one way out (a few effects in a row; two parallel branches into an Add or Mix; an effect whose slider is driven by an
+    LFO; two branches averaged on one port).  One signal crosses between stages, so the graph can be cut there.
+    fir_at=k puts a short FIR node after stage k."""
+    import math
+    import random
+    rnd = random.Random(seed)
+    nodes, links = [(0, "input", {})], []
+    nid = [0]
+
+    def add(tn, f):
+        nid[0] += 1
+        nodes.append((nid[0], tn, f))
+        return nid[0]
+
+    def effect():
+        tn = rnd.choice(["gain", "biquad", "low_pass", "high_pass", "distort", "reverb", "envelope"])
+        f = {"gain": {"level": rnd.choice([0.7, 1.0, 1.2])}, "biquad": dict(BQ), "low_pass": {"ratio": rnd.choice([0.3, 0.6])},
+             "high_pass": {"ratio": rnd.choice([0.2, 0.5])},
+             "distort": {"level": rnd.choice([1.5, 3.0]), "mode": rnd.choice(["HardClip", "SoftClip", "RecipSoftClip"])},
+             "reverb": {"seconds": rnd.choice([0.003, 0.006]), "decay": rnd.choice([0.3, 0.5])},
+             "envelope": {"attack": 4.0, "release": 100.0}}[tn]
+        return add(tn, f)
+
+    s = 0
+    for b in range(n_blocks):
+        kind = rnd.choice(["row", "row", "parallel", "lfo", "fan_in"])
+        if kind == "row":
+            for _ in range(rnd.choice([1, 2, 3])):
+                e = effect()
+                links.append((s, e, "in"))
+                s = e
+        elif kind == "parallel":
+            a, c = effect(), effect()
+            links += [(s, a, "in"), (s, c, "in")]
+            m = add("mix", {"ratio": rnd.choice([0.25, 0.5])}) if rnd.random() < 0.5 else add("add", {})
+            links += [(a, m, "a"), (c, m, "b")]
+            s = m
+        elif kind == "lfo":
+            l = add("signal_gen", {"amplitude": 0.8, "frequency": rnd.choice([3.0, 440.0]), "mode": rnd.choice(["Triangle", "Square"])})
+            gn = add("gain", {"level": 1.0})
+            links += [(s, gn, "in"), (l, gn, "level")]
+            s = gn
+        else:
+            a, c, d = effect(), effect(), effect()
+            links += [(s, a, "in"), (s, c, "in"), (a, d, "in"), (c, d, "in")]
+            s = d
+        if fir_at == b:
+            h = [math.exp(-5.0 * j / 32) * (1.0 if j % 2 else -0.5) / 3.0 for j in range(32)]
+            f = add("fir", {"taps": h[::-1], "mode": "Balanced"})
+            links.append((s, f, "in"))
+            s = f
+    nodes.append((999, "output", {}))
+    links.append((s, 999, "in"))
+    return build(nodes, links)

@@ -182,3 +182,28 @@ def test_series_plan_cuts_at_the_nodes_all_signal_passes(dspfx):
     assert links[:3] == [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (E.GRAPH_INPUT, 1, E.PORT_MAIN), (0, 1, E.PORT_SIDE)]
     assert G.series_plan(G.Graph(graphs.cab_rig(bypass=True))) is None   # a link around the FIR node
     assert G.series_plan(G.Graph(graphs.diamond())) is None              # nothing to cut at
+
+
+def test_segment_plan_cuts_long_graphs_where_one_signal_crosses(dspfx, tmp_path):
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    for seed in range(12):
+        g = G.Graph(graphs.long_rig(seed, 12, fir_at=5 if seed % 2 else None))
+        n_nodes = sum(1 for n in g.nodes.values() if n.spec is not None)
+        steps = G.series_plan(g)
+        assert steps is not None and n_nodes > E.GRAPH_MAX_NODES
+        assert sum(len(s[1]) if s[0] == "graph" else 1 for s in steps) == n_nodes          # every node exactly once
+        for k, (kind, *what) in enumerate(steps):
+            if kind != "graph":
+                continue
+            specs, links = what
+            assert len(specs) <= E.GRAPH_MAX_NODES and all(s < d for s, d, _ in links)
+            raw_out = [l for l in links if l[2] & E.PORT_RAW]
+            hands_over = k + 1 < len(steps) and steps[k + 1][0] == "graph"               # next is a kernel, not a FIR node
+            assert len(raw_out) == (1 if hands_over else 0) and all(l[1] == len(specs) for l in raw_out)
+    # the RAW handover in generated code: a copy, not an average
+    g = G.Graph(graphs.long_rig(0, 12))
+    specs, links = G.series_plan(g)[0][1:]
+    src = _compile_generated(E, specs, links, tmp_path, "handover")
+    assert "g_copy<F, CPL>(y, v%d)" % (len(specs) - 1) in src
+    assert G.segment_plan(G.Graph(graphs.diamond()), max_nodes=3) is None     # no point that a single signal crosses

@@ -254,6 +254,37 @@ def test_graph_with_a_fir_node_in_series(dspfx, G, N, tile):
     b.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_long_graph_as_a_series_of_kernels(dspfx, G, seed):
+    """25-32 node pedalboards (stages in series, each a small sub-graph): more than one kernel holds, so the graph is
+    cut where a single signal crosses (the handover link is RAW) and, on odd seeds, around a FIR node.  Bit-identical
+    to the run-by-run evaluation; <= 1 ulp against the oracle (FIR tolerance on odd seeds)."""
+    import torch
+    N, B, nf = 128, 128, 512
+    tile = 64 if seed % 4 >= 2 else 0
+    text = graphs.long_rig(seed, 12, fir_at=5 if seed % 2 else None)
+    a = G.GraphEngine(text, N, B, tile_channels=tile)
+    b = G.GraphEngine(text, N, B, tile_channels=tile, fused=False)
+    assert a.fused is None and len(a.series) >= 2 and len(a.series) < len(b.runs), a.describe()
+    x = O.noise(0x5EED000D + seed, np.arange(N), np.arange(nf))
+    got = np.empty_like(x)
+    for f0 in range(0, nf, B):
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
+        ya = a.process(dx, B).clone()
+        yb = b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), (seed, f0)
+        got[f0:f0 + B] = dspfx.from_layout(ya.cpu().numpy(), B, N, tile)
+    ref = graph_eval.run_graph(a.g, x[:, :16])
+    assert np.isfinite(ref).all() and np.abs(ref).max() > 0
+    if seed % 2:
+        assert np.abs(got[:, :16] - ref).max() <= 1e-5 * np.abs(ref).max()
+    else:
+        assert ulp_diff(got[:, :16], ref).max() <= 1, seed
+    a.close()
+    b.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
@@ -266,6 +297,9 @@ def test_graph_set_rejections(dspfx):
     assert ei.value.status == -1
     with pytest.raises(E.DspfxError) as ei:
         eng.set_graph([gain], [(E.GRAPH_INPUT, 0, E.PORT_SLIDER + 1)])
+    assert ei.value.status == -1
+    with pytest.raises(E.DspfxError) as ei:      # a RAW link is its port's only link
+        eng.set_graph([gain, gain], [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (0, 1, E.PORT_MAIN | E.PORT_RAW), (E.GRAPH_INPUT, 1, E.PORT_MAIN)])
     assert ei.value.status == -1
     with pytest.raises(E.DspfxError) as ei:      # Fuzz has its own kernel
         eng.set_graph([E.NodeSpec(E.DISTORT, [2.0], mode=E.FUZZ)], [(E.GRAPH_INPUT, 0, E.PORT_MAIN)])
