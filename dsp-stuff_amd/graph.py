@@ -6,9 +6,10 @@ A graph of at most 16 fusable nodes becomes ONE kernel generated for its wiring 
 node outputs stay in registers and a block costs one read of the Input node's buffer and one write of the Output node's.
 
 A graph whose FIR / Fuzz nodes (kernels of their own) are passed by all the signal -- an amp chain into a cabinet
-impulse response into a reverb -- is cut at those nodes and every segment between them is one such kernel (`series_plan`).
+impulse response into a reverb -- is cut at those nodes, a graph of more than 16 nodes where a single signal crosses,
+and every segment is one such kernel (`segment_plan`).
 
-Anything else (more nodes, a link that bypasses a FIR or Fuzz node, a channel count that is not a multiple of 64, no
+Anything else (no such cutting, a link that bypasses a FIR or Fuzz node, a channel count that is not a multiple of 64, no
 run-time compiler) is cut into maximal linear runs; each run is one fused `Engine` (one kernel launch per block, its
 own per-channel state), runs are evaluated in topological order, and the only extra device work is
 `dspfx_link_average` where a port has more than one incoming link.  What a run consumes:
