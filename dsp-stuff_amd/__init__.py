@@ -36,7 +36,7 @@ LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
 GRAPH_MAX_NODES = 16
 ERR_UNSUPPORTED = -5
-GRAPH_INPUT, GRAPH_ZERO = -1, -2
+GRAPH_INPUT, GRAPH_ZERO, GRAPH_INPUT2 = -1, -2, -3
 PORT_MAIN, PORT_SIDE, PORT_SLIDER = 0, 1, 2
 PORT_RAW = 256
 

@@ -439,7 +439,9 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
     };
     std::string body;
     auto gather = [&](const std::string &dst, const std::vector<GLink> &srcs, bool declare) {
-        auto name = [](int sidx) { return sidx == DSPFX_GRAPH_INPUT ? std::string("x") : "v" + std::to_string(sidx); };
+        auto name = [](int sidx) {
+            return sidx == DSPFX_GRAPH_INPUT ? std::string("x") : sidx == DSPFX_GRAPH_INPUT2 ? std::string("x2") : "v" + std::to_string(sidx);
+        };
         body += "        ";
         if (declare) body += "float " + dst + "[F][CPL]; ";
         if (srcs.size() == 1 && srcs[0].raw) {
@@ -460,8 +462,11 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
     };
     const std::string FAST = fast ? "true" : "false";
     for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
-    bool uses_input = false;
-    for (const GLink &l : links) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+    bool uses_input = false, uses_input2 = false;
+    for (const GLink &l : links) {
+        uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+        uses_input2 = uses_input2 || l.src == DSPFX_GRAPH_INPUT2;
+    }
     for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
         if (e->nodes[(size_t)(first + i)].d.kind == DSPFX_REVERB)
             body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(gslot<" + std::to_string(i) +
@@ -509,8 +514,9 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
     std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[GRAPH_SLOTS] = {";
     for (int i = 0; i < GRAPH_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < GRAPH_SLOTS ? ", " : "");
     src += std::string("};\n    static constexpr bool uses_input = ") + (uses_input ? "true" : "false") + ";\n";
-    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], float (&y)[F][CPL],\n"
-           "                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
+    src += std::string("    static constexpr bool uses_input2 = ") + (uses_input2 ? "true" : "false") + ";\n";
+    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], const float (&x2)[F][CPL],\n"
+           "                                               float (&y)[F][CPL], float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
     src += body;
     src += "    }\n};\n}  // namespace dspfx\n";
     return src;
@@ -946,6 +952,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
             if (st.count == 0 && !(last && (mix || e->partials_override || e->mp_building)) && src == out) continue;   // nothing to do
+            if (e->graph_mode && !side)
+                for (const dspfx_graph_link &l : e->wiring)
+                    if (l.src == DSPFX_GRAPH_INPUT2) return fail(e, DSPFX_ERR_INVALID, "this graph reads a second block (DSPFX_GRAPH_INPUT2): side must not be null");
             GraphArgs ga;                   // a graph kernel reads the slots beyond ChainArgs from it
             memset(&ga, 0, sizeof ga);
             ChainArgs &a = ga.c;
@@ -1277,7 +1286,7 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {
         const dspfx_graph_link &l = links[i];
-        if (l.dst < 0 || l.dst > n_nodes || l.src < DSPFX_GRAPH_ZERO || l.src >= l.dst)
+        if (l.dst < 0 || l.dst > n_nodes || l.src < DSPFX_GRAPH_INPUT2 || l.src >= l.dst)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
         const int port = l.port & ~DSPFX_PORT_RAW;
         bool ok = port == DSPFX_PORT_MAIN;
@@ -2040,9 +2049,13 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
     }
     if (side && !e->graph_mode) b += 4.0;   // a fused graph's "b" ports are fed from registers
     if (e->graph_mode) {                    // ... and a graph without an Input link never reads `in`
-        bool uses_input = false;
-        for (const dspfx_graph_link &l : e->wiring) uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+        bool uses_input = false, uses_input2 = false;
+        for (const dspfx_graph_link &l : e->wiring) {
+            uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
+            uses_input2 = uses_input2 || l.src == DSPFX_GRAPH_INPUT2;
+        }
         if (!uses_input) b -= 4.0;
+        if (uses_input2) b += 4.0;
     }
     return b;
 }

@@ -104,20 +104,27 @@ __device__ __forceinline__ void g_mix_mod(float (&v)[F][CPL], const float (&b)[F
 // ---- the kernel ---------------------------------------------------------------------------------------
 // PROG (generated):  static constexpr int sigs[GRAPH_SLOTS]  node signatures (state rows to load / store)
 //                    static constexpr bool uses_input        false: no link leaves the Input node, `in` is not read
-//                    template <int F, int CPL> static void run(g, x, y, st, cx)   x = Input block, y = Output block
+//                    static constexpr bool uses_input2       true: some link reads the second block (`side`)
+//                    template <int F, int CPL> static void run(g, x, x2, y, st, cx)   x / x2 = Input blocks, y = Output block
 template <int F, int CPL, class PROG>
 __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAPH_SLOTS][4][CPL], size_t c, const WaveAddr &w,
                                             unsigned f0, int lane, unsigned wave_global) {
     const ChainArgs &a = g.c;
-    float x[F][CPL], y[F][CPL];
+    float x[F][CPL], x2[F][CPL], y[F][CPL];
     if constexpr (PROG::uses_input) {
 #pragma unroll
         for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), x[f], true);
     } else {
         g_zero<F, CPL>(x);
     }
+    if constexpr (PROG::uses_input2) {            // DSPFX_GRAPH_INPUT2: the block passed as `side`
+#pragma unroll
+        for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.side + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), x2[f], true);
+    } else {
+        g_zero<F, CPL>(x2);
+    }
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, nullptr, 0, true};
-    PROG::template run<F, CPL>(g, x, y, st, cx);
+    PROG::template run<F, CPL>(g, x, x2, y, st, cx);
 #pragma unroll
     for (int f = 0; f < F; ++f)
         store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), y[f], true);

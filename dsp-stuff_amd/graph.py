@@ -34,7 +34,7 @@ from __future__ import annotations
 import json
 from typing import Dict, List, Optional, Tuple
 
-from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_MAX_NODES, GRAPH_ZERO, LINK_INPUT, LINK_INTERNAL,
+from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_INPUT2, GRAPH_MAX_NODES, GRAPH_ZERO, LINK_INPUT, LINK_INTERNAL,
                LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_RAW, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine, NodeSpec)
 from .config import _TABLE, DspConfigError, _node_from_cfg
 
@@ -252,7 +252,11 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
       * where a segment would exceed `max_nodes`, at a point of the evaluation order that ONE signal crosses: the
         segment's Output link hands that signal over as it is (PORT_RAW), the next segment's Input is that buffer.
 
-    Every segment is a single-input single-output sub-DAG for `dspfx_graph_set`.  None when no such cutting exists
+    A FIR / Fuzz node fed by ONE signal that also goes on beside it (the dry path around a cabinet) is allowed: the
+    segment hands that signal over as it is, the node ("node_hop" step) applies the hop itself, and the following
+    segment reads the node as its Input and the signal as its second block (GRAPH_INPUT2, the engine's `side`).
+
+    Every segment is a sub-DAG with one Output for `dspfx_graph_set`.  None when no such cutting exists
     (some link bypasses a FIR / Fuzz node, one of them has a connected slider port, a stretch of more than
     `max_nodes` nodes has no single-signal crossing)."""
     nodes = [nid for nid in g.order if g.nodes[nid].spec is not None]
@@ -291,7 +295,7 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
         return [v for v in values if any(u >= p for u in users.get(v, []))]
 
     steps = []
-    start, cur_in = 0, in_id
+    start, cur_in, cur_in2 = 0, in_id, None            # cur_in2: a signal carried around the previous FIR / Fuzz node
 
     def emit(lo, hi, sink_links, raw):
         seg = order[lo:hi]
@@ -302,6 +306,8 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
                 return GRAPH_ZERO
             if sv == cur_in:
                 return GRAPH_INPUT
+            if sv == cur_in2:
+                return GRAPH_INPUT2
             return idx[sv]                             # KeyError = a signal from further back: caught below
 
         links = []
@@ -324,25 +330,35 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
                 while i - start > max_nodes:
                     best = None
                     for p in range(start + 1, min(start + max_nodes, i - 1) + 1):
-                        live = live_after([cur_in] + order[start:p], p)
-                        if len(live) == 1 and live[0] != cur_in:
+                        live = live_after([cur_in, cur_in2] + order[start:p], p)
+                        if len(live) == 1 and live[0] not in (cur_in, cur_in2):
                             best = (p, live[0])
                     if best is None:
                         return None
                     emit(start, best[0], [best[1]], True)
                     start, cur_in = best
+                    cur_in2 = None
                 if at_end:
                     emit(start, i, g.nodes[out_id].main, False)
                     break
                 u = g.nodes[order[i]]
                 if u.ctl or u.side:
                     return None
-                # everything alive here must be read by this node's main port and by nothing later
-                if any(v not in u.main or any(x > i for x in users.get(v, []))
-                       for v in live_after([cur_in] + order[start:i], i)):
+                live = live_after([cur_in, cur_in2] + order[start:i], i)
+                if all(v in u.main and not any(x > i for x in users.get(v, [])) for v in live):
+                    # everything alive here is read by this node's main port and by nothing later
+                    emit(start, i, u.main, False)
+                    steps.append(("node", u.spec))
+                    cur_in2 = None
+                elif len(live) == 1 and u.main == live and (live[0] in order[start:i] or (live[0] == cur_in and start == i)):
+                    # one signal feeds the node AND goes on beside it (the dry path around a cabinet): hand it over as it
+                    # is, the node applies its own hop, the next segment reads the node as Input and the signal as Input 2
+                    if start < i:
+                        emit(start, i, live, True)
+                    steps.append(("node_hop", u.spec))
+                    cur_in2 = live[0]
+                else:
                     return None
-                emit(start, i, u.main, False)
-                steps.append(("node", u.spec))
                 start, cur_in = i + 1, order[i]
             i += 1
     except KeyError:
@@ -369,7 +385,7 @@ class GraphEngine:
         self.N, self.B, self.tile = channels, max_frames, tile_channels
         self.dev = torch.device("cuda", device)
         self.fused: Optional[Engine] = None
-        self.series = []
+        self.series, self.series_kind = [], []
         self.runs, self.run_of = [], {}
         self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
         self.final = self._buf()
@@ -394,16 +410,19 @@ class GraphEngine:
         if steps is not None:
             try:
                 for kind, *what in steps:
-                    eng = Engine(channels, max_frames, link_flags=0, device=device, tile_channels=tile_channels)
+                    # "node": the hop into it is the previous segment's Output average; "node_hop": a raw handover
+                    eng = Engine(channels, max_frames, link_flags=LINK_INPUT if kind == "node_hop" else 0, device=device,
+                                 tile_channels=tile_channels)
                     self.series.append((eng, self._buf()))
+                    self.series_kind.append((kind, kind == "graph" and any(l[0] == GRAPH_INPUT2 for l in what[1])))
                     if kind == "graph":
                         eng.set_graph(*what)
                     else:
-                        eng.set_chain(what)          # the hop into it is the previous segment's Output average
+                        eng.set_chain(what)
             except DspfxError as e:
                 for eng, _ in self.series:
                     eng.close()
-                self.series = []
+                self.series, self.series_kind = [], []
                 if e.status != ERR_UNSUPPORTED:
                     raise
         if self.series:
@@ -454,8 +473,11 @@ class GraphEngine:
             return self.final
         if self.series:
             buf = self.zeros if x is None else x
-            for eng, out in self.series:
-                eng.process(buf, out=out, n_frames=nf, stream=stream)
+            beside = None                      # what went into the last FIR / Fuzz node: the signal carried around it
+            for (eng, out), (kind, reads2) in zip(self.series, self.series_kind):
+                eng.process(buf, out=out, side=beside if reads2 else None, n_frames=nf, stream=stream)
+                if kind != "graph":
+                    beside = buf
                 buf = out
             return buf
         for nid in self.g.order:

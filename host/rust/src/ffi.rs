@@ -70,6 +70,7 @@ pub const DSPFX_MAX_LINKS: u32 = 16;
 pub const DSPFX_GRAPH_MAX_NODES: u32 = 16;
 pub const DSPFX_GRAPH_INPUT: i32 = -1;
 pub const DSPFX_GRAPH_ZERO: i32 = -2;
+pub const DSPFX_GRAPH_INPUT2: i32 = -3;
 pub const DSPFX_PORT_MAIN: i32 = 0;
 pub const DSPFX_PORT_SIDE: i32 = 1;
 pub const DSPFX_PORT_SLIDER: i32 = 2;

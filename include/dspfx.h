@@ -279,7 +279,7 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * them in the order given, (0 + x1 + ... + xk) / f32(0.0001 + k); a port without links reads zeros (main,
  * "b") or keeps its slider value (slider ports).  Ports: DSPFX_PORT_MAIN, DSPFX_PORT_SIDE (port "b" of
  * ADD / MIX), DSPFX_PORT_SLIDER + k (the `as_input` port of slider k, dsp-stuff-derive/src/lib.rs:135-153).
- * The engine's link_flags do not apply (every hop is explicit), `side` of the process calls is ignored and
+ * The engine's link_flags do not apply (every hop is explicit), `side` of the process calls is DSPFX_GRAPH_INPUT2 and
  * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 64 == 0 (whole waves).
  * DSPFX_ERR_UNSUPPORTED: the graph cannot be fused (too many nodes, a FIR / Fuzz node, channel count) or the
  * run-time compiler is unavailable: evaluate it run by run instead (dsp-stuff_amd/graph.py does).
@@ -288,6 +288,10 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
 #define DSPFX_GRAPH_MAX_NODES 16
 #define DSPFX_GRAPH_INPUT (-1)
 #define DSPFX_GRAPH_ZERO (-2)
+/* a second block from memory: the buffer passed as `side` to the process calls (must then be non-null).  Lets a graph
+ * that was cut into consecutive kernels carry a signal AROUND a node that has a kernel of its own -- the dry path
+ * beside a FIR cabinet: the kernel after the FIR node reads the FIR output as its Input and the dry signal here. */
+#define DSPFX_GRAPH_INPUT2 (-3)
 #define DSPFX_PORT_MAIN 0
 #define DSPFX_PORT_SIDE 1
 #define DSPFX_PORT_SLIDER 2

@@ -143,11 +143,12 @@ def random_dag(seed, n_nodes=8, libm=False):
     return build(nodes, links)
 
 
-def cab_rig(taps=64, bypass=False, cut="fir"):
+def cab_rig(taps=64, bypass=False, cut="fir", dry=False):
     """The shape of a guitar rig: drive stage with a parallel clean path -> cabinet impulse response (FIR) -> Fuzz-free
     tail with a delay mixed against the dry signal.  All the signal passes through the FIR node, so the graph is two
     fusable segments around it.  bypass=True adds a link around the FIR node (then it is not); cut="fuzz" puts a
-    Distort/Fuzz node (block-global, also a kernel of its own) in the FIR node's place."""
+    Distort/Fuzz node (block-global, also a kernel of its own) in the FIR node's place.  dry=True: the cabinet is fed by
+    the Add alone and the same signal is mixed back in after it (wet / dry): one signal around the FIR node."""
     import math
     h = [math.exp(-6.0 * j / taps) * (1.0 if j % 3 else -0.7) / 4.0 for j in range(taps)]
     nodes = [(0, "input", {}), (1, "gain", {"level": 1.5}), (2, "distort", {"level": 4.0, "mode": "SoftClip"}),
@@ -159,6 +160,9 @@ def cab_rig(taps=64, bypass=False, cut="fir"):
              (5, 6, "in"), (5, 7, "a"), (6, 7, "b"), (7, 8, "in"), (8, 9, "in")]
     if bypass:
         links.append((4, 7, "a"))
+    if dry:
+        links = [l for l in links if l[:2] not in ((2, 5), (5, 7))] + [(6, 7, "a"), (4, 7, "b")]
+        links = [l for l in links if l != (6, 7, "b")]
     return build(nodes, links)
 
 

@@ -180,7 +180,12 @@ def test_series_plan_cuts_at_the_nodes_all_signal_passes(dspfx):
     specs, links = steps[2][1], steps[2][2]
     assert [s.kind for s in specs] == [E.REVERB, E.MIX, E.HIGH_PASS]
     assert links[:3] == [(E.GRAPH_INPUT, 0, E.PORT_MAIN), (E.GRAPH_INPUT, 1, E.PORT_MAIN), (0, 1, E.PORT_SIDE)]
-    assert G.series_plan(G.Graph(graphs.cab_rig(bypass=True))) is None   # a link around the FIR node
+    assert G.series_plan(G.Graph(graphs.cab_rig(bypass=True))) is None   # a link around the FIR node next to others into it
+    # wet / dry: ONE signal feeds the FIR node and also goes on beside it
+    steps = G.series_plan(G.Graph(graphs.cab_rig(dry=True)))
+    assert [s[0] for s in steps] == ["graph", "node_hop", "graph"]
+    assert steps[0][2][-1] == (3, 4, E.PORT_MAIN | E.PORT_RAW)          # the Add's output handed over as it is
+    assert (E.GRAPH_INPUT2, 1, E.PORT_SIDE) in steps[2][2]              # ... and read as the Mix's "b" port after the FIR node
     assert G.series_plan(G.Graph(graphs.diamond())) is None              # nothing to cut at
 
 

@@ -240,6 +240,25 @@ def test_graph_with_a_fir_node_in_series(dspfx, G, N, tile):
     c = G.GraphEngine(graphs.cab_rig(bypass=True), N, B, tile_channels=tile)
     assert not c.series and c.fused is None and len(c.runs) > 1
     c.close()
+    # wet / dry: the signal that feeds the cabinet also goes on beside it -> handed over raw, the FIR engine applies its own
+    # hop, the kernel after it reads the FIR output as Input and the dry signal as its second block
+    a = G.GraphEngine(graphs.cab_rig(dry=True), N, B, tile_channels=tile)
+    b = G.GraphEngine(graphs.cab_rig(dry=True), N, B, tile_channels=tile, fused=False)
+    assert [k for k, _ in a.series_kind] == ["graph", "node_hop", "graph"] and a.series_kind[2][1], a.series_kind
+    got = np.empty_like(x)
+    for f0 in range(0, nf, B):
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
+        ya = a.process(dx, B).clone()
+        yb = b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), f0
+        got[f0:f0 + B] = dspfx.from_layout(ya.cpu().numpy(), B, N, tile)
+    ref = graph_eval.run_graph(a.g, x)
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    with pytest.raises(dspfx.DspfxError):            # the second block is not optional for that kernel
+        a.series[2][0].process(torch.from_numpy(dspfx.to_layout(x[:B], tile)).cuda(), n_frames=B)
+    a.close()
+    b.close()
     # the same rig around a Fuzz node (block-global over 128 frames: its own kernel too)
     a = G.GraphEngine(graphs.cab_rig(cut="fuzz"), N, B, tile_channels=tile)
     b = G.GraphEngine(graphs.cab_rig(cut="fuzz"), N, B, tile_channels=tile, fused=False)
