@@ -212,3 +212,25 @@ def test_segment_plan_cuts_long_graphs_where_one_signal_crosses(dspfx, tmp_path)
     src = _compile_generated(E, specs, links, tmp_path, "handover")
     assert "g_copy<F, CPL>(y, v%d)" % (len(specs) - 1) in src
     assert G.segment_plan(G.Graph(graphs.diamond()), max_nodes=3) is None     # no point that a single signal crosses
+
+
+def _graph_goldens():
+    import glob
+    import os
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "graphs")
+    out = []
+    for path in sorted(glob.glob(os.path.join(d, "*.npz"))):
+        z = np.load(path)
+        out.append((os.path.basename(path)[:-4], str(z["doc"]), z["x"], z["y"]))
+    return out
+
+
+def test_graph_golden_vectors_pin_the_oracle(dspfx):
+    """tests/golden/graphs/*.npz (made by tests/golden/make_graph_golden.py): the committed documents still parse to the
+    same graphs and the oracle's node-by-node evaluation still gives the committed outputs, bit for bit."""
+    from dsp_stuff_amd import graph as G
+    cases = _graph_goldens()
+    assert len(cases) >= 8
+    for name, doc, x, y in cases:
+        got = graph_eval.run_graph(G.Graph(doc), x)
+        assert np.array_equal(got.view(np.uint32), y.view(np.uint32)), name

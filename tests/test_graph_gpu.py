@@ -304,6 +304,31 @@ def test_long_graph_as_a_series_of_kernels(dspfx, G, seed):
     b.close()
 
 
+def test_graph_golden_vectors(dspfx, G):
+    """The HIP path against the committed graph golden vectors (tests/golden/graphs/): every plan form -- one kernel,
+    segments around a FIR node (with and without a dry path), a long graph in two kernels."""
+    import torch
+    from test_graph_cpu import _graph_goldens
+    forms = set()
+    for name, doc, x, y in _graph_goldens():
+        N, B = 64, 128
+        xs = np.tile(x, (1, 22))[:, :N]                       # the 3 channels repeated across a wave
+        ge = G.GraphEngine(doc, N, B)
+        forms.add("one" if ge.fused is not None else "segments" if ge.series else "runs")
+        got = np.empty_like(xs)
+        for f0 in range(0, xs.shape[0], B):
+            out = ge.process(torch.from_numpy(xs[f0:f0 + B].copy()).cuda(), B)
+            torch.cuda.synchronize()
+            got[f0:f0 + B] = out.cpu().numpy().reshape(B, N)
+        assert np.array_equal(got[:, :3], got[:, 3:6]), name          # channels are independent
+        if "fir" in name or "cab" in name:
+            assert np.abs(got[:, :3] - y).max() <= 1e-5 * np.abs(y).max(), name
+        else:
+            assert ulp_diff(got[:, :3], y).max() <= 1, name
+        ge.close()
+    assert forms == {"one", "segments"}, forms
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
