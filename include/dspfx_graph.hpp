@@ -1,0 +1,392 @@
+// dspfx_graph.hpp -- a saved graph of the reference (its `DSPConfig` JSON) on the engine, from C++.
+//
+// The reference GUI saves the graph as (dsp-stuff/src/runtime.rs:44-48, 560-564, 606-612)
+//     {"nodes": [{"id": N, "typename": cfg_name, "position": [x, y], "cfg": {...}}],
+//      "links": [{"lhs": [node_id, out_port_id], "rhs": [node_id, in_port_id]}]}
+// where a node's `cfg` holds its id, its port maps {"inputs": {name: port_id}, "outputs": {...}} and every
+// field tagged `save` (dsp-stuff-derive/src/lib.rs:233-293).  `SavedGraph` parses such a document, orders the nodes
+// topologically (document order among the ready ones, like the Python mirror dsp-stuff_amd/graph.py) and hands the
+// graph to `Engine::set_graph` (dspfx.h: dspfx_graph_set -- one generated kernel for the whole DAG).
+//
+// Same rules as the Python mirror: Mux / Demux are routing (identity on the selected port; a demux's unselected output
+// is a connected pipe of zeros), the display-only nodes (pitch, wave_view, spectrogram) are dropped, muff is outside
+// the accelerated path, a slider port takes at most one link, LowPass's cfg_name quirk (nodes/low_pass.rs:9: it saves
+// itself as "high_pass") is the document's business.  Graphs that one kernel cannot hold (more than
+// DSPFX_GRAPH_MAX_NODES nodes, a FIR or Fuzz node) need the cutting that graph.py's `segment_plan` does; here
+// `fused_plan` reports them (returns false).
+#ifndef DSPFX_GRAPH_HPP
+#define DSPFX_GRAPH_HPP
+
+#include <algorithm>
+#include <cctype>
+#include <cstdlib>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "dspfx.hpp"
+
+namespace dspfx {
+
+struct ConfigError : std::runtime_error {
+    explicit ConfigError(const std::string &m) : std::runtime_error("DSPConfig: " + m) {}
+};
+
+// ---- the little JSON this needs ------------------------------------------------------------------------------------
+namespace json {
+struct Value {
+    enum Type { Null, Bool, Number, String, Array, Object } type = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<Value> arr;
+    std::vector<std::pair<std::string, Value>> obj;   // document order
+    const Value *find(const std::string &key) const {
+        for (const auto &kv : obj)
+            if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    const Value &at(const std::string &key) const {
+        const Value *v = find(key);
+        if (!v) throw ConfigError("missing field \"" + key + "\"");
+        return *v;
+    }
+};
+class Parser {
+  public:
+    explicit Parser(const std::string &s) : s_(s) {}
+    Value parse() {
+        Value v = value();
+        ws();
+        if (i_ != s_.size()) fail("trailing characters");
+        return v;
+    }
+
+  private:
+    const std::string &s_;
+    std::size_t i_ = 0;
+    [[noreturn]] void fail(const char *what) const { throw ConfigError(std::string("not JSON: ") + what + " at offset " + std::to_string(i_)); }
+    void ws() {
+        while (i_ < s_.size() && (s_[i_] == ' ' || s_[i_] == '\n' || s_[i_] == '\t' || s_[i_] == '\r')) ++i_;
+    }
+    bool lit(const char *w) {
+        const std::size_t n = std::char_traits<char>::length(w);
+        if (s_.compare(i_, n, w) != 0) return false;
+        i_ += n;
+        return true;
+    }
+    std::string string() {
+        std::string out;
+        ++i_;   // opening quote
+        while (true) {
+            if (i_ >= s_.size()) fail("unterminated string");
+            const char c = s_[i_++];
+            if (c == '"') return out;
+            if (c != '\\') { out += c; continue; }
+            if (i_ >= s_.size()) fail("unterminated escape");
+            const char e = s_[i_++];
+            switch (e) {
+            case '"': case '\\': case '/': out += e; break;
+            case 'b': out += '\b'; break;
+            case 'f': out += '\f'; break;
+            case 'n': out += '\n'; break;
+            case 'r': out += '\r'; break;
+            case 't': out += '\t'; break;
+            case 'u': {   // names in these documents are ASCII; anything else is kept as UTF-8 of the code unit
+                if (i_ + 4 > s_.size()) fail("short \\u escape");
+                const unsigned cp = (unsigned)std::strtoul(s_.substr(i_, 4).c_str(), nullptr, 16);
+                i_ += 4;
+                if (cp < 0x80) out += (char)cp;
+                else if (cp < 0x800) { out += (char)(0xC0 | (cp >> 6)); out += (char)(0x80 | (cp & 0x3F)); }
+                else { out += (char)(0xE0 | (cp >> 12)); out += (char)(0x80 | ((cp >> 6) & 0x3F)); out += (char)(0x80 | (cp & 0x3F)); }
+                break;
+            }
+            default: fail("unknown escape");
+            }
+        }
+    }
+    Value value() {
+        ws();
+        if (i_ >= s_.size()) fail("unexpected end");
+        Value v;
+        const char c = s_[i_];
+        if (c == '{') {
+            v.type = Value::Object;
+            ++i_;
+            ws();
+            if (i_ < s_.size() && s_[i_] == '}') { ++i_; return v; }
+            while (true) {
+                ws();
+                if (i_ >= s_.size() || s_[i_] != '"') fail("expected a key");
+                std::string k = string();
+                ws();
+                if (i_ >= s_.size() || s_[i_++] != ':') fail("expected ':'");
+                v.obj.emplace_back(std::move(k), value());
+                ws();
+                if (i_ < s_.size() && s_[i_] == ',') { ++i_; continue; }
+                if (i_ < s_.size() && s_[i_] == '}') { ++i_; return v; }
+                fail("expected ',' or '}'");
+            }
+        }
+        if (c == '[') {
+            v.type = Value::Array;
+            ++i_;
+            ws();
+            if (i_ < s_.size() && s_[i_] == ']') { ++i_; return v; }
+            while (true) {
+                v.arr.push_back(value());
+                ws();
+                if (i_ < s_.size() && s_[i_] == ',') { ++i_; continue; }
+                if (i_ < s_.size() && s_[i_] == ']') { ++i_; return v; }
+                fail("expected ',' or ']'");
+            }
+        }
+        if (c == '"') { v.type = Value::String; v.str = string(); return v; }
+        if (lit("true")) { v.type = Value::Bool; v.b = true; return v; }
+        if (lit("false")) { v.type = Value::Bool; return v; }
+        if (lit("null")) return v;
+        char *end = nullptr;
+        v.num = std::strtod(s_.c_str() + i_, &end);
+        if (end == s_.c_str() + i_) fail("unexpected character");
+        i_ = (std::size_t)(end - s_.c_str());
+        v.type = Value::Number;
+        return v;
+    }
+};
+inline Value parse(const std::string &s) { return Parser(s).parse(); }
+}  // namespace json
+
+// ---- the saved graph -----------------------------------------------------------------------------------------------
+class SavedGraph {
+  public:
+    static constexpr int ZERO = -1;   // pseudo producer: the unselected output of a demux (a connected pipe of zeros)
+    struct GNode {
+        int id = 0;
+        std::string typename_;
+        json::Value cfg;
+        bool has_spec = false;
+        Node spec;
+        std::vector<int> main, side;                       // producer ids in link order
+        std::map<int, std::vector<int>> ctl;               // slider index -> producers
+        std::vector<std::pair<int, std::string>> outs;     // (consumer id, port name)
+    };
+
+    explicit SavedGraph(const std::string &text, bool page_round = false) {
+        const json::Value doc = json::parse(text);
+        if (doc.type != json::Value::Object) throw ConfigError("not a DSPConfig document");
+        for (const json::Value &n : doc.at("nodes").arr) {
+            GNode g;
+            g.id = (int)n.at("id").num;
+            g.typename_ = n.at("typename").str;
+            g.cfg = n.at("cfg");
+            const std::string &tn = g.typename_;
+            if (tn == "pitch" || tn == "wave_view" || tn == "spectrogram") { dropped_.push_back(g.id); continue; }
+            if (tn == "muff") throw ConfigError("node type \"muff\" is outside the accelerated path");
+            if (tn == "mux" || tn == "demux") {
+                const json::Value *sel = g.cfg.find(tn == "mux" ? "in_port" : "out_port");
+                const std::string s = sel ? sel->str : "A";
+                if (s != "A" && s != "B") throw ConfigError(tn + " node: unknown port selection " + s);
+                g.has_spec = true;
+                g.spec = Gain(1.0f);           // x * 1.0f: the copy_from_slice of mux.rs:54 / demux.rs:51,54
+            } else if (tn != "input" && tn != "output") {
+                g.has_spec = true;
+                g.spec = spec_from_cfg(tn, g.cfg, page_round);
+            }
+            index_[g.id] = nodes_.size();
+            nodes_.push_back(std::move(g));
+        }
+        for (const GNode &n : nodes_) {
+            if (n.typename_ == "input") inputs_.push_back(n.id);
+            if (n.typename_ == "output") outputs_.push_back(n.id);
+        }
+        if (inputs_.size() > 1 || outputs_.size() != 1) throw ConfigError("expected at most one input node and exactly one output node");
+        for (const json::Value &l : doc.at("links").arr) add_link(l);
+        for (const GNode &n : nodes_)
+            for (const auto &kv : n.ctl)
+                if (kv.second.size() > 1) throw ConfigError("slider port " + std::to_string(kv.first) + " of node " + std::to_string(n.id) + " averages several links");
+        toposort();
+    }
+
+    const std::vector<int> &order() const { return order_; }
+    const GNode &node(int id) const { return nodes_[index_.at(id)]; }
+
+    // The graph as dspfx_graph_set takes it (nodes in topological order, links in the order collect_and_average adds
+    // them); false when it cannot be one kernel: more than DSPFX_GRAPH_MAX_NODES nodes, a FIR or Fuzz node.
+    bool fused_plan(std::vector<Node> &specs, std::vector<dspfx_graph_link> &links) const {
+        std::vector<int> ord;
+        for (int id : order_)
+            if (node(id).has_spec) ord.push_back(id);
+        if (ord.size() > DSPFX_GRAPH_MAX_NODES) return false;
+        std::map<int, int> idx;
+        for (std::size_t i = 0; i < ord.size(); ++i) {
+            const dspfx_node_desc &d = node(ord[i]).spec.d;
+            if (d.kind == DSPFX_FIR || (d.kind == DSPFX_DISTORT && d.mode == DSPFX_DIST_FUZZ)) return false;
+            idx[ord[i]] = (int)i;
+        }
+        auto src = [&](int s) {
+            if (s == ZERO) return (int)DSPFX_GRAPH_ZERO;
+            return node(s).typename_ == "input" ? (int)DSPFX_GRAPH_INPUT : idx.at(s);
+        };
+        specs.clear();
+        links.clear();
+        for (int id : ord) {
+            const GNode &n = node(id);
+            specs.push_back(n.spec);
+            for (int s : n.main) links.push_back({src(s), idx.at(id), DSPFX_PORT_MAIN});
+            for (int s : n.side) links.push_back({src(s), idx.at(id), DSPFX_PORT_SIDE});
+            for (const auto &kv : n.ctl)
+                for (int s : kv.second) links.push_back({src(s), idx.at(id), DSPFX_PORT_SLIDER + kv.first});
+        }
+        for (int s : node(outputs_[0]).main) links.push_back({src(s), (int)ord.size(), DSPFX_PORT_MAIN});
+        return true;
+    }
+
+    // Install the graph on an engine (Error with DSPFX_ERR_UNSUPPORTED when it needs cutting: see graph.py).
+    void install(Engine &e) const {
+        std::vector<Node> specs;
+        std::vector<dspfx_graph_link> links;
+        if (!fused_plan(specs, links)) throw Error(DSPFX_ERR_UNSUPPORTED, "this graph does not fit one kernel (segment_plan in graph.py cuts such graphs)");
+        e.set_graph(specs, links);
+    }
+
+  private:
+    struct Row {
+        int kind;
+        std::vector<std::string> fields;
+        std::string main_port;                  // "" = a source without a main port
+        std::vector<std::string> ctl_ports;
+    };
+    // typename -> (kind, saved slider fields in params order, main input port, `as_input` control ports)
+    static const std::map<std::string, Row> &table() {
+        static const std::map<std::string, Row> t = {
+            {"gain", {DSPFX_GAIN, {"level"}, "in", {"level"}}},
+            {"biquad", {DSPFX_BIQUAD, {"a0", "a1", "a2", "b0", "b1", "b2"}, "in", {}}},
+            {"low_pass", {DSPFX_LOW_PASS, {"ratio"}, "in", {}}},
+            {"high_pass", {DSPFX_HIGH_PASS, {"ratio"}, "in", {}}},
+            {"reverb", {DSPFX_REVERB, {"decay"}, "in", {}}},
+            {"distort", {DSPFX_DISTORT, {"level"}, "in", {"level"}}},
+            {"overdrive", {DSPFX_OVERDRIVE, {"boost", "drive", "level"}, "in", {"boost", "drive", "level"}}},
+            {"chebyshev", {DSPFX_CHEBYSHEV, {"level_pos", "level_neg"}, "in", {}}},
+            {"fir", {DSPFX_FIR, {}, "in", {}}},
+            {"add", {DSPFX_ADD, {}, "a", {}}},
+            {"mix", {DSPFX_MIX, {"ratio"}, "a", {"ratio"}}},
+            {"envelope", {DSPFX_ENVELOPE, {"attack", "release"}, "in", {}}},
+            {"signal_gen", {DSPFX_SIGNAL_GEN, {"amplitude", "frequency"}, "", {"amplitude", "frequency"}}},
+        };
+        return t;
+    }
+    static int index_of(const std::vector<std::string> &names, const std::string &what, const char *kind) {
+        const auto it = std::find(names.begin(), names.end(), what);
+        if (it == names.end()) throw ConfigError(std::string("unknown ") + kind + " \"" + what + "\"");
+        return (int)(it - names.begin());
+    }
+    static Node spec_from_cfg(const std::string &tn, const json::Value &cfg, bool page_round) {
+        const auto it = table().find(tn);
+        if (it == table().end()) throw ConfigError("unknown node type \"" + tn + "\"");
+        const Row &row = it->second;
+        Node n = make(row.kind);
+        for (std::size_t k = 0; k < row.fields.size(); ++k) {
+            const json::Value *v = cfg.find(row.fields[k]);
+            if (!v) throw ConfigError(tn + " node lacks saved field \"" + row.fields[k] + "\"");
+            n.d.params[k] = (float)v->num;
+        }
+        if (row.kind == DSPFX_REVERB)     // restoring a reverb runs refresh_seconds (lib.rs:319-337): reverb.rs:58
+            n.d.delay_len = dspfx_delay_len((float)cfg.at("seconds").num, page_round ? 1 : 0);
+        if (row.kind == DSPFX_DISTORT) {
+            const json::Value *m = cfg.find("mode");
+            n.d.mode = index_of({"HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"},
+                                m ? m->str : "SoftClip", "distort mode");
+        }
+        if (row.kind == DSPFX_SIGNAL_GEN) {
+            const json::Value *m = cfg.find("mode");
+            n.d.mode = index_of({"Sine", "Triangle", "Square", "Constant"}, m ? m->str : "Sine", "signal_gen mode");
+        }
+        if (row.kind == DSPFX_FIR) {
+            const json::Value *m = cfg.find("mode");
+            n.d.mode = index_of({"Balanced", "Average"}, m ? m->str : "Balanced", "fir mode");
+            const json::Value *t = cfg.find("taps");          // stored time-reversed (fir.rs:163,168)
+            if (!t) n.taps = {1.0};
+            else
+                for (const json::Value &x : t->arr) n.taps.push_back(x.num);
+            if (n.taps.empty()) throw ConfigError("fir node needs a non-empty taps array");
+        }
+        return n;
+    }
+    GNode &mut(int id) {
+        const auto it = index_.find(id);
+        if (it == index_.end()) throw ConfigError("link refers to a missing node");
+        return nodes_[it->second];
+    }
+    static std::string port_name(const GNode &n, int port_id, const char *which) {
+        const json::Value *m = n.cfg.find(which);
+        if (m)
+            for (const auto &kv : m->obj)
+                if ((int)kv.second.num == port_id) return kv.first;
+        throw ConfigError(std::string("link refers to an unknown port ") + std::to_string(port_id) + " of node " + std::to_string(n.id));
+    }
+    static std::string lower(std::string s) {
+        for (char &c : s) c = (char)std::tolower((unsigned char)c);
+        return s;
+    }
+    static std::string sel(const GNode &n, const char *field) {
+        const json::Value *v = n.cfg.find(field);
+        return lower(v ? v->str : "A");
+    }
+    void add_link(const json::Value &l) {
+        int ln = (int)l.at("lhs").arr.at(0).num;
+        const int lp = (int)l.at("lhs").arr.at(1).num, rn = (int)l.at("rhs").arr.at(0).num, rp = (int)l.at("rhs").arr.at(1).num;
+        if (std::find(dropped_.begin(), dropped_.end(), rn) != dropped_.end()) return;
+        GNode &src = mut(ln);
+        GNode &dst = mut(rn);
+        const std::string oname = port_name(src, lp, "outputs"), pname = port_name(dst, rp, "inputs");
+        if (src.typename_ == "demux" && oname != sel(src, "out_port")) ln = ZERO;   // demux.rs:49-56: the other output stays zeroed
+        else src.outs.emplace_back(rn, pname);
+        if (dst.typename_ == "output") { dst.main.push_back(ln); return; }
+        if (dst.typename_ == "mux") {
+            if (pname == sel(dst, "in_port")) dst.main.push_back(ln);
+            else if (ln != ZERO) src.outs.back().second = "unused";   // mux.rs:47-50: the unselected port is never read
+            return;
+        }
+        if (dst.typename_ == "demux") { dst.main.push_back(ln); return; }
+        const Row &row = table().at(dst.typename_);
+        const auto ctl = std::find(row.ctl_ports.begin(), row.ctl_ports.end(), pname);
+        if (!row.main_port.empty() && pname == row.main_port) dst.main.push_back(ln);
+        else if (pname == "b" && (row.kind == DSPFX_ADD || row.kind == DSPFX_MIX)) dst.side.push_back(ln);
+        else if (ctl != row.ctl_ports.end()) dst.ctl[index_of(row.fields, pname, "slider")].push_back(ln);
+        else throw ConfigError("node " + std::to_string(rn) + " (" + dst.typename_ + ") has no input port \"" + pname + "\"");
+    }
+    std::vector<int> producers(const GNode &n) const {
+        std::vector<int> p;
+        for (int s : n.main) if (s != ZERO) p.push_back(s);
+        for (int s : n.side) if (s != ZERO) p.push_back(s);
+        for (const auto &kv : n.ctl)
+            for (int s : kv.second) if (s != ZERO) p.push_back(s);
+        return p;
+    }
+    void toposort() {
+        std::map<int, int> indeg;
+        std::vector<int> ready;
+        for (const GNode &n : nodes_) {
+            indeg[n.id] = (int)producers(n).size();
+            if (indeg[n.id] == 0) ready.push_back(n.id);          // document order: deterministic
+        }
+        for (std::size_t k = 0; k < ready.size(); ++k) {
+            const int i = ready[k];
+            order_.push_back(i);
+            for (const auto &o : node(i).outs) {
+                if (o.second == "unused") continue;
+                if (--indeg[o.first] == 0) ready.push_back(o.first);
+            }
+        }
+        if (order_.size() != nodes_.size()) throw ConfigError("graph has a cycle");
+    }
+
+    std::vector<GNode> nodes_;
+    std::map<int, std::size_t> index_;
+    std::vector<int> dropped_, inputs_, outputs_, order_;
+};
+
+}  // namespace dspfx
+
+#endif  // DSPFX_GRAPH_HPP
