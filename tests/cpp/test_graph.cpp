@@ -36,6 +36,14 @@ static int ulp(float a, float b) {
 }
 
 int main(int argc, char **argv) {
+    if (argc >= 2 && std::strncmp(argv[1], "--dump-chain", 12) == 0) {   // a chain written the way File > Save would
+        using namespace dspfx;
+        const std::vector<Node> chain = {BiQuad(1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f), LowPass(0.3f), Distort(3.0f, Mode::Tanh),
+                                         ReverbSamples(24000, 0.4f), Mix(0.25f), Overdrive(2.0f, 0.5f, 0.75f), Fir({0.5, 0.25, -0.125}, FirMode::Average),
+                                         Envelope(4.0f, 100.0f), Gain(0.1f)};
+        std::printf("%s\n", dump_dspconfig(chain, std::strcmp(argv[1], "--dump-chain-faithful") == 0).c_str());
+        return 0;
+    }
     if (argc < 3) return 2;
     try {
         using namespace dspfx;

@@ -1,6 +1,7 @@
 """The C++ saved-graph importer (include/dspfx_graph.hpp: JSON parser, port / link resolution, Mux / Demux routing,
 topological order, the plan for dspfx_graph_set) against the Python mirror: same plan for every test graph (no GPU
 needed), and on the GPU box the graphs run from C++ match the committed golden vectors."""
+import json
 import os
 import subprocess
 
@@ -101,3 +102,26 @@ def test_cpp_importer_runs_the_golden_graphs(dspfx, tmp_path):
         assert r.returncode == 0, (name, r.stdout, r.stderr)
         ran += 1
     assert ran >= 8
+
+
+def test_cpp_exporter_writes_what_the_importers_read(dspfx, tmp_path):
+    """dump_dspconfig in C++ (a chain written the way File > Save would): the Python importer reads back the chain, the C++
+    importer plans it, and the LowPass cfg_name quirk (saved as "high_pass") is reproduced on request."""
+    from dsp_stuff_amd import config
+    E = dspfx
+    _build()
+    r = subprocess.run([EXE, "--dump-chain"], capture_output=True, text=True)
+    assert r.returncode == 0
+    chain, info = config.load_dspconfig(r.stdout)
+    want = [E.BiQuad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025), E.LowPass(0.3), E.Distort(3.0, E.TANH), E.Reverb(delay_samples=24000, decay=0.4),
+            E.Mix(0.25), E.Overdrive(2.0, 0.5, 0.75), E.Fir([0.5, 0.25, -0.125], E.FIR_AVERAGE), E.Envelope(4.0, 100.0), E.Gain(0.1)]
+    assert len(chain) == len(want) and info["side_from_input"]
+    for a, b in zip(chain, want):
+        assert (a.kind, a.mode, a.delay_len) == (b.kind, b.mode, b.delay_len)
+        assert [np.float32(v) for v in a.params] == [np.float32(v) for v in b.params]
+        if b.taps_reversed is not None:
+            assert np.array_equal(np.asarray(a.taps_reversed, np.float64), np.asarray(b.taps_reversed, np.float64))
+    faithful = subprocess.run([EXE, "--dump-chain-faithful"], capture_output=True, text=True).stdout
+    chain2, _ = config.load_dspconfig(faithful)
+    assert chain2[1].kind == E.HIGH_PASS                                  # low_pass.rs:9: a saved LowPass restores as a HighPass
+    assert json.loads(r.stdout)["nodes"][2]["typename"] == "low_pass" and json.loads(faithful)["nodes"][2]["typename"] == "high_pass"
