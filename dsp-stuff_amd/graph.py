@@ -244,13 +244,17 @@ def _unfusable(sp) -> bool:
 
 def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
     """A graph too large for one kernel, or with FIR / Fuzz nodes (kernels of their own), as a SERIES of engines:
-    [("graph", specs, links), ("node", spec), ("graph", ...), ...].  Two kinds of boundary:
+    [("graph", specs, links, in_ref, in2_ref), ("node", spec, in_ref), ("graph", ...), ...] -- a ref is the index of the
+    step whose output block is read, -1 = the graph's Input block.  Two kinds of boundary:
 
       * in front of a FIR / Fuzz node that all the live signal goes into -- an amp chain into a cabinet impulse
         response into a reverb: the segment's Output is that node's averaged main port, the node follows, the next
         segment's Input is the node's output;
-      * where a segment would exceed `max_nodes`, at a point of the evaluation order that ONE signal crosses: the
+      * where a segment would exceed `max_nodes`, at a point of the evaluation order that ONE new signal crosses: the
         segment's Output link hands that signal over as it is (PORT_RAW), the next segment's Input is that buffer.
+
+    At either boundary one OLDER signal -- the current segment's own Input or second block, e.g. the dry signal of a
+    wet / dry rig -- may stay alive beside the new one: the next segment reads it as its second block (GRAPH_INPUT2).
 
     A FIR / Fuzz node fed by ONE signal that also goes on beside it (the dry path around a cabinet) is allowed: the
     segment hands that signal over as it is, the node ("node_hop" step) applies the hop itself, and the following
@@ -295,7 +299,9 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
         return [v for v in values if any(u >= p for u in users.get(v, []))]
 
     steps = []
-    start, cur_in, cur_in2 = 0, in_id, None            # cur_in2: a signal carried around the previous FIR / Fuzz node
+    start = 0
+    cur_in, ref_in = in_id, -1                         # the signal the current segment reads as its Input, and whose buffer it is
+    cur_in2, ref_in2 = None, None                      # a second, older signal still alive (GRAPH_INPUT2)
 
     def emit(lo, hi, sink_links, raw):
         seg = order[lo:hi]
@@ -318,7 +324,11 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
             for kk, srcs in sorted(n.ctl.items()):
                 links += [(src(sv), idx[nid], PORT_SLIDER + kk) for sv in srcs]
         links += [(src(sv), len(seg), PORT_MAIN | (PORT_RAW if raw else 0)) for sv in sink_links]
-        steps.append(("graph", [g.nodes[nid].spec for nid in seg], links))
+        steps.append(("graph", [g.nodes[nid].spec for nid in seg], links, ref_in, ref_in2))
+        return len(steps) - 1
+
+    def ref_of(sv):
+        return ref_in if sv == cur_in else ref_in2
 
     try:
         i = start
@@ -326,18 +336,21 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
             at_end = i == len(order)
             cut_node = (not at_end) and _unfusable(g.nodes[order[i]].spec)
             if at_end or cut_node:
-                # the stretch [start, i) must fit: cut it at single-signal crossings while it does not
+                # the stretch [start, i) must fit: cut it where ONE new signal crosses (an older one may go on beside it)
                 while i - start > max_nodes:
                     best = None
                     for p in range(start + 1, min(start + max_nodes, i - 1) + 1):
                         live = live_after([cur_in, cur_in2] + order[start:p], p)
-                        if len(live) == 1 and live[0] not in (cur_in, cur_in2):
-                            best = (p, live[0])
+                        olds = [v for v in live if v in (cur_in, cur_in2)]
+                        news = [v for v in live if v not in olds]
+                        if len(news) == 1 and len(olds) <= 1:
+                            best = (p, news[0], olds)
                     if best is None:
                         return None
-                    emit(start, best[0], [best[1]], True)
-                    start, cur_in = best
-                    cur_in2 = None
+                    p, v, olds = best
+                    k = emit(start, p, [v], True)
+                    cur_in2, ref_in2 = (olds[0], ref_of(olds[0])) if olds else (None, None)
+                    start, cur_in, ref_in = p, v, k
                 if at_end:
                     emit(start, i, g.nodes[out_id].main, False)
                     break
@@ -345,21 +358,23 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
                 if u.ctl or u.side:
                     return None
                 live = live_after([cur_in, cur_in2] + order[start:i], i)
-                if all(v in u.main and not any(x > i for x in users.get(v, [])) for v in live):
-                    # everything alive here is read by this node's main port and by nothing later
-                    emit(start, i, u.main, False)
-                    steps.append(("node", u.spec))
-                    cur_in2 = None
+                carried = [v for v in live if v in (cur_in, cur_in2) and v not in u.main]   # older signals going around the node
+                rest = [v for v in live if v not in carried]
+                if len(carried) <= 1 and all(v in u.main and not any(x > i for x in users.get(v, [])) for v in rest):
+                    # everything else alive here is read by this node's main port and by nothing later
+                    keep = (carried[0], ref_of(carried[0])) if carried else (None, None)
+                    k = emit(start, i, u.main, False)
+                    steps.append(("node", u.spec, k))
+                    cur_in2, ref_in2 = keep
                 elif len(live) == 1 and u.main == live and (live[0] in order[start:i] or (live[0] == cur_in and start == i)):
                     # one signal feeds the node AND goes on beside it (the dry path around a cabinet): hand it over as it
                     # is, the node applies its own hop, the next segment reads the node as Input and the signal as Input 2
-                    if start < i:
-                        emit(start, i, live, True)
-                    steps.append(("node_hop", u.spec))
-                    cur_in2 = live[0]
+                    k = emit(start, i, live, True) if start < i else ref_in
+                    steps.append(("node_hop", u.spec, k))
+                    cur_in2, ref_in2 = live[0], k
                 else:
                     return None
-                start, cur_in = i + 1, order[i]
+                start, cur_in, ref_in = i + 1, order[i], len(steps) - 1
             i += 1
     except KeyError:
         return None                                    # a link from before the previous boundary: no series form
@@ -374,11 +389,11 @@ def series_plan(g: Graph):
 class GraphEngine:
     """N independent copies of a saved graph.  `process(x)` takes the Input node's block [n_frames][N] (device
     tensor, the engine's layout) and returns the Output node's block.
-    fused: None = one generated kernel for the whole graph when it can be had, else run by run; True = insist on
-    the one kernel; False = always run by run."""
+    fused: None = one generated kernel for the whole graph when it can be had, else a series of them (segment_plan),
+    else run by run; True = insist on the one kernel; False = always run by run."""
 
     def __init__(self, text: str, channels: int, max_frames: int = 128, device: int = 0, tile_channels: int = 0,
-                 page_round: bool = False, fused: Optional[bool] = None):
+                 page_round: bool = False, fused: Optional[bool] = None, max_nodes: Optional[int] = None):
         import torch
         self.torch = torch
         self.g = Graph(text, page_round)
@@ -389,7 +404,8 @@ class GraphEngine:
         self.runs, self.run_of = [], {}
         self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
         self.final = self._buf()
-        plan = fused_plan(self.g) if fused is not False else None
+        # max_nodes (tests): cut the graph as if a kernel held only that many nodes
+        plan = fused_plan(self.g) if fused is not False and max_nodes is None else None
         if plan is not None:
             eng = Engine(channels, max_frames, device=device, tile_channels=tile_channels)
             try:
@@ -406,7 +422,7 @@ class GraphEngine:
             return
         # FIR / Fuzz nodes in series with fusable sub-graphs: one generated kernel per segment
         self.series = []                   # [(engine, out buffer)]
-        steps = series_plan(self.g) if fused is None else None
+        steps = (segment_plan(self.g, max_nodes) if max_nodes is not None else series_plan(self.g)) if fused is None else None
         if steps is not None:
             try:
                 for kind, *what in steps:
@@ -414,11 +430,13 @@ class GraphEngine:
                     eng = Engine(channels, max_frames, link_flags=LINK_INPUT if kind == "node_hop" else 0, device=device,
                                  tile_channels=tile_channels)
                     self.series.append((eng, self._buf()))
-                    self.series_kind.append((kind, kind == "graph" and any(l[0] == GRAPH_INPUT2 for l in what[1])))
                     if kind == "graph":
-                        eng.set_graph(*what)
+                        specs, links, in_ref, in2_ref = what
+                        self.series_kind.append((kind, in_ref, in2_ref if any(l[0] == GRAPH_INPUT2 for l in links) else None))
+                        eng.set_graph(specs, links)
                     else:
-                        eng.set_chain(what)
+                        self.series_kind.append((kind, what[1], None))
+                        eng.set_chain([what[0]])
             except DspfxError as e:
                 for eng, _ in self.series:
                     eng.close()
@@ -472,14 +490,14 @@ class GraphEngine:
             self.fused.process(self.zeros if x is None else x, out=self.final, n_frames=nf, stream=stream)
             return self.final
         if self.series:
-            buf = self.zeros if x is None else x
-            beside = None                      # what went into the last FIR / Fuzz node: the signal carried around it
-            for (eng, out), (kind, reads2) in zip(self.series, self.series_kind):
-                eng.process(buf, out=out, side=beside if reads2 else None, n_frames=nf, stream=stream)
-                if kind != "graph":
-                    beside = buf
-                buf = out
-            return buf
+            x0 = self.zeros if x is None else x
+
+            def block(ref):
+                return x0 if ref == -1 else self.series[ref][1]
+
+            for (eng, out), (kind, in_ref, in2_ref) in zip(self.series, self.series_kind):
+                eng.process(block(in_ref), out=out, side=None if in2_ref is None else block(in2_ref), n_frames=nf, stream=stream)
+            return self.series[-1][1]
         for nid in self.g.order:
             n = self.g.nodes[nid]
             if n.spec is None:

@@ -166,11 +166,12 @@ def cab_rig(taps=64, bypass=False, cut="fir", dry=False):
     return build(nodes, links)
 
 
-def long_rig(seed, n_blocks=10, fir_at=None):
+def long_rig(seed, n_blocks=10, fir_at=None, dry_mix=False):
     """A pedalboard longer than one kernel holds: `n_blocks` stages in series, each a small sub-graph with one way in and
     one way out (a few effects in a row; two parallel branches into an Add or Mix; an effect whose slider is driven by an
     LFO; two branches averaged on one port).  One signal crosses between stages, so the graph can be cut there.
-    fir_at=k puts a short FIR node after stage k."""
+    fir_at=k puts a short FIR node after stage k; dry_mix=True ends in a Mix of the rig's output with the graph's Input
+    (wet / dry over the whole rig: the Input stays alive beside every stage)."""
     import math
     import random
     rnd = random.Random(seed)
@@ -219,6 +220,10 @@ def long_rig(seed, n_blocks=10, fir_at=None):
             f = add("fir", {"taps": h[::-1], "mode": "Balanced"})
             links.append((s, f, "in"))
             s = f
+    if dry_mix:
+        m = add("mix", {"ratio": 0.35})
+        links += [(s, m, "a"), (0, m, "b")]
+        s = m
     nodes.append((999, "output", {}))
     links.append((s, 999, "in"))
     return build(nodes, links)

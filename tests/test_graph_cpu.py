@@ -174,6 +174,7 @@ def test_series_plan_cuts_at_the_nodes_all_signal_passes(dspfx):
     steps = G.series_plan(g)
     assert [s[0] for s in steps] == ["graph", "node", "graph"]
     specs, links = steps[0][1], steps[0][2]
+    assert steps[0][3:] == (-1, None) and steps[1][2] == 0 and steps[2][3:] == (1, None)   # whose block each step reads
     assert [s.kind for s in specs] == [E.GAIN, E.DISTORT, E.BIQUAD, E.ADD]
     assert links[-2:] == [(3, 4, E.PORT_MAIN), (1, 4, E.PORT_MAIN)]  # the FIR node's two incoming links = the segment's Output
     assert steps[1][1].kind == E.FIR
@@ -186,6 +187,17 @@ def test_series_plan_cuts_at_the_nodes_all_signal_passes(dspfx):
     assert [s[0] for s in steps] == ["graph", "node_hop", "graph"]
     assert steps[0][2][-1] == (3, 4, E.PORT_MAIN | E.PORT_RAW)          # the Add's output handed over as it is
     assert (E.GRAPH_INPUT2, 1, E.PORT_SIDE) in steps[2][2]              # ... and read as the Mix's "b" port after the FIR node
+    assert steps[1][2] == 0 and steps[2][3:] == (1, 0)                  # the FIR reads step 0; the last kernel steps 1 and 0
+    # wet / dry over a whole long rig: the graph's Input block stays alive beside every stage, as each kernel's second block
+    for seed in range(6):
+        g = G.Graph(graphs.long_rig(seed, 12, fir_at=5 if seed % 2 else None, dry_mix=True))
+        steps = G.series_plan(g)
+        assert steps is not None and len(steps) >= 2, seed
+        last = steps[-1]
+        assert last[0] == "graph" and last[4] == -1 and any(l[0] == E.GRAPH_INPUT2 for l in last[2])
+        for st in steps[1:]:
+            if st[0] == "graph":
+                assert st[4] == -1                                       # carried from the very first block
     assert G.series_plan(G.Graph(graphs.diamond())) is None              # nothing to cut at
 
 
@@ -201,17 +213,20 @@ def test_segment_plan_cuts_long_graphs_where_one_signal_crosses(dspfx, tmp_path)
         for k, (kind, *what) in enumerate(steps):
             if kind != "graph":
                 continue
-            specs, links = what
+            specs, links = what[:2]
             assert len(specs) <= E.GRAPH_MAX_NODES and all(s < d for s, d, _ in links)
             raw_out = [l for l in links if l[2] & E.PORT_RAW]
             hands_over = k + 1 < len(steps) and steps[k + 1][0] == "graph"               # next is a kernel, not a FIR node
             assert len(raw_out) == (1 if hands_over else 0) and all(l[1] == len(specs) for l in raw_out)
     # the RAW handover in generated code: a copy, not an average
     g = G.Graph(graphs.long_rig(0, 12))
-    specs, links = G.series_plan(g)[0][1:]
+    specs, links = G.series_plan(g)[0][1:3]
     src = _compile_generated(E, specs, links, tmp_path, "handover")
     assert "g_copy<F, CPL>(y, v%d)" % (len(specs) - 1) in src
-    assert G.segment_plan(G.Graph(graphs.diamond()), max_nodes=3) is None     # no point that a single signal crosses
+    # a kernel of at most 3 nodes: the diamond is cut twice, each time with an older signal carried beside the new one
+    steps = G.segment_plan(G.Graph(graphs.diamond()), max_nodes=3)
+    assert [(s[0], len(s[1]), s[3], s[4]) for s in steps] == [("graph", 1, -1, None), ("graph", 2, 0, -1), ("graph", 3, 1, 0)]
+    assert G.segment_plan(G.Graph(graphs.random_dag(3, 12)), max_nodes=4) is None    # wide fan-in everywhere: nothing to cut at
 
 
 def _graph_goldens():

@@ -244,7 +244,7 @@ def test_graph_with_a_fir_node_in_series(dspfx, G, N, tile):
     # hop, the kernel after it reads the FIR output as Input and the dry signal as its second block
     a = G.GraphEngine(graphs.cab_rig(dry=True), N, B, tile_channels=tile)
     b = G.GraphEngine(graphs.cab_rig(dry=True), N, B, tile_channels=tile, fused=False)
-    assert [k for k, _ in a.series_kind] == ["graph", "node_hop", "graph"] and a.series_kind[2][1], a.series_kind
+    assert a.series_kind == [("graph", -1, None), ("node_hop", 0, None), ("graph", 1, 0)], a.series_kind
     got = np.empty_like(x)
     for f0 in range(0, nf, B):
         dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + B], tile)).cuda()
@@ -327,6 +327,64 @@ def test_graph_golden_vectors(dspfx, G):
             assert ulp_diff(got[:, :3], y).max() <= 1, name
         ge.close()
     assert forms == {"one", "segments"}, forms
+
+
+@pytest.mark.parametrize("max_nodes", [2, 3, 5])
+def test_cutting_into_small_kernels_changes_nothing(dspfx, G, max_nodes):
+    """The series planner under stress: pretend a kernel holds only 2 / 3 / 5 nodes, so that graphs which are normally one
+    kernel get cut wherever one new signal crosses (with an older one carried beside it as the second block).  Whatever
+    can be cut must give the one-kernel result bit for bit."""
+    import torch
+    N, B = 256, 128
+    cut = 0
+    docs = [graph_text(n) for n in NAMES] + [graphs.long_rig(s, 4, dry_mix=bool(s % 2)) for s in range(8)] + \
+           [graphs.random_dag(s, 8) for s in range(8)]
+    for k, text in enumerate(docs):
+        steps = G.segment_plan(G.Graph(text), max_nodes)
+        if steps is None or len(steps) < 2:
+            continue
+        cut += 1
+        a = G.GraphEngine(text, N, B, max_nodes=max_nodes)
+        b = G.GraphEngine(text, N, B, fused=True)
+        assert len(a.series) >= 2, (k, a.describe())
+        x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+        for blk in range(4):
+            b.util.fill_noise(x, B, blk * B, 0x5EED000E + k)
+            ya = a.process(x, B).clone()
+            yb = b.process(x, B)
+            torch.cuda.synchronize()
+            assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), (k, max_nodes, blk, a.series_kind)
+        a.close()
+        b.close()
+    assert cut >= 6, cut
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_wet_dry_over_a_long_rig(dspfx, G, seed):
+    """The graph's Input mixed back in after 25-32 nodes (and a FIR node on odd seeds): the Input block stays alive
+    beside every kernel of the series as its second block."""
+    import torch
+    N, B, nf = 128, 128, 512
+    text = graphs.long_rig(seed, 12, fir_at=5 if seed % 2 else None, dry_mix=True)
+    a = G.GraphEngine(text, N, B)
+    b = G.GraphEngine(text, N, B, fused=False)
+    assert len(a.series) >= 2 and a.series_kind[-1][2] == -1, a.series_kind
+    x = O.noise(0x5EED000F + seed, np.arange(N), np.arange(nf))
+    got = np.empty_like(x)
+    for f0 in range(0, nf, B):
+        dx = torch.from_numpy(x[f0:f0 + B].copy()).cuda()
+        ya = a.process(dx, B).clone()
+        yb = b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), (seed, f0)
+        got[f0:f0 + B] = ya.cpu().numpy().reshape(B, N)
+    ref = graph_eval.run_graph(a.g, x[:, :8])
+    if seed % 2:
+        assert np.abs(got[:, :8] - ref).max() <= 1e-5 * np.abs(ref).max()
+    else:
+        assert ulp_diff(got[:, :8], ref).max() <= 1, seed
+    a.close()
+    b.close()
 
 
 def test_graph_set_rejections(dspfx):

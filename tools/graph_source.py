@@ -28,6 +28,6 @@ else:
         for k, (kind, *what) in enumerate(steps):
             if kind == "graph":
                 print("// segment %d: graph kernel, %d nodes" % (k, len(what[0])))
-                print(E.graph_source(*what))
+                print(E.graph_source(*what[:2]))
             else:
                 print("// segment %d: %s node (its own kernel)\n" % (k, "FIR" if what[0].kind == E.FIR else "Fuzz"))
