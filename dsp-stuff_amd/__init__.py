@@ -13,6 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from dataclasses import dataclass, field
 from typing import Optional, Sequence, Tuple
 
@@ -88,6 +89,15 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}` "
                           "(or __graft_entry__.build()); there is no fallback implementation")
+    # One HIP runtime per process: PyTorch ships its own copy of the ROCm libraries, and a process that maps the system's
+    # libamdhip64 (through libdspfx.so) BEFORE importing torch ends up with two runtimes, of which only the first to
+    # initialise sees the GPU (measured: tools/probe_import_order.py -- either torch or this library reports no device).
+    # Importing torch first makes libdspfx.so bind to the copy torch loaded.  Hosts without torch just use the system's.
+    if "torch" not in sys.modules:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     L = C.CDLL(LIB_PATH)
     vp, f32p = C.c_void_p, C.c_void_p
     L.dspfx_abi_version.restype = C.c_uint32

@@ -256,6 +256,9 @@ class SavedGraph {
         enum Kind { GraphKernel, NodeAveraged, NodeHop } kind = GraphKernel;
         std::vector<Node> specs;                 // GraphKernel: the segment's nodes; otherwise the one FIR / Fuzz node
         std::vector<dspfx_graph_link> links;     // GraphKernel only
+        int in_ref = -1;                         // whose output block this step reads: a step index, -1 = the graph's Input block
+        int in2_ref = NO_REF;                    // GraphKernel: the block read as DSPFX_GRAPH_INPUT2 (`side`), when it reads one
+        static constexpr int NO_REF = -2;
         bool reads_second_block() const {
             for (const dspfx_graph_link &l : links)
                 if (l.src == DSPFX_GRAPH_INPUT2) return true;
@@ -270,7 +273,9 @@ class SavedGraph {
     //   * the same with ONE signal that also goes on beside the node (wet / dry): the segment hands it over RAW, the node's
     //     engine applies the hop (NodeHop: link_flags = DSPFX_LINK_INPUT) and the next segment reads the node as Input
     //     and that signal as DSPFX_GRAPH_INPUT2 (`side`);
-    //   * where a stretch exceeds max_nodes, at a point that a single signal crosses (RAW handover).
+    //   * where a stretch exceeds max_nodes, at a point that a single NEW signal crosses (RAW handover).
+    // At any boundary one OLDER signal (the segment's own Input or second block: the dry signal of a wet / dry rig) may stay
+    // alive beside the new one; the next segment reads it as DSPFX_GRAPH_INPUT2.
     // false when no such cutting exists (the graph is then evaluated run by run: graph.py shows how).
     bool segment_plan(std::vector<Step> &steps, int max_nodes = DSPFX_GRAPH_MAX_NODES) const {
         steps.clear();
@@ -313,7 +318,7 @@ class SavedGraph {
                 if (u >= p) return true;
             return false;
         };
-        int start = 0, cur_in = in_id, cur_in2 = NONE;
+        int start = 0, cur_in = in_id, cur_in2 = NONE, ref_in = -1, ref_in2 = Step::NO_REF;
         auto live_after = [&](int hi, int p) {          // of {cur_in, cur_in2} + order[start:hi]: still read at p or later
             std::vector<int> live;
             if (cur_in != NONE && read_at_or_after(cur_in, p)) live.push_back(cur_in);
@@ -323,7 +328,7 @@ class SavedGraph {
             return live;
         };
         bool ok = true;
-        auto emit = [&](int lo, int hi, const std::vector<int> &sink, bool raw) {
+        auto emit = [&](int lo, int hi, const std::vector<int> &sink, bool raw) -> int {
             Step st;
             std::map<int, int> idx;
             for (int k = lo; k < hi; ++k) idx[order[(std::size_t)k]] = k - lo;
@@ -344,24 +349,33 @@ class SavedGraph {
                     for (int sv : kv.second) st.links.push_back({src(sv), k - lo, DSPFX_PORT_SLIDER + kv.first});
             }
             for (int sv : sink) st.links.push_back({src(sv), hi - lo, DSPFX_PORT_MAIN | (raw ? DSPFX_PORT_RAW : 0)});
+            st.in_ref = ref_in;
+            st.in2_ref = st.reads_second_block() ? ref_in2 : Step::NO_REF;
             steps.push_back(std::move(st));
+            return (int)steps.size() - 1;
         };
+        auto ref_of = [&](int sv) { return sv == cur_in ? ref_in : ref_in2; };
+        auto is_old = [&](int v) { return v == cur_in || v == cur_in2; };
         const int n = (int)order.size();
         for (int i = 0; i <= n && ok; ++i) {
             const bool at_end = i == n;
             const bool cut_node = !at_end && unfusable(node(order[(std::size_t)i]).spec);
             if (!at_end && !cut_node) continue;
-            while (i - start > max_nodes) {            // cut the stretch at single-signal crossings while it does not fit
-                int best_p = -1, best_v = NONE;
+            while (i - start > max_nodes) {            // cut the stretch where ONE new signal crosses while it does not fit
+                int best_p = -1, best_v = NONE, best_old = NONE;
                 for (int p = start + 1; p <= std::min(start + max_nodes, i - 1); ++p) {
-                    const std::vector<int> live = live_after(p, p);
-                    if (live.size() == 1 && live[0] != cur_in && live[0] != cur_in2) { best_p = p; best_v = live[0]; }
+                    std::vector<int> olds, news;
+                    for (int v : live_after(p, p)) (is_old(v) ? olds : news).push_back(v);
+                    if (news.size() == 1 && olds.size() <= 1) { best_p = p; best_v = news[0]; best_old = olds.empty() ? NONE : olds[0]; }
                 }
                 if (best_p < 0) return false;
-                emit(start, best_p, {best_v}, true);
+                const int old_ref = best_old == NONE ? Step::NO_REF : ref_of(best_old);
+                const int k = emit(start, best_p, {best_v}, true);
+                cur_in2 = best_old;
+                ref_in2 = old_ref;
                 start = best_p;
                 cur_in = best_v;
-                cur_in2 = NONE;
+                ref_in = k;
             }
             if (at_end) {
                 emit(start, i, node(out_id).main, false);
@@ -370,26 +384,32 @@ class SavedGraph {
             const GNode &u = node(order[(std::size_t)i]);
             if (!u.ctl.empty() || !u.side.empty()) return false;
             const std::vector<int> live = live_after(i, i);
-            bool all_into_u = true;
-            for (int v : live)
-                all_into_u = all_into_u && std::find(u.main.begin(), u.main.end(), v) != u.main.end() && !read_at_or_after(v, i + 1);
+            auto in_main = [&](int v) { return std::find(u.main.begin(), u.main.end(), v) != u.main.end(); };
+            std::vector<int> carried, rest;            // carried: older signals going around the node
+            for (int v : live) ((is_old(v) && !in_main(v)) ? carried : rest).push_back(v);
+            bool all_into_u = carried.size() <= 1;
+            for (int v : rest) all_into_u = all_into_u && in_main(v) && !read_at_or_after(v, i + 1);
             Step nd;
             nd.specs = {u.spec};
             if (all_into_u) {
-                emit(start, i, u.main, false);
+                const int keep = carried.empty() ? NONE : carried[0], keep_ref = carried.empty() ? Step::NO_REF : ref_of(carried[0]);
+                nd.in_ref = emit(start, i, u.main, false);
                 nd.kind = Step::NodeAveraged;
-                cur_in2 = NONE;
+                cur_in2 = keep;
+                ref_in2 = keep_ref;
             } else if (live.size() == 1 && u.main == live &&
                        ((pos.count(live[0]) && pos[live[0]] >= start && pos[live[0]] < i && live[0] != out_id) || (live[0] == cur_in && start == i))) {
-                if (start < i) emit(start, i, live, true);
+                nd.in_ref = start < i ? emit(start, i, live, true) : ref_in;
                 nd.kind = Step::NodeHop;
                 cur_in2 = live[0];
+                ref_in2 = nd.in_ref;
             } else {
                 return false;
             }
             steps.push_back(std::move(nd));
             start = i + 1;
             cur_in = order[(std::size_t)i];
+            ref_in = (int)steps.size() - 1;
         }
         return ok;
     }

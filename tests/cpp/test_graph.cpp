@@ -57,7 +57,8 @@ int main(int argc, char **argv) {
             if (!one && !series) { std::printf("run by run\n"); return 0; }
             if (!one) {
                 for (const SavedGraph::Step &st : steps) {
-                    std::printf("step %s\n", st.kind == SavedGraph::Step::GraphKernel ? "graph" : st.kind == SavedGraph::Step::NodeHop ? "node_hop" : "node");
+                    std::printf("step %s %d %d\n", st.kind == SavedGraph::Step::GraphKernel ? "graph" : st.kind == SavedGraph::Step::NodeHop ? "node_hop" : "node",
+                                st.in_ref, st.in2_ref);
                     for (const Node &n : st.specs) std::printf("node %d %d %a %u %zu\n", n.d.kind, n.d.mode, n.d.params[0], n.d.delay_len, n.taps.size());
                     for (const dspfx_graph_link &l : st.links) std::printf("link %d %d %d\n", l.src, l.dst, l.port);
                 }
@@ -75,7 +76,7 @@ int main(int argc, char **argv) {
         // one engine, or the series segment_plan made: every step's block goes through host buffers here (a host that
         // keeps its blocks on the device chains dspfx_process calls instead, as dsp-stuff_amd/graph.py does)
         std::vector<Engine> engines;
-        std::vector<bool> reads2, is_node;
+        std::vector<bool> reads2, is_node;   // (kept for the printout below)
         if (one) {
             engines.emplace_back(N, BUF_SIZE, 0);
             g.install(engines.back());
@@ -90,17 +91,18 @@ int main(int argc, char **argv) {
                 is_node.push_back(st.kind != SavedGraph::Step::GraphKernel);
             }
         }
-        std::vector<std::vector<float>> bufs(engines.size() + 1, std::vector<float>(BUF_SIZE * N));
+        std::vector<int> in_ref, in2_ref;
+        if (one) { in_ref = {-1}; in2_ref = {SavedGraph::Step::NO_REF}; }
+        for (const SavedGraph::Step &st : steps) { in_ref.push_back(st.in_ref); in2_ref.push_back(st.in2_ref); }
+        std::vector<std::vector<float>> bufs(engines.size() + 1, std::vector<float>(BUF_SIZE * N));   // [0] = the Input block, [k+1] = step k's output
         int worst = 0;
         double max_abs = 0, max_err = 0;
         for (uint32_t f0 = 0; f0 + BUF_SIZE <= frames; f0 += BUF_SIZE) {
             for (uint32_t f = 0; f < BUF_SIZE; ++f)
                 for (uint32_t c = 0; c < N; ++c) bufs[0][f * N + c] = x[(f0 + f) * C + c % C];
-            const float *beside = nullptr;
-            for (std::size_t k = 0; k < engines.size(); ++k) {
-                engines[k].process_host(bufs[k].data(), bufs[k + 1].data(), BUF_SIZE, reads2[k] ? beside : nullptr);
-                if (is_node[k]) beside = bufs[k].data();
-            }
+            for (std::size_t k = 0; k < engines.size(); ++k)
+                engines[k].process_host(bufs[(std::size_t)(in_ref[k] + 1)].data(), bufs[k + 1].data(), BUF_SIZE,
+                                        in2_ref[k] == SavedGraph::Step::NO_REF ? nullptr : bufs[(std::size_t)(in2_ref[k] + 1)].data());
             const std::vector<float> &yb = bufs.back();
             for (uint32_t f = 0; f < BUF_SIZE; ++f)
                 for (uint32_t c = 0; c < N; ++c) {

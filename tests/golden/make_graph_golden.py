@@ -19,6 +19,7 @@ CASES = {
     "diamond": graphs.diamond(), "lfo_tremolo": graphs.lfo_tremolo(), "fan_in_three": graphs.fan_in_three(),
     "routing_ba": graphs.routing("B", "A"), "cab_rig": graphs.cab_rig(), "cab_rig_wet_dry": graphs.cab_rig(dry=True),
     "long_rig_0": graphs.long_rig(0, 12), "long_rig_1_fir": graphs.long_rig(1, 12, fir_at=5),
+    "long_rig_2_wet_dry": graphs.long_rig(2, 12, dry_mix=True), "long_rig_3_fir_wet_dry": graphs.long_rig(3, 12, fir_at=5, dry_mix=True),
 }
 for name, text in CASES.items():
     x = O.noise(0x5EED00AA, np.arange(3), np.arange(512))

@@ -52,13 +52,17 @@ def test_cpp_importer_plans_what_the_python_mirror_plans(dspfx, tmp_path):
         for (k, m, p, d), (wk, wm, wp, wd) in zip(got_nodes, want):
             assert (k, m, d) == (wk, wm, wd) and p[:len(wp)] == wp, (k, m, p, d, wk, wm, wp, wd)
     # graphs that need cutting: the same series of engines as graph.py's segment_plan
+    E = dspfx
     series = [graphs.cab_rig(), graphs.cab_rig(dry=True), graphs.cab_rig(cut="fuzz")] + \
-             [graphs.long_rig(s, 12, fir_at=5 if s % 2 else None) for s in range(10)]
+             [graphs.long_rig(s, 12, fir_at=5 if s % 2 else None, dry_mix=s >= 5) for s in range(10)]
     for text in series:
         steps = G.series_plan(G.Graph(text))
         want = []
         for kind, *what in steps:
-            want.append("step " + kind)
+            in_ref, in2_ref = (what[2], what[3]) if kind == "graph" else (what[1], None)
+            if kind == "graph" and not any(l[0] == E.GRAPH_INPUT2 for l in what[1]):
+                in2_ref = None
+            want.append("step %s %d %d" % (kind, in_ref, -2 if in2_ref is None else in2_ref))
             specs = what[0] if kind == "graph" else [what[0]]
             for sp in specs:
                 p0 = float(np.float32(sp.params[0])) if sp.params else None
