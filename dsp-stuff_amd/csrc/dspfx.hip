@@ -295,9 +295,12 @@ struct JitKernel {
     int vgprs = 0;          // registers per lane the compiler allocated (occupancy: 512 / vgprs waves per SIMD)
 };
 std::mutex g_jit_mu;
-std::map<std::string, JitKernel *> g_jit;     // key -> kernel (nullptr = tried and failed)
+std::map<std::string, JitKernel *> g_jit;     // key -> kernel
 
+// Where chain_kernels.hip.h / graph_kernel.hip.h are: next to the library, or DSPFX_KERNEL_HEADERS when they are installed
+// elsewhere (read per compile).
 std::string csrc_dir() {
+    if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
     Dl_info info;
     if (!dladdr((const void *)&dspfx_abi_version, &info) || !info.dli_fname) return "";
     std::string p(info.dli_fname);
@@ -306,7 +309,7 @@ std::string csrc_dir() {
 }
 
 // Compile `src` (which includes headers from this library's directory), load it on the current device and look up the
-// kernel named by `expr`.  Cached per `key` for the life of the process, failures included.
+// kernel named by `expr`.  Cached per `key` for the life of the process.
 const JitKernel *jit_compile(const std::string &key, const std::string &src, const std::string &expr, const int (&sigs)[MAX_SLOTS],
                              int n_slots, int f, int cpl, bool mod) {
     std::lock_guard<std::mutex> lk(g_jit_mu);
@@ -352,7 +355,7 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
         }
         (void)hiprtcDestroyProgram(&prog);
     }
-    g_jit[key] = res;
+    if (res) g_jit[key] = res;   // failures are not remembered: a missing header directory can be put right while the process lives
     return res;
 }
 

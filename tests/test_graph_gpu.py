@@ -387,6 +387,41 @@ def test_wet_dry_over_a_long_rig(dspfx, G, seed):
     b.close()
 
 
+def test_without_the_kernel_headers_everything_still_runs(dspfx, G, monkeypatch, tmp_path):
+    """The run-time compiler needs the kernel headers next to the library (or in DSPFX_KERNEL_HEADERS).  Without them
+    dspfx_graph_set reports DSPFX_ERR_UNSUPPORTED and the graph is evaluated run by run on the interpreter kernels --
+    same bits as with them."""
+    import torch
+    E = dspfx
+    N, B = 256, 128
+    text = graphs.fan_in_three()          # a wiring no other test compiled with these settings? (the cache is per source text)
+    good = G.GraphEngine(text, N, B)
+    assert good.fused is not None
+    monkeypatch.setenv("DSPFX_KERNEL_HEADERS", str(tmp_path))           # an empty directory
+    monkeypatch.setenv("DSPFX_JIT", "1")
+    eng = E.Engine(N, B)
+    specs, links = G.fused_plan(G.Graph(graphs.random_dag(4242, 7)))
+    with pytest.raises(E.DspfxError) as ei:
+        eng.set_graph(specs, links)
+    assert ei.value.status == E.ERR_UNSUPPORTED and "compiled" in str(ei.value)
+    eng.set_chain([E.Gain(0.5), E.LowPass(0.25), E.HighPass(0.125)])   # a chain shape nothing else uses: not in the cache either
+    assert "jit_" not in eng.describe() and "dyn" in eng.describe(), eng.describe()
+    eng.close()
+    bad = G.GraphEngine(graphs.random_dag(4243, 7), N, B)               # falls back by itself
+    assert bad.fused is None and bad.runs
+    monkeypatch.delenv("DSPFX_KERNEL_HEADERS")
+    ref = G.GraphEngine(graphs.random_dag(4243, 7), N, B, fused=True)
+    x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+    for k in range(3):
+        ref.util.fill_noise(x, B, k * B, 0x5EED0010)
+        ya = bad.process(x, B).clone()
+        yb = ref.process(x, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), k
+    for e in (good, bad, ref):
+        e.close()
+
+
 def test_graph_set_rejections(dspfx):
     E = dspfx
     eng = E.Engine(128, 128)
