@@ -451,6 +451,10 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
             body += "g_copy<F, CPL>(" + dst + ", " + name(srcs[0].src) + ");\n";
             return;
         }
+        if (srcs.empty() && declare) {                  // an unconnected input port of a node
+            body += "g_unplugged<F, CPL>(" + dst + ");\n";
+            return;
+        }
         body += "g_zero<F, CPL>(" + dst + ");";
         for (const GLink &l : srcs) {
             if (l.src == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";

@@ -22,7 +22,7 @@ struct CheckProg {
         float v1[F][CPL]; g_zero<F, CPL>(v1); g_acc<F, CPL>(v1, v0); g_acc_zero<F, CPL>(v1); g_div<false, F, CPL>(v1, 0x1.00034p+1f, 0x1.fff98p-2);
         ring_apply<F, CPL, false>(gslot<1>(g), v1, pre1, cx);
         // node 3: a generator whose frequency slider is fed by node 1
-        float v3[F][CPL]; g_zero<F, CPL>(v3);
+        float v3[F][CPL]; g_unplugged<F, CPL>(v3);
         float p3_0[F][CPL]; g_fill<F, CPL>(p3_0, gslot<3>(g).p[0]);
         float p3_1[F][CPL]; g_zero<F, CPL>(p3_1); g_acc<F, CPL>(p3_1, v1); g_div<true, F, CPL>(p3_1, 0x1.0006p+0f, 0x1.fff2p-1);
         g_slider<F, CPL>(p3_1, 0x1.99999ap-4f, 0x1.388p+14f);
@@ -48,7 +48,7 @@ struct CheckProg {
         distort_mod_core<D_TANH, F, CPL>(v6, p6_0);
         // node 7: Add with an unconnected "b" port, Gain-style slider on a plain node is gain_mod_core
         float v7[F][CPL]; g_zero<F, CPL>(v7); g_acc<F, CPL>(v7, v6); g_div<true, F, CPL>(v7, 0x1.0006p+0f, 0x1.fff2p-1);
-        float b7[F][CPL]; g_zero<F, CPL>(b7);
+        float b7[F][CPL]; g_unplugged<F, CPL>(b7);
         g_add<F, CPL>(v7, b7);
         gain_mod_core<F, CPL>(v7, p2_0);
         g_mix<F, CPL>(v7, b2, gslot<2>(g).p[0]);

@@ -394,8 +394,7 @@ def test_without_the_kernel_headers_everything_still_runs(dspfx, G, monkeypatch,
     import torch
     E = dspfx
     N, B = 256, 128
-    text = graphs.fan_in_three()          # a wiring no other test compiled with these settings? (the cache is per source text)
-    good = G.GraphEngine(text, N, B)
+    good = G.GraphEngine(graphs.fan_in_three(), N, B)
     assert good.fused is not None
     monkeypatch.setenv("DSPFX_KERNEL_HEADERS", str(tmp_path))           # an empty directory
     monkeypatch.setenv("DSPFX_JIT", "1")
@@ -420,6 +419,31 @@ def test_without_the_kernel_headers_everything_still_runs(dspfx, G, monkeypatch,
         assert torch.equal(ya.view(torch.int32), yb.view(torch.int32)), k
     for e in (good, bad, ref):
         e.close()
+
+
+def test_unplugged_ports_give_positive_zero(dspfx):
+    """An effect with nothing plugged in feeds the Output node: the reference's arithmetic gives +0.0 (0 - (+0) = +0, then
+    0 + that, then the division).  With a literal zero in the generated code the compiler turned `(0 - z) / c` into
+    `(-z) / c` = -0.0 (found by tools/graph_sweep.py, seed 2044); unconnected ports are opaque zeros since."""
+    import torch
+    E = dspfx
+    N, B = 64, 128
+    x = torch.zeros(B * N, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    hp, sq, si = E.HighPass(0.5), E.SignalGen(-0.5, 9000.0, E.SIG_SQUARE), E.SignalGen(0.7, 220.0, E.SIG_SINE)
+    M, S = E.PORT_MAIN, E.PORT_SLIDER
+    cases = [([hp], [(0, 1, M)]),
+             ([hp, sq, si], [(0, 1, S), (1, 2, S), (0, 3, M), (2, 3, M)]),                 # generators whose amplitude is driven to 0: +-0 terms
+             ([hp, sq, si], [(0, 1, S), (1, 2, S), (0, 3, M), (1, 3, M), (2, 3, M)]),
+             ([E.Gain(2.0), hp], [(E.GRAPH_ZERO, 0, M), (0, 1, M), (1, 2, M)])]           # a connected pipe of zeros (demux) in front
+    for specs, links in cases:
+        eng = E.Engine(N, B)
+        eng.set_graph(specs, links)
+        for k in range(3):
+            eng.process(x, out=y, n_frames=B)
+            torch.cuda.synchronize()
+            assert int((y.view(torch.int32) != 0).sum()) == 0, (len(specs), k)     # every sample is +0.0: no sign bit, no value
+        eng.close()
 
 
 def test_graph_set_rejections(dspfx):

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """A wider sweep than the test suite runs: random DAGs (tests/graphs.py random_dag) as one generated kernel
  (a) of the exact-arithmetic kinds against the oracle's node-by-node evaluation (ulp), 
- (b) of every fusable kind against the run-by-run evaluation on the GPU (bits).
+ (b) of every fusable kind against the run-by-run evaluation on the GPU (bits),
+ (c) graphs cut into a series of small kernels (segment_plan with max_nodes 2..6) against the one-kernel result (bits).
 usage: graph_sweep.py [first_seed] [count]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ from chains import ulp_diff
 s0 = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 cnt = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 t0 = time.time()
-worst, nonzero, bad = 0, 0, []
+worst, nonzero, bad, cuts = 0, 0, [], 0
 for seed in range(s0, s0 + cnt):
     n = 4 + seed % 13                       # 4..16 nodes
     N, B, nf = 64, 128, 384
@@ -54,4 +55,24 @@ for seed in range(s0, s0 + cnt):
             bad.append(("runs", seed, k))
             break
     a.close(); b.close()
+    # (c) the series planner: cut as if a kernel held only m nodes, against the one-kernel result
+    for text in (graphs.long_rig(seed, 5, dry_mix=bool(seed % 2)), graphs.random_dag(seed, 8)):
+        for m in (2, 3, 4, 6):
+            steps = G.segment_plan(G.Graph(text), m)
+            if steps is None or len(steps) < 2:
+                continue
+            cuts += 1
+            a = G.GraphEngine(text, 256, B, max_nodes=m)
+            b = G.GraphEngine(text, 256, B, fused=True)
+            xs = torch.empty(B * 256, dtype=torch.float32, device="cuda")
+            for k in range(3):
+                b.util.fill_noise(xs, B, k * B, 0x5EED3000 + seed)
+                ya = a.process(xs, B).clone()
+                yb = b.process(xs, B)
+                torch.cuda.synchronize()
+                if not torch.equal(ya.view(torch.int32), yb.view(torch.int32)):
+                    bad.append(("segments", seed, m, k))
+                    break
+            a.close(); b.close()
+print("series plans checked: %d" % cuts)
 print("seeds %d..%d: worst ulp vs oracle %d (%d graphs with non-zero output), mismatches %s, %.0f s" % (s0, s0 + cnt - 1, worst, nonzero, bad, time.time() - t0))
