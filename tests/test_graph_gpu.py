@@ -92,6 +92,7 @@ def test_random_dag_matches_reference_semantics(dspfx, G, seed):
     assert np.isfinite(ref).all()
     d = ulp_diff(got, ref)
     assert d.max() <= 1, (seed, int(d.max()), text)
+    assert np.array_equal(np.signbit(got), np.signbit(ref)), seed          # +0 / -0 included (ulp_diff calls them equal)
     ge.close()
 
 
