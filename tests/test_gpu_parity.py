@@ -934,6 +934,7 @@ def test_random_chains_of_exact_nodes(dspfx, torch_cuda, seed):
         assert np.array_equal(np.isfinite(got), ok), (seed, case)
         d = ulp_diff(got[ok], ref[ok])
         assert d.size == 0 or d.max() <= 1, (seed, case, [(n.kind, n.mode) for n in chain], N, block, tile, lf, int(d.max()))
+        assert np.array_equal(np.signbit(got[ok]), np.signbit(ref[ok])), (seed, case)     # the sign of zeros too
 
 
 @pytest.mark.parametrize("N,tile", [(4096 + 64 * 300 + 37, 0), (65536, 256), (100, 0)])
