@@ -532,6 +532,19 @@ class GraphEngine:
         self.util.link_average([self._source(s, x) for s in out_node.main], self.final, nf, stream)
         return self.final
 
+    def tune_placement(self, x, n_frames: Optional[int] = None, stream: int = 0):
+        """Re-tune the delay rings' placement of every generated kernel against the blocks it will really read and write
+        (`dspfx_tune_placement`; resets DSP state).  `x` is the Input block the host will keep passing to `process`."""
+        nf = min(self.B, 128) if n_frames is None else int(n_frames)
+        if self.fused is not None:
+            self.fused.tune_placement(x, self.final, nf, stream=stream)
+            return
+        x0 = self.zeros if x is None else x
+        for (eng, out), (kind, in_ref, in2_ref) in zip(self.series, self.series_kind):
+            src = x0 if in_ref == -1 else self.series[in_ref][1]
+            side = None if in2_ref is None else (x0 if in2_ref == -1 else self.series[in2_ref][1])
+            eng.tune_placement(src, out, nf, side=side, stream=stream)
+
     def close(self):
         if self.fused is not None:
             self.fused.close()

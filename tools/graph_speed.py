@@ -16,8 +16,7 @@ x = torch.empty(B * N, dtype=torch.float32, device="cuda")
 for fused in (None, False):
     ge = G.GraphEngine(text, N, B, tile_channels=256, fused=fused)
     ge.util.fill_noise(x, B, 0)
-    if ge.fused is not None:
-        ge.fused.tune_placement(x, ge.final, B)
+    ge.tune_placement(x, B)
     for _ in range(20): ge.process(x, B)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
