@@ -273,8 +273,8 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * read of the Input node's buffer and one write of the Output node's, whatever the wiring.
  *
  * `nodes` are given in an order in which every link goes forward (src < dst).  A link connects the output of
- * node `src` (or DSPFX_GRAPH_INPUT: the block passed as `in`; or DSPFX_GRAPH_ZERO: a connected pipe that
- * carries zeros, the unselected output of a demux) to port `port` of node `dst` (dst == n_nodes: the Output
+ * node `src` (or DSPFX_GRAPH_INPUT: the block passed as `in`; DSPFX_GRAPH_INPUT2: the block passed as `side`;
+ * DSPFX_GRAPH_ZERO: a connected pipe that carries zeros, the unselected output of a demux) to port `port` of node `dst` (dst == n_nodes: the Output
  * node, whose only port is MAIN; its value is the block written to `out`).  A port with k links averages
  * them in the order given, (0 + x1 + ... + xk) / f32(0.0001 + k); a port without links reads zeros (main,
  * "b") or keeps its slider value (slider ports).  Ports: DSPFX_PORT_MAIN, DSPFX_PORT_SIDE (port "b" of
@@ -282,7 +282,8 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * The engine's link_flags do not apply (every hop is explicit), `side` of the process calls is DSPFX_GRAPH_INPUT2 and
  * control ports cannot be passed to dspfx_process_ctl.  Needs channels % 64 == 0 (whole waves).
  * DSPFX_ERR_UNSUPPORTED: the graph cannot be fused (too many nodes, a FIR / Fuzz node, channel count) or the
- * run-time compiler is unavailable: evaluate it run by run instead (dsp-stuff_amd/graph.py does).
+ * run-time compiler is unavailable: cut it into a series of such kernels (DSPFX_PORT_RAW, DSPFX_GRAPH_INPUT2: segment_plan in
+ * dsp-stuff_amd/graph.py and include/dspfx_graph.hpp) or evaluate it run by run (graph.py).
  * dspfx_chain_set returns the engine to chain mode.  (dspfx_chain_set itself uses the same generated kernel for a
  * run of 9..16 fusable nodes without Add / Mix on engines above 131072 channels: one launch instead of two.) */
 #define DSPFX_GRAPH_MAX_NODES 16
@@ -300,9 +301,9 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * engine reads that buffer as its Input (dsp-stuff_amd/graph.py, segment_plan). */
 #define DSPFX_PORT_RAW 256
 typedef struct dspfx_graph_link {
-    int32_t src;    /* producing node index, DSPFX_GRAPH_INPUT or DSPFX_GRAPH_ZERO */
+    int32_t src;    /* producing node index, DSPFX_GRAPH_INPUT, DSPFX_GRAPH_INPUT2 or DSPFX_GRAPH_ZERO */
     int32_t dst;    /* consuming node index, or n_nodes for the Output node */
-    int32_t port;   /* DSPFX_PORT_* of the consumer */
+    int32_t port;   /* DSPFX_PORT_* of the consumer (| DSPFX_PORT_RAW) */
 } dspfx_graph_link;
 int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
                     int n_links);
