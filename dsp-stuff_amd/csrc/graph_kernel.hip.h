@@ -41,16 +41,18 @@ __device__ __forceinline__ void g_zero(float (&r)[F][CPL]) {      // node.rs:165
 // AMDGPU backend turns `(0.0 - z) * c` and `(0.0 - z) / c` into `(-z) * c`, `(-z) / c` (a source modifier; measured with
 // -fno-fast-math) -- which is -0 where the reference's arithmetic gives +0 (an unplugged high-pass into the Output node:
 // tools/graph_sweep.py seed 2044).  The chain kernels never see constant inputs; here they would.
+__device__ __forceinline__ float opaque_zero() {
+    float z = 0.0f;
+    asm volatile("" : "+s"(z));               // one scalar register; the compiler no longer knows its value
+    return z;
+}
 template <int F, int CPL>
 __device__ __forceinline__ void g_unplugged(float (&r)[F][CPL]) {
+    const float z = opaque_zero();
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            float z = 0.0f;
-            asm volatile("" : "+v"(z));
-            r[f][j] = z;
-        }
+        for (int j = 0; j < CPL; ++j) r[f][j] = z;
 }
 template <int F, int CPL>
 __device__ __forceinline__ void g_fill(float (&r)[F][CPL], float x) {   // an unconnected slider port: the slider value
@@ -75,14 +77,11 @@ __device__ __forceinline__ void g_acc(float (&r)[F][CPL], const float (&s)[F][CP
 }
 template <int F, int CPL>
 __device__ __forceinline__ void g_acc_zero(float (&r)[F][CPL]) {   // a connected pipe that carries zeros (opaque: see g_unplugged)
+    const float z = opaque_zero();
 #pragma unroll
     for (int f = 0; f < F; ++f)
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) {
-            float z = 0.0f;
-            asm volatile("" : "+v"(z));
-            r[f][j] = r[f][j] + z;
-        }
+        for (int j = 0; j < CPL; ++j) r[f][j] = r[f][j] + z;
 }
 template <bool FAST, int F, int CPL>
 __device__ __forceinline__ void g_div(float (&r)[F][CPL], float div, double rc) {   // node.rs:189-191: buf /= 0.0001 + k
