@@ -63,7 +63,8 @@ def parse():
     ap.add_argument("--taps", type=int, default=None)
     ap.add_argument("--no-mix", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline duration")
+    ap.add_argument("--no-others", action="store_true", help="do not time cfg3 / cfg2 / cfg4 after the headline config")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target CPU-baseline duration")
     ap.add_argument("--link-flags", type=int, default=3)
     ap.add_argument("--probe", type=int, default=1,
                     help="also rate 3 x K candidate sample buffers before the timed region (default 1 = off)")
@@ -87,10 +88,21 @@ def build_chain(pkg, cfg):
     raise ValueError(cfg["chain"])
 
 
-def cpu_baseline(chain, cfg, link_flags, target_s):
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
     """The reference CPU path stand-in: the C restatement (oracle/), built -O3
     -march=native -ffp-contract=off ON THIS BOX, channel-at-a-time / node-at-a-time /
-    128-frame blocks like node.rs:267-352, threaded over channels on all host cores."""
+    128-frame blocks like node.rs:267-352 (gather, /1.0001, process, scatter per node):
+    (i) one thread, (ii) threaded over channels on all host cores."""
     from __graft_entry__ import load_oracle
     O = load_oracle()
     cores = os.cpu_count() or 1
@@ -109,20 +121,20 @@ def cpu_baseline(chain, cfg, link_flags, target_s):
     descs = [n.oracle_desc() for n in chain]
     block = 128
 
-    def run(n_channels, n_blocks):
+    def run(n_channels, n_blocks, threads):
         import ctypes as C
         protos = [O.node_from_desc(d, _lib=L) for d in descs]
         hs = (C.c_void_p * len(protos))(*[p.h for p in protos])
         t0 = time.perf_counter()
-        L.orc_run_noise_channels(hs, len(protos), link_flags, SEED, 0, n_channels, 0, n_blocks, block, None, None, cores)
+        L.orc_run_noise_channels(hs, len(protos), link_flags, SEED, 0, n_channels, 0, n_blocks, block, None, None, threads)
         return time.perf_counter() - t0
 
     is_fir = cfg["chain"] == "fir"
     # FIR: 48 blocks = 6144 samples, so most of the sample is past the 4096-sample warm-up (whose
     # shorter dot products are cheaper); the probe uses the same block count so the rate transfers
     ch, nb = (cores, 48) if is_fir else (cores * 64, 64)
-    run(cores, 1)                                     # touch code/pages
-    t = run(ch, nb)                                   # probe
+    run(cores, 1, cores)                              # touch code/pages
+    t = run(ch, nb, cores)                            # probe
     rate = ch * nb * block / max(t, 1e-6)
     # scale the sample to ~target_s of CPU work: >= 1 ring period of blocks for the delay chains,
     # channels capped so the per-channel delay rings (96 KB each at D=24000) stay within ~6 GB of host RAM
@@ -137,63 +149,52 @@ def cpu_baseline(chain, cfg, link_flags, target_s):
         ch2 -= ch2 % cores or 0
         ch2 = max(ch2, cores)
         nb2 = int(max(nb2, min(1 << 14, rate * target_s / (ch2 * block))))
-    t2 = run(ch2, nb2)
-    return {"value": ch2 * nb2 * block / t2, "unit": "samples/s", "cores": cores,
-            "kind": "port",
-            "sample": f"{ch2} channels x {nb2} blocks of 128 frames, same chain/params/noise, {t2:.1f} s; "
-                      f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
-                      f"pthreads over channels; excludes the reference's tokio/ring/pool overhead"}
+    t2 = run(ch2, nb2, cores)
+    res = {"value": ch2 * nb2 * block / t2, "unit": "samples/s", "cores": cores, "cpu_model": cpu_model(),
+           "kind": "port",
+           "sample": f"{ch2} channels x {nb2} blocks of 128 frames, same chain/params/noise, {t2:.1f} s; "
+                     f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
+                     f"pthreads over channels; excludes the reference's tokio/ring/pool overhead"}
+    if with_single:
+        # (i) ONE thread, reference-structured: what one tokio worker of the reference could do at best
+        ch1, nb1 = (1, 48) if is_fir else (16, 256)
+        t1 = run(ch1, nb1, 1)
+        r1 = ch1 * nb1 * block / max(t1, 1e-6)
+        scale = int(max(1, min(256, 0.3 * target_s * r1 / (ch1 * nb1 * block))))
+        if scale > 1:
+            ch1 *= scale
+            t1 = run(ch1, nb1, 1)
+        res["single_thread"] = {"value": ch1 * nb1 * block / t1, "unit": "samples/s", "cores": 1,
+                                "sample": f"{ch1} channels x {nb1} blocks, one thread, {t1:.1f} s"}
+    return res
 
 
-def main():
-    args = parse()
+class Ctx:
+    """What one process shares between the configs it measures."""
+    pass
+
+
+def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
+    """One configuration: build the engine, settle, W warm-up steps, K timed steps.  Returns a dict."""
     import torch
     import torch.distributed as dist
-    from __graft_entry__ import load_package
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
-    # exercised on a 1-GPU box (the driver launches the real N>1 runs with torch.distributed.run)
-    use_dist = world > 1 or os.environ.get("DSPFX_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-
-    pkg = load_package()
-    from dsp_stuff_amd import parallel as P
-    cfg = dict(CONFIGS[args.config])
-    for k in ("channels", "frames", "delay", "taps"):
-        if getattr(args, k) is not None:
-            cfg[k] = getattr(args, k)
+    pkg, P, dev, world = ctx.pkg, ctx.P, ctx.dev, ctx.world
+    cfg = dict(CONFIGS[cfg_name])
+    cfg.update(overrides or {})
     N, B = cfg["channels"], cfg["frames"]
     use_mix = not args.no_mix
     chain = build_chain(pkg, cfg)
+    is_fir = cfg["chain"] == "fir"
 
-    shard = P.weak_shard(N, world, rank)      # weak scaling: N channels on every rank
-    eng = pkg.Engine(shard.channels, B, link_flags=args.link_flags, device=local_rank,
+    shard = P.weak_shard(N, world, ctx.rank)      # weak scaling: N channels on every rank
+    eng = pkg.Engine(shard.channels, B, link_flags=args.link_flags, device=ctx.local_rank,
                      channel_offset=shard.offset, tile_channels=args.tile)
     eng.set_chain(chain)
-    # the chain kernels get their own high-priority stream: the mix bus' small kernels and the RCCL
-    # all-reduce on the second stream must not delay the next block's launch
-    if os.environ.get("DSPFX_BENCH_HIPRIO", "1") == "1":
-        compute_stream = torch.cuda.Stream(device=dev, priority=-1)
-        torch.cuda.set_stream(compute_stream)
-    stream = torch.cuda.current_stream().cuda_stream
+    stream = ctx.compute_stream.cuda_stream
 
-    # Placement.  How fast the chain kernel streams depends on where the delay ring's groups sit physically relative
-    # to the sample buffers (profiles/r01_placement.txt: byte-identical engines ran at 0.355 or 0.40 ms).  The
-    # engine therefore re-times its candidate ring groups against the buffers used below and keeps the fastest
-    # (dspfx_tune_placement); `--probe K` additionally rates K x 3 candidate sample buffers.  All of it happens
-    # before the timed region and is reported in the output line.
+    # ---- every host-side allocation happens HERE, before any settling: the chip's power management reacts to
+    # idle gaps of a few tens of ms with a transient of ~50 launches (fast, then 5-15 % slow, then steady:
+    # profiles/r02_idle_transient.txt), so nothing may pause the queue between settling and the timed region
     n_in = 2
 
     def alloc_buf(block=None):
@@ -202,23 +203,42 @@ def main():
             eng.fill_noise(t, B, block * B, SEED, stream)
         return t
 
+    mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(4)] if use_mix else [None] * 4
+    total_channels = shard.total_channels
+    # Mix bus.  One GPU: pipelined INSIDE the chain kernel (dspfx_process_mixpipe: block k's launch also finishes
+    # the bus of blocks k-1 / k-2 and applies the Output hop), so the compute stream holds nothing but chain
+    # kernels -- no second stream, no events (measured: the event marker between kernels cost 13 us per step,
+    # profiles/r01_mixpipe.txt).  Several GPUs: the same pipeline, the per-rank sums of BATCH blocks all-reduced in
+    # one RCCL call on the second stream (parallel.PipelinedMixBus).
+    # DSPFX_BENCH_MIX = pipe | deferred | inline selects the path for A/B runs.
+    dist_run = ctx.use_dist or world > 1
+    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "pipe")
+    mix_stream = ctx.mix_stream
+    ms = mix_stream.cuda_stream
+    BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
+    bus_world = 2 if (ctx.use_dist and world == 1) else world          # forced-dist: take the collective path
+    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
+    pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev)
+            if (use_mix and dist_run and mix_mode == "pipe") else None)
+    pipe_fill = [0]
+
     # one full revolution of the delay ring per measurement: ring groups differ in placement quality too, and a
     # probe that only walks a few of them mispredicts the timed region (seen: 0.355 probed, 0.406 timed)
     probe_steps = max(24, -(-int(cfg.get("delay") or 0) // B))
 
-    def probe(xs_, y_, steps=probe_steps):
+    def probe(xs_, y_, steps_=probe_steps):
         for k in range(4):
             eng.process(xs_[k % len(xs_)], out=y_, n_frames=B, stream=stream)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for k in range(steps):
+        for k in range(steps_):
             eng.process(xs_[k % len(xs_)], out=y_, n_frames=B, stream=stream)
         e1.record()
         torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / steps
+        return e0.elapsed_time(e1) / steps_
 
     probe_log = None
-    if args.probe > 1 and cfg["chain"] != "fir":
+    if args.probe > 1 and not is_fir:
         # Optional rating of candidate sample buffers (--probe K): each is rated on its own, first as the input
         # (fixed output buffer), then the rest as the output (best input).
         K = 3 * args.probe
@@ -242,37 +262,15 @@ def main():
     # its candidate groups with the real chain kernel on these buffers and keeps the fastest.  This is what removes
     # the slow mode (profiles/r01_placement.txt: 0.39-0.40 -> 0.355 ms in every one of 18 installs).  Setup only.
     tune_log = None
-    if os.environ.get("DSPFX_BENCH_TUNE", "1") == "1" and cfg["chain"] != "fir":
+    if os.environ.get("DSPFX_BENCH_TUNE", "1") == "1" and not is_fir and (cfg.get("delay") or 0) * N * 4 >= (1 << 30):
         before = probe(xs, y)
         t_tune = time.perf_counter()
         eng.tune_placement(xs[0], y, min(B, 128), stream=stream)
         torch.cuda.synchronize()
         tune_s = time.perf_counter() - t_tune
-        tune_log = {"ms_before": round(before, 4), "ms_after": round(probe(xs, y), 4), "seconds": round(tune_s, 2)}
+        tune_log = {"ms_before": round(before, 4), "seconds": round(tune_s, 2)}
     for j, x_ in enumerate(xs):     # block j of the noise stream in input j
         eng.fill_noise(x_, B, j * B, SEED, stream)
-    mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(4)] if use_mix else [None] * 4
-    total_channels = shard.total_channels
-    # Mix bus.  One GPU: pipelined INSIDE the chain kernel (dspfx_process_mixpipe: block k's launch also finishes
-    # the bus of blocks k-1 / k-2 and applies the Output hop), so the compute stream holds nothing but chain
-    # kernels -- no second stream, no events (measured: the event marker between kernels cost 13 us per step,
-    # profiles/r01_mixpipe.txt).  Several GPUs: per-wave partials are collected on a second stream, all-reduced
-    # over RCCL and divided there, overlapping the next block's chain kernel (parallel.MixBus).
-    # DSPFX_BENCH_MIX = pipe | deferred | inline selects the path for A/B runs.
-    dist_run = use_dist or world > 1
-    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "pipe")
-    mix_stream = torch.cuda.Stream(device=dev)
-    ms = mix_stream.cuda_stream
-    # Several GPUs with the in-kernel pipeline: the per-rank sums of BATCH blocks are all-reduced in one RCCL
-    # call on the second stream (one event marker on the compute stream per BATCH blocks instead of per block),
-    # then divided by the global channel count there (parallel.MixBus over a [BATCH * B] buffer).
-    BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
-    bus_world = 2 if (use_dist and world == 1) else world          # forced-dist: take the collective path
-    compute_stream_obj = torch.cuda.current_stream()
-    bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
-    pbus = (P.PipelinedMixBus(eng, total_channels, B, compute_stream_obj, mix_stream, bus_world, batch=BATCH, device=dev)
-            if (use_mix and dist_run and mix_mode == "pipe") else None)
-    pipe_fill = [0]
 
     def step(k):
         if not use_mix:
@@ -309,7 +307,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if use_dist:
+        if ctx.use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -322,27 +320,53 @@ def main():
     n_stages = len(stage_lines)
     region_timing = n_stages == 1
     if not region_timing:
-        eng.profile_enable(args.steps + 8)
+        eng.profile_enable(steps + 8)
         eng.profile_enable(0)
-    for k in range(args.warmup):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    es0, es1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    # ---- settle: the step of the timed region, back to back, for >= one revolution of the delay rings (they then
+    # hold real data) and >= SETTLE seconds of GPU time, so that clocks / power are in their steady state.  The W
+    # warm-up steps follow without any host-side pause, then drain + fence (microseconds), then the timed region.
+    settle_s = float(os.environ.get("DSPFX_BENCH_SETTLE", "0.3"))
+    for k in range(8):
+        step(k)
+    es0.record()
+    for k in range(16):
+        step(k)
+    es1.record()
+    es1.synchronize()
+    est_ms = max(es0.elapsed_time(es1) / 16, 1e-3)
+    settle_steps = int(max(probe_steps + 8, min(20000, settle_s * 1e3 / est_ms)))
+    es0.record()
+    for k in range(settle_steps):
+        step(k)
+    es1.record()
+    for k in range(warmup):
         step(k)
     drain()
     fence()
+    settle_ms = es0.elapsed_time(es1) / settle_steps
+    if tune_log is not None:
+        tune_log["ms_after"] = round(settle_ms, 4)
     if not region_timing:
         eng.profile_enable(1)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # one-workgroup marker kernels (sin_ before, cos_ after) delimit the timed region in a rocprofv3 kernel trace
+    # (tools/trace_phases.py); both are outside the event pair
+    ctx.mark.sin_()
     t0 = time.perf_counter()
     ev0.record()
-    for k in range(args.steps):
+    for k in range(steps):
         step(k)
     ev1.record()
     t_submitted = time.perf_counter() - t0     # host-side submission time of the K steps
+    ctx.mark.cos_()
     drain()
     fence()
     dt = time.perf_counter() - t0
     region_ms = ev0.elapsed_time(ev1)
     if region_timing:
-        kern_ms_total, kern_launches = region_ms, args.steps
+        kern_ms_total, kern_launches = region_ms, steps
         kern_name = stage_lines[-1].split("kernel ")[1].split(" ")[0]
         kern_method = "one HIP-event pair around the timed region on the compute stream / launches"
     else:
@@ -350,16 +374,15 @@ def main():
         kern_ms_total, kern_launches, kern_name = eng.profile_read()
         kern_method = "HIP events around every launch of the dominant stage"
 
-    if use_dist:
+    if ctx.use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    samples = float(total_channels) * B * args.steps
+    samples = float(total_channels) * B * steps
     value = samples / dt
     bps = eng.algorithmic_bytes_per_sample(B)
     kern_ms = kern_ms_total / max(kern_launches, 1)
-    is_fir = cfg["chain"] == "fir"
     if is_fir:
         flops = 2.0 * cfg["taps"] * N * B
         achieved = flops / (kern_ms * 1e-3) / 1e12
@@ -371,42 +394,122 @@ def main():
                 "frac": achieved / HBM_PEAK_GBPS}
     roof.update({"kernel": kern_name, "kernel_ms_avg": kern_ms, "launches": kern_launches, "timing": kern_method,
                  "algorithmic_bytes_per_sample": bps, "traffic": None})
-    # HBM bytes per launch from the committed PMC pass of this same command, if one exists
+    # HBM bytes per launch from the committed PMC pass of this same command, if one exists (not measured in this run)
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
             t = json.load(open(tr))
-            ent = t.get(f"{args.config}:{N}:{B}")
+            ent = t.get(f"{cfg_name}:{N}:{B}")
             if ent:
                 roof["traffic"] = ent["hbm_bytes_per_launch"]
                 roof["traffic_source"] = ent.get("source")
         except Exception:
             pass
+    res = {
+        "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg,
+        "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
+                   "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
+                   "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
+                   "placement_probe": probe_log, "placement_tuning": tune_log,
+                   "settle": {"steps": settle_steps, "ms_per_step": round(settle_ms, 4)},
+                   "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
+                   "plan": eng.describe().strip().split("\n")[1:]},
+        "gpu_event_ms_per_step": region_ms / steps, "host_submit_ms_per_step": t_submitted * 1e3 / steps,
+        "block_budget_ms": B / 48.0,
+    }
+    del pbus, bus, xs, y, mixes
+    eng.close()
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    ctx = Ctx()
+    world = ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = ctx.rank = int(os.environ.get("RANK", "0"))
+    ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(ctx.local_rank)
+    dev = ctx.dev = torch.device("cuda", ctx.local_rank)
+    # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
+    # exercised on a 1-GPU box (the driver launches the real N>1 runs with torch.distributed.run)
+    ctx.use_dist = world > 1 or os.environ.get("DSPFX_BENCH_FORCE_DIST") == "1"
+    if ctx.use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    ctx.pkg = load_package()
+    from dsp_stuff_amd import parallel as P
+    ctx.P = P
+    # the chain kernels get their own high-priority stream: the mix bus' small kernels and the RCCL
+    # all-reduce on the second stream must not delay the next block's launch
+    if os.environ.get("DSPFX_BENCH_HIPRIO", "1") == "1":
+        ctx.compute_stream = torch.cuda.Stream(device=dev, priority=-1)
+        torch.cuda.set_stream(ctx.compute_stream)
+    else:
+        ctx.compute_stream = torch.cuda.current_stream()
+    ctx.mix_stream = torch.cuda.Stream(device=dev)
+    ctx.mark = torch.zeros(64, dtype=torch.float32, device=dev)
+    # everything that is lazy on first use (torch code objects of the marker kernels, RCCL's communicator) is used
+    # once NOW: a first call between warm-up and the timed region stalls the queue for ~20 ms, and an idle gap of
+    # >= 10 ms is followed by ~40 slow launches (profiles/r02_idle_transient.txt)
+    ctx.mark.sin_()
+    ctx.mark.cos_()
+    if ctx.use_dist:
+        dist.barrier()
+        dist.all_reduce(ctx.mark)
+    torch.cuda.synchronize()
+
+    over = {k: getattr(args, k) for k in ("channels", "frames", "delay", "taps") if getattr(args, k) is not None}
+    r = measure(ctx, args, args.config, args.steps, args.warmup, over)
+
+    # The other single-GPU BASELINE configs, timed in the same run with the same K / W (extra key; the line's
+    # `value` stays the headline config's).  Default invocation on one GPU only.
+    others = None
+    if args.config == "cfg5" and world == 1 and not over and not args.no_others:
+        others = {}
+        for name in ("cfg3", "cfg2", "cfg4"):
+            try:
+                o = measure(ctx, args, name, args.steps, args.warmup)
+                others[name] = {"workload": o["config"]["workload"], "value": o["value"], "unit": "samples/s",
+                                "ms_per_step": o["ms_per_step"], "block_budget_ms": o["block_budget_ms"],
+                                "roofline": o["roofline"], "plan": o["config"]["plan"],
+                                "settle": o["config"]["settle"], "placement_tuning": o["config"]["placement_tuning"]}
+            except Exception as ex:   # never lose the headline line
+                others[name] = {"error": str(ex)[:300]}
 
     if rank != 0:
-        if use_dist:
+        if ctx.use_dist:
             dist.destroy_process_group()
         return
 
+    value = r["value"]
     line = {
         "metric": "mono-channel-samples/sec through 5-node chain @128-frame blocks" if args.config == "cfg5"
                   else f"mono-channel-samples/sec ({args.config})",
         "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
-                   "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
-                   "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}", "placement_probe": probe_log, "placement_tuning": tune_log,
-                   "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
-                   "plan": eng.describe().strip().split("\n")[1:]},
-        "roofline": roof,
+        "config": r["config"],
+        "roofline": r["roofline"],
         "realtime_channels": value / 48000.0,
-        "block_latency_ms": dt * 1e3 / args.steps, "block_budget_ms": B / 48.0,
-        "gpu_event_ms_per_step": region_ms / args.steps, "host_submit_ms_per_step": t_submitted * 1e3 / args.steps,
+        "block_latency_ms": r["ms_per_step"], "block_budget_ms": r["block_budget_ms"],
+        "gpu_event_ms_per_step": r["gpu_event_ms_per_step"], "host_submit_ms_per_step": r["host_submit_ms_per_step"],
     }
+    if others is not None:
+        line["other_configs"] = others
     if world == 1 and not args.no_cpu_baseline:
         try:
-            line["cpu_baseline"] = cpu_baseline(chain, cfg, args.link_flags, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(r["chain"], r["cfg"], args.link_flags, args.cpu_seconds)
             line["cpu_baseline"]["gpu_over_cpu"] = value / line["cpu_baseline"]["value"]
         except Exception as ex:   # the baseline is reporting only; never lose the GPU line
             line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
@@ -414,7 +517,7 @@ def main():
     else:
         line["cpu_baseline"] = None      # N > 1, or switched off with --no-cpu-baseline
     print(json.dumps(line))
-    if use_dist:
+    if ctx.use_dist:
         dist.destroy_process_group()
 
 
