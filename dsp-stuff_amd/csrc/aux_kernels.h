@@ -18,6 +18,13 @@ struct FuzzArgs {
     float level;
     float hop_div;
     int hop;
+    // the `level` control port (distort.rs:176-180 maps it for every mode; fuzz zips it per sample, 154-160):
+    // ctl = connected signal in the sample layout (or nullptr), latch = per-channel latched slider [N] (or nullptr)
+    int ctl_hop;        // the control link's collect_and_average hop
+    const float *ctl;
+    float *latch;
+    int latch_valid;
+    int pad_;
     Layout lay;
 };
 void launch_fuzz(const FuzzArgs &a, hipStream_t s);

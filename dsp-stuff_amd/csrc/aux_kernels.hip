@@ -45,10 +45,23 @@ __global__ void __launch_bounds__(WG) fuzz_kernel(const FuzzArgs a) {
         }
         const float mx = __uint_as_float(wg_max(0, m));
         const double rmx = 1.0 / (double)mx;
+        // level per sample (dsp-stuff-derive/src/lib.rs:135-153): a connected port maps its signal to 0..=30 and latches
+        // the block's first value per channel; otherwise the latched value or the slider
+        const bool has_ctl = a.ctl != nullptr;                      // wave-uniform
+        const float *pctl = has_ctl ? a.ctl + a.lay.at(0, cc) : nullptr;
+        float lconst = a.level;
+        if (!has_ctl && a.latch_valid) lconst = a.latch[cc];
         unsigned mzb = 0;
 #pragma unroll
         for (int f = 0; f < FUZZ_F; ++f) {
-            const float qv = div_lane(clip1(x[f] * a.level), mx, rmx);   // 158
+            float lv = lconst;
+            if (has_ctl) {
+                float s = __builtin_nontemporal_load(pctl + (size_t)(f0 + f) * ld);
+                if (a.ctl_hop) s = link_hop<false>(s, a.hop_div, 0.0);
+                lv = slider_map(s, 0.0f, 30.0f);                     // distort.rs:37 `range = 0.0..=30.0`
+                if (f == 0 && q == 0 && active) a.latch[cc] = lv;     // lib.rs:148: element 0 of the 128-frame block
+            }
+            const float qv = div_lane(clip1(x[f] * lv), mx, rmx);        // 158
             const float e = exp_cr(-fabsf(qv));                          // q.copysign(-1.0).exp()
             const float z = -fabsf(1.0f - e);                            // (1.0 - e).copysign(-1.0)
             x[f] = z;

@@ -252,13 +252,24 @@ __device__ __forceinline__ void store_vec(float *p, const float (&v)[CPL], bool 
 // x / c for a wave-uniform constant c.  FAST: (float)((double)x * rc) with rc = RN_f64(1/c):
 // the exact quotient of two f32 values is never closer than 2^-49 (relative) to an f32
 // rounding boundary while the f64 product is within 2^-52 of it, so the single final
-// rounding equals IEEE f32 division; the few constants with exact-tie quotients in the
-// subnormal range (even integers) are caught by the exhaustive 2^32-input check the host
-// runs per constant (verify_div_kernel) and then take the IEEE path (FAST = false).
+// rounding equals IEEE f32 division.  Subnormal quotients have fewer than 24 bits, so there an exact quotient CAN be
+// a tie: x / c = (2k+1) 2^-150 needs x = (c/2)(2k+1) 2^-149 on the subnormal grid, i.e. c/2 an integer -- ties exist
+// only for EVEN INTEGER c (and any quotient that is not a tie stays >= 2^-48 away from one).  The host therefore
+// takes FAST for every other constant outright and runs the exhaustive 2^32-input check (verify_div_kernel) for
+// even integers that are not powers of two; those that fail it take the IEEE path (FAST = false).
 template <bool FAST>
 __device__ __forceinline__ float div_c(float x, float c, double rc) {
     if constexpr (FAST) return (float)((double)x * rc);
     else return x / c;
+}
+
+// x / c for a per-lane divisor c with rc = 1.0 / (double)c: the f64 product rounds to the IEEE f32 quotient whenever
+// that quotient is a normal number (no f32 quotient lies within 2^-49 of a rounding boundary unless it is an exact
+// tie, and ties only exist among subnormal results); subnormal results take the IEEE division.
+__device__ __forceinline__ float div_lane(float x, float c, double rc) {
+    float q = (float)((double)x * rc);
+    if (!(__builtin_fabsf(q) >= 0x1p-126f)) q = x / c;
+    return q;
 }
 
 // node.rs:162-194 with one connected pipe: buf = 0.0; buf += x; buf /= 0.0001f + 1.0f
@@ -383,15 +394,6 @@ __device__ __forceinline__ float exp_cr(float x) {
     const float r = (float)exp_f64(y);
     return x != x ? x : r;
 }
-// x / c for a per-lane divisor c with rc = 1.0 / (double)c: the f64 product rounds to the IEEE f32 quotient whenever
-// that quotient is a normal number (no f32 quotient lies within 2^-49 of a rounding boundary unless it is an exact
-// tie, and ties only exist among subnormal results); subnormal results take the IEEE division.
-__device__ __forceinline__ float div_lane(float x, float c, double rc) {
-    float q = (float)((double)x * rc);
-    if (!(__builtin_fabsf(q) >= 0x1p-126f)) q = x / c;
-    return q;
-}
-
 // distort.rs:63-145, every mode except Fuzz, for level >= 0.001 (the `level < 0.001`
 // bypass is wave-uniform while level is a slider value and is tested once per chunk
 // by the caller).  Branch-free selects: lanes never diverge.

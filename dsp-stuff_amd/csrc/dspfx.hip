@@ -167,36 +167,54 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
                         "%s failed: %s", #call, hipGetErrorString(err__));                      \
     } while (0)
 
-// Exact-division cache: divisor bits -> "fast path proven equal to IEEE division for all 2^32 inputs".
-// DSPFX_FAST_DIV=0 forces the IEEE path (A/B measurements).
-bool divisor_is_fast(float c) {
+// Is (float)((double)x * RN_f64(1/c)) == x / c for every f32 x?  (div_c in chain_kernels.hip.h has the argument.)
+//   * c not an even integer, or a power of two: yes, by the theorem there -- decided here, no device involved, so a
+//     slider store, a fan-in divisor f32(0.0001 + k) or dspfx_graph_source never launch anything;
+//   * c an even integer that is not a power of two (6, 10, 12, ... -- exact ties exist among its subnormal quotients):
+//     the exhaustive 2^32-input check decides, on the CURRENT device (plan() selects the engine's device first).  Only
+//     COMPLETED checks are cached: a HIP failure answers "not fast" for this call and is asked again next time;
+//     have_device = false only consults the cache.
+// DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; read per call so a test can flip it between engines).
+bool divisor_is_fast(float c, bool have_device = true) {
     static std::mutex mu;
     static std::map<uint32_t, bool> cache;
-    static const bool disabled = getenv("DSPFX_FAST_DIV") && atoi(getenv("DSPFX_FAST_DIV")) == 0;
-    if (disabled) return false;
+    if (const char *fd = getenv("DSPFX_FAST_DIV"))
+        if (atoi(fd) == 0) return false;
     if (!(c == c) || c == 0.0f || std::isinf(c)) return false;
+    const float ac = fabsf(c), half = ac * 0.5f;
+    int ex = 0;
+    const bool even_integer = ac >= 2.0f && half == floorf(half);
+    const bool pow2 = frexpf(ac, &ex) == 0.5f;
+    if (!even_integer || pow2) return true;
     uint32_t bits;
     memcpy(&bits, &c, 4);
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(bits);
     if (it != cache.end()) return it->second;
-    bool ok = false;
+    if (!have_device) return false;
+    bool done = false, ok = false;
     unsigned long long *d = nullptr, h = 1;
     if (hipMalloc((void **)&d, sizeof h) == hipSuccess) {
         if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
-            hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess)
+            hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            done = true;
             ok = h == 0;
+        }
         (void)hipFree(d);
+    }
+    if (!done) {
+        (void)hipGetLastError();
+        return false;
     }
     cache[bits] = ok;
     return ok;
 }
 
-bool node_divisors_fast(const Node &n) {
+bool node_divisors_fast(const Node &n, bool have_device = true) {
     if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
         if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
-        if (!divisor_is_fast(n.d.params[0])) return false;
-        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f)) return false;
+        if (!divisor_is_fast(n.d.params[0], have_device)) return false;
+        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f, have_device)) return false;
     }
     return true;
 }
@@ -267,10 +285,10 @@ Pref read_pref() {
     return p;
 }
 
-bool stage_fast_div(const dspfx_engine *e, const Stage &st) {
-    if (!divisor_is_fast(e->hop_div)) return false;
+bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device = true) {
+    if (!divisor_is_fast(e->hop_div, have_device)) return false;
     for (int i = 0; i < st.count; ++i)
-        if (!node_divisors_fast(e->nodes[st.first + i])) return false;
+        if (!node_divisors_fast(e->nodes[st.first + i], have_device)) return false;
     return true;
 }
 
@@ -407,7 +425,7 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
 int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]) {
     switch (d.kind) {
     case DSPFX_GAIN: lo[0] = 0.0f; hi[0] = 10.0f; return 1;                                    // gain.rs:14
-    case DSPFX_DISTORT: lo[0] = 0.0f; hi[0] = 30.0f; return d.mode == DSPFX_DIST_FUZZ ? 0 : 1;   // distort.rs:37
+    case DSPFX_DISTORT: lo[0] = 0.0f; hi[0] = 30.0f; return 1;                                 // distort.rs:37 (every mode, Fuzz included: 176-180)
     case DSPFX_OVERDRIVE: lo[0] = 0.0f; hi[0] = 30.0f; lo[1] = 0.0f; hi[1] = 1.0f; lo[2] = 0.0f; hi[2] = 1.0f; return 3;
     case DSPFX_MIX: lo[0] = 0.0f; hi[0] = 1.0f; return 1;                                       // mix.rs:15
     case DSPFX_SIGNAL_GEN: lo[0] = -1.0f; hi[0] = 1.0f; lo[1] = 0.1f; hi[1] = 20000.0f; return 2;   // signal_gen.rs:31-37
@@ -433,7 +451,8 @@ struct GLink {
 };
 
 // The generated translation unit: `struct Prog` with the wiring of nodes [first, first + n) spelled out on register arrays.
-std::string graph_source(const dspfx_engine *e, int first, int n, const std::vector<GLink> &links, bool fast, int (&sigs)[GRAPH_SLOTS]) {
+std::string graph_source(const dspfx_engine *e, int first, int n, const std::vector<GLink> &links, bool fast, int (&sigs)[GRAPH_SLOTS],
+                         bool have_device = true) {
     auto port_links = [&](int dst, int port) {
         std::vector<GLink> v;
         for (const GLink &l : links)
@@ -462,7 +481,7 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
         }
         if (!srcs.empty()) {
             const float div = dspfx_link_divisor(srcs.size());
-            body += std::string(" g_div<") + (divisor_is_fast(div) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
+            body += std::string(" g_div<") + (divisor_is_fast(div, have_device) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
                     hexd(1.0 / (double)div) + ");";
         }
         body += "\n";
@@ -1076,7 +1095,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             }
         } else if (st.type == ST_FUZZ) {
             const Node &n = e->nodes[st.first];
-            FuzzArgs f{src, out, N, nframes, n.d.params[0], e->hop_div, node_hop(e, st.first), lay};
+            FuzzArgs f{src, out, N, nframes, n.d.params[0], e->hop_div, node_hop(e, st.first),
+                       (e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0, n.ctl_now[0], n.latch[0], n.latch_valid & 1, 0, lay};
             ProfScope ps(e, si, stream);
             launch_fuzz(f, stream);
             HIPCHK(e, hipGetLastError());
@@ -1354,7 +1374,10 @@ extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, con
     st.first = 0;
     st.count = n_nodes;
     int sigs[GRAPH_SLOTS];
-    const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st), sigs);
+    tmp.hop_div = dspfx_link_divisor(1);
+    // no device is touched: divisions already proven in this process are written in their exact-product form, all others
+    // in the IEEE form (nothing is verified, nothing is cached)
+    const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st, false), sigs, false);
     if (src.size() + 1 > cap) return DSPFX_ERR_INVALID;
     memcpy(dst, src.c_str(), src.size() + 1);
     return DSPFX_OK;
@@ -1374,7 +1397,17 @@ extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value
         HIPCHK(e, hipSetDevice(e->device));
         HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
     }
-    if (n.d.kind == DSPFX_DISTORT) return plan(e);   // a new divisor: re-verify / re-pick the kernel
+    if (n.d.kind == DSPFX_DISTORT) {
+        // A new clip level is a new constant divisor.  Whether its fast form is exact is decided on the host (see
+        // divisor_is_fast) for everything but the even integers, so a slider store launches nothing and keeps the
+        // kernel it has; only a store that flips the verdict of the node's stage (to or from an even integer that
+        // failed its check) re-plans, and that picks among kernels that already exist.
+        for (const Stage &st : e->stages)
+            if (st.type == ST_FUSED && node >= st.first && node < st.first + st.count) {
+                HIPCHK(e, hipSetDevice(e->device));
+                if (stage_fast_div(e, st) != st.fast_div) return plan(e);
+            }
+    }
     return DSPFX_OK;
 }
 
@@ -1580,15 +1613,14 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
         int n_sliders = 0;
         switch (n.d.kind) {
         case DSPFX_GAIN: n_sliders = 1; break;
-        case DSPFX_DISTORT: n_sliders = n.d.mode == DSPFX_DIST_FUZZ ? 0 : 1; break;
+        case DSPFX_DISTORT: n_sliders = 1; break;   // Fuzz too: distort.rs:176-180 maps the level port before the mode switch
         case DSPFX_OVERDRIVE: n_sliders = 3; break;
         case DSPFX_MIX: n_sliders = 1; break;
         case DSPFX_SIGNAL_GEN: n_sliders = 2; break;
         default: break;
         }
         if (c.param < 0 || c.param >= n_sliders)
-            return fail(e, n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ ? DSPFX_ERR_UNSUPPORTED : DSPFX_ERR_INVALID,
-                        "node %d has no `as_input` slider %d", c.node, c.param);
+            return fail(e, DSPFX_ERR_INVALID, "node %d has no `as_input` slider %d", c.node, c.param);
         if (!n.latch[c.param]) HIPCHK(e, hipMalloc((void **)&n.latch[c.param], (size_t)e->desc.channels * sizeof(float)));
     }
     // split like dspfx_process does, offsetting the control signals with the samples

@@ -173,7 +173,9 @@ int dspfx_chain_len(const dspfx_engine *e);
 
 /* Slider store + `after_settings_change` (dsp-stuff-derive/src/lib.rs:487-492,
  * 560-568): BIQUAD renormalises by a0 and ZEROES its state (biquad.rs:62-76);
- * other kinds just take the value from the next block on. */
+ * other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
+ * exactness of a DISTORT level as a constant divisor is decided on the host; only a level that is an even integer
+ * other than a power of two runs the 2 ms device check, once per value and process). */
 int dspfx_set_param(dspfx_engine *e, int node, int param, float value);
 int dspfx_set_mode(dspfx_engine *e, int node, int mode);
 /* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring. */
@@ -204,7 +206,8 @@ int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *ou
  * drive 1, level 2; MIX ratio 0; SIGNAL_GEN amplitude 0, frequency 1); `signal` is a device buffer in the sample layout.  Per sample the
  * slider takes lo + (hi-lo)*clamp((x+1)/2, 0, 1) over its reference range; the first value of each
  * 128-frame block is latched per channel and keeps applying once the port is disconnected
- * (lib.rs:148-151) until dspfx_set_param overwrites it.  DISTORT/Fuzz does not take a control port. */
+ * (lib.rs:148-151) until dspfx_set_param overwrites it.  Every DISTORT mode takes the port, Fuzz included
+ * (distort.rs:176-180 maps it before the mode switch; fuzz zips it per sample, 154-160). */
 typedef struct dspfx_ctl {
     int32_t node;
     int32_t param;
@@ -334,9 +337,11 @@ int dspfx_sync(dspfx_engine *e, void *stream);
 int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap);
 /* Division by a wave-uniform constant c (the link divisor, SoftClip's 3.0, a clip level)
  * is evaluated as (float)((double)x * (1.0/c)) when that is bit-identical to IEEE f32
- * x / c for EVERY one of the 2^32 possible x; this runs that exhaustive check on the
- * device and returns the number of mismatching inputs (0 => the fast form is exact for
- * c; otherwise the engine keeps IEEE division for c). */
+ * x / c for EVERY one of the 2^32 possible x.  That holds for every c that is not an even
+ * integer (only those have exact ties among their subnormal quotients: csrc/chain_kernels.hip.h,
+ * div_c); the engine takes it for granted there and runs this exhaustive check for even
+ * integers.  The call runs the check on the device for ANY c and returns the number of
+ * mismatching inputs (0 => the fast form is exact for c), so the rule itself is testable. */
 int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches);
 /* The Tanh / Sin / Atan modes (distort.rs:109,117,125; overdrive.rs:38; chebyshev.rs:34,40; signal_gen.rs:64)
  * evaluate in f64 and round once.  The engine's own f64 tanh (func 0) / sin (func 1) / atan (func 2) are cheaper than the math library's; this compares the two

@@ -188,11 +188,11 @@ void orc_fir_set_taps(orc_node *n, const double *taps_reversed, uint32_t n_taps)
     memcpy(n->taps, taps_reversed, sizeof(double) * n_taps);
     n->n_taps = n_taps;
     n->ip[1] = n_taps;
-    /* the reference keeps `state` across tap reloads (fir.rs:64-65 is never cleared);
-     * a fresh node starts with an empty VecDeque. We only (re)start empty here. */
-    free(n->dq);
-    n->dq = NULL;
-    n->dq_cap = n->dq_head = n->dq_len = 0;
+    /* fir.rs:153-171: loading an impulse response replaces `taps` ONLY.  `state` (fir.rs:64-65) is never
+     * cleared, so the deque -- and with it every sample the node has seen -- survives the reload; fir_process
+     * below then pops at most one sample per step (fir.rs:195-197), i.e. a deque longer than the new tap count
+     * STAYS longer and its OLDEST samples pair with the taps (a pure extra delay of len - T samples), and a
+     * shorter one keeps growing front-aligned like the warm-up.  A fresh node starts with an empty deque. */
 }
 
 void orc_node_reset(orc_node *n) {
@@ -340,22 +340,37 @@ static float do_chebyshev(float sample, float level_pos, float level_neg) {
     }
 }
 
-/* fir.rs:192-223 with an explicit model of std VecDeque<f64> (grow-by-doubling
- * from 4, head advances on pop_front) so the a/b slice split is reproduced. */
+/* fir.rs:192-223 with an explicit model of std VecDeque<f64> so the a/b slice split (as_slices, 201-202) is
+ * reproduced: capacity grows by doubling from 4 (RawVec amortised growth, 8-byte elements), push_back writes at
+ * (head + len) % cap, pop_front advances head, and growing a WRAPPED deque moves its shorter part the way
+ * VecDeque::handle_capacity_increase does (std >= 1.67; the reference pins a 2023+ nightly):
+ *   A  head <= old_cap - len (contiguous): nothing moves, head stays;
+ *   B  the wrapped-around front part [0, tail_len) is the shorter one and fits: it is copied behind old_cap;
+ *   C  otherwise the part [head, old_cap) moves to the END of the new buffer and head follows it.
+ * While warming up from empty no pop has happened, so head is 0 and A applies; B / C only arise after a tap
+ * reload with a longer impulse response (orc_fir_set_taps keeps the deque). */
 static void fir_push_back(orc_node *n, double v) {
     if (n->dq_len == n->dq_cap) {
-        uint32_t ncap = n->dq_cap ? n->dq_cap * 2 : 4;
+        const uint32_t old_cap = n->dq_cap;
+        const uint32_t ncap = old_cap ? old_cap * 2 : 4;
         double *nd = (double *)malloc(sizeof(double) * ncap);
-        /* std's grow keeps logical order; a wrapped deque gets its head part
-         * moved to the end of the new allocation or the tail part appended --
-         * either way element order is preserved.  We re-linearise to head=0
-         * only when the deque was contiguous from 0 (always true while
-         * warming up: no pop_front has happened before len reaches n_taps). */
-        for (uint32_t i = 0; i < n->dq_len; i++) nd[i] = n->dq[(n->dq_head + i) % (n->dq_cap ? n->dq_cap : 1)];
+        if (old_cap) memcpy(nd, n->dq, sizeof(double) * old_cap);   /* realloc keeps the old slots in place */
+        if (n->dq_head <= old_cap - n->dq_len) {
+            /* A */
+        } else {
+            const uint32_t head_len = old_cap - n->dq_head;
+            const uint32_t tail_len = n->dq_len - head_len;
+            if (head_len > tail_len && ncap - old_cap >= tail_len) {
+                memcpy(nd + old_cap, nd, sizeof(double) * tail_len);                 /* B */
+            } else {
+                const uint32_t new_head = ncap - head_len;
+                memmove(nd + new_head, nd + n->dq_head, sizeof(double) * head_len);  /* C */
+                n->dq_head = new_head;
+            }
+        }
         free(n->dq);
         n->dq = nd;
         n->dq_cap = ncap;
-        n->dq_head = 0;
     }
     n->dq[(n->dq_head + n->dq_len) % n->dq_cap] = v;
     n->dq_len++;

@@ -107,6 +107,11 @@ class Node:
     def set_param(self, idx, v):
         self.L.orc_node_set_param(self.h, idx, float(v))
 
+    def set_taps(self, taps_reversed):
+        """Impulse-response reload (fir.rs:153-171): new taps, the deque of past samples is KEPT."""
+        t = np.ascontiguousarray(taps_reversed, dtype=np.float64)
+        self.L.orc_fir_set_taps(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), len(t))
+
     def reset(self):
         self.L.orc_node_reset(self.h)
 

@@ -249,13 +249,106 @@ def test_fast_constant_division_is_exhaustively_exact(dspfx, torch_cuda, monkeyp
             ch = [dspfx.Distort(level, mode), dspfx.Gain(1.0)]
             y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
             assert ulp_diff(y, ref).max() == 0, (level, mode)
-    # the forced-IEEE build of the same chain gives the same bits as the fast one
+    # the forced-IEEE form of the same chain gives the same bits as the fast one: DSPFX_FAST_DIV is read when a chain
+    # is planned, so an engine created under it runs the interpreter with every division in its IEEE form
     ch = chain5(dspfx, delay=128)
     y_fast = run_gpu(dspfx, torch_cuda, ch, x, 3)
+    eng = dspfx.Engine(x.shape[1], 128)
+    eng.set_chain(ch)
+    fast_plan = eng.describe()
     monkeypatch.setenv("DSPFX_FAST_DIV", "0")
-    # (the switch is read once per process; a fresh interpreter is needed for a true A/B --
-    #  bench.py does that; here we at least cover subnormal inputs through the default path)
+    eng2 = dspfx.Engine(x.shape[1], 128)
+    eng2.set_chain(ch)
+    assert "dyn" in eng2.describe() and eng2.describe() != fast_plan       # really another kernel: the IEEE interpreter
+    y_ieee = run_gpu(dspfx, torch_cuda, ch, x, 3)
+    monkeypatch.delenv("DSPFX_FAST_DIV")
+    assert np.array_equal(y_fast.view(np.uint32), y_ieee.view(np.uint32))
     assert ulp_diff(y_fast, run_oracle(ch, x, 3)).max() <= 1
+
+
+def test_distort_level_slider_moves_without_replanning(dspfx, torch_cuda):
+    """Whether x / level may take the exact-product form is decided on the host: only even integers can have
+    exact ties among their subnormal quotients.  Any level gives the oracle's bits; a slider store keeps the kernel
+    unless it moves to / from an even integer that failed the exhaustive check."""
+    x = noise_block(128, 128)
+    x[0, :6] = [4.2e-45, -4.2e-45, 1e-44, 3e-39, 1.5e-44, 2.9e-44]
+    failing = [c for c in (6.0, 10.0, 12.0, 14.0) if dspfx.verify_fast_division(c) > 0]
+    for mode in (dspfx.HARD_CLIP, dspfx.SOFT_CLIP):
+        ch = [dspfx.Distort(3.0, mode), dspfx.Gain(1.0)]
+        eng = dspfx.Engine(128, 128)
+        eng.set_chain(ch)
+        plan0 = eng.describe()
+        dx = torch_cuda.from_numpy(x).cuda()
+        for level in (0.37, 30.0 - 2 ** -19, 7.0, 0.0005, 2.5, 1e-3, 4.0, 16.0) + tuple(failing[:1]) + (3.0,):
+            eng.set_param(0, 0, level)
+            assert (eng.describe() == plan0) == (level not in failing), level
+            y = eng.process(dx, out=torch_cuda.empty_like(dx), n_frames=128).cpu().numpy()
+            ref = run_oracle([dspfx.Distort(level, mode), dspfx.Gain(1.0)], x, 3)
+            assert ulp_diff(y, ref).max() == 0, (mode, level)
+
+
+def test_only_even_integers_can_fail_the_division_proof(dspfx, torch_cuda):
+    """The host rule behind the fast constant division: constants that are not even integers never fail the
+    exhaustive 2^32-input check (their subnormal quotients have no exact ties).  Checked on the device for a
+    seeded sample of slider values, link divisors and awkward constants."""
+    rng = np.random.default_rng(2)
+    consts = [float(dspfx.link_divisor(k)) for k in (1, 2, 3, 5, 16)] + [3.0, 5.0, 7.0, 9.0, 15.0, 29.0, 1.5, 2.5, 6.5,
+              0.001, 1e-3 + 1e-9, 30.0 - 2 ** -19, 1.0, 2.0, 4.0, 8.0, 16.0, 0.5, 0.25, 3.0e-5, 12345.678, 2.0 ** 24 + 2]
+    consts += [float(np.float32(v)) for v in rng.uniform(0.001, 30.0, 12)]
+    consts += [float(np.float32(v)) for v in 2.0 ** rng.uniform(-20, 20, 6)]
+    for c in consts:
+        even_int = c >= 2 and (c / 2) == int(c / 2) and (c / 2) < 2 ** 31
+        pow2 = np.frexp(c)[0] == 0.5
+        if even_int and not pow2:
+            continue
+        assert dspfx.verify_fast_division(c) == 0, c
+
+
+def test_fuzz_level_control_port(dspfx, torch_cuda):
+    """The reference maps the level port for EVERY distort mode before the mode switch (distort.rs:176-180) and fuzz
+    zips it per sample (154-160): a connected port modulates the level per sample, latches the first value of each
+    128-frame block per channel, and the latch keeps applying after the port is disconnected."""
+    N, B, blocks = 96, 128, 5
+    x = noise_block(N, B * blocks)
+    sig = (noise_block(N, B * blocks, seed=31) * F(1.4)).astype(F)          # exceeds [-1, 1]: exercises the clamp
+    for lf, tile in ((3, 0), (0, 0), (3, 64)):
+        Nn = N if not tile else 128
+        xx, ss = (x[:, :Nn], sig[:, :Nn]) if Nn <= N else (noise_block(Nn, B * blocks), (noise_block(Nn, B * blocks, seed=31) * F(1.4)).astype(F))
+        chain = [dspfx.Gain(0.9), dspfx.Distort(3.0, dspfx.FUZZ), dspfx.BiQuad()]
+        eng = dspfx.Engine(Nn, B, link_flags=lf, tile_channels=tile)
+        eng.set_chain(chain)
+        descs = [n.oracle_desc() for n in chain]
+        nodes = []
+        got, ref = np.empty_like(xx), np.empty_like(xx)
+
+        def run(b, connected):
+            sl = slice(b * B, (b + 1) * B)
+            dx = torch_cuda.from_numpy(dspfx.to_layout(xx[sl], tile)).cuda()
+            dc = torch_cuda.from_numpy(dspfx.to_layout(ss[sl], tile)).cuda()
+            dy = torch_cuda.empty_like(dx)
+            eng.process(dx, out=dy, n_frames=B, ctl={(1, 0): dc} if connected else None)
+            torch_cuda.cuda.synchronize()
+            got[sl] = dspfx.from_layout(dy.cpu().numpy(), B, Nn, tile)
+            ref[sl] = O.run_channels(descs, xx[sl], lf, ctl={(1, 0): ss[sl]} if connected else None, nodes_out=nodes)
+
+        run(0, True)
+        run(1, True)
+        run(2, False)                      # disconnected: the per-channel latched levels apply
+        eng.set_param(1, 0, 2.5)           # a slider store overwrites the latch
+        for chn in nodes:
+            chn[1].set_param(0, 2.5)
+        run(3, False)
+        run(4, True)
+        # a channel whose latched level is 0 (its control signal was <= -1 at the block's first sample) goes silent
+        # inside fuzz in block 2: 0/0 = NaN like the reference, and the biquad behind it keeps the NaN
+        nan = np.isnan(ref)
+        assert np.array_equal(np.isnan(got), nan) and 0 < nan.mean() < 0.5
+        fin = ~nan
+        assert np.abs(got[fin] - ref[fin]).max() <= 4e-6 * np.abs(ref[fin]).max(), (lf, tile, np.abs(got[fin] - ref[fin]).max())
+        assert (ulp_diff(got[fin], ref[fin]) > 4).mean() < 0.02
+        # the modulation really matters: a constant level gives something else
+        const = run_oracle(chain, xx[:B], lf)
+        assert np.abs(const - ref[:B]).max() > 1e-3
 
 
 def test_control_ports(dspfx, torch_cuda):

@@ -36,8 +36,12 @@ def main():
             start = None
     out = {"trace": sys.argv[1], "regions": []}
     names = ["cfg5", "cfg3", "cfg2", "cfg4"]
-    for k, (a, b) in enumerate(regions):
+    k = -1
+    for (a, b) in regions:
         inner = rows[a + 1:b]
+        if not inner:            # the markers' own warm-up at start-up
+            continue
+        k += 1
         cnt = collections.Counter(r["Kernel_Name"] for r in inner)
         tot = collections.Counter()
         for r in inner:
