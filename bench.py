@@ -218,7 +218,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
     bus_world = 2 if (ctx.use_dist and world == 1) else world          # forced-dist: take the collective path
     bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
-    pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev)
+    pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
+                              comm=ctx.comm)
             if (use_mix and dist_run and mix_mode == "pipe") else None)
     pipe_fill = [0]
 
@@ -410,6 +411,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
+                   "collective": (None if not dist_run else "dspfx_mix_allreduce (RCCL behind the C ABI)" if ctx.comm is not None
+                                  else "torch.distributed all_reduce"),
                    "placement_probe": probe_log, "placement_tuning": tune_log,
                    "settle": {"steps": settle_steps, "ms_per_step": round(settle_ms, 4)},
                    "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
@@ -464,9 +467,20 @@ def main():
     # >= 10 ms is followed by ~40 slow launches (profiles/r02_idle_transient.txt)
     ctx.mark.sin_()
     ctx.mark.cos_()
+    ctx.comm = None
     if ctx.use_dist:
         dist.barrier()
         dist.all_reduce(ctx.mark)
+        # The mix bus' own communicator, behind the C ABI (dspfx_comm_create / dspfx_mix_allreduce: what a Rust or C++
+        # host calls): rank 0 makes the id, torch.distributed only carries the 128 bytes to the other ranks.
+        # DSPFX_BENCH_COMM=torch keeps torch.distributed's all_reduce instead (A/B).
+        if os.environ.get("DSPFX_BENCH_COMM", "abi") == "abi":
+            idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.comm = ctx.pkg.Comm(ctx.local_rank, world, rank, bytes(idt.cpu().tolist()))
+            dist.barrier()
     torch.cuda.synchronize()
 
     over = {k: getattr(args, k) for k in ("channels", "frames", "delay", "taps") if getattr(args, k) is not None}

@@ -50,7 +50,10 @@ EXPORTS = [
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
+    "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
+    "dspfx_comm_last_error", "dspfx_mix_allreduce",
 ]
+COMM_ID_BYTES = 128
 
 
 class DspfxError(RuntimeError):
@@ -146,6 +149,15 @@ def lib():
     L.dspfx_verify_libm.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.dspfx_profile_enable.argtypes = [vp, C.c_int]
     L.dspfx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.c_int]
+    L.dspfx_comm_unique_id.argtypes = [vp]
+    L.dspfx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.dspfx_comm_destroy.argtypes = [vp]
+    L.dspfx_comm_destroy.restype = None
+    L.dspfx_comm_size.argtypes = [vp]
+    L.dspfx_comm_rank.argtypes = [vp]
+    L.dspfx_comm_last_error.argtypes = [vp]
+    L.dspfx_comm_last_error.restype = C.c_char_p
+    L.dspfx_mix_allreduce.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_algorithmic_bytes_per_sample.restype = C.c_double
     L.dspfx_algorithmic_bytes_per_sample.argtypes = [vp, C.c_uint32]
     _lib = L
@@ -459,6 +471,12 @@ class Engine:
         self._chk(self.L.dspfx_mix_finish(self.h, _ptr(mix), int(n_frames), int(n_connected),
                                           C.c_void_p(stream) if stream else None))
 
+    def mix_allreduce(self, comm: "Comm", mix, n_frames: int, n_connected: int = 0, stream: int = 0):
+        """Sum this rank's un-normalised bus over the communicator's ranks (ONE RCCL all-reduce of n_frames floats, in
+        place, asynchronous on `stream`), then the Output hop with the global channel count when n_connected != 0."""
+        self._chk(self.L.dspfx_mix_allreduce(self.h, comm.h, _ptr(mix), int(n_frames), int(n_connected),
+                                             C.c_void_p(stream) if stream else None))
+
     def tune_placement(self, x, out, n_frames: int, side=None, stream: int = 0):
         """Re-tune the delay rings' placement with the real chain kernels on the caller's buffers (resets DSP state)."""
         self._chk(self.L.dspfx_tune_placement(self.h, _ptr(x), _ptr(side), _ptr(out), int(n_frames),
@@ -518,6 +536,41 @@ class Engine:
 
     def algorithmic_bytes_per_sample(self, n_frames: int) -> float:
         return float(self.L.dspfx_algorithmic_bytes_per_sample(self.h, int(n_frames)))
+
+
+def comm_unique_id() -> bytes:
+    """The 128-byte id rank 0 creates and hands to every rank (dspfx_comm_unique_id)."""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    rc = lib().dspfx_comm_unique_id(buf)
+    if rc != 0:
+        raise DspfxError(rc, lib().dspfx_comm_last_error(None).decode() or lib().dspfx_strerror(rc).decode())
+    return buf.raw
+
+
+class Comm:
+    """The mix bus' communicator: one per process / GPU (include/dspfx.h, dspfx_comm_create).  `uid` = the bytes of
+    comm_unique_id() from rank 0 (may be None for a single rank: then no RCCL communicator is created)."""
+
+    def __init__(self, device: int, n_ranks: int, rank: int, uid: Optional[bytes] = None):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.n_ranks, self.rank = int(n_ranks), int(rank)
+        rc = self.L.dspfx_comm_create(int(device), int(n_ranks), int(rank), uid, C.byref(self.h))
+        if rc != 0:
+            self.h = C.c_void_p()
+            raise DspfxError(rc, self.L.dspfx_comm_last_error(None).decode() or self.L.dspfx_strerror(rc).decode())
+
+    def close(self):
+        h = getattr(self, "h", None)
+        if h is not None and h.value:
+            self.L.dspfx_comm_destroy(h)
+            h.value = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def graph_source(nodes: Sequence[NodeSpec], links: Sequence[Tuple[int, int, int]]) -> str:

@@ -190,7 +190,10 @@ def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpa
     if not (chain and chain[0].kind == SIGNAL_GEN):
         in_id, in_port = nid(), nid()
         nodes.append({"id": in_id, "typename": "input", "position": [0.0, 0.0],
-                      "cfg": {"id": in_id, "inputs": {}, "outputs": {"out": in_port}}})
+                      # InputConfig (nodes/input.rs:32-38): id, selected_host, selected_device, outputs -- restore()
+                      # unwraps the deserialisation, so every field must be there; an unknown host name simply
+                      # opens no device (input.rs:197-204).  "ALSA" is cpal's default host on Linux.
+                      "cfg": {"id": in_id, "selected_host": "ALSA", "selected_device": None, "outputs": {"out": in_port}}})
         prev = (in_id, in_port)
     for k, n in enumerate(chain):
         tn = _KIND_TO_TYPENAME[n.kind]
@@ -225,6 +228,7 @@ def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpa
         prev = (node_id, outs["out"])
     out_id, out_port = nid(), nid()
     nodes.append({"id": out_id, "typename": "output", "position": [120.0 * (len(chain) + 1), 0.0],
-                  "cfg": {"id": out_id, "inputs": {"in": out_port}, "outputs": {}}})
+                  # OutputConfig (nodes/output.rs:32-38): id, selected_host, selected_device, inputs
+                  "cfg": {"id": out_id, "selected_host": "ALSA", "selected_device": None, "inputs": {"in": out_port}}})
     links.append({"lhs": list(prev), "rhs": [out_id, out_port]})
     return json.dumps({"nodes": nodes, "links": links})

@@ -1136,6 +1136,86 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 #undef DSPFX_ST
 }
 
+// ---- the fused chain kernel, time-sliced: few channels ------------------------------------------------
+// With <= 2 waves per SIMD (N <= 131072 at one channel per lane) nothing hides a wave's memory and instruction
+// latency: the 65536-channel 3-node chain ran at 0.49 of the HBM peak (profiles/r01_small_n.txt).  Here a workgroup
+// owns 64*CPL channels and its four waves each take S = 32 of the block's 128 frames: every wave issues ALL its loads
+// (samples and delay taps) at once, the four waves then compute one after the other -- wave q starts from the state
+// wave q-1 left in LDS, so every recurrence sees its frames in order, bit for bit as in chain_kernel -- and each
+// wave's stores trail its own compute.  Four times the waves per SIMD, the same arithmetic.
+template <int S, int CPL, class SL>
+__global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
+    __shared__ float lds_st[MAX_SLOTS][4][CPL][64];
+    if (a.mp_stage) mixpipe_prologue(a);
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
+    const unsigned group = work_block(a.xcd_remap);                        // channel group of 64*CPL channels
+    const unsigned wave_global = a.wave_base + group;
+    const size_t rel = ((size_t)group * 64 + lane) * CPL;
+    if (rel >= a.n_launch) return;                 // uniform over the whole workgroup: no barrier is left waiting
+    const size_t c = a.c_base + rel;
+    const WaveAddr w = wave_addr(a, c);
+    const unsigned f_begin = (unsigned)q * S;
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    float v[S][CPL];
+#pragma unroll
+    for (int f = 0; f < S; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+    // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
+#define DSPFX_TAPS(I)                                                                                            \
+    float tap##I[sig_is<K_REVERB>(SL::v[I]) ? S : 1][CPL];                                                       \
+    if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
+        _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
+            load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, f), cx.ring_off), tap##I[f], true);  \
+    }
+    DSPFX_FOR_SLOTS(DSPFX_TAPS)
+#undef DSPFX_TAPS
+    float st[MAX_SLOTS][4][CPL];
+#pragma unroll 1
+    for (int turn = 0; turn < 4; ++turn) {
+        if (q == turn) {
+#define DSPFX_LDST(I)                                                                                            \
+    if (turn == 0) load_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);                             \
+    else {                                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                            \
+            _Pragma("unroll") for (int j = 0; j < CPL; ++j)                                                      \
+                st[I][k][j] = k < slot_nstate<SL::v[I]>(a.slot[I]) ? lds_st[I][k][j][lane] : 0.0f;               \
+    }
+            DSPFX_FOR_SLOTS(DSPFX_LDST)
+#undef DSPFX_LDST
+#define DSPFX_RUN(I)                                                                                             \
+    if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
+        if constexpr (sig_hop(SL::v[I])) apply_hop<S, CPL, true>(v, cx.hop_div, cx.hop_rc);                      \
+        const float decay = a.slot[I].p[0];                                                                      \
+        _Pragma("unroll") for (int f = 0; f < S; ++f) {                                                          \
+            _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
+            store_vec<CPL, false, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, f), cx.ring_off), v[f], true);     \
+        }                                                                                                        \
+    } else {                                                                                                     \
+        run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, st[I], cx);                                 \
+    }
+            DSPFX_FOR_SLOTS(DSPFX_RUN)
+#undef DSPFX_RUN
+#define DSPFX_STST(I)                                                                                            \
+    if (turn == 3) {                                                                                             \
+        if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes);  \
+        store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);                                       \
+    } else {                                                                                                     \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                            \
+            if (k < slot_nstate<SL::v[I]>(a.slot[I])) {                                                          \
+                _Pragma("unroll") for (int j = 0; j < CPL; ++j) lds_st[I][k][j][lane] = st[I][k][j];             \
+            }                                                                                                    \
+    }
+            DSPFX_FOR_SLOTS(DSPFX_STST)
+#undef DSPFX_STST
+#pragma unroll
+            for (int f = 0; f < S; ++f)
+                if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+            if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- the fused chain kernel, interpreting any chain ----------------------------------
 // One lane = one channel.  The node loop runs at run time (wave-uniform scalar
 // branches); per-node filter state is staged in LDS ([row][lane], conflict-free)

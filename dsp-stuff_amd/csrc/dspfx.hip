@@ -59,6 +59,7 @@ struct Stage {
     StageType type;
     int first, count;
     const Variant *var = nullptr;   // ST_FUSED
+    const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
     mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
     mutable bool var_mod_tried = false;
     bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
@@ -593,7 +594,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     const Variant *best = nullptr;
     int best_score = -1;
     for (const Variant *v : all) {
-        if (v->guard || v->mod) continue;
+        if (v->guard || v->mod || v->ts) continue;
         const bool is_dyn = v->sigs[0] == SIG_DYN;
         if (is_dyn) {
             bool need = false;
@@ -635,6 +636,33 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
     // no compiled-in specialisation: instantiate one at run time (large engines, or DSPFX_JIT=1)
     if (best && best->sigs[0] == SIG_DYN && pref.stat != 0)
         if (const Variant *j = jit_variant(e, st, false)) return j;
+    return best;
+}
+
+// Few channels (at most two waves per SIMD at one channel per lane): the time-sliced kernel of the same chain shape, if the
+// library has one.  DSPFX_VARIANT="ts=0" switches it off, "ts=1" forces it at any size (A/B runs).
+const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    int want = -1;
+    if (const char *sv = getenv("DSPFX_VARIANT"))
+        if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
+    if (want == 0 || (want < 0 && N > 131072u) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    const Pref pref = read_pref();
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    const Variant *best = nullptr;
+    for (const Variant *v : all) {
+        if (!v->ts || v->n_slots != st.count || N < 64u * (unsigned)v->cpl || N % (unsigned)v->cpl) continue;
+        bool ok = true;
+        for (int i = 0; i < st.count && ok; ++i) {
+            const Node &n = e->nodes[st.first + i];
+            const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+            ok = v->sigs[i] == sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+        }
+        if (!ok) continue;
+        const int want_cpl = pref.cpl > 0 ? pref.cpl : 1;
+        if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
+    }
     return best;
 }
 
@@ -709,6 +737,7 @@ int plan(dspfx_engine *e) {
             if (!st.var)
                 return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
                                                                     : "no kernel variant for stage");
+            st.var_ts = e->graph_mode ? nullptr : pick_ts_variant(e, st);
         }
     for (const Node &nd : e->nodes) {
         if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
@@ -1027,6 +1056,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     tail = e->tail_mod;
                 }
             }
+            // few channels, a whole 128-frame block, no control ports in play: four time slices per channel group
+            if (st.var_ts && v == st.var && nframes == 4u * (uint32_t)st.var_ts->ts) v = st.var_ts;
             const uint32_t per_wave = 64u * v->cpl;
             const uint32_t n_main = N - N % per_wave;
             const uint32_t waves_main = n_main / per_wave;
@@ -1034,7 +1065,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
             a.mix_stride = waves_main + (N - n_main + 63) / 64;
             if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
-            const unsigned grid_main = (waves_main * 64 + WG - 1) / WG;
+            const unsigned grid_main = v->ts ? waves_main : (waves_main * 64 + WG - 1) / WG;   // time-sliced: one workgroup per channel group
             if (e->mp_building && last) {   // pipelined mix bus: earlier blocks' reductions ride in this launch
                 const int cur = (int)(e->mp_count & 1), prev = cur ^ 1;
                 a.mixpart = e->mixpart2[cur];
@@ -1065,7 +1096,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     a.n_launch = w1 - w0;
                     a.wave_base = w0 / per_wave;
                     ProfScope ps(e, si, stream);
-                    if (launch_variant(v, a, ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream))
+                    if (launch_variant(v, a, v->ts ? (w1 - w0) / per_wave : ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream))
                         return fail(e, DSPFX_ERR_HIP, "kernel launch failed");
                 }
             } else if (n_main) {
@@ -1449,7 +1480,10 @@ extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reve
     n.taps.assign(taps_reversed, taps_reversed + n_taps);
     n.d.n_taps = n_taps;
     n.d.mode = mode;
-    return alloc_node_state(e, n);
+    if (!n.fir.ring) return alloc_node_state(e, n);
+    // fir.rs:153-171 replaces `taps` only: `state` (fir.rs:64-65) is never cleared, so the history survives
+    const int rc = fir_set_taps(n.fir, n.taps.data(), n_taps, mode);
+    return rc ? fail(e, rc, "FIR tap reload failed: %s", fir_last_error()) : DSPFX_OK;
 }
 
 extern "C" int dspfx_reset(dspfx_engine *e) {
@@ -1471,6 +1505,51 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
 // Placement tuning against the caller's own buffers (see include/dspfx.h).  Every candidate 128-row group of every
 // large delay ring is timed with the REAL chain (all stages, the engine's chosen kernels) reading `in` and writing
 // `out`: the node temporarily becomes a 128-row ring made of that one group.  The fastest groups are kept.
+// The engine's DSP state survives: filter / generator state is snapshotted and restored around the probes, every ring
+// group's rows are parked in a scratch group while it is probed and put back (or moved into the candidate that
+// replaces it, at the same ring position), the ring position is untouched.  (Engines with a FIR node still reset:
+// its history cannot be parked that cheaply.)
+namespace {
+struct TuneGuard {   // whatever happens inside the probe loop, the node gets its real ring geometry back and nothing leaks
+    dspfx_engine *e;
+    Node *n = nullptr;
+    uint32_t D0 = 0, pos0 = 0, min0 = 0;
+    float **table0 = nullptr, **d_one = nullptr;
+    float *park = nullptr;
+    hipEvent_t ea = nullptr, eb = nullptr;
+    std::vector<float *> extras;            // candidates allocated here and not (yet) adopted by the ring
+    std::vector<std::pair<float *, size_t>> snaps;   // device copies of node state: (copy, node index)
+    explicit TuneGuard(dspfx_engine *e_) : e(e_) {}
+    void arm(Node &node) {
+        n = &node;
+        D0 = node.D;
+        pos0 = node.pos;
+        min0 = e->min_delay;
+        table0 = node.d_groups;
+    }
+    void disarm() {
+        if (!n) return;
+        n->D = D0;
+        n->pos = pos0;
+        n->d_groups = table0;
+        e->min_delay = min0;
+        n = nullptr;
+    }
+    ~TuneGuard() {
+        disarm();
+        for (float *g : extras)
+            if (g) (void)hipFree(g);
+        for (auto &sn : snaps)
+            if (sn.first) (void)hipFree(sn.first);
+        if (d_one) (void)hipFree(d_one);
+        if (park) (void)hipFree(park);
+        if (ea) (void)hipEventDestroy(ea);
+        if (eb) (void)hipEventDestroy(eb);
+        (void)hipGetLastError();
+    }
+};
+}  // namespace
+
 extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                                     void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
@@ -1480,9 +1559,26 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
     if (e->collect_due || e->mp_count) return fail(e, DSPFX_ERR_STATE, "flush the mix pipeline before tuning");
     HIPCHK(e, hipSetDevice(e->device));
     hipStream_t s = (hipStream_t)stream;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    HIPCHK(e, hipEventCreate(&ea));
-    HIPCHK(e, hipEventCreate(&eb));
+    bool has_fir = false, any = false;
+    for (const Node &n : e->nodes) {
+        has_fir = has_fir || n.d.kind == DSPFX_FIR;
+        any = any || (n.d.kind == DSPFX_REVERB && n.group_floats * sizeof(float) >= ((size_t)64 << 20));
+    }
+    if (!any) return DSPFX_OK;               // nothing large enough to be placement-sensitive: state untouched
+    TuneGuard tg(e);
+    if (hipEventCreate(&tg.ea) != hipSuccess || hipEventCreate(&tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventCreate failed");
+    // snapshot the small per-channel state (biquad / one-pole / generator / envelope rows): the probes run the real chain
+    if (!has_fir) {
+        HIPCHK(e, hipStreamSynchronize(s));
+        for (size_t i = 0; i < e->nodes.size(); ++i) {
+            Node &n = e->nodes[i];
+            if (!n.state || !n.state_bytes || n.d.kind == DSPFX_REVERB) continue;
+            float *copy = nullptr;
+            if (hipMalloc((void **)&copy, n.state_bytes) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "no room for a state snapshot");
+            tg.snaps.emplace_back(copy, i);
+            if (hipMemcpyAsync(copy, n.state, n.state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "state snapshot failed");
+        }
+    }
     int rc = DSPFX_OK;
     const size_t tile_frames = e->desc.max_frames;   // the buffers are laid out like a full block of the engine
     for (Node &n : e->nodes) {
@@ -1491,49 +1587,49 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         if (gbytes < ((size_t)64 << 20)) continue;
         const size_t G = n.groups.size();
         size_t free_b = 0, total_b = 0;
-        HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
-        const size_t reserve = (size_t)8 << 30;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipMemGetInfo failed");
+        const size_t reserve = ((size_t)8 << 30) + gbytes;             // room for the caller + the parking group
         size_t extra = free_b > reserve ? std::min(G, (free_b - reserve) / gbytes) : 0;
+        if (!tg.park && !has_fir && big_alloc((void **)&tg.park, gbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return fail(e, DSPFX_ERR_OOM, "no room to park a ring group (%zu MiB)", gbytes >> 20);
+        }
         std::vector<float *> cand = n.groups;
         for (size_t k = 0; k < extra; ++k) {
             float *g = nullptr;
-            if (big_alloc((void **)&g, gbytes) != hipSuccess) break;
-            if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); break; }
+            if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); (void)hipGetLastError(); break; }
             cand.push_back(g);
+            tg.extras.push_back(g);
         }
-        // the node as a one-group ring
-        const uint32_t D0 = n.D, pos0 = n.pos, min0 = e->min_delay;
-        float **table0 = n.d_groups;
-        float **d_one = nullptr;
-        HIPCHK(e, hipMalloc((void **)&d_one, sizeof(float *)));
+        if (!tg.d_one && hipMalloc((void **)&tg.d_one, sizeof(float *)) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "hipMalloc failed");
+        // the node as a one-group ring (the guard puts the real geometry back on every exit path)
+        tg.arm(n);
         n.D = RING_GROUP_ROWS;
-        n.d_groups = d_one;
+        n.d_groups = tg.d_one;
         std::vector<float> t(cand.size(), 0.0f);
         for (size_t g = 0; g < cand.size() && rc == DSPFX_OK; ++g) {
-            HIPCHK(e, hipMemcpyAsync(d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s));
+            const bool live = g < G && !has_fir;        // holds ring rows that must survive
+            if (live && hipMemcpyAsync(tg.park, cand[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
+            if (rc == DSPFX_OK && hipMemcpyAsync(tg.d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
             float best = 1e30f;
             for (int rep = 0; rep < 3 && rc == DSPFX_OK; ++rep) {
                 n.pos = 0;
-                (void)hipEventRecord(ea, s);
+                (void)hipEventRecord(tg.ea, s);
                 rc = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
-                (void)hipEventRecord(eb, s);
+                (void)hipEventRecord(tg.eb, s);
                 if (rc) break;
-                HIPCHK(e, hipEventSynchronize(eb));
+                if (hipEventSynchronize(tg.eb) != hipSuccess) { rc = fail(e, DSPFX_ERR_HIP, "hipEventSynchronize failed"); break; }
                 float ms = 0.0f;
-                (void)hipEventElapsedTime(&ms, ea, eb);
+                (void)hipEventElapsedTime(&ms, tg.ea, tg.eb);
                 if (rep) best = std::min(best, ms);
             }
             t[g] = best;
+            if (live && rc == DSPFX_OK && hipMemcpyAsync(cand[g], tg.park, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
+                rc = fail(e, DSPFX_ERR_HIP, "restoring a ring group failed");
         }
-        n.D = D0;
-        n.pos = pos0;
-        n.d_groups = table0;
-        e->min_delay = min0;
-        (void)hipFree(d_one);
-        if (rc) {
-            for (size_t i = G; i < cand.size(); ++i) (void)hipFree(cand[i]);
-            break;
-        }
+        tg.disarm();
+        if (rc) return rc;
         if (getenv("DSPFX_RING_TUNE_DEBUG")) {
             fprintf(stderr, "placement tuning ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
             for (float v : t) fprintf(stderr, " %.3f", v);
@@ -1544,24 +1640,34 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
         std::vector<char> keep(cand.size(), 0);
         for (size_t i = 0; i < G; ++i) keep[order[i]] = 1;
-        std::vector<float *> chosen;
+        // ring position p keeps its rows: a dropped group's rows move into the kept extra that takes its place
+        std::vector<size_t> spare;
+        for (size_t i = G; i < cand.size(); ++i)
+            if (keep[i]) spare.push_back(i);
         int replaced = 0;
-        for (size_t i = 0; i < cand.size(); ++i) {
-            if (keep[i]) {
-                chosen.push_back(cand[i]);
-                if (i >= G) ++replaced;
-            } else {
-                (void)hipFree(cand[i]);
-            }
+        size_t next_spare = 0;
+        for (size_t p = 0; p < G; ++p) {
+            if (keep[p]) continue;
+            const size_t x = spare[next_spare++];
+            if (!has_fir && hipMemcpyAsync(cand[x], cand[p], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "moving a ring group failed");
+            std::swap(cand[p], cand[x]);              // cand[p] is the ring's group now, cand[x] the dropped allocation
+            ++replaced;
         }
-        n.groups = chosen;
+        HIPCHK(e, hipStreamSynchronize(s));
+        for (size_t i = G; i < cand.size(); ++i) (void)hipFree(cand[i]);      // dropped originals and unused extras
+        tg.extras.clear();
+        cand.resize(G);
+        n.groups = cand;
         n.ring_replaced = replaced;
         HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
     }
-    (void)hipEventDestroy(ea);
-    (void)hipEventDestroy(eb);
-    if (rc) return rc;
-    return dspfx_reset(e);   // probing ran garbage through the filters and the rings
+    if (has_fir) return dspfx_reset(e);   // probing ran blocks through the FIR history: start clean
+    for (auto &sn : tg.snaps) {
+        Node &n = e->nodes[sn.second];
+        if (hipMemcpyAsync(n.state, sn.first, n.state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "restoring node state failed");
+    }
+    HIPCHK(e, hipStreamSynchronize(s));
+    return DSPFX_OK;
 }
 
 extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
@@ -1874,6 +1980,130 @@ extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, 
     return DSPFX_OK;
 }
 
+// ------------------------------------------------------- the mix bus across GPUs
+// RCCL through dlopen: the library must load (and every single-GPU entry point work) where RCCL is absent, and in a
+// process that already maps a copy of RCCL (PyTorch ships its own) the collective must use THAT copy and the HIP
+// runtime it is bound to -- two RCCLs over one runtime is asking for trouble.
+namespace {
+struct IdBlob {               // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
+    char bytes[DSPFX_COMM_ID_BYTES];
+};
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, IdBlob, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+};
+Rccl *rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names)                         // a copy already in the process wins
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (const char *p = getenv("DSPFX_RCCL_LIB"))
+            if (!r.lib) r.lib = dlopen(p, RTLD_NOW);
+        for (const char *n : names)
+            if (!r.lib) r.lib = dlopen(n, RTLD_NOW);
+        if (!r.lib) {
+            r.err = "RCCL not found (librccl.so / librccl.so.1; DSPFX_RCCL_LIB overrides)";
+            return;
+        }
+        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
+        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
+        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
+        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
+        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
+        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
+            r.err = "RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+            r.lib = nullptr;
+        }
+    });
+    return &r;
+}
+constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // rccl.h: ncclFloat32 / ncclSum
+}  // namespace
+
+struct dspfx_comm {
+    void *comm = nullptr;     // ncclComm_t; null for a single rank
+    int n_ranks = 1, rank = 0, device = 0;
+    std::string err;
+};
+
+extern "C" int dspfx_comm_unique_id(void *id_out) {
+    if (!id_out) return DSPFX_ERR_INVALID;
+    Rccl *r = rccl();
+    if (!r->lib) return DSPFX_ERR_UNSUPPORTED;
+    static_assert(sizeof(IdBlob) == DSPFX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    return r->GetUniqueId(id_out) == 0 ? DSPFX_OK : DSPFX_ERR_HIP;
+}
+
+extern "C" int dspfx_comm_create(int device, int n_ranks, int rank, const void *id, dspfx_comm **out) {
+    if (!out) return DSPFX_ERR_INVALID;
+    *out = nullptr;
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !id)) return DSPFX_ERR_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
+    if (device < 0 || device >= ndev) return DSPFX_ERR_INVALID;
+    dspfx_comm *c = new dspfx_comm();
+    c->n_ranks = n_ranks;
+    c->rank = rank;
+    c->device = device;
+    if (n_ranks > 1 || id) {                 // with an id even one rank gets a real communicator (exercises the RCCL path)
+        Rccl *r = rccl();
+        if (!r->lib) {
+            delete c;
+            return DSPFX_ERR_UNSUPPORTED;
+        }
+        if (hipSetDevice(device) != hipSuccess) {
+            delete c;
+            return DSPFX_ERR_HIP;
+        }
+        IdBlob blob;
+        memcpy(blob.bytes, id, sizeof blob.bytes);
+        const int rc = r->CommInitRank(&c->comm, n_ranks, blob, rank);
+        if (rc != 0) {
+            delete c;
+            return DSPFX_ERR_HIP;
+        }
+    }
+    *out = c;
+    return DSPFX_OK;
+}
+
+extern "C" void dspfx_comm_destroy(dspfx_comm *c) {
+    if (!c) return;
+    if (c->comm) {
+        (void)hipSetDevice(c->device);
+        (void)rccl()->CommDestroy(c->comm);
+    }
+    delete c;
+}
+
+extern "C" int dspfx_comm_size(const dspfx_comm *c) { return c ? c->n_ranks : DSPFX_ERR_INVALID; }
+extern "C" int dspfx_comm_rank(const dspfx_comm *c) { return c ? c->rank : DSPFX_ERR_INVALID; }
+extern "C" const char *dspfx_comm_last_error(const dspfx_comm *c) { return c ? c->err.c_str() : rccl()->err.c_str(); }
+
+extern "C" int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, uint32_t n_frames, uint64_t n_connected,
+                                   void *stream) {
+    if (!e || !c || !mix) return DSPFX_ERR_INVALID;
+    if (n_frames == 0) return DSPFX_OK;
+    if (c->device != e->device) return fail(e, DSPFX_ERR_INVALID, "communicator lives on device %d, engine on %d", c->device, e->device);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (c->comm) {   // nodes/output.rs:215-249 + node.rs:181-183 across the shards: ONE all-reduce of n_frames floats
+        const int rc = rccl()->AllReduce(mix, mix, n_frames, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream);
+        if (rc != 0) {
+            c->err = rccl()->GetErrorString ? rccl()->GetErrorString(rc) : "ncclAllReduce failed";
+            return fail(e, DSPFX_ERR_HIP, "ncclAllReduce: %s", c->err.c_str());
+        }
+    }
+    if (n_connected) return dspfx_mix_finish(e, mix, n_frames, n_connected, stream);   // node.rs:189-191 with the GLOBAL count
+    return DSPFX_OK;
+}
+
 // -------------------------------------------------------------------- state
 
 extern "C" int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
@@ -2116,6 +2346,10 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
             s += buf;
             if (st.var && !st.var->launch) {   // compiled at run time: say what the compiler allocated
                 snprintf(buf, sizeof buf, ", %d VGPRs", reinterpret_cast<const JitKernel *>(st.var)->vgprs);
+                s += buf;
+            }
+            if (st.var_ts) {
+                snprintf(buf, sizeof buf, "; %d-frame blocks: time-sliced %s", 4 * st.var_ts->ts, st.var_ts->name);
                 s += buf;
             }
             s += "):";

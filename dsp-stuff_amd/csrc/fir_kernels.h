@@ -1,18 +1,24 @@
 // fir_kernels.h -- FIR convolution stage (nodes/fir.rs:179-225) over N channels.
 //
-// History lives in HBM as a ring of R = T-1+max_frames rows, f32 (the reference widens
-// f32 samples to f64, so f32 storage is exact), tiled by 32 channels:
+// History lives in HBM as a ring of R rows, f32 (the reference widens f32 samples to f64, so f32 storage
+// is exact), tiled by 32 channels:
 //     ring[(c / 32) * R + (t mod R)][c % 32]
-// so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous
-// HBM stream of 128-byte rows.  A block first appends its own samples, then every
-// output is a dot product over the T most recent rows:
-//   - fir_mfma_kernel : out^T[B x 32ch] = W[B x K] * H[K x 32ch] on v_mfma_f32_32x32x2_f32
-//     (exact f32 FMA chain, flushed into a second accumulator every 512 terms); W is the
-//     Toeplitz matrix of the taps, generated on the fly from a zero-padded table in LDS;
-//   - fir_exact_kernel: sequential f64 accumulation, bit-faithful to the reference's
-//     arithmetic (small T, cross-checks).  The reference's warm-up quirk (fir.rs:193-214: while the
-// VecDeque holds L < T samples, state[k] pairs with taps[k]) is reproduced by the
-// index map  w(m, n) = taps_rev[m - max(0, n-T+1)]  for max(0, n-T+1) <= m <= n.
+// so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous HBM stream of 128-byte
+// rows.  Every output is a dot product over the samples the reference's VecDeque holds at that step:
+//   - fir_mfma_kernel : out^T[B x 32ch] = W[B x K] * H[K x 32ch] on v_mfma_f32_32x32x2_f32 (exact f32 FMA
+//     chain, flushed into a second accumulator every 512 terms); W is the Toeplitz matrix of the taps,
+//     generated on the fly from a zero-padded table in LDS.  In steady state the kernel also APPENDS the block:
+//     the newest B rows of its K sweep come straight from the caller's `in` (hop applied) and are written to
+//     the ring on the way -- no separate append pass.  Weight tiles that are entirely zero (the corners of the
+//     Toeplitz band) are skipped.  Non-finite samples are replaced by 0 in the MFMA operand (0 x inf in the
+//     band's zero corners would otherwise poison neighbouring outputs) and flagged per tile;
+//   - fir_exact_kernel: sequential f64 accumulation in deque order, split at the deque's wrap point into the
+//     reference's two partial sums (`a`, `b`: fir.rs:201-216), bit-faithful; serves tiny filters, taps that do
+//     not fit LDS, cross-checks, and re-computes every tile flagged non-finite after the MFMA pass.
+// The deque itself is modelled on the host: `front` = absolute index of its oldest sample (so its length is
+// n_seen - front: T in steady state, < T while warming up -- fir.rs:193-214 then pairs state[k] with taps[k] --
+// and > T after a reload with a shorter impulse response, fir.rs:153-171 + 193-197: a pure extra delay), plus the
+// ring-buffer bookkeeping of std VecDeque (capacity, head) that decides the a/b split.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,17 +31,23 @@ struct FirState {
     float *ring = nullptr;        // [ceil(N/32)][R][32]
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path
+    unsigned long long *nf_time = nullptr;   // [tiles]: 1 + absolute time of the newest non-finite sample of the tile (0: none)
     uint32_t T = 0, R = 0, N = 0, max_frames = 0, pad_lo = 0, pad_hi = 0, tiles = 0;
     int mode = 0;                 // 0 Balanced, 1 Average (fir.rs:187-190)
     uint64_t n_seen = 0;          // samples consumed since the history was last empty
+    uint64_t front = 0;           // absolute index of the deque's oldest sample (deque length = n_seen - front)
+    uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
+    int last_fused = 0;           // the last block ran the fused append (reporting)
 };
 
 int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,
                   uint32_t max_frames);
+// Impulse-response reload (fir.rs:153-171): new taps, the history and the deque's length are KEPT.
+int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode);
 void fir_free(FirState &s);
 void fir_reset(FirState &s);
-// ev_begin/ev_end (optional) are recorded around the compute kernel(s) only, not the append pass
+// ev_begin/ev_end (optional) are recorded around the compute kernel(s)
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
                 const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
 size_t fir_state_bytes(const FirState &s);

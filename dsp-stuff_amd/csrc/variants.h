@@ -20,12 +20,18 @@ struct Variant {
     bool mod;              // interpreter instantiation that evaluates control ports
     bool libm;             // interpreter instantiation that includes the f64-libm nodes
     void (*launch)(const ChainArgs &, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t);
+    int ts = 0;            // time-sliced kernel (chain_ts_kernel): one workgroup per 64*cpl channels, n_frames must be 4 * ts
 };
 
 template <int F, int CPL, class SL>
 void launch_static(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
     (void)lds_bytes;
     hipLaunchKernelGGL((chain_kernel<F, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
+}
+template <int S, int CPL, class SL>
+void launch_ts(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
+    (void)lds_bytes;
+    hipLaunchKernelGGL((chain_ts_kernel<S, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
 }
 template <int F, int CPL, bool GUARD, bool MOD, bool LIBM>
 void launch_dyn(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
@@ -39,6 +45,8 @@ const Variant *variants_static5(int *n);
 
 #define DSPFX_STATIC_VARIANT(NAME, NSLOTS, F, CPL, ...) \
     Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, false, true, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
+#define DSPFX_TS_VARIANT(NAME, NSLOTS, S, CPL, ...) \
+    Variant { NAME, {__VA_ARGS__}, NSLOTS, S, CPL, false, false, true, &launch_ts<S, CPL, SigList<__VA_ARGS__>>, S }
 #define DSPFX_DYN_VARIANT(NAME, F, GUARD, MOD, LIBM) \
     Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, 1, GUARD, MOD, LIBM> }
 #define DSPFX_DYN_VARIANT_C(NAME, F, CPL, LIBM) \

@@ -49,11 +49,16 @@ class MixBus:
     """
 
     def __init__(self, total_channels: int, n_frames: int,
-                 finish: Callable[[object, int, int], None], group=None, world: Optional[int] = None):
+                 finish: Callable[[object, int, int], None], group=None, world: Optional[int] = None,
+                 allreduce: Optional[Callable[[object, int, int], None]] = None):
         self.total_channels = int(total_channels)
         self.n_frames = int(n_frames)
         self.finish = finish
         self.group = group
+        # allreduce(mix, n_frames, total_channels): the C-ABI collective (Engine.mix_allreduce over a dsp_stuff_amd.Comm:
+        # RCCL all-reduce + Output hop, stream-ordered on the caller's current stream).  When given it replaces the
+        # torch.distributed call below -- the path a Rust / C++ host takes; torch.distributed stays for the CPU (gloo) tests.
+        self.allreduce = allreduce
         if world is None:
             import torch.distributed as dist
             world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
@@ -61,6 +66,9 @@ class MixBus:
         self._pending = None
 
     def submit(self, mix):
+        if self.allreduce is not None:
+            self.allreduce(mix, self.n_frames, self.total_channels)
+            return
         if self.world == 1:
             self.finish(mix, self.n_frames, self.total_channels)
             return
@@ -94,14 +102,18 @@ class PipelinedMixBus:
     """
 
     def __init__(self, engine, total_channels: int, n_frames: int, compute_stream, mix_stream, world: int,
-                 batch: int = 8, device=None):
+                 batch: int = 8, device=None, comm=None):
         import torch
         self.torch, self.eng = torch, engine
         self.nf, self.batch = int(n_frames), int(batch)
         self.cs, self.ms = compute_stream, mix_stream
         self.rings = [torch.zeros(self.batch * self.nf, dtype=torch.float32, device=device) for _ in range(3)]
+        # comm (dsp_stuff_amd.Comm): the collective goes through the C ABI (dspfx_mix_allreduce: RCCL + Output hop on the
+        # second stream); without one, torch.distributed's all_reduce on that stream
+        allreduce = (lambda m, nf, n: engine.mix_allreduce(comm, m, nf, n, mix_stream.cuda_stream)) if comm is not None else None
         self.bus = MixBus(total_channels, self.batch * self.nf,
-                          lambda m, nf, n: engine.mix_finish(m, nf, n, mix_stream.cuda_stream), world=world)
+                          lambda m, nf, n: engine.mix_finish(m, nf, n, mix_stream.cuda_stream), world=world,
+                          allreduce=allreduce)
         self.count = 0            # blocks submitted since the last drain
         self.submitted = 0        # batches handed to the second stream
         self.events = {}          # batch index -> event recorded on the second stream after its submit

@@ -9,6 +9,12 @@ pub struct dspfx_engine {
     _private: [u8; 0],
 }
 
+/// Opaque communicator handle (`typedef struct dspfx_comm dspfx_comm`).
+#[repr(C)]
+pub struct dspfx_comm {
+    _private: [u8; 0],
+}
+
 #[repr(C)]
 #[derive(Clone, Copy, Debug)]
 pub struct dspfx_engine_desc {
@@ -52,6 +58,7 @@ pub struct dspfx_graph_link {
 pub const DSPFX_ABI_VERSION: u32 = 1;
 pub const DSPFX_BUF_SIZE: u32 = 128; // dsp-stuff/src/node.rs:257
 pub const DSPFX_MAX_NODES: u32 = 32;
+pub const DSPFX_COMM_ID_BYTES: usize = 128;
 
 // dspfx_status
 pub const DSPFX_OK: c_int = 0;
@@ -143,6 +150,15 @@ extern "C" {
     pub fn dspfx_process_partials(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_mix_collect(e: *mut dspfx_engine, mix: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_mix_finish(e: *mut dspfx_engine, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
+
+    // the mix bus across GPUs: one RCCL all-reduce of n_frames floats per block (include/dspfx.h)
+    pub fn dspfx_comm_unique_id(id_out: *mut c_void) -> c_int;
+    pub fn dspfx_comm_create(device: c_int, n_ranks: c_int, rank: c_int, id: *const c_void, out: *mut *mut dspfx_comm) -> c_int;
+    pub fn dspfx_comm_destroy(c: *mut dspfx_comm);
+    pub fn dspfx_comm_size(c: *const dspfx_comm) -> c_int;
+    pub fn dspfx_comm_rank(c: *const dspfx_comm) -> c_int;
+    pub fn dspfx_comm_last_error(c: *const dspfx_comm) -> *const c_char;
+    pub fn dspfx_mix_allreduce(e: *mut dspfx_engine, c: *mut dspfx_comm, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
 
     pub fn dspfx_process_mixpipe(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_mixpipe_flush(e: *mut dspfx_engine, mix_older: *mut f32, mix_newer: *mut f32, n_connected: u64, stream: *mut c_void) -> c_int;

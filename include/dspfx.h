@@ -180,7 +180,11 @@ int dspfx_set_param(dspfx_engine *e, int node, int param, float value);
 int dspfx_set_mode(dspfx_engine *e, int node, int mode);
 /* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring. */
 int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
-/* Fir tap reload (fir.rs:153-171); history restarts empty. */
+/* Fir tap reload (fir.rs:153-171).  Like the reference it replaces the taps ONLY: the history is kept (`state`,
+ * fir.rs:64-65, is never cleared), and because at most one sample is popped per step (fir.rs:193-197) a history longer
+ * than the new tap count STAYS longer -- its oldest samples pair with the taps, i.e. the output is the new convolution
+ * delayed by (old length - new length) samples -- while a shorter one goes on filling front-aligned like the warm-up.
+ * dspfx_reset (or a new dspfx_chain_set) starts from an empty history. */
 int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode);
 /* Zero every node's DSP state (fresh nodes); parameters are kept. */
 int dspfx_reset(dspfx_engine *e);
@@ -220,8 +224,11 @@ int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float
  * buffers it is streamed with (placement).  dspfx_chain_set already keeps the fastest of up to 2x
  * candidate groups, judged with scratch buffers; this call repeats that with the real chain kernels reading
  * `in` and writing `out` -- the buffers the host will keep using -- and keeps the fastest groups again.
- * `in` / `out` are laid out like a block of max_frames frames; n_frames <= 128 of it are streamed per probe.
- * Setup-time only (about 3 s at 94 GiB); it RESETS all DSP state.  Results never change, only speed. */
+ * `in` / `out` are laid out like a block of max_frames frames; n_frames <= 128 of it are streamed per probe (`out` is
+ * overwritten).  About 3 s at 94 GiB.  DSP state is PRESERVED -- filter state is snapshotted and restored, every ring
+ * group's rows are parked while it is probed and end up at the same ring position -- so a live host can call it again
+ * after it re-allocated its buffers (flush the mix pipeline first; engines with a FIR node still reset).  Results never
+ * change, only speed. */
 int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                          void *stream);
 /* Page-locked host memory for the blocks handed to dspfx_process_host.  From ordinary (pageable) buffers the two
@@ -259,6 +266,31 @@ int dspfx_mixpipe_flush(dspfx_engine *e, float *mix_older, float *mix_newer, uin
 /* Output-node hop of the mix bus (node.rs:189-191): mix[f] /= link_divisor(n_connected),
  * in place on the device; call after the cross-GPU all-reduce with the GLOBAL channel count. */
 int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream);
+
+/* ---- the mix bus across GPUs ------------------------------------------------------------------------
+ * Channels shard over the GPUs of a node with no data-path exchange; the one collective of the path is the mix bus:
+ * the Output node's sum over ALL channels (nodes/output.rs:215-249 feeding node.rs:162-194).  Each rank owns one
+ * engine; its un-normalised bus (dspfx_process(mix) / dspfx_process_mixpipe with n_connected = 0) is summed over
+ * the ranks by ONE RCCL ncclAllReduce(sum, float, n_frames) over xGMI, then divided by f32(0.0001 + N_total).
+ *
+ * One process per GPU.  Rank 0 calls dspfx_comm_unique_id and hands the DSPFX_COMM_ID_BYTES bytes to the other ranks
+ * over whatever channel the host already has (the Rust host's control socket, a file, MPI); every rank then calls
+ * dspfx_comm_create(device, n_ranks, rank, id) -- collectively, it blocks until all ranks have joined.  RCCL is
+ * loaded at run time (the copy already mapped into the process, else librccl.so.1): a host that never calls these
+ * entry points needs no RCCL.  n_ranks = 1 is allowed (no collective runs; the calls still divide).
+ * dspfx_mix_allreduce is asynchronous on `stream`, in place on `mix` (device, n_frames f32), deterministic for a
+ * given rank count (RCCL's reduction order is fixed by the topology), and applies the Output hop when
+ * n_connected != 0: mix[f] = (sum over ranks of mix[f]) / dspfx_link_divisor(n_connected). */
+typedef struct dspfx_comm dspfx_comm;
+#define DSPFX_COMM_ID_BYTES 128
+int dspfx_comm_unique_id(void *id_out);
+int dspfx_comm_create(int device, int n_ranks, int rank, const void *id, dspfx_comm **out);
+void dspfx_comm_destroy(dspfx_comm *c);
+int dspfx_comm_size(const dspfx_comm *c);
+int dspfx_comm_rank(const dspfx_comm *c);
+const char *dspfx_comm_last_error(const dspfx_comm *c);
+int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, uint32_t n_frames, uint64_t n_connected,
+                        void *stream);
 
 /* collect_and_average for a port with n_srcs connected pipes (node.rs:162-194), element-wise on whole
  * blocks: dst = (0 + srcs[0] + srcs[1] + ...) / f32(0.0001 + n_srcs), added in the order given.

@@ -8,6 +8,7 @@
 // (node.rs:173,271,280) become dspfx::Error exceptions here; nothing falls back to the CPU.
 #pragma once
 #include <cstddef>
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <stdexcept>
@@ -169,6 +170,11 @@ class Engine {
     void mix_finish(float *mix, std::uint32_t n_frames, std::uint64_t n_connected, void *stream = nullptr) {
         chk(dspfx_mix_finish(e_, mix, n_frames, n_connected, stream));
     }
+    // the mix bus across GPUs: sum this rank's un-normalised bus over the communicator's ranks (ONE RCCL all-reduce of
+    // n_frames floats, in place, asynchronous on `stream`), then the Output hop with the GLOBAL channel count
+    void mix_allreduce(dspfx_comm *comm, float *mix, std::uint32_t n_frames, std::uint64_t n_connected, void *stream = nullptr) {
+        chk(dspfx_mix_allreduce(e_, comm, mix, n_frames, n_connected, stream));
+    }
     // re-tune the delay rings' placement against the buffers the host will keep using (resets DSP state)
     void tune_placement(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr, void *stream = nullptr) {
         chk(dspfx_tune_placement(e_, in, side, out, n_frames, stream));
@@ -186,6 +192,32 @@ class Engine {
     }
     dspfx_engine *e_ = nullptr;
     std::uint32_t channels_;
+};
+
+// The mix bus' communicator: one per process / GPU (include/dspfx.h).  Rank 0 calls Comm::unique_id() and hands the
+// bytes to every rank over the host's own channel; every rank then constructs its Comm (collective).
+class Comm {
+  public:
+    using Id = std::array<unsigned char, DSPFX_COMM_ID_BYTES>;
+    static Id unique_id() {
+        Id id{};
+        const int rc = dspfx_comm_unique_id(id.data());
+        if (rc != DSPFX_OK) throw Error(rc, dspfx_comm_last_error(nullptr));
+        return id;
+    }
+    Comm(int device, int n_ranks, int rank, const Id *id = nullptr) {
+        const int rc = dspfx_comm_create(device, n_ranks, rank, id ? id->data() : nullptr, &c_);
+        if (rc != DSPFX_OK) throw Error(rc, dspfx_comm_last_error(nullptr));
+    }
+    ~Comm() { dspfx_comm_destroy(c_); }
+    Comm(const Comm &) = delete;
+    Comm &operator=(const Comm &) = delete;
+    int size() const { return dspfx_comm_size(c_); }
+    int rank() const { return dspfx_comm_rank(c_); }
+    dspfx_comm *raw() { return c_; }
+
+  private:
+    dspfx_comm *c_ = nullptr;
 };
 
 // Reference-shaped node: what a `GpuChain: SimpleNode` in the Rust host does per block.

@@ -587,7 +587,7 @@ inline std::string dump_dspconfig(const std::vector<Node> &chain, bool faithful_
         in_id = next_id++;
         in_port = next_id++;
         nodes += "{\"id\": " + std::to_string(in_id) + ", \"typename\": \"input\", \"position\": [0.0, 0.0], \"cfg\": {\"id\": " +
-                 std::to_string(in_id) + ", \"inputs\": {}, \"outputs\": {\"out\": " + std::to_string(in_port) + "}}}";
+                 std::to_string(in_id) + ", \"selected_host\": \"ALSA\", \"selected_device\": null, \"outputs\": {\"out\": " + std::to_string(in_port) + "}}}";
         prev_node = in_id;
         prev_port = in_port;
     }
@@ -634,7 +634,7 @@ inline std::string dump_dspconfig(const std::vector<Node> &chain, bool faithful_
     const int out_id = next_id++, out_port = next_id++;
     if (!nodes.empty()) nodes += ", ";
     nodes += "{\"id\": " + std::to_string(out_id) + ", \"typename\": \"output\", \"position\": [" + num(120.0 * (double)(chain.size() + 1), 9) +
-             ", 0.0], \"cfg\": {\"id\": " + std::to_string(out_id) + ", \"inputs\": {\"in\": " + std::to_string(out_port) + "}, \"outputs\": {}}}";
+             ", 0.0], \"cfg\": {\"id\": " + std::to_string(out_id) + ", \"selected_host\": \"ALSA\", \"selected_device\": null, \"inputs\": {\"in\": " + std::to_string(out_port) + "}}}";
     if (prev_node >= 0) link(prev_node, prev_port, out_id, out_port);
     return "{\"nodes\": [" + nodes + "], \"links\": [" + links + "]}";
 }

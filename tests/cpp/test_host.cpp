@@ -86,6 +86,31 @@ int main(int argc, char **argv) {
             std::printf("FAIL: graph_source\n");
             return 1;
         }
+        // the mix bus across GPUs through the C ABI: a ONE-rank communicator made from a real unique id (so RCCL's
+        // ncclCommInitRank / ncclAllReduce really run on this GPU), in place on a page-locked buffer, then the Output hop
+        {
+            Comm::Id id = Comm::unique_id();
+            Comm comm(0, 1, 0, &id);
+            if (comm.size() != 1 || comm.rank() != 0) { std::printf("FAIL: comm size/rank\n"); return 1; }
+            void *pinned = nullptr;
+            if (dspfx_host_alloc(BUF_SIZE * sizeof(float), &pinned) != DSPFX_OK) { std::printf("FAIL: host_alloc\n"); return 1; }
+            float *pm = static_cast<float *>(pinned);
+            for (uint32_t f = 0; f < BUF_SIZE; ++f) pm[f] = mix[f];
+            const std::uint64_t n_total = 3 * N;
+            eng.mix_allreduce(comm.raw(), pm, BUF_SIZE, n_total);
+            dspfx_sync(eng.raw(), nullptr);
+            const float div = dspfx_link_divisor(n_total);
+            for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                if (ulp(pm[f], mix[f] / div) != 0) { std::printf("FAIL: mix_allreduce at %u: %g vs %g\n", f, pm[f], mix[f] / div); return 1; }
+            Comm solo(0, 1, 0);                                  // no id: no RCCL communicator, the call still divides
+            for (uint32_t f = 0; f < BUF_SIZE; ++f) pm[f] = mix[f];
+            eng.mix_allreduce(solo.raw(), pm, BUF_SIZE, n_total);
+            dspfx_sync(eng.raw(), nullptr);
+            for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                if (ulp(pm[f], mix[f] / div) != 0) { std::printf("FAIL: solo mix_allreduce at %u\n", f); return 1; }
+            dspfx_host_free(pinned);
+            std::printf("mix_allreduce over a 1-rank RCCL communicator ok\n");
+        }
         // error behaviour: exceptions, not aborts
         bool threw = false;
         try { eng.set_chain({ReverbSamples(64)}); } catch (const Error &e) { threw = e.status == DSPFX_ERR_INVALID; }

@@ -18,11 +18,11 @@ def mods(dspfx):
 # from the cited structs, ids out of order, LowPass saved under its (buggy) cfg_name "high_pass".
 REFERENCE_STYLE = {
     "nodes": [
-        {"id": 7, "typename": "output", "position": [900.0, 80.0], "cfg": {"id": 7, "inputs": {"in": 31}, "outputs": {}}},
+        {"id": 7, "typename": "output", "position": [900.0, 80.0], "cfg": {"id": 7, "selected_host": "ALSA", "selected_device": "default", "inputs": {"in": 31}}},
         {"id": 2, "typename": "biquad", "position": [200.0, 50.0],
          "cfg": {"id": 2, "inputs": {"in": 11}, "outputs": {"out": 12},
                  "a0": 1.0, "a1": -0.24, "a2": 0.0, "b0": 0.758, "b1": 0.0, "b2": 0.0}},
-        {"id": 0, "typename": "input", "position": [10.0, 50.0], "cfg": {"id": 0, "inputs": {}, "outputs": {"out": 10}}},
+        {"id": 0, "typename": "input", "position": [10.0, 50.0], "cfg": {"id": 0, "selected_host": "ALSA", "selected_device": None, "outputs": {"out": 10}}},
         {"id": 3, "typename": "distort", "position": [350.0, 50.0],
          "cfg": {"id": 3, "inputs": {"in": 13, "level": 14}, "outputs": {"out": 15}, "level": 3.0, "mode": "SoftClip"}},
         {"id": 4, "typename": "reverb", "position": [500.0, 50.0],
@@ -197,3 +197,63 @@ def test_sinc_resampler_properties(mods):
     spec = np.abs(np.fft.rfft(s * np.hanning(len(s))))
     f_peak = np.argmax(spec) * 48000.0 / len(s)
     assert abs(f_peak - 1000.0) < 48000.0 / len(s) and 0.95 < np.abs(s).max() < 1.05
+
+
+# field sets of the structs the reference deserialises a saved node into (serde: a missing field fails, and every
+# `restore` unwraps): InputConfig nodes/input.rs:32-38, OutputConfig nodes/output.rs:32-38, and the derive-generated
+# `<Node>Config` = id + inputs + outputs + every #[dsp(save)] field (dsp-stuff-derive/src/lib.rs:233-270; the save
+# attributes are on nodes/*.rs)
+_REFERENCE_CFG_FIELDS = {
+    "input": {"id", "selected_host", "selected_device", "outputs"},
+    "output": {"id", "selected_host", "selected_device", "inputs"},
+    "gain": {"id", "inputs", "outputs", "level"},
+    "biquad": {"id", "inputs", "outputs", "a0", "a1", "a2", "b0", "b1", "b2"},
+    "high_pass": {"id", "inputs", "outputs", "ratio"},          # LowPass saves under this name too (low_pass.rs:9)
+    "low_pass": {"id", "inputs", "outputs", "ratio"},
+    "reverb": {"id", "inputs", "outputs", "seconds", "decay"},
+    "distort": {"id", "inputs", "outputs", "level", "mode"},
+    "overdrive": {"id", "inputs", "outputs", "boost", "drive", "level"},
+    "chebyshev": {"id", "inputs", "outputs", "level_pos", "level_neg"},
+    "fir": {"id", "inputs", "outputs", "mode", "file_name", "taps"},
+    "add": {"id", "inputs", "outputs"},
+    "mix": {"id", "inputs", "outputs", "ratio"},
+    "signal_gen": {"id", "inputs", "outputs", "amplitude", "frequency", "mode"},
+    "envelope": {"id", "inputs", "outputs", "attack", "release"},
+}
+_REFERENCE_PORTS = {   # input port names: declared `input =`s, then the as_input sliders in field order (lib.rs:214-216)
+    "gain": ["in", "level"], "biquad": ["in"], "high_pass": ["in"], "low_pass": ["in"], "reverb": ["in"],
+    "distort": ["in", "level"], "overdrive": ["in", "boost", "drive", "level"], "chebyshev": ["in"], "fir": ["in"],
+    "add": ["a", "b"], "mix": ["a", "b", "ratio"], "signal_gen": ["amplitude", "frequency"], "envelope": ["in"],
+}
+
+
+def test_exported_documents_deserialise_into_the_reference_config_structs(mods):
+    """What dump_dspconfig writes must load in the reference: every node's cfg carries exactly the fields of the
+    struct its `restore` deserialises (and unwraps), input / output nodes included (selected_host, selected_device)."""
+    import json
+    pkg, config = mods[0], mods[1]
+    chains = [
+        [pkg.Gain(0.8), pkg.BiQuad(), pkg.LowPass(0.3), pkg.HighPass(0.2), pkg.Reverb(seconds=0.25), pkg.Distort(3.0, pkg.TANH),
+         pkg.Overdrive(5.0, 0.5, 0.7), pkg.Chebyshev(2.0, 1.0), pkg.Fir([1.0, 0.5, 0.25], pkg.FIR_AVERAGE), pkg.Add(), pkg.Mix(0.4),
+         pkg.Envelope(3.0, 40.0)],
+        [pkg.SignalGen(0.5, 220.0, pkg.SIG_TRIANGLE), pkg.Gain(0.5)],
+    ]
+    seen = set()
+    for chain in chains:
+        for bug in (True, False):
+            doc = json.loads(config.dump_dspconfig(chain, faithful_lowpass_bug=bug))
+            for n in doc["nodes"]:
+                tn = n["typename"]
+                assert set(n["cfg"]) == _REFERENCE_CFG_FIELDS[tn], (tn, sorted(n["cfg"]))
+                assert n["cfg"]["id"] == n["id"]
+                if tn in ("input", "output"):
+                    assert isinstance(n["cfg"]["selected_host"], str) and n["cfg"]["selected_device"] is None
+                else:
+                    want = _REFERENCE_PORTS[tn]
+                    if tn == "high_pass" and "ratio" in n["cfg"]:
+                        want = ["in"]
+                    assert list(n["cfg"]["inputs"]) == want and list(n["cfg"]["outputs"]) == ["out"], (tn, n["cfg"]["inputs"])
+                seen.add(tn)
+            chain2, _ = config.load_dspconfig(json.dumps(doc))       # and our own loader still reads it
+            assert len(chain2) == len(chain)
+    assert seen >= set(_REFERENCE_CFG_FIELDS) - {"low_pass"} or seen >= set(_REFERENCE_CFG_FIELDS)

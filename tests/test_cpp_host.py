@@ -36,3 +36,4 @@ def test_cpp_host_parity_on_gpu():
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max ulp" in r.stdout
+    assert "mix_allreduce over a 1-rank RCCL communicator ok" in r.stdout

@@ -426,12 +426,12 @@ def test_control_ports(dspfx, torch_cuda):
                 got[sl] = dspfx.from_layout(dxx.cpu().numpy(), 256, Nc, tile)
             ref = O.run_channels([n.oracle_desc() for n in chain], xc, lf, ctl=ctl_c)
             assert ulp_diff(got, ref).max() <= 1, (lf, tile)
-    # Fuzz has no control port here; bad slider indices are rejected
+    # bad slider indices are rejected (Fuzz's level port itself is a real port: test_fuzz_level_control_port)
     eng = dspfx.Engine(N, B)
     eng.set_chain([dspfx.Distort(3.0, dspfx.FUZZ), dspfx.BiQuad()])
     t = torch_cuda.zeros((B, N), device="cuda")
     with pytest.raises(dspfx.DspfxError):
-        eng.process(t, n_frames=B, ctl={(0, 0): t})
+        eng.process(t, n_frames=B, ctl={(0, 1): t})
     with pytest.raises(dspfx.DspfxError):
         eng.process(t, n_frames=B, ctl={(1, 0): t})
 
@@ -693,9 +693,9 @@ def test_fir_random_vs_oracle(dspfx, torch_cuda, monkeypatch, T, kernel):
     y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
     assert fir_rel_rms(y, ref) < FIR_RMS_TOL
     if kernel == "0":
-        # f64 accumulate like the reference; only the VecDeque a/b slice split (two f32 roundings
-        # instead of one) differs: a couple of ulps of the output scale (gain + hops follow)
-        assert np.abs(y - ref).max() <= 3e-7 * np.abs(ref).max()
+        # f64 accumulation in deque order, split at the VecDeque's wrap point like the reference (fir.rs:201-216):
+        # the exact kernel reproduces the oracle bit for bit, gains and hops included
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32))
 
 
 @pytest.mark.parametrize("N,block", [(1, 128), (31, 128), (33, 64), (100, 256), (96, 32), (64, 100)])
@@ -710,10 +710,13 @@ def test_fir_mfma_ragged_shapes(dspfx, torch_cuda, monkeypatch, N, block):
     assert np.abs(y - ref).max() < 2e-5
 
 
-def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch):
+@pytest.mark.parametrize("fuse", ["0", "1"])
+def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, fuse):
     """Integer taps and samples are exact in f32: the MFMA path must equal the oracle bit for bit,
-    including every warm-up output (fir.rs:193-214 pairs state[k] with taps[k] while filling)."""
+    including every warm-up output (fir.rs:193-214 pairs state[k] with taps[k] while filling).
+    fuse = 1: the MFMA kernel appends the block itself (its newest rows come straight from `in`)."""
     monkeypatch.setenv("DSPFX_FIR_KERNEL", "1")
+    monkeypatch.setenv("DSPFX_FIR_FUSE", fuse)
     rng = np.random.default_rng(5)
     T = 300
     h = rng.integers(-4, 5, T).astype(np.float64)
@@ -758,6 +761,110 @@ def test_fir_state_export_import(dspfx, torch_cuda):
         b.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
     torch_cuda.cuda.synchronize()
     assert np.allclose(dy.cpu().numpy()[384:], full[384:], rtol=0, atol=2e-6)
+
+
+def _run_fir_blocks(dspfx, torch_cuda, eng, x, block=128):
+    y = np.empty_like(x)
+    for f0 in range(0, x.shape[0], block):
+        dx = torch_cuda.from_numpy(np.ascontiguousarray(x[f0:f0 + block])).cuda()
+        dy = torch_cuda.empty_like(dx)
+        eng.process(dx, out=dy, n_frames=dx.shape[0])
+        torch_cuda.cuda.synchronize()
+        y[f0:f0 + block] = dy.cpu().numpy()
+    return y
+
+
+@pytest.mark.parametrize("kernel", ["0", "1"])
+def test_fir_exact_kernel_is_bit_exact_and_mfma_within_tolerance(dspfx, torch_cuda, monkeypatch, kernel):
+    """The exact kernel accumulates in f64 in deque order AND splits the sum where the reference's VecDeque wraps
+    (fir.rs:201-216: two partial sums, each rounded to f32, then added): bit for bit the oracle, warm-up and steady
+    state, for tap counts on both sides of the deque's capacity doublings."""
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
+    for T in (1, 2, 5, 16, 31, 64, 100, 256, 300):
+        x = noise_block(40, 128 * 6 + 77)
+        for mode in (dspfx.FIR_BALANCED, dspfx.FIR_AVERAGE):
+            ch = [dspfx.Fir(fir_taps(T), mode)]
+            eng = dspfx.Engine(40, 128, link_flags=0)
+            eng.set_chain(ch)
+            y, ref = _run_fir_blocks(dspfx, torch_cuda, eng, x), run_oracle(ch, x, 0)
+            if kernel == "0":
+                assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), (T, mode, ulp_diff(y, ref).max())
+            else:
+                assert fir_rel_rms(y, ref) < FIR_RMS_TOL, (T, mode)
+
+
+@pytest.mark.parametrize("kernel", ["0", "1", "fused"])
+def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel):
+    """dspfx_set_taps = the impulse-response reload of fir.rs:153-171: the taps change, `state` does not.  A history
+    longer than the new tap count stays longer (one pop per step, fir.rs:193-197): the output is the new convolution
+    delayed by the difference; a shorter one goes on filling front-aligned.  Against the oracle, whose node takes the
+    same reloads; integer data is exact on both kernels, random data exact on the f64 kernel."""
+    if kernel == "fused":
+        monkeypatch.setenv("DSPFX_FIR_FUSE", "1")
+        kernel = "1"
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
+    rng = np.random.default_rng(8)
+    N = 70
+    for integers in (True, False):
+        plan = [(40, 300), (7, 200), (150, 333), (150, 64), (3, 128), (600, 700), (33, 128 * 3)]
+        mk = (lambda T: rng.integers(-4, 5, T).astype(np.float64)) if integers else (lambda T: rng.uniform(-1, 1, T))
+        x = (rng.integers(-8, 9, (sum(n for _, n in plan), N)).astype(F) if integers
+             else noise_block(N, sum(n for _, n in plan)))
+        h0 = mk(plan[0][0])
+        eng = dspfx.Engine(N, 128, link_flags=0)
+        eng.set_chain([dspfx.Fir(h0)])
+        nodes = [O.Node(O.FIR, taps_reversed=h0[::-1]) for _ in range(N)]
+        f0, got, ref = 0, [], []
+        for k, (T, n) in enumerate(plan):
+            if k:
+                h = mk(T)
+                eng.set_taps(0, h)
+                for nd in nodes:
+                    nd.set_taps(h[::-1])
+            seg = x[f0:f0 + n]
+            got.append(_run_fir_blocks(dspfx, torch_cuda, eng, seg))
+            ref.append(np.stack([np.concatenate([nodes[c].process(seg[i:i + 128, c]) for i in range(0, n, 128)]) for c in range(N)], axis=1))
+            f0 += n
+        got, ref = np.concatenate(got), np.concatenate(ref)
+        if integers or kernel == "0":
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (integers, np.abs(got - ref).max())
+        else:
+            assert fir_rel_rms(got, ref) < FIR_RMS_TOL
+    # the delay really is there: 40 taps -> 7 taps leaves the output 33 samples late
+    assert eng.describe()
+
+
+@pytest.mark.parametrize("kernel", ["0", "1", "fused"])
+def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cuda, monkeypatch, kernel):
+    """inf / NaN samples: the reference's sums turn inf / NaN exactly while the sample is inside the deque (T outputs)
+    and only in that channel.  The MFMA sweep multiplies the zero corners of its Toeplitz band with the history, where
+    0 x inf would poison neighbouring outputs: non-finite samples are zeroed in the operand, flagged per tile, and the
+    flagged tiles are recomputed by the exact kernel -- so the inf / NaN pattern equals the oracle's and every finite
+    output stays within the FIR tolerance."""
+    if kernel == "fused":       # the MFMA kernel appends the block itself
+        monkeypatch.setenv("DSPFX_FIR_FUSE", "1")
+        kernel = "1"
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
+    T, N, nf = 200, 100, 128 * 8
+    x = noise_block(N, nf)
+    x[130, 3] = np.inf
+    x[131, 3] = -np.inf          # inf - inf inside one window
+    x[300, 40] = np.nan
+    x[5, 64] = -np.inf           # during the warm-up
+    x[700, 99] = np.inf
+    for taps in (fir_taps(T), np.r_[fir_taps(T - 50), np.zeros(50)]):      # zero taps: 0 x inf = NaN in the reference too
+        ch = [dspfx.Fir(taps)]
+        eng = dspfx.Engine(N, 128, link_flags=3)
+        eng.set_chain(ch)
+        y, ref = _run_fir_blocks(dspfx, torch_cuda, eng, x), run_oracle(ch, x, 3)
+        assert np.array_equal(np.isnan(y), np.isnan(ref))
+        assert np.array_equal(np.isposinf(y), np.isposinf(ref)) and np.array_equal(np.isneginf(y), np.isneginf(ref))
+        fin = np.isfinite(ref)
+        assert (~fin).sum() >= 4 * T and fin[:, [0, 1, 2, 4, 41, 63, 65, 98]].all()       # neighbours in the tile: untouched
+        err = y[fin].astype(np.float64) - ref[fin].astype(np.float64)
+        assert np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref[fin].astype(np.float64) ** 2)) < FIR_RMS_TOL
+        if kernel == "0":
+            assert np.array_equal(y[fin].view(np.uint32), ref[fin].view(np.uint32))
 
 
 # ---- SignalGen: the reference's control source (signal_gen.rs:55-129) ------------------------------
@@ -1080,6 +1187,60 @@ def test_mix_bus_pipelined_inside_the_kernel(dspfx, torch_cuda, N, tile):
         eng.process_mixpipe(dx, y, None, 64)
 
 
+def test_mix_allreduce_through_the_c_abi(dspfx, torch_cuda):
+    """dspfx_comm_create / dspfx_mix_allreduce: the mix bus' one collective behind the C ABI.  A 1-rank communicator made
+    from a real unique id runs RCCL's ncclCommInitRank and ncclAllReduce on this GPU (the sum over one rank is the
+    identity), then the Output hop with the global count; parallel.PipelinedMixBus driven through it equals the
+    single-GPU bus bit for bit."""
+    from dsp_stuff_amd import parallel as P
+    N, B = 4096 * 3, 128
+    uid = dspfx.comm_unique_id()
+    assert len(uid) == dspfx.COMM_ID_BYTES and any(uid)
+    comm = dspfx.Comm(0, 1, 0, uid)
+    chain = chain5(dspfx, 256)
+    ref_eng, eng = dspfx.Engine(N, B), dspfx.Engine(N, B)
+    ref_eng.set_chain(chain)
+    eng.set_chain(chain)
+    blocks = 11
+    x = noise_block(N, B * blocks, seed=3)
+    want = []
+    for k in range(blocks):
+        dx = torch_cuda.from_numpy(x[k * B:(k + 1) * B]).cuda()
+        y, m, m2 = torch_cuda.empty_like(dx), torch_cuda.empty(B, device="cuda"), torch_cuda.empty(B, device="cuda")
+        ref_eng.process(dx, out=y, mix=m, n_frames=B)
+        m2.copy_(m)
+        ref_eng.mix_finish(m, B, 5 * N)
+        eng_tmp_sum = m2                                     # the un-normalised bus of this block
+        ref_eng.mix_allreduce(comm, eng_tmp_sum, B, 5 * N)   # direct call: all-reduce over one rank + Output hop
+        torch_cuda.cuda.synchronize()
+        assert np.array_equal(m.cpu().numpy().view(np.uint32), eng_tmp_sum.cpu().numpy().view(np.uint32))
+        want.append(m.cpu().numpy())
+    cs, ms = torch_cuda.cuda.Stream(), torch_cuda.cuda.Stream()
+    with torch_cuda.cuda.stream(cs):
+        pb = P.PipelinedMixBus(eng, 5 * N, B, cs, ms, world=1, batch=4, device="cuda", comm=comm)
+        dxs = [torch_cuda.from_numpy(x[k * B:(k + 1) * B]).cuda() for k in range(blocks)]
+        y = torch_cuda.empty_like(dxs[0])
+        torch_cuda.cuda.synchronize()
+        got = {}
+        for k in range(blocks):
+            pb.step(dxs[k], y)
+            if k >= 2 and (k - 2 + 1) % 4 == 0:
+                torch_cuda.cuda.synchronize()
+                q = (k - 2) // 4
+                for j in range(q * 4, (q + 1) * 4):
+                    got[j] = pb._row(j).cpu().numpy().copy()
+        rows = {j: pb._row(j) for j in range(blocks) if j not in got}
+        pb.drain()
+        torch_cuda.cuda.synchronize()
+        for j, r in rows.items():
+            got[j] = r.cpu().numpy().copy()
+    for j in range(blocks):
+        assert np.array_equal(got[j].view(np.uint32), want[j].view(np.uint32)), j
+    comm.close()
+    with pytest.raises(dspfx.DspfxError):
+        dspfx.Comm(0, 2, 5, uid)                             # rank out of range
+
+
 def test_pipelined_mix_bus_with_batched_collective_path(dspfx, torch_cuda):
     """parallel.PipelinedMixBus (the multi-GPU form of the in-kernel pipeline; world = 1 here, so the RCCL call
     is skipped but rings, events, batching and drain are the real thing): every block's bus equals
@@ -1129,7 +1290,8 @@ def test_pipelined_mix_bus_with_batched_collective_path(dspfx, torch_cuda):
 
 def test_tune_placement_changes_speed_not_results(dspfx, torch_cuda):
     """dspfx_tune_placement re-times the ring groups with the real chain on the caller's buffers and keeps the
-    fastest; it resets DSP state and must not change a single output bit."""
+    fastest; it PRESERVES the DSP state (filter rows snapshotted, ring groups parked and put back at the same ring
+    position) and must not change a single output bit -- called before the first block and in the middle of a run."""
     N, B, blocks = 131072, 128, 5            # 64 MiB ring groups: large enough for the tuner to engage
     chain = chain5(dspfx, 300)               # 3 groups, the last one partly used
     x = noise_block(N, B * blocks)
@@ -1138,20 +1300,22 @@ def test_tune_placement_changes_speed_not_results(dspfx, torch_cuda):
     ref.set_chain(chain)
     dxs = [torch_cuda.from_numpy(dspfx.to_layout(x[k * B:(k + 1) * B], 256)).cuda() for k in range(blocks)]
     y, y_ref = torch_cuda.empty_like(dxs[0]), torch_cuda.empty_like(dxs[0])
-    eng.process(dxs[0], out=y, n_frames=B)                       # some state, which tuning must wipe
     eng.tune_placement(dxs[0], y, B)
     assert "re-placed" in eng.describe()
+    scratch = torch_cuda.empty_like(dxs[0])
     for k in range(blocks):
         eng.process(dxs[k], out=y, n_frames=B)
         ref.process(dxs[k], out=y_ref, n_frames=B)
         torch_cuda.cuda.synchronize()
         assert torch_cuda.equal(y, y_ref), k
+        if k in (1, 2, 3):            # mid-run, ring part full (D = 300: the position wraps inside the third group)
+            eng.tune_placement(dxs[(k + 2) % blocks], scratch, B)
     with pytest.raises(dspfx.DspfxError):
         eng.tune_placement(dxs[0], None, B)
     eng.process_mixpipe(dxs[0], y, None, B)
     with pytest.raises(dspfx.DspfxError):                       # blocks in the mix pipeline: flush first
         eng.tune_placement(dxs[0], y, B)
-    # no large ring: a no-op that still resets state
+    # no large ring: a no-op
     small = dspfx.Engine(4096, B)
     small.set_chain(chain3(dspfx, 256))
     t = torch_cuda.zeros((B, 4096), device="cuda")
