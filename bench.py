@@ -169,6 +169,21 @@ def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
     return res
 
 
+def make_comm(ctx):
+    """The mix bus' own communicator behind the C ABI (rank 0 makes the id, torch.distributed only carries the bytes)."""
+    import torch
+    import torch.distributed as dist
+    if ctx.comm is not None or not ctx.use_dist or os.environ.get("DSPFX_BENCH_COMM", "abi") != "abi":
+        return
+    idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=ctx.dev)
+    if ctx.rank == 0:
+        idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(idt, 0)
+    ctx.comm = ctx.pkg.Comm(ctx.local_rank, ctx.world, ctx.rank, bytes(idt.cpu().tolist()))
+    dist.barrier()
+    torch.cuda.synchronize()
+
+
 class Ctx:
     """What one process shares between the configs it measures."""
     pass
@@ -195,7 +210,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     # ---- every host-side allocation happens HERE, before any settling: the chip's power management reacts to
     # idle gaps of a few tens of ms with a transient of ~50 launches (fast, then 5-15 % slow, then steady:
     # profiles/r02_idle_transient.txt), so nothing may pause the queue between settling and the timed region
-    n_in = 2
+    n_in = int(os.environ.get("DSPFX_BENCH_NIN", "2"))
 
     def alloc_buf(block=None):
         t = torch.empty(B * N, dtype=torch.float32, device=dev)
@@ -218,9 +233,6 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
     bus_world = 2 if (ctx.use_dist and world == 1) else world          # forced-dist: take the collective path
     bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
-    pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
-                              comm=ctx.comm)
-            if (use_mix and dist_run and mix_mode == "pipe") else None)
     pipe_fill = [0]
 
     # one full revolution of the delay ring per measurement: ring groups differ in placement quality too, and a
@@ -272,6 +284,11 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
         tune_log = {"ms_before": round(before, 4), "seconds": round(tune_s, 2)}
     for j, x_ in enumerate(xs):     # block j of the noise stream in input j
         eng.fill_noise(x_, B, j * B, SEED, stream)
+    if os.environ.get("DSPFX_BENCH_COMM_EARLY", "0") != "1":
+        make_comm(ctx)              # after the engine's large allocations and the tuning (A/B: DSPFX_BENCH_COMM_EARLY=1)
+    pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
+                              comm=ctx.comm)
+            if (use_mix and dist_run and mix_mode == "pipe") else None)
 
     def step(k):
         if not use_mix:
@@ -471,16 +488,10 @@ def main():
     if ctx.use_dist:
         dist.barrier()
         dist.all_reduce(ctx.mark)
-        # The mix bus' own communicator, behind the C ABI (dspfx_comm_create / dspfx_mix_allreduce: what a Rust or C++
-        # host calls): rank 0 makes the id, torch.distributed only carries the 128 bytes to the other ranks.
-        # DSPFX_BENCH_COMM=torch keeps torch.distributed's all_reduce instead (A/B).
-        if os.environ.get("DSPFX_BENCH_COMM", "abi") == "abi":
-            idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
-            if rank == 0:
-                idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            ctx.comm = ctx.pkg.Comm(ctx.local_rank, world, rank, bytes(idt.cpu().tolist()))
-            dist.barrier()
+        # The mix bus' own communicator lives behind the C ABI (dspfx_comm_create / dspfx_mix_allreduce: what a Rust or
+        # C++ host calls); it is made in measure().  DSPFX_BENCH_COMM=torch keeps torch.distributed's all_reduce (A/B).
+        if os.environ.get("DSPFX_BENCH_COMM_EARLY", "0") == "1":
+            make_comm(ctx)
     torch.cuda.synchronize()
 
     over = {k: getattr(args, k) for k in ("channels", "frames", "delay", "taps") if getattr(args, k) is not None}

@@ -37,7 +37,9 @@ LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
 GRAPH_MAX_NODES = 16
 ERR_UNSUPPORTED = -5
-GRAPH_INPUT, GRAPH_ZERO, GRAPH_INPUT2 = -1, -2, -3
+GRAPH_INPUT, GRAPH_ZERO, GRAPH_INPUT2, GRAPH_INPUT3, GRAPH_INPUT4 = -1, -2, -3, -4, -5
+GRAPH_INPUTS = (GRAPH_INPUT, GRAPH_INPUT2, GRAPH_INPUT3, GRAPH_INPUT4)     # link source of input block k
+GRAPH_MAX_IO = 4
 PORT_MAIN, PORT_SIDE, PORT_SLIDER = 0, 1, 2
 PORT_RAW = 256
 
@@ -50,7 +52,7 @@ EXPORTS = [
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
-    "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
+    "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
 ]
 COMM_ID_BYTES = 128
@@ -149,6 +151,7 @@ def lib():
     L.dspfx_verify_libm.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.dspfx_profile_enable.argtypes = [vp, C.c_int]
     L.dspfx_profile_read.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t, C.c_int]
+    L.dspfx_process_io.argtypes = [vp, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p), C.c_int, f32p, C.c_uint32, vp]
     L.dspfx_comm_unique_id.argtypes = [vp]
     L.dspfx_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.dspfx_comm_destroy.argtypes = [vp]
@@ -439,6 +442,15 @@ class Engine:
         else:
             self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames), st))
         return out
+
+    def process_io(self, ins, outs, n_frames: int, mix=None, stream: int = 0):
+        """A graph engine with several input / output blocks (dspfx_process_io): ins[k] = input block k, outs[m] = output
+        block m; unused entries may be None."""
+        ia = (C.c_void_p * max(1, len(ins)))(*[(_ptr(t).value if t is not None else None) for t in ins])
+        oa = (C.c_void_p * max(1, len(outs)))(*[(_ptr(t).value if t is not None else None) for t in outs])
+        self._chk(self.L.dspfx_process_io(self.h, ia, len(ins), oa, len(outs), _ptr(mix), int(n_frames),
+                                          C.c_void_p(stream) if stream else None))
+        return outs[0]
 
     def process_partials(self, x, out=None, side=None, n_frames: Optional[int] = None, stream: int = 0):
         """Pipelined mix bus, part 1 (stream A): the chain, partial sums stay inside the engine."""

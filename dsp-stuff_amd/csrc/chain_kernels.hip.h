@@ -1139,13 +1139,15 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // ---- the fused chain kernel, time-sliced: few channels ------------------------------------------------
 // With <= 2 waves per SIMD (N <= 131072 at one channel per lane) nothing hides a wave's memory and instruction
 // latency: the 65536-channel 3-node chain ran at 0.49 of the HBM peak (profiles/r01_small_n.txt).  Here a workgroup
-// owns 64*CPL channels and its four waves each take S = 32 of the block's 128 frames: every wave issues ALL its loads
-// (samples and delay taps) at once, the four waves then compute one after the other -- wave q starts from the state
-// wave q-1 left in LDS, so every recurrence sees its frames in order, bit for bit as in chain_kernel -- and each
-// wave's stores trail its own compute.  Four times the waves per SIMD, the same arithmetic.
+// owns 64*CPL channels and its four waves each take S = 32 of the block's 128 frames.  Every wave issues ALL its loads
+// (samples and delay taps) at once and walks the chain node by node on its own slice: stateless nodes and delay lines
+// (whose taps never depend on the block itself) run in all four waves at the same time; a node with per-channel state
+// (biquad, one-pole, envelope, generator) is a recurrence over time, so the waves take turns at it -- wave q starts from
+// the state wave q-1 left in LDS -- and every recurrence still sees its frames in order: bit for bit chain_kernel's
+// results, with four times the waves per SIMD.
 template <int S, int CPL, class SL>
 __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
-    __shared__ float lds_st[MAX_SLOTS][4][CPL][64];
+    __shared__ float lds_st[4][CPL][64];           // the state rows of the node whose turns are being taken
     if (a.mp_stage) mixpipe_prologue(a);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
@@ -1169,19 +1171,6 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     }
     DSPFX_FOR_SLOTS(DSPFX_TAPS)
 #undef DSPFX_TAPS
-    float st[MAX_SLOTS][4][CPL];
-#pragma unroll 1
-    for (int turn = 0; turn < 4; ++turn) {
-        if (q == turn) {
-#define DSPFX_LDST(I)                                                                                            \
-    if (turn == 0) load_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);                             \
-    else {                                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                            \
-            _Pragma("unroll") for (int j = 0; j < CPL; ++j)                                                      \
-                st[I][k][j] = k < slot_nstate<SL::v[I]>(a.slot[I]) ? lds_st[I][k][j][lane] : 0.0f;               \
-    }
-            DSPFX_FOR_SLOTS(DSPFX_LDST)
-#undef DSPFX_LDST
 #define DSPFX_RUN(I)                                                                                             \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         if constexpr (sig_hop(SL::v[I])) apply_hop<S, CPL, true>(v, cx.hop_div, cx.hop_rc);                      \
@@ -1190,30 +1179,37 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
             _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
             store_vec<CPL, false, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, f), cx.ring_off), v[f], true);     \
         }                                                                                                        \
-    } else {                                                                                                     \
-        run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, st[I], cx);                                 \
-    }
-            DSPFX_FOR_SLOTS(DSPFX_RUN)
-#undef DSPFX_RUN
-#define DSPFX_STST(I)                                                                                            \
-    if (turn == 3) {                                                                                             \
-        if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes);  \
-        store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);                                       \
-    } else {                                                                                                     \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                            \
-            if (k < slot_nstate<SL::v[I]>(a.slot[I])) {                                                          \
-                _Pragma("unroll") for (int j = 0; j < CPL; ++j) lds_st[I][k][j][lane] = st[I][k][j];             \
+    } else if constexpr (SL::v[I] != SIG_NONE && kind_nstate(sig_kind(SL::v[I])) == 0) {                         \
+        float none[4][CPL];                                                                                      \
+        run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, none, cx);                                  \
+    } else if constexpr (SL::v[I] != SIG_NONE) {                                                                 \
+        constexpr int NS = kind_nstate(sig_kind(SL::v[I]));                                                      \
+        _Pragma("unroll 1") for (int turn = 0; turn < 4; ++turn) {                                               \
+            if (q == turn) {                                                                                     \
+                float st[4][CPL];                                                                                \
+                if (turn == 0) load_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                    \
+                else {                                                                                           \
+                    _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                \
+                        _Pragma("unroll") for (int j = 0; j < CPL; ++j) st[k][j] = k < NS ? lds_st[k][j][lane] : 0.0f; \
+                }                                                                                                \
+                run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, st, cx);                            \
+                if (turn == 3) {                                                                                 \
+                    if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st, a.nframes); \
+                    store_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                              \
+                } else {                                                                                         \
+                    _Pragma("unroll") for (int k = 0; k < NS; ++k)                                               \
+                        _Pragma("unroll") for (int j = 0; j < CPL; ++j) lds_st[k][j][lane] = st[k][j];           \
+                }                                                                                                \
             }                                                                                                    \
+            __syncthreads();                                                                                     \
+        }                                                                                                        \
     }
-            DSPFX_FOR_SLOTS(DSPFX_STST)
-#undef DSPFX_STST
+    DSPFX_FOR_SLOTS(DSPFX_RUN)
+#undef DSPFX_RUN
 #pragma unroll
-            for (int f = 0; f < S; ++f)
-                if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
-            if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
-        }
-        __syncthreads();
-    }
+    for (int f = 0; f < S; ++f)
+        if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+    if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
 }
 
 // ---- the fused chain kernel, interpreting any chain ----------------------------------

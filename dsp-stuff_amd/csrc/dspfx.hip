@@ -102,6 +102,11 @@ struct dspfx_engine {
     hipStream_t hs_in = nullptr, hs_out = nullptr, hs_run = nullptr;
     std::vector<hipEvent_t> hev;
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
+    // dspfx_process_io: input blocks 2.. and output blocks 1.. of the call being launched (graph engines), and the float
+    // offset of the sub-block being launched
+    const float *io_in[GRAPH_IO] = {nullptr, nullptr, nullptr, nullptr};
+    float *io_out[GRAPH_IO] = {nullptr, nullptr, nullptr, nullptr};
+    size_t io_off = 0;
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
     const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr, *dyn_mod2 = nullptr;
@@ -378,14 +383,17 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
     return res;
 }
 
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod) {
+// ts: the time-sliced kernel chain_ts_kernel<f, cpl, ...> (f = frames per slice) instead of chain_kernel<f, cpl, ...>
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false) {
     char key[256];
-    int off = snprintf(key, sizeof key, "d%d_f%d_c%d%s", device, f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
+    int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
     for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
-    std::string expr = "dspfx::chain_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
+    std::string expr = std::string(ts ? "dspfx::chain_ts_kernel<" : "dspfx::chain_kernel<") + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
     for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
-    expr += mod ? ">, true>" : "> >";
-    return jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
+    expr += (mod && !ts) ? ">, true>" : "> >";
+    const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
+    if (k && ts) const_cast<JitKernel *>(k)->var.ts = f;
+    return k;
 }
 
 // A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.
@@ -401,12 +409,18 @@ int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned
     return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
 }
 
+// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
+// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
+// 128-frame block goes through the time-sliced kernel (measured on the 3-node chain, rocprofv3 kernel averages:
+// 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt).
+constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 81920;
+
 // Run-time specialised kernel for a fused stage (nullptr: not wanted / not possible).  mod = with control ports.
 const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
     const uint32_t N = e->desc.channels;
     const char *jit_env = getenv("DSPFX_JIT");
     const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N > 131072u);
+    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS);
     if (!want_jit || st.count < 1 || !st.fast_div) return nullptr;
     int sigs[MAX_SLOTS];
     for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
@@ -417,7 +431,8 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
     }
     const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
     if (N < 64u * (unsigned)cpl) return nullptr;
-    const JitKernel *k = jit_get(e->device, sigs, st.count, 8, cpl, mod);
+    const int f = (N <= 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt)
+    const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
     return k ? &k->var : nullptr;
 }
 
@@ -444,6 +459,11 @@ std::string hexd(double v) {
     return b;
 }
 
+// Input block a link source stands for (DSPFX_GRAPH_INPUT.. -> 0..GRAPH_IO-1), or -1 for a node / the zero pipe.
+int graph_input_block(int src) {
+    return src == DSPFX_GRAPH_INPUT ? 0 : src == DSPFX_GRAPH_INPUT2 ? 1 : src == DSPFX_GRAPH_INPUT3 ? 2 : src == DSPFX_GRAPH_INPUT4 ? 3 : -1;
+}
+
 // One link of the program being generated; node indices are local to the stage.  raw: the only link into its port and
 // taken as it is -- a hop of a chain engine whose DSPFX_LINK_* flag is off.
 struct GLink {
@@ -463,7 +483,8 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
     std::string body;
     auto gather = [&](const std::string &dst, const std::vector<GLink> &srcs, bool declare) {
         auto name = [](int sidx) {
-            return sidx == DSPFX_GRAPH_INPUT ? std::string("x") : sidx == DSPFX_GRAPH_INPUT2 ? std::string("x2") : "v" + std::to_string(sidx);
+            const int blk = graph_input_block(sidx);
+            return blk >= 0 ? "xs[" + std::to_string(blk) + "]" : "v" + std::to_string(sidx);
         };
         body += "        ";
         if (declare) body += "float " + dst + "[F][CPL]; ";
@@ -489,10 +510,11 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
     };
     const std::string FAST = fast ? "true" : "false";
     for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
-    bool uses_input = false, uses_input2 = false;
+    unsigned in_mask = 0;
+    int n_out = 1;
     for (const GLink &l : links) {
-        uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
-        uses_input2 = uses_input2 || l.src == DSPFX_GRAPH_INPUT2;
+        if (graph_input_block(l.src) >= 0) in_mask |= 1u << graph_input_block(l.src);
+        if (l.dst >= n) n_out = std::max(n_out, l.dst - n + 1);
     }
     for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
         if (e->nodes[(size_t)(first + i)].d.kind == DSPFX_REVERB)
@@ -536,14 +558,16 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
         else body += "apply_node<" + KM + ", F, CPL, false, " + FAST + ">(" + slot + ", " + v + ", st[" + I + "], cx);";
         body += "\n";
     }
-    body += "        // Output node\n";
-    gather("y", port_links(n, DSPFX_PORT_MAIN), false);
+    for (int m = 0; m < n_out; ++m) {
+        body += m == 0 ? "        // Output node\n" : "        // output block " + std::to_string(m) + "\n";
+        gather("ys[" + std::to_string(m) + "]", port_links(n + m, DSPFX_PORT_MAIN), false);
+    }
     std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[GRAPH_SLOTS] = {";
     for (int i = 0; i < GRAPH_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < GRAPH_SLOTS ? ", " : "");
-    src += std::string("};\n    static constexpr bool uses_input = ") + (uses_input ? "true" : "false") + ";\n";
-    src += std::string("    static constexpr bool uses_input2 = ") + (uses_input2 ? "true" : "false") + ";\n";
-    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], const float (&x2)[F][CPL],\n"
-           "                                               float (&y)[F][CPL], float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
+    src += "};\n    static constexpr unsigned in_mask = " + std::to_string(in_mask) + ";\n";
+    src += "    static constexpr int n_out = " + std::to_string(n_out) + ";\n";
+    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&xs)[GRAPH_IO][F][CPL], float (&ys)[GRAPH_IO][F][CPL],\n"
+           "                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
     src += body;
     src += "    }\n};\n}  // namespace dspfx\n";
     return src;
@@ -646,7 +670,7 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
     int want = -1;
     if (const char *sv = getenv("DSPFX_VARIANT"))
         if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
-    if (want == 0 || (want < 0 && N > 131072u) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    if (want == 0 || (want < 0 && N > TS_MAX_CHANNELS) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     const Pref pref = read_pref();
     std::vector<const Variant *> all;
     collect_variants(all);
@@ -663,7 +687,20 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
         const int want_cpl = pref.cpl > 0 ? pref.cpl : 1;
         if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
     }
-    return best;
+    if (best) return best;
+    // no compiled-in time-sliced kernel for this chain shape: instantiate one at run time, like the standard kernel
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0 || N % 64u) return nullptr;
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true);
+    return k ? &k->var : nullptr;
 }
 
 // Chain engines: may a fusable run of more than MAX_SLOTS nodes become one generated kernel?  The conditions of the
@@ -1007,11 +1044,19 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
             if (st.count == 0 && !(last && (mix || e->partials_override || e->mp_building)) && src == out) continue;   // nothing to do
-            if (e->graph_mode && !side)
-                for (const dspfx_graph_link &l : e->wiring)
-                    if (l.src == DSPFX_GRAPH_INPUT2) return fail(e, DSPFX_ERR_INVALID, "this graph reads a second block (DSPFX_GRAPH_INPUT2): side must not be null");
             GraphArgs ga;                   // a graph kernel reads the slots beyond ChainArgs from it
             memset(&ga, 0, sizeof ga);
+            if (e->graph_mode) {
+                const int n_nodes = (int)e->nodes.size();
+                for (const dspfx_graph_link &l : e->wiring) {
+                    const int blk = graph_input_block(l.src);
+                    if (blk == 1 && !side) return fail(e, DSPFX_ERR_INVALID, "this graph reads a second block (DSPFX_GRAPH_INPUT2): side must not be null");
+                    if (blk >= 2 && !e->io_in[blk]) return fail(e, DSPFX_ERR_INVALID, "this graph reads input block %d: pass it with dspfx_process_io", blk);
+                    if (l.dst > n_nodes && !e->io_out[l.dst - n_nodes]) return fail(e, DSPFX_ERR_INVALID, "this graph writes output block %d: pass it with dspfx_process_io", l.dst - n_nodes);
+                }
+                for (int k = 2; k < GRAPH_IO; ++k) ga.xin[k - 2] = e->io_in[k] ? e->io_in[k] + e->io_off : nullptr;
+                for (int m = 1; m < GRAPH_IO; ++m) ga.xout[m - 1] = e->io_out[m] ? e->io_out[m] + e->io_off : nullptr;
+            }
             ChainArgs &a = ga.c;
             a.in = src;
             a.side = side;
@@ -1344,7 +1389,7 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {
         const dspfx_graph_link &l = links[i];
-        if (l.dst < 0 || l.dst > n_nodes || l.src < DSPFX_GRAPH_INPUT2 || l.src >= l.dst)
+        if (l.dst < 0 || l.dst >= n_nodes + DSPFX_GRAPH_MAX_IO || l.src < DSPFX_GRAPH_INPUT4 || (l.src >= l.dst && l.dst < n_nodes) || l.src >= n_nodes)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
         const int port = l.port & ~DSPFX_PORT_RAW;
         bool ok = port == DSPFX_PORT_MAIN;
@@ -1565,6 +1610,9 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         any = any || (n.d.kind == DSPFX_REVERB && n.group_floats * sizeof(float) >= ((size_t)64 << 20));
     }
     if (!any) return DSPFX_OK;               // nothing large enough to be placement-sensitive: state untouched
+    if (e->graph_mode)                       // a region kernel with extra blocks: its buffers are not all known here
+        for (const dspfx_graph_link &l : e->wiring)
+            if (graph_input_block(l.src) >= 2 || l.dst > (int)e->nodes.size()) return DSPFX_OK;
     TuneGuard tg(e);
     if (hipEventCreate(&tg.ea) != hipSuccess || hipEventCreate(&tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventCreate failed");
     // snapshot the small per-channel state (biquad / one-pole / generator / envelope rows): the probes run the real chain
@@ -1689,11 +1737,33 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
         const uint32_t nf = std::min(sub, n_frames - f0);
         // frame f0 of a block starts f0 rows in: a row is N floats (frame-major) or W floats (tiled)
         const size_t off = (size_t)f0 * (e->desc.tile_channels ? e->desc.tile_channels : N);
+        e->io_off = off;
         const int rc = run_subblock(e, in + off, side ? side + off : nullptr, out + off, mix ? mix + f0 : nullptr,
                                     nf, e->ctl_tile_frames ? e->ctl_tile_frames : n_frames, s);
+        e->io_off = 0;
         if (rc) return rc;
     }
     return DSPFX_OK;
+}
+
+extern "C" int dspfx_process_io(dspfx_engine *e, const float *const *ins, int n_ins, float *const *outs, int n_outs, float *mix,
+                                uint32_t n_frames, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (n_ins < 0 || n_ins > DSPFX_GRAPH_MAX_IO || n_outs < 1 || n_outs > DSPFX_GRAPH_MAX_IO || (n_ins > 0 && !ins) || !outs || !outs[0])
+        return fail(e, DSPFX_ERR_INVALID, "process_io: 0..%d input blocks, 1..%d output blocks (the first one non-null)", DSPFX_GRAPH_MAX_IO, DSPFX_GRAPH_MAX_IO);
+    if (!e->graph_mode && (n_ins > 2 || n_outs > 1)) return fail(e, DSPFX_ERR_INVALID, "only a graph engine (dspfx_graph_set) takes extra blocks");
+    for (int k = 0; k < GRAPH_IO; ++k) {
+        e->io_in[k] = k < n_ins ? ins[k] : nullptr;
+        e->io_out[k] = k < n_outs ? outs[k] : nullptr;
+    }
+    // a graph that never reads `in` still gets a valid pointer (the kernel does not touch it)
+    const float *in0 = (n_ins > 0 && ins[0]) ? ins[0] : outs[0];
+    const int rc = dspfx_process(e, in0, n_ins > 1 ? ins[1] : nullptr, outs[0], mix, n_frames, stream);
+    for (int k = 0; k < GRAPH_IO; ++k) {
+        e->io_in[k] = nullptr;
+        e->io_out[k] = nullptr;
+    }
+    return rc;
 }
 
 extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
@@ -2317,14 +2387,15 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
         }
     }
     if (side && !e->graph_mode) b += 4.0;   // a fused graph's "b" ports are fed from registers
-    if (e->graph_mode) {                    // ... and a graph without an Input link never reads `in`
-        bool uses_input = false, uses_input2 = false;
+    if (e->graph_mode) {                    // ... and a graph reads / writes exactly the blocks its links name
+        unsigned in_mask = 0;
+        int n_out = 1;
         for (const dspfx_graph_link &l : e->wiring) {
-            uses_input = uses_input || l.src == DSPFX_GRAPH_INPUT;
-            uses_input2 = uses_input2 || l.src == DSPFX_GRAPH_INPUT2;
+            if (graph_input_block(l.src) >= 0) in_mask |= 1u << graph_input_block(l.src);
+            n_out = std::max(n_out, l.dst - (int)e->nodes.size() + 1);
         }
-        if (!uses_input) b -= 4.0;
-        if (uses_input2) b += 4.0;
+        b -= 4.0;                           // `in` was counted above
+        b += 4.0 * __builtin_popcount(in_mask) + 4.0 * (n_out - 1);
     }
     return b;
 }

@@ -18,9 +18,15 @@ namespace dspfx {
 // A graph may hold twice the nodes of a fused chain stage: the chain kernels' argument block stays as it is and
 // the graph kernel's appends the slots beyond it.
 constexpr int GRAPH_SLOTS = 16;
+// A generated kernel may read up to GRAPH_IO blocks and write up to GRAPH_IO blocks (a REGION of a graph that was cut
+// into several kernels: the signals crossing the cut, side inputs and control signals from other regions).  Block 0 / 1
+// of the inputs are the engine's `in` / `side`, output 0 is `out`; the rest travel here.
+constexpr int GRAPH_IO = 4;
 struct GraphArgs {
     ChainArgs c;                              // first: the engine builds a ChainArgs and launches either kind of kernel
     SlotArgs more[GRAPH_SLOTS - MAX_SLOTS];   // slots MAX_SLOTS .. GRAPH_SLOTS-1
+    const float *xin[GRAPH_IO - 2];           // input blocks 2 .. GRAPH_IO-1
+    float *xout[GRAPH_IO - 1];                // output blocks 1 .. GRAPH_IO-1
 };
 template <int I>
 __host__ __device__ __forceinline__ const SlotArgs &gslot(const GraphArgs &g) {
@@ -121,32 +127,36 @@ __device__ __forceinline__ void g_mix_mod(float (&v)[F][CPL], const float (&b)[F
 
 // ---- the kernel ---------------------------------------------------------------------------------------
 // PROG (generated):  static constexpr int sigs[GRAPH_SLOTS]  node signatures (state rows to load / store)
-//                    static constexpr bool uses_input        false: no link leaves the Input node, `in` is not read
-//                    static constexpr bool uses_input2       true: some link reads the second block (`side`)
-//                    template <int F, int CPL> static void run(g, x, x2, y, st, cx)   x / x2 = Input blocks, y = Output block
+//                    static constexpr unsigned in_mask       bit k: input block k is read (0 = `in`, 1 = `side`, 2.. = xin)
+//                    static constexpr int n_out              output blocks written (>= 1; 0 = `out`, 1.. = xout)
+//                    template <int F, int CPL> static void run(g, xs, ys, st, cx)   xs[k] = input block k, ys[m] = output block m
 template <int F, int CPL, class PROG>
 __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAPH_SLOTS][4][CPL], size_t c, const WaveAddr &w,
                                             unsigned f0, int lane, unsigned wave_global) {
     const ChainArgs &a = g.c;
-    float x[F][CPL], x2[F][CPL], y[F][CPL];
-    if constexpr (PROG::uses_input) {
+    float xs[GRAPH_IO][F][CPL], ys[GRAPH_IO][F][CPL];
 #pragma unroll
-        for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), x[f], true);
-    } else {
-        g_zero<F, CPL>(x);
-    }
-    if constexpr (PROG::uses_input2) {            // DSPFX_GRAPH_INPUT2: the block passed as `side`
+    for (int k = 0; k < GRAPH_IO; ++k) {
+        if ((PROG::in_mask >> k) & 1u) {
+            const float *src = k == 0 ? a.in : k == 1 ? a.side : g.xin[k >= 2 ? k - 2 : 0];
 #pragma unroll
-        for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.side + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), x2[f], true);
-    } else {
-        g_zero<F, CPL>(x2);
+            for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(src + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), xs[k][f], true);
+        } else {
+            g_zero<F, CPL>(xs[k]);
+        }
     }
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, nullptr, 0, true};
-    PROG::template run<F, CPL>(g, x, x2, y, st, cx);
+    PROG::template run<F, CPL>(g, xs, ys, st, cx);
 #pragma unroll
-    for (int f = 0; f < F; ++f)
-        store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), y[f], true);
-    if (a.mixpart) mixbus_partial<F, CPL>(a, y, true, f0, lane, wave_global);
+    for (int m = 0; m < GRAPH_IO; ++m) {
+        if (m < PROG::n_out) {
+            float *dst = m == 0 ? a.out : g.xout[m >= 1 ? m - 1 : 0];
+#pragma unroll
+            for (int f = 0; f < F; ++f)
+                store_vec<CPL, false, S_OUT>(lane_ptr(dst + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), ys[m][f], true);
+        }
+    }
+    if (a.mixpart) mixbus_partial<F, CPL>(a, ys[0], true, f0, lane, wave_global);
 }
 
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves), like chain_kernel.

@@ -9,11 +9,14 @@ struct CheckProg {
     static constexpr int sigs[GRAPH_SLOTS] = {sig(K_GAIN), sig(K_REVERB), sig(K_MIX), sig(K_SIGNAL_GEN, G_SINE), sig(K_OVERDRIVE),
                                               sig(K_BIQUAD), sig(K_DISTORT, D_TANH), sig(K_ADD), sig(K_LOW_PASS), SIG_NONE, SIG_NONE,
                                               SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE, SIG_NONE};
-    static constexpr bool uses_input = true;
-    static constexpr bool uses_input2 = true;
+    static constexpr unsigned in_mask = 0x7;      // `in`, `side` and one extra block
+    static constexpr int n_out = 2;
     template <int F, int CPL>
-    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&x)[F][CPL], const float (&x2)[F][CPL],
-                                               float (&y)[F][CPL], float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {
+    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&xs)[GRAPH_IO][F][CPL], float (&ys)[GRAPH_IO][F][CPL],
+                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {
+        const float (&x)[F][CPL] = xs[0];
+        const float (&x2)[F][CPL] = xs[1];
+        float (&y)[F][CPL] = ys[0];
         RingPre<F, CPL> pre1; ring_prefetch<F, CPL, false>(gslot<1>(g), cx, pre1);
         // node 0: one link from the Input node
         float v0[F][CPL]; g_zero<F, CPL>(v0); g_acc<F, CPL>(v0, x); g_div<true, F, CPL>(v0, 0x1.0006p+0f, 0x1.fff2p-1);
@@ -57,6 +60,8 @@ struct CheckProg {
         apply_node<K_LOW_PASS, 0, F, CPL, false, true>(gslot<8>(g), v8, st[8], cx);
         // Output node: two links
         g_zero<F, CPL>(y); g_acc<F, CPL>(y, v8); g_acc<F, CPL>(y, x2); g_div<true, F, CPL>(y, 0x1.00034p+1f, 0x1.fff98p-2);
+        // a second output block: a signal handed to the next region as it is, and an average over an extra input
+        g_zero<F, CPL>(ys[1]); g_acc<F, CPL>(ys[1], v5); g_acc<F, CPL>(ys[1], xs[2]); g_div<true, F, CPL>(ys[1], 0x1.00034p+1f, 0x1.fff98p-2);
     }
 };
 template __global__ void graph_kernel<8, 2, CheckProg>(const GraphArgs);

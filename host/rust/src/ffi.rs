@@ -78,6 +78,9 @@ pub const DSPFX_GRAPH_MAX_NODES: u32 = 16;
 pub const DSPFX_GRAPH_INPUT: i32 = -1;
 pub const DSPFX_GRAPH_ZERO: i32 = -2;
 pub const DSPFX_GRAPH_INPUT2: i32 = -3;
+pub const DSPFX_GRAPH_INPUT3: i32 = -4;
+pub const DSPFX_GRAPH_INPUT4: i32 = -5;
+pub const DSPFX_GRAPH_MAX_IO: u32 = 4;
 pub const DSPFX_PORT_MAIN: i32 = 0;
 pub const DSPFX_PORT_SIDE: i32 = 1;
 pub const DSPFX_PORT_SLIDER: i32 = 2;
@@ -162,6 +165,7 @@ extern "C" {
 
     pub fn dspfx_process_mixpipe(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_mixpipe_flush(e: *mut dspfx_engine, mix_older: *mut f32, mix_newer: *mut f32, n_connected: u64, stream: *mut c_void) -> c_int;
+    pub fn dspfx_process_io(e: *mut dspfx_engine, ins: *const *const f32, n_ins: c_int, outs: *const *mut f32, n_outs: c_int, mix: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_graph_set(e: *mut dspfx_engine, nodes: *const dspfx_node_desc, n_nodes: c_int, links: *const dspfx_graph_link, n_links: c_int) -> c_int;
     pub fn dspfx_graph_source(nodes: *const dspfx_node_desc, n_nodes: c_int, links: *const dspfx_graph_link, n_links: c_int, dst: *mut c_char, cap: usize) -> c_int;
     pub fn dspfx_link_average(e: *mut dspfx_engine, srcs: *const *const f32, n_srcs: c_int, dst: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;

@@ -328,6 +328,15 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
  * that was cut into consecutive kernels carry a signal AROUND a node that has a kernel of its own -- the dry path
  * beside a FIR cabinet: the kernel after the FIR node reads the FIR output as its Input and the dry signal here. */
 #define DSPFX_GRAPH_INPUT2 (-3)
+/* Regions of a graph that was cut into several kernels exchange more than two signals: a generated kernel may read up to
+ * DSPFX_GRAPH_MAX_IO blocks and write up to DSPFX_GRAPH_MAX_IO blocks.  Inputs: DSPFX_GRAPH_INPUT (block 0),
+ * DSPFX_GRAPH_INPUT2 (block 1), DSPFX_GRAPH_INPUT3, DSPFX_GRAPH_INPUT4; a link into an Add / Mix "b" port or a slider
+ * port from one of them is a side input / control signal read from memory.  Outputs: dst == n_nodes is output block 0
+ * (the Output node: `out`), dst == n_nodes + m output block m -- averaged like any port, or DSPFX_PORT_RAW to hand one
+ * signal over untouched.  Blocks beyond `in` / `side` / `out` are passed with dspfx_process_io. */
+#define DSPFX_GRAPH_MAX_IO 4
+#define DSPFX_GRAPH_INPUT3 (-4)
+#define DSPFX_GRAPH_INPUT4 (-5)
 #define DSPFX_PORT_MAIN 0
 #define DSPFX_PORT_SIDE 1
 #define DSPFX_PORT_SLIDER 2
@@ -342,6 +351,11 @@ typedef struct dspfx_graph_link {
 } dspfx_graph_link;
 int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
                     int n_links);
+/* dspfx_process for a graph engine with several input / output blocks: ins[k] = input block k (ins[0] = `in`, ins[1] =
+ * `side`), outs[m] = output block m (outs[0] = `out`).  Entries the graph does not use may be NULL; n_ins, n_outs <=
+ * DSPFX_GRAPH_MAX_IO.  `mix` sums output block 0. */
+int dspfx_process_io(dspfx_engine *e, const float *const *ins, int n_ins, float *const *outs, int n_outs, float *mix,
+                     uint32_t n_frames, void *stream);
 /* The translation unit dspfx_graph_set would compile for this graph (the generated `struct Prog`; it includes
  * csrc/graph_kernel.hip.h), NUL-terminated into dst[cap].  Needs no engine and no device: for inspection and for
  * checking the generator where there is no GPU (without one every division is written in its IEEE form, since the

@@ -1187,6 +1187,42 @@ def test_mix_bus_pipelined_inside_the_kernel(dspfx, torch_cuda, N, tile):
         eng.process_mixpipe(dx, y, None, 64)
 
 
+@pytest.mark.parametrize("which", ["chain3", "chain5"])
+def test_time_sliced_kernel_equals_the_standard_one(dspfx, torch_cuda, monkeypatch, which):
+    """Engines of at most 131072 channels run whole 128-frame blocks of the BASELINE chains through chain_ts_kernel: a
+    workgroup owns 64 channels, its four waves take 32 frames each, state passes from wave to wave through LDS.  Every
+    recurrence still sees its frames in order: outputs, mix bus and carried state must equal the standard kernel bit
+    for bit (and the oracle within the chain's bar), in both layouts, with a ragged channel count, across blocks."""
+    chain = chain3(dspfx, 300) if which == "chain3" else chain5(dspfx, 300)
+    for N, tile in ((64 * 37 + 5, 0), (4096, 256), (8192, 0)):
+        x = noise_block(N, 128 * 5)
+        outs = {}
+        for ts in ("1", "0"):
+            monkeypatch.setenv("DSPFX_VARIANT", "ts=" + ts)
+            eng = dspfx.Engine(N, 128, link_flags=3, tile_channels=tile)
+            eng.set_chain(chain)
+            assert ("time-sliced" in eng.describe()) == (ts == "1"), eng.describe()
+            ys, ms = [], []
+            for k in range(5):
+                nf = 64 if k == 3 else 128        # a short block in between: the standard kernel takes it, state carries on
+                dx = torch_cuda.from_numpy(dspfx.to_layout(x[k * 128:k * 128 + nf], tile)).cuda()
+                dy, dm = torch_cuda.empty_like(dx), torch_cuda.empty(nf, device="cuda")
+                eng.process(dx, out=dy, mix=dm, n_frames=nf)
+                torch_cuda.cuda.synchronize()
+                ys.append(dspfx.from_layout(dy.cpu().numpy(), nf, N, tile))
+                ms.append(dm.cpu().numpy().copy())
+            outs[ts] = (ys, ms, eng.state_export(0 if which == "chain5" else 1))
+        for a, b in zip(outs["1"][0], outs["0"][0]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        for a, b in zip(outs["1"][1], outs["0"][1]):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+        assert np.array_equal(outs["1"][2], outs["0"][2])
+        monkeypatch.delenv("DSPFX_VARIANT")
+        ref = run_oracle(chain, x[:256], 3)
+        got = np.concatenate(outs["1"][0][:2])
+        assert ulp_diff(got, ref).max() <= 1
+
+
 def test_mix_allreduce_through_the_c_abi(dspfx, torch_cuda):
     """dspfx_comm_create / dspfx_mix_allreduce: the mix bus' one collective behind the C ABI.  A 1-rank communicator made
     from a real unique id runs RCCL's ncclCommInitRank and ncclAllReduce on this GPU (the sum over one rank is the

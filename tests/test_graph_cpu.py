@@ -222,7 +222,7 @@ def test_segment_plan_cuts_long_graphs_where_one_signal_crosses(dspfx, tmp_path)
     g = G.Graph(graphs.long_rig(0, 12))
     specs, links = G.series_plan(g)[0][1:3]
     src = _compile_generated(E, specs, links, tmp_path, "handover")
-    assert "g_copy<F, CPL>(y, v%d)" % (len(specs) - 1) in src
+    assert "g_copy<F, CPL>(ys[0], v%d)" % (len(specs) - 1) in src
     # a kernel of at most 3 nodes: the diamond is cut twice, each time with an older signal carried beside the new one
     steps = G.segment_plan(G.Graph(graphs.diamond()), max_nodes=3)
     assert [(s[0], len(s[1]), s[3], s[4]) for s in steps] == [("graph", 1, -1, None), ("graph", 2, 0, -1), ("graph", 3, 1, 0)]
