@@ -37,9 +37,9 @@ LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
 GRAPH_MAX_NODES = 16
 ERR_UNSUPPORTED = -5
-GRAPH_INPUT, GRAPH_ZERO, GRAPH_INPUT2, GRAPH_INPUT3, GRAPH_INPUT4 = -1, -2, -3, -4, -5
-GRAPH_INPUTS = (GRAPH_INPUT, GRAPH_INPUT2, GRAPH_INPUT3, GRAPH_INPUT4)     # link source of input block k
-GRAPH_MAX_IO = 4
+GRAPH_INPUT, GRAPH_ZERO, GRAPH_INPUT2 = -1, -2, -3
+GRAPH_MAX_IO = 16
+GRAPH_INPUTS = (GRAPH_INPUT, GRAPH_INPUT2) + tuple(-(2 + k) for k in range(2, GRAPH_MAX_IO))     # link source of input block k
 PORT_MAIN, PORT_SIDE, PORT_SLIDER = 0, 1, 2
 PORT_RAW = 256
 

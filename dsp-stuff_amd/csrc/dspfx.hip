@@ -104,8 +104,8 @@ struct dspfx_engine {
     uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
     // dspfx_process_io: input blocks 2.. and output blocks 1.. of the call being launched (graph engines), and the float
     // offset of the sub-block being launched
-    const float *io_in[GRAPH_IO] = {nullptr, nullptr, nullptr, nullptr};
-    float *io_out[GRAPH_IO] = {nullptr, nullptr, nullptr, nullptr};
+    const float *io_in[GRAPH_IO] = {};
+    float *io_out[GRAPH_IO] = {};
     size_t io_off = 0;
     // staging for dspfx_process_host
     float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
@@ -461,7 +461,9 @@ std::string hexd(double v) {
 
 // Input block a link source stands for (DSPFX_GRAPH_INPUT.. -> 0..GRAPH_IO-1), or -1 for a node / the zero pipe.
 int graph_input_block(int src) {
-    return src == DSPFX_GRAPH_INPUT ? 0 : src == DSPFX_GRAPH_INPUT2 ? 1 : src == DSPFX_GRAPH_INPUT3 ? 2 : src == DSPFX_GRAPH_INPUT4 ? 3 : -1;
+    if (src == DSPFX_GRAPH_INPUT) return 0;
+    if (src == DSPFX_GRAPH_INPUT2) return 1;
+    return (src <= -4 && src > -2 - DSPFX_GRAPH_MAX_IO) ? -src - 2 : -1;
 }
 
 // One link of the program being generated; node indices are local to the stage.  raw: the only link into its port and
@@ -1389,7 +1391,7 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
     std::map<std::pair<int, int>, int> fan_in;
     for (int i = 0; i < n_links; ++i) {
         const dspfx_graph_link &l = links[i];
-        if (l.dst < 0 || l.dst >= n_nodes + DSPFX_GRAPH_MAX_IO || l.src < DSPFX_GRAPH_INPUT4 || (l.src >= l.dst && l.dst < n_nodes) || l.src >= n_nodes)
+        if (l.dst < 0 || l.dst >= n_nodes + DSPFX_GRAPH_MAX_IO || l.src <= -2 - DSPFX_GRAPH_MAX_IO || (l.src >= l.dst && l.dst < n_nodes) || l.src >= n_nodes)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
         const int port = l.port & ~DSPFX_PORT_RAW;
         bool ok = port == DSPFX_PORT_MAIN;

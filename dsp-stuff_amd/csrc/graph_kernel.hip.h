@@ -21,7 +21,7 @@ constexpr int GRAPH_SLOTS = 16;
 // A generated kernel may read up to GRAPH_IO blocks and write up to GRAPH_IO blocks (a REGION of a graph that was cut
 // into several kernels: the signals crossing the cut, side inputs and control signals from other regions).  Block 0 / 1
 // of the inputs are the engine's `in` / `side`, output 0 is `out`; the rest travel here.
-constexpr int GRAPH_IO = 4;
+constexpr int GRAPH_IO = 16;
 struct GraphArgs {
     ChainArgs c;                              // first: the engine builds a ChainArgs and launches either kind of kernel
     SlotArgs more[GRAPH_SLOTS - MAX_SLOTS];   // slots MAX_SLOTS .. GRAPH_SLOTS-1

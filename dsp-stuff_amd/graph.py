@@ -34,8 +34,9 @@ from __future__ import annotations
 import json
 from typing import Dict, List, Optional, Tuple
 
-from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_INPUT2, GRAPH_MAX_NODES, GRAPH_ZERO, LINK_INPUT, LINK_INTERNAL,
-               LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_RAW, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine, NodeSpec)
+from . import (ADD, DISTORT, ERR_UNSUPPORTED, FIR, FUZZ, GAIN, GRAPH_INPUT, GRAPH_INPUT2, GRAPH_INPUTS, GRAPH_MAX_IO, GRAPH_MAX_NODES, GRAPH_ZERO,
+               LINK_INPUT, LINK_INTERNAL, LINK_SIDE_RAW, MIX, PORT_MAIN, PORT_RAW, PORT_SIDE, PORT_SLIDER, SIGNAL_GEN, DspfxError, Engine,
+               NodeSpec)
 from .config import _TABLE, DspConfigError, _node_from_cfg
 
 _UNSUPPORTED = {"muff"}                                # GPL crate, source not in the reference tree
@@ -381,6 +382,138 @@ def segment_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES):
     return steps
 
 
+def _late_source_order(g: Graph) -> List[int]:
+    """Topological order of the effect nodes in which sources fed by nothing (generators, unplugged effects) come as late
+    as possible -- right before their first consumer -- so that they do not keep a signal alive across cutting points."""
+    nodes = [nid for nid in g.order if g.nodes[nid].spec is not None]
+    fed = {}
+    for nid in g.order:
+        fed[nid] = g.nodes[nid].typename == "input" or any(fed[p] for p in g.producers(g.nodes[nid]))
+    order, placed = [], set()
+
+    def place(nid):
+        if nid in placed:
+            return
+        for p in g.producers(g.nodes[nid]):
+            if g.nodes[p].spec is not None and not fed[p]:
+                place(p)
+        placed.add(nid)
+        order.append(nid)
+
+    for nid in nodes:
+        if fed[nid]:
+            place(nid)
+    for nid in nodes:
+        place(nid)
+    return order
+
+
+def region_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES, max_io: int = GRAPH_MAX_IO):
+    """ANY graph as a short series of generated kernels: the evaluation order is cut into REGIONS of at most `max_nodes`
+    fusable nodes, each one kernel with up to `max_io` input blocks (signals from the Input node, from earlier regions,
+    from FIR / Fuzz nodes -- read as main inputs, Add / Mix side inputs or control signals alike) and up to `max_io`
+    output blocks (every signal a later step still reads, handed over untouched).  FIR / Fuzz nodes keep their own
+    kernels between the regions; the last region also evaluates the Output node's port.  Steps:
+
+      ("region", specs, links, in_refs, n_out)     links as for dspfx_graph_set: sources GRAPH_INPUTS[k] = in_refs[k],
+                                                    dst == len(specs) + m = output block m (block 0 of the last region
+                                                    is the Output node's average, every other block a PORT_RAW handover)
+      ("node", spec, main_refs, ctl_refs)          a FIR / Fuzz node: main port averaged over main_refs, slider k fed
+                                                    by ctl_refs[k]
+      ("output", refs)                             the Output node's average when no region is left to carry it
+
+    A ref is -1 (the graph's Input block), (step index, output block) or None (a connected pipe of zeros).
+    None when some region would need more than `max_io` blocks either way."""
+    order = _late_source_order(g)
+    out_id = g.outputs[0]
+    pos = {nid: i for i, nid in enumerate(order)}
+    pos[out_id] = len(order)
+    last_use: Dict[int, int] = {}
+    for nid in order + [out_id]:
+        for p in g.producers(g.nodes[nid]):
+            last_use[p] = max(last_use.get(p, -1), pos[nid])
+    loc: Dict[int, object] = {}
+    if g.inputs:
+        loc[g.inputs[0]] = -1
+    steps = []
+
+    def ref(v):
+        return None if v == ZERO else loc[v]
+
+    i = 0
+    while i < len(order):
+        nid = order[i]
+        n = g.nodes[nid]
+        if _unfusable(n.spec):
+            steps.append(("node", n.spec, [ref(v) for v in n.main], {k: ref(srcs[0]) for k, srcs in n.ctl.items()}))
+            loc[nid] = (len(steps) - 1, 0)
+            i += 1
+            continue
+        best = None
+        end = i
+        while end < len(order) and end - i < max_nodes and not _unfusable(g.nodes[order[end]].spec):
+            end += 1
+            region = order[i:end]
+            inside = set(region)
+            final = end == len(order)
+            ext: List[int] = []
+            consumers = region + ([out_id] if final else [])
+            for c in consumers:
+                for v in g.producers(g.nodes[c]):
+                    if v not in inside and v not in ext:
+                        ext.append(v)
+            outs = [v for v in region if last_use.get(v, -1) >= end and not (final and last_use.get(v, -1) == len(order) and
+                                                                              all(pos[u] < end or u == out_id for u in _users(g, v)))]
+            if final:
+                outs = []
+            n_out = (1 if final else 0) + len(outs)
+            if len(ext) <= max_io and n_out <= max_io:
+                best = (end, region, ext, outs, final)
+        if best is None:
+            return None
+        end, region, ext, outs, final = best
+        idx = {v: k for k, v in enumerate(region)}
+        blk = {v: k for k, v in enumerate(ext)}
+
+        def src(v):
+            if v == ZERO:
+                return GRAPH_ZERO
+            return idx[v] if v in idx else GRAPH_INPUTS[blk[v]]
+
+        links = []
+        for v in region:
+            m = g.nodes[v]
+            links += [(src(s), idx[v], PORT_MAIN) for s in m.main]
+            links += [(src(s), idx[v], PORT_SIDE) for s in m.side]
+            for kk, srcs in sorted(m.ctl.items()):
+                links += [(src(s), idx[v], PORT_SLIDER + kk) for s in srcs]
+        nn = len(region)
+        if final:
+            links += [(src(s), nn, PORT_MAIN) for s in g.nodes[out_id].main]
+        if not final and not outs:
+            outs = [region[-1]]                          # nothing of this region is read later (dead branch): still one block
+        base = 1 if final else 0
+        for m_, v in enumerate(outs):
+            links.append((idx[v], nn + base + m_, PORT_MAIN | PORT_RAW))
+        steps.append(("region", [g.nodes[v].spec for v in region], links, [loc[v] for v in ext], base + len(outs)))
+        for m_, v in enumerate(outs):
+            loc[v] = (len(steps) - 1, base + m_)
+        i = end
+    if not steps or steps[-1][0] != "region" or len(steps[-1][1]) == 0 or not _is_final_region(steps[-1], g):
+        steps.append(("output", [ref(v) for v in g.nodes[out_id].main]))
+    return steps
+
+
+def _users(g: Graph, v: int) -> List[int]:
+    return [nid for nid, n in g.nodes.items() if v in g.producers(n)]
+
+
+def _is_final_region(step, g: Graph) -> bool:
+    """Does this region step carry the Output node's port (a non-RAW link into output block 0)?"""
+    specs, links = step[1], step[2]
+    return any(d == len(specs) and not (p & PORT_RAW) for _, d, p in links) or not g.nodes[g.outputs[0]].main
+
+
 def series_plan(g: Graph):
     """`segment_plan` for graphs that need it: None for a graph that is one kernel anyway."""
     return None if fused_plan(g) is not None else segment_plan(g)
@@ -393,7 +526,8 @@ class GraphEngine:
     else run by run; True = insist on the one kernel; False = always run by run."""
 
     def __init__(self, text: str, channels: int, max_frames: int = 128, device: int = 0, tile_channels: int = 0,
-                 page_round: bool = False, fused: Optional[bool] = None, max_nodes: Optional[int] = None):
+                 page_round: bool = False, fused: Optional[bool] = None, max_nodes: Optional[int] = None,
+                 regions: Optional[bool] = None):
         import torch
         self.torch = torch
         self.g = Graph(text, page_round)
@@ -401,9 +535,15 @@ class GraphEngine:
         self.dev = torch.device("cuda", device)
         self.fused: Optional[Engine] = None
         self.series, self.series_kind = [], []
+        self.regions = []
         self.runs, self.run_of = [], {}
         self.zeros = torch.zeros(max_frames * channels, dtype=torch.float32, device=self.dev)
         self.final = self._buf()
+        # regions=True (tests): go straight to the general region plan; False: never use it
+        if regions:
+            if not self._build_regions(region_plan(self.g, max_nodes or GRAPH_MAX_NODES), device):
+                raise DspConfigError("this graph has no region plan")
+            return
         # max_nodes (tests): cut the graph as if a kernel held only that many nodes
         plan = fused_plan(self.g) if fused is not False and max_nodes is None else None
         if plan is not None:
@@ -446,6 +586,9 @@ class GraphEngine:
         if self.series:
             self.util = self.series[0][0]
             return
+        # anything else: regions with several input / output blocks each (region_plan), FIR / Fuzz nodes in between
+        if fused is None and regions is not False and self._build_regions(region_plan(self.g, max_nodes or GRAPH_MAX_NODES), device):
+            return
         self.runs, self.run_of = plan_runs(self.g)
         for r in self.runs:
             head = r.nodes[0]
@@ -464,9 +607,51 @@ class GraphEngine:
     def _buf(self):
         return self.torch.empty(self.B * self.N, dtype=self.torch.float32, device=self.dev)
 
+    def _build_regions(self, steps, device) -> bool:
+        """Engines and buffers for a region plan; False (nothing kept) when there is no plan or a kernel cannot be had."""
+        if not steps:
+            return False
+        built = []
+        try:
+            for kind, *what in steps:
+                if kind == "region":
+                    specs, links, in_refs, n_out = what
+                    eng = Engine(self.N, self.B, link_flags=0, device=device, tile_channels=self.tile)
+                    built.append(dict(kind=kind, eng=eng, ins=in_refs, outs=[self._buf() for _ in range(n_out)]))
+                    eng.set_graph(specs, links)
+                elif kind == "node":
+                    spec, main_refs, ctl_refs = what
+                    flags = LINK_INTERNAL | (LINK_INPUT if len(main_refs) == 1 else 0)     # k links: averaged here, taken raw
+                    eng = Engine(self.N, self.B, link_flags=flags, device=device, tile_channels=self.tile)
+                    built.append(dict(kind=kind, eng=eng, main=main_refs, ctl=ctl_refs, outs=[self._buf()],
+                                      scratch=self._buf() if len(main_refs) > 1 else None))
+                    eng.set_chain([spec])
+                else:
+                    built.append(dict(kind=kind, eng=None, refs=what[0], outs=[self.final]))
+        except DspfxError as e:
+            for st in built:
+                if st["eng"] is not None:
+                    st["eng"].close()
+            if e.status != ERR_UNSUPPORTED:
+                raise
+            return False
+        self.regions = built
+        self.util = next(st["eng"] for st in built if st["eng"] is not None) if any(st["eng"] for st in built) else \
+            Engine(self.N, self.B, device=device, tile_channels=self.tile)
+        return True
+
     def describe(self) -> str:
         if self.fused is not None:
             return "one kernel: " + " | ".join(l for l in self.fused.describe().splitlines() if l.startswith("stage"))
+        if self.regions:
+            out = []
+            for k, st in enumerate(self.regions):
+                if st["eng"] is None:
+                    out.append(f"step {k}: Output node average of {len(st['refs'])} blocks")
+                    continue
+                what = f"region, {len(st['ins'])} in / {len(st['outs'])} out" if st["kind"] == "region" else "node"
+                out.append(f"step {k} ({what}): " + " | ".join(l for l in st["eng"].describe().splitlines() if l.startswith("stage")))
+            return "\n".join(out)
         if self.series:
             return "\n".join(f"segment {k}: " + " | ".join(l for l in eng.describe().splitlines() if l.startswith("stage"))
                              for k, (eng, _) in enumerate(self.series))
@@ -489,6 +674,29 @@ class GraphEngine:
         if self.fused is not None:
             self.fused.process(self.zeros if x is None else x, out=self.final, n_frames=nf, stream=stream)
             return self.final
+        if self.regions:
+            x0 = self.zeros if x is None else x
+
+            def at(ref):
+                return x0 if ref == -1 else self.zeros if ref is None else self.regions[ref[0]]["outs"][ref[1]]
+
+            for st in self.regions:
+                if st["kind"] == "region":
+                    st["eng"].process_io([at(r) for r in st["ins"]], st["outs"], nf, stream=stream)
+                elif st["kind"] == "node":
+                    refs = st["main"]
+                    if len(refs) == 1:
+                        src = at(refs[0])
+                    elif not refs:
+                        src = self.zeros
+                    else:
+                        st["eng"].link_average([at(r) for r in refs], st["scratch"], nf, stream)
+                        src = st["scratch"]
+                    ctl = {(0, k): at(r) for k, r in st["ctl"].items()}
+                    st["eng"].process(src, out=st["outs"][0], n_frames=nf, stream=stream, ctl=ctl or None)
+                else:
+                    self.util.link_average([at(r) for r in st["refs"]], self.final, nf, stream)
+            return self.regions[-1]["outs"][0]
         if self.series:
             x0 = self.zeros if x is None else x
 
@@ -536,6 +744,8 @@ class GraphEngine:
         """Re-tune the delay rings' placement of every generated kernel against the blocks it will really read and write
         (`dspfx_tune_placement`; resets DSP state).  `x` is the Input block the host will keep passing to `process`."""
         nf = min(self.B, 128) if n_frames is None else int(n_frames)
+        if self.regions:
+            return                      # region kernels exchange several blocks: not tuned (dspfx_tune_placement skips them too)
         if self.fused is not None:
             self.fused.tune_placement(x, self.final, nf, stream=stream)
             return
@@ -548,6 +758,9 @@ class GraphEngine:
     def close(self):
         if self.fused is not None:
             self.fused.close()
+        for st in self.regions:
+            if st["eng"] is not None:
+                st["eng"].close()
         for eng, _ in self.series:
             eng.close()
         for r in self.runs:

@@ -78,9 +78,11 @@ pub const DSPFX_GRAPH_MAX_NODES: u32 = 16;
 pub const DSPFX_GRAPH_INPUT: i32 = -1;
 pub const DSPFX_GRAPH_ZERO: i32 = -2;
 pub const DSPFX_GRAPH_INPUT2: i32 = -3;
-pub const DSPFX_GRAPH_INPUT3: i32 = -4;
-pub const DSPFX_GRAPH_INPUT4: i32 = -5;
-pub const DSPFX_GRAPH_MAX_IO: u32 = 4;
+pub const DSPFX_GRAPH_MAX_IO: u32 = 16;
+/// Link source of input block k (`DSPFX_GRAPH_INPUT_N`).
+pub const fn dspfx_graph_input_n(k: i32) -> i32 {
+    if k == 0 { DSPFX_GRAPH_INPUT } else if k == 1 { DSPFX_GRAPH_INPUT2 } else { -(2 + k) }
+}
 pub const DSPFX_PORT_MAIN: i32 = 0;
 pub const DSPFX_PORT_SIDE: i32 = 1;
 pub const DSPFX_PORT_SLIDER: i32 = 2;

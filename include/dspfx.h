@@ -330,13 +330,12 @@ int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, fl
 #define DSPFX_GRAPH_INPUT2 (-3)
 /* Regions of a graph that was cut into several kernels exchange more than two signals: a generated kernel may read up to
  * DSPFX_GRAPH_MAX_IO blocks and write up to DSPFX_GRAPH_MAX_IO blocks.  Inputs: DSPFX_GRAPH_INPUT (block 0),
- * DSPFX_GRAPH_INPUT2 (block 1), DSPFX_GRAPH_INPUT3, DSPFX_GRAPH_INPUT4; a link into an Add / Mix "b" port or a slider
+ * DSPFX_GRAPH_INPUT2 (block 1), DSPFX_GRAPH_INPUT_N(k) for block k (= -(2 + k) from block 2 on); a link into an Add / Mix "b" port or a slider
  * port from one of them is a side input / control signal read from memory.  Outputs: dst == n_nodes is output block 0
  * (the Output node: `out`), dst == n_nodes + m output block m -- averaged like any port, or DSPFX_PORT_RAW to hand one
  * signal over untouched.  Blocks beyond `in` / `side` / `out` are passed with dspfx_process_io. */
-#define DSPFX_GRAPH_MAX_IO 4
-#define DSPFX_GRAPH_INPUT3 (-4)
-#define DSPFX_GRAPH_INPUT4 (-5)
+#define DSPFX_GRAPH_MAX_IO 16
+#define DSPFX_GRAPH_INPUT_N(k) ((k) == 0 ? DSPFX_GRAPH_INPUT : (k) == 1 ? DSPFX_GRAPH_INPUT2 : -(2 + (k)))   /* link source of input block k */
 #define DSPFX_PORT_MAIN 0
 #define DSPFX_PORT_SIDE 1
 #define DSPFX_PORT_SLIDER 2

@@ -227,3 +227,17 @@ def long_rig(seed, n_blocks=10, fir_at=None, dry_mix=False):
     nodes.append((999, "output", {}))
     links.append((s, 999, "in"))
     return build(nodes, links)
+
+
+def around_fir_and_fuzz(taps=48):
+    """What the series form cannot express: several signals go AROUND a FIR node and a Fuzz node, and the Fuzz node's
+    level slider is driven by an LFO (distort.rs:176-180 maps the level port for every mode).
+    input -> gain -> fuzz(level <- lfo) -> fir -> add.a ; gain -> biquad -> add.b ; mix(a <- add, b <- fuzz) ; output <- mix, gain."""
+    import math
+    h = [math.exp(-0.08 * j) * (1 if j % 3 else -0.6) for j in range(taps)]
+    return build(
+        [(0, "input", {}), (1, "gain", {"level": 0.8}), (2, "signal_gen", {"amplitude": 0.6, "frequency": 300.0, "mode": "Triangle"}),
+         (3, "distort", {"level": 3.0, "mode": "Fuzz"}), (4, "fir", {"mode": "Balanced", "file_name": None, "taps": h[::-1]}),
+         (5, "biquad", BQ), (6, "add", {}), (7, "mix", {"ratio": 0.4}), (9, "output", {})],
+        [(0, 1, "in"), (1, 3, "in"), (2, 3, "level"), (3, 4, "in"), (1, 5, "in"), (4, 6, "a"), (5, 6, "b"), (6, 7, "a"), (3, 7, "b"),
+         (7, 9, "in"), (1, 9, "in")])

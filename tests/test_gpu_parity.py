@@ -1511,7 +1511,9 @@ def test_default_variant_selection_above_131072_channels_matches_small_engines(d
         half = 65536 + 512
         a, am, sa = run(0, half)
         b, bm, _ = run(half, N - half)
-        assert "_c2" not in sa and "jit_" not in sa, sa
+        # the halves are small engines: one channel per lane; from 16384 channels on they too get a run-time specialised
+        # kernel (and the time-sliced one for whole 128-frame blocks) unless that is switched off
+        assert "_c2" not in sa.split(";")[0] and (("jit_" in sa and "time-sliced" in sa) if not tile else "jit_" not in sa), sa
         assert np.array_equal(big.view(np.uint32), np.concatenate([a, b], axis=1).view(np.uint32)), (N, tile)
         assert np.allclose(big_mix, am + bm, rtol=1e-5, atol=1e-2)
 

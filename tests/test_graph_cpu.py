@@ -249,3 +249,46 @@ def test_graph_golden_vectors_pin_the_oracle(dspfx):
     for name, doc, x, y in cases:
         got = graph_eval.run_graph(G.Graph(doc), x)
         assert np.array_equal(got.view(np.uint32), y.view(np.uint32)), name
+
+
+def test_region_plan_covers_any_graph(dspfx, tmp_path):
+    """region_plan: ANY graph as a few generated kernels with several input / output blocks each.  Every node lands in
+    exactly one step, links inside a region go forward, a region reads / writes at most GRAPH_MAX_IO blocks, every ref
+    points at an earlier step, and the generated multi-block source compiles without a GPU."""
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    for seed, n in [(1, 40), (2, 40), (3, 30), (6, 40), (11, 23), (12, 17), (13, 5)]:
+        g = G.Graph(graphs.random_dag(seed, n))
+        steps = G.region_plan(g)
+        assert steps is not None
+        n_nodes = sum(1 for m in g.nodes.values() if m.spec is not None)
+        assert sum(len(s[1]) if s[0] == "region" else (1 if s[0] == "node" else 0) for s in steps) == n_nodes
+        assert sum(1 for s in steps if s[0] == "region") <= -(-n_nodes // E.GRAPH_MAX_NODES) + 1
+        for k, (kind, *what) in enumerate(steps):
+            if kind != "region":
+                continue
+            specs, links, in_refs, n_out = what
+            assert len(specs) <= E.GRAPH_MAX_NODES and len(in_refs) <= E.GRAPH_MAX_IO and 1 <= n_out <= E.GRAPH_MAX_IO
+            assert all(r == -1 or (r[0] < k and r[1] < (steps[r[0]][4] if steps[r[0]][0] == "region" else 1)) for r in in_refs)
+            for s_, d_, p_ in links:
+                assert s_ < d_ or s_ < 0
+                assert d_ < len(specs) + n_out
+                if s_ in E.GRAPH_INPUTS:
+                    assert E.GRAPH_INPUTS.index(s_) < len(in_refs)
+            written = {d_ - len(specs) for _, d_, _ in links if d_ >= len(specs)}
+            assert written == set(range(n_out)) or (0 not in written and k + 1 == len(steps))   # an Output node with nothing plugged in
+    # FIR / Fuzz nodes stay steps of their own, with any number of signals around them and a node-fed level port
+    g = G.Graph(graphs.around_fir_and_fuzz())
+    assert G.fused_plan(g) is None and G.series_plan(g) is None
+    steps = G.region_plan(g)
+    kinds = [s[0] for s in steps]
+    assert kinds.count("node") == 2 and kinds[-1] == "region"
+    fuzz = next(s for s in steps if s[0] == "node" and s[1].kind == E.DISTORT)
+    assert list(fuzz[3]) == [0] and fuzz[3][0] is not None                      # its level slider reads a block
+    # the multi-block source compiles: several inputs, several outputs
+    g = G.Graph(graphs.random_dag(2, 40))
+    steps = G.region_plan(g)
+    mid = steps[1]
+    assert len(mid[3]) >= 3 and mid[4] >= 2
+    src = _compile_generated(E, mid[1], mid[2], tmp_path, "region")
+    assert "xs[2]" in src and "ys[1]" in src and "static constexpr int n_out = %d" % mid[4] in src

@@ -238,8 +238,13 @@ def test_graph_with_a_fir_node_in_series(dspfx, G, N, tile):
     assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
     a.close()
     b.close()
+    # a link AROUND the cabinet next to others into it: no series form; the general region plan takes it (the FIR node
+    # between two generated kernels, the bypassing signal one of the blocks they exchange), run by run only on request
     c = G.GraphEngine(graphs.cab_rig(bypass=True), N, B, tile_channels=tile)
-    assert not c.series and c.fused is None and len(c.runs) > 1
+    assert not c.series and c.fused is None and c.regions and [st["kind"] for st in c.regions].count("node") == 1
+    c.close()
+    c = G.GraphEngine(graphs.cab_rig(bypass=True), N, B, tile_channels=tile, fused=False)
+    assert not c.series and not c.regions and len(c.runs) > 1
     c.close()
     # wet / dry: the signal that feeds the cabinet also goes on beside it -> handed over raw, the FIR engine applies its own
     # hop, the kernel after it reads the FIR output as Input and the dry signal as its second block
@@ -502,3 +507,78 @@ def test_graph_partition_and_rejections(dspfx, G):
     with pytest.raises(Exception) as ei:
         G.Graph(json.dumps(two))
     assert "averages several links" in str(ei.value)
+
+
+@pytest.mark.parametrize("seed,n", [(1, 40), (2, 40), (13, 23)])
+def test_region_plan_equals_run_by_run_and_the_oracle(dspfx, G, seed, n):
+    """A 40-node random DAG has no single-signal cut: it runs as three generated kernels exchanging several blocks
+    (region_plan + dspfx_process_io).  Same f32 operations in the same order as the run-by-run evaluation: bit-identical;
+    <= 1 ulp from the oracle (exact-arithmetic kinds)."""
+    import torch
+    N, B, blocks = 4096, 128, 4
+    text = graphs.random_dag(seed, n)
+    a = G.GraphEngine(text, N, B, regions=True)
+    b = G.GraphEngine(text, N, B, fused=False)
+    assert a.regions and not b.regions and sum(1 for st in a.regions if st["kind"] == "region") <= -(-n // 16)
+    x = O.noise(0x5EED0040 + seed, np.arange(N), np.arange(B * blocks))
+    got = np.empty_like(x)
+    for k in range(blocks):
+        dx = torch.from_numpy(x[k * B:(k + 1) * B]).cuda()
+        ya, yb = a.process(dx, B), b.process(dx, B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya, yb), (k, a.describe())
+        got[k * B:(k + 1) * B] = ya.cpu().numpy().reshape(B, N)
+    chans = np.r_[0:24, N - 8:N]
+    ref = graph_eval.run_graph(a.g, x[:, chans])
+    assert ulp_diff(got[:, chans], ref).max() <= 1
+    # the default selection picks the region plan for this graph too (no one-kernel, no series form)
+    c = G.GraphEngine(text, N, B)
+    assert c.regions and c.fused is None and not c.series
+    for e in (a, b, c):
+        e.close()
+
+
+def test_signals_around_fir_and_fuzz_nodes_with_a_node_fed_level_port(dspfx, G):
+    """Several signals bypass a FIR node and a Fuzz node whose level slider is driven by an LFO: no series form; the
+    region plan keeps both nodes as steps of their own between generated kernels.  Equal to run by run within the Fuzz /
+    FIR bars, and to the oracle."""
+    import torch
+    N, B, blocks = 2048, 128, 5
+    text = graphs.around_fir_and_fuzz()
+    a = G.GraphEngine(text, N, B)
+    b = G.GraphEngine(text, N, B, fused=False)
+    assert a.regions and [st["kind"] for st in a.regions].count("node") == 2, a.describe()
+    x = O.noise(0x5EED0051, np.arange(N), np.arange(B * blocks))
+    ga, gb = np.empty_like(x), np.empty_like(x)
+    for k in range(blocks):
+        dx = torch.from_numpy(x[k * B:(k + 1) * B]).cuda()
+        ya, yb = a.process(dx, B), b.process(dx, B)
+        torch.cuda.synchronize()
+        ga[k * B:(k + 1) * B] = ya.cpu().numpy().reshape(B, N)
+        gb[k * B:(k + 1) * B] = yb.cpu().numpy().reshape(B, N)
+    assert np.array_equal(ga.view(np.uint32), gb.view(np.uint32))          # the same kernels for FIR / Fuzz, the same f32 ops around
+    chans = np.r_[0:16, N - 4:N]
+    ref = graph_eval.run_graph(a.g, x[:, chans])
+    assert np.abs(ga[:, chans] - ref).max() <= 1e-5 * np.abs(ref).max()
+    a.close()
+    b.close()
+
+
+def test_golden_graphs_through_the_region_plan(dspfx, G):
+    """Every committed graph golden through the general region plan (forced): the oracle's outputs within the bars of
+    test_graph_golden_vectors."""
+    import torch
+    from test_graph_cpu import _graph_goldens
+    for name, doc, x, y in _graph_goldens():
+        N = 64
+        xx = np.tile(x, (1, -(-N // x.shape[1])))[:, :N].astype(F)
+        ge = G.GraphEngine(doc, N, 128, regions=True)
+        got = np.empty_like(xx)
+        for f0 in range(0, xx.shape[0], 128):
+            dx = torch.from_numpy(np.ascontiguousarray(xx[f0:f0 + 128])).cuda()
+            out = ge.process(dx, 128)
+            torch.cuda.synchronize()
+            got[f0:f0 + 128] = out.cpu().numpy().reshape(128, N)
+        ref = np.tile(y, (1, -(-N // y.shape[1])))[:, :N]
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, ge.describe())
+        ge.close()
