@@ -462,10 +462,7 @@ def region_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES, max_io: int = GRAPH_
                 for v in g.producers(g.nodes[c]):
                     if v not in inside and v not in ext:
                         ext.append(v)
-            outs = [v for v in region if last_use.get(v, -1) >= end and not (final and last_use.get(v, -1) == len(order) and
-                                                                              all(pos[u] < end or u == out_id for u in _users(g, v)))]
-            if final:
-                outs = []
+            outs = [] if final else [v for v in region if last_use.get(v, -1) >= end]      # read by a later step
             n_out = (1 if final else 0) + len(outs)
             if len(ext) <= max_io and n_out <= max_io:
                 best = (end, region, ext, outs, final)
@@ -499,19 +496,9 @@ def region_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES, max_io: int = GRAPH_
         for m_, v in enumerate(outs):
             loc[v] = (len(steps) - 1, base + m_)
         i = end
-    if not steps or steps[-1][0] != "region" or len(steps[-1][1]) == 0 or not _is_final_region(steps[-1], g):
+    if not steps or steps[-1][0] != "region":        # the graph ends in a FIR / Fuzz node (or has no effect node at all)
         steps.append(("output", [ref(v) for v in g.nodes[out_id].main]))
     return steps
-
-
-def _users(g: Graph, v: int) -> List[int]:
-    return [nid for nid, n in g.nodes.items() if v in g.producers(n)]
-
-
-def _is_final_region(step, g: Graph) -> bool:
-    """Does this region step carry the Output node's port (a non-RAW link into output block 0)?"""
-    specs, links = step[1], step[2]
-    return any(d == len(specs) and not (p & PORT_RAW) for _, d, p in links) or not g.nodes[g.outputs[0]].main
 
 
 def series_plan(g: Graph):

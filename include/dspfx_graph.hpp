@@ -414,6 +414,149 @@ class SavedGraph {
         return ok;
     }
 
+    // One step of the general plan (region_plan): a generated kernel over a REGION of the graph with several input and
+    // output blocks, a FIR / Fuzz node between regions, or the Output node's average when no region is left to carry it.
+    struct Ref {                                   // whose block: step >= 0 -> that step's output block `block`;
+        int step = -1, block = 0;                  // step == -1 -> the graph's Input block; step == -2 -> a pipe of zeros
+        bool operator==(const Ref &o) const { return step == o.step && block == o.block; }
+    };
+    struct RegionStep {
+        enum Kind { Region, NodeStep, OutputAvg } kind = Region;
+        std::vector<Node> specs;                   // Region: its nodes; NodeStep: the one node
+        std::vector<dspfx_graph_link> links;       // Region: sources DSPFX_GRAPH_INPUT_N(k) = in_refs[k]; dst == specs.size() + m = output block m
+        std::vector<Ref> in_refs;                  // Region
+        int n_out = 1;                             // Region
+        std::vector<Ref> main_refs;                // NodeStep: main port averaged over these; OutputAvg: the Output node's links
+        std::map<int, Ref> ctl_refs;               // NodeStep: slider k <- block
+    };
+
+    // ANY graph as a short series of generated kernels -- the same plan as dsp-stuff_amd/graph.py region_plan, which
+    // documents it: the evaluation order is cut into regions of at most max_nodes fusable nodes, each one kernel reading up
+    // to max_io blocks (from the Input node, earlier regions, FIR / Fuzz nodes; as main inputs, Add / Mix side inputs or
+    // control signals alike) and writing up to max_io blocks (every signal a later step still reads, handed over RAW); the
+    // last region also evaluates the Output node's port.  false when some region would need more blocks either way.
+    bool region_plan(std::vector<RegionStep> &steps, int max_nodes = DSPFX_GRAPH_MAX_NODES, int max_io = DSPFX_GRAPH_MAX_IO) const {
+        steps.clear();
+        const int out_id = outputs_[0];
+        std::map<int, bool> fed;
+        for (int id : order_) {
+            bool f = node(id).typename_ == "input";
+            for (int p : producers(node(id))) f = f || fed[p];
+            fed[id] = f;
+        }
+        std::vector<int> nodes, order;
+        for (int id : order_)
+            if (node(id).has_spec) nodes.push_back(id);
+        std::map<int, bool> placed;
+        auto place = [&](auto &&self, int id) -> void {      // sources fed by nothing come right before their first consumer
+            if (placed[id]) return;
+            for (int p : producers(node(id)))
+                if (node(p).has_spec && !fed[p]) self(self, p);
+            placed[id] = true;
+            order.push_back(id);
+        };
+        for (int id : nodes)
+            if (fed[id]) place(place, id);
+        for (int id : nodes) place(place, id);
+        const int n = (int)order.size();
+        std::map<int, int> pos, last_use;
+        for (int i = 0; i < n; ++i) pos[order[(std::size_t)i]] = i;
+        pos[out_id] = n;
+        auto note = [&](int id) {
+            for (int p : producers(node(id))) {
+                const auto it = last_use.find(p);
+                if (it == last_use.end() || it->second < pos[id]) last_use[p] = pos[id];
+            }
+        };
+        for (int id : order) note(id);
+        note(out_id);
+        std::map<int, Ref> loc;
+        if (!inputs_.empty()) loc[inputs_[0]] = Ref{-1, 0};
+        auto ref = [&](int v) { return v == ZERO ? Ref{-2, 0} : loc.at(v); };
+        int i = 0;
+        bool carries_output = false;
+        while (i < n) {
+            const GNode &nd = node(order[(std::size_t)i]);
+            if (unfusable(nd.spec)) {
+                RegionStep st;
+                st.kind = RegionStep::NodeStep;
+                st.specs = {nd.spec};
+                for (int v : nd.main) st.main_refs.push_back(ref(v));
+                for (const auto &kv : nd.ctl) st.ctl_refs[kv.first] = ref(kv.second[0]);
+                steps.push_back(std::move(st));
+                loc[nd.id] = Ref{(int)steps.size() - 1, 0};
+                carries_output = false;
+                ++i;
+                continue;
+            }
+            int best_end = -1;
+            std::vector<int> best_ext, best_outs;
+            bool best_final = false;
+            for (int end = i + 1; end <= n && end - i <= max_nodes && !unfusable(node(order[(std::size_t)end - 1]).spec); ++end) {
+                const bool final = end == n;
+                std::vector<int> ext, outs;
+                auto inside = [&](int v) { const auto it = pos.find(v); return it != pos.end() && it->second >= i && it->second < end && v != out_id; };
+                auto scan = [&](int id) {
+                    for (int v : producers(node(id)))
+                        if (!inside(v) && std::find(ext.begin(), ext.end(), v) == ext.end()) ext.push_back(v);
+                };
+                for (int k = i; k < end; ++k) scan(order[(std::size_t)k]);
+                if (final) scan(out_id);
+                if (!final)
+                    for (int k = i; k < end; ++k) {
+                        const auto it = last_use.find(order[(std::size_t)k]);
+                        if (it != last_use.end() && it->second >= end) outs.push_back(order[(std::size_t)k]);
+                    }
+                const int n_out = (final ? 1 : 0) + (int)outs.size();
+                if ((int)ext.size() <= max_io && n_out <= max_io) {
+                    best_end = end;
+                    best_ext = ext;
+                    best_outs = outs;
+                    best_final = final;
+                }
+            }
+            if (best_end < 0) return false;
+            RegionStep st;
+            std::map<int, int> idx;
+            for (int k = i; k < best_end; ++k) idx[order[(std::size_t)k]] = k - i;
+            auto src = [&](int v) {
+                if (v == ZERO) return (int)DSPFX_GRAPH_ZERO;
+                const auto it = idx.find(v);
+                if (it != idx.end()) return it->second;
+                const int blk = (int)(std::find(best_ext.begin(), best_ext.end(), v) - best_ext.begin());
+                return (int)DSPFX_GRAPH_INPUT_N(blk);
+            };
+            for (int k = i; k < best_end; ++k) {
+                const GNode &m = node(order[(std::size_t)k]);
+                st.specs.push_back(m.spec);
+                for (int v : m.main) st.links.push_back({src(v), k - i, DSPFX_PORT_MAIN});
+                for (int v : m.side) st.links.push_back({src(v), k - i, DSPFX_PORT_SIDE});
+                for (const auto &kv : m.ctl)
+                    for (int v : kv.second) st.links.push_back({src(v), k - i, DSPFX_PORT_SLIDER + kv.first});
+            }
+            const int nn = best_end - i;
+            if (best_final)
+                for (int v : node(out_id).main) st.links.push_back({src(v), nn, DSPFX_PORT_MAIN});
+            if (!best_final && best_outs.empty()) best_outs.push_back(order[(std::size_t)best_end - 1]);   // a dead branch: still one block
+            const int base = best_final ? 1 : 0;
+            for (std::size_t m = 0; m < best_outs.size(); ++m)
+                st.links.push_back({idx.at(best_outs[m]), nn + base + (int)m, DSPFX_PORT_MAIN | DSPFX_PORT_RAW});
+            for (int v : best_ext) st.in_refs.push_back(loc.at(v));
+            st.n_out = base + (int)best_outs.size();
+            steps.push_back(std::move(st));
+            for (std::size_t m = 0; m < best_outs.size(); ++m) loc[best_outs[m]] = Ref{(int)steps.size() - 1, base + (int)m};
+            carries_output = best_final;
+            i = best_end;
+        }
+        if (!carries_output) {
+            RegionStep st;
+            st.kind = RegionStep::OutputAvg;
+            for (int v : node(out_id).main) st.main_refs.push_back(ref(v));
+            steps.push_back(std::move(st));
+        }
+        return true;
+    }
+
   private:
     static constexpr int NONE = -1000000;      // "no such signal" (node ids are the document's, ZERO is -1)
     static bool unfusable(const Node &n) { return n.d.kind == DSPFX_FIR || (n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ); }

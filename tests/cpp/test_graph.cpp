@@ -53,6 +53,103 @@ int main(int argc, char **argv) {
         const bool one = g.fused_plan(specs, links);
         std::vector<SavedGraph::Step> steps;
         const bool series = !one && g.segment_plan(steps);
+        if (std::strcmp(argv[2], "--plan-regions") == 0) {                 // the general plan (SavedGraph::region_plan)
+            std::vector<SavedGraph::RegionStep> rs;
+            if (!g.region_plan(rs)) { std::printf("no region plan\n"); return 0; }
+            for (const SavedGraph::RegionStep &st : rs) {
+                std::printf("step %s %d\n", st.kind == SavedGraph::RegionStep::Region ? "region" : st.kind == SavedGraph::RegionStep::NodeStep ? "node" : "output",
+                            st.kind == SavedGraph::RegionStep::Region ? st.n_out : 0);
+                for (const SavedGraph::Ref &r : st.in_refs) std::printf("in %d %d\n", r.step, r.block);
+                for (const SavedGraph::Ref &r : st.main_refs) std::printf("main %d %d\n", r.step, r.block);
+                for (const auto &kv : st.ctl_refs) std::printf("ctl %d %d %d\n", kv.first, kv.second.step, kv.second.block);
+                for (const Node &n : st.specs) std::printf("node %d %d %a %u %zu\n", n.d.kind, n.d.mode, n.d.params[0], n.d.delay_len, n.taps.size());
+                for (const dspfx_graph_link &l : st.links) std::printf("link %d %d %d\n", l.src, l.dst, l.port);
+            }
+            return 0;
+        }
+        if (argc >= 7 && std::strcmp(argv[6], "--regions") == 0) {
+            // Run the graph through the region plan from C++: every block lives in page-locked host memory (device-visible,
+            // so the g++-only test needs no HIP headers) and the regions exchange blocks through dspfx_process_io.
+            std::vector<SavedGraph::RegionStep> rs;
+            if (!g.region_plan(rs)) { std::printf("no region plan\n"); return 2; }
+            const std::vector<float> x = floats(argv[2]), y = floats(argv[3]);
+            const uint32_t C = (uint32_t)std::atoi(argv[4]), frames = (uint32_t)std::atoi(argv[5]), N = 64;
+            auto pinned = [&]() {
+                void *p = nullptr;
+                if (dspfx_host_alloc((size_t)BUF_SIZE * N * sizeof(float), &p) != DSPFX_OK) throw Error(DSPFX_ERR_OOM, "dspfx_host_alloc");
+                std::memset(p, 0, (size_t)BUF_SIZE * N * sizeof(float));
+                return static_cast<float *>(p);
+            };
+            float *xin = pinned(), *zeros = pinned(), *final_out = pinned();
+            std::vector<Engine> engines;
+            std::vector<std::vector<float *>> outs(rs.size());
+            std::vector<float *> scratch(rs.size(), nullptr);
+            std::vector<int> eng_of(rs.size(), -1);
+            for (std::size_t k = 0; k < rs.size(); ++k) {
+                const SavedGraph::RegionStep &st = rs[k];
+                if (st.kind == SavedGraph::RegionStep::OutputAvg) { outs[k] = {final_out}; continue; }
+                if (st.kind == SavedGraph::RegionStep::Region) {
+                    engines.emplace_back(N, BUF_SIZE, 0);
+                    engines.back().set_graph(st.specs, st.links);
+                    for (int m = 0; m < st.n_out; ++m) outs[k].push_back(pinned());
+                } else {
+                    engines.emplace_back(N, BUF_SIZE, DSPFX_LINK_INTERNAL | (st.main_refs.size() == 1 ? DSPFX_LINK_INPUT : 0u));
+                    engines.back().set_chain(st.specs);
+                    outs[k].push_back(pinned());
+                    if (st.main_refs.size() > 1) scratch[k] = pinned();
+                }
+                eng_of[k] = (int)engines.size() - 1;
+            }
+            auto at = [&](const SavedGraph::Ref &r) -> float * { return r.step == -1 ? xin : r.step == -2 ? zeros : outs[(std::size_t)r.step][(std::size_t)r.block]; };
+            int worst = 0;
+            double max_abs = 0, max_err = 0;
+            for (uint32_t f0 = 0; f0 + BUF_SIZE <= frames; f0 += BUF_SIZE) {
+                for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                    for (uint32_t c = 0; c < N; ++c) xin[f * N + c] = x[(f0 + f) * C + c % C];
+                for (std::size_t k = 0; k < rs.size(); ++k) {
+                    const SavedGraph::RegionStep &st = rs[k];
+                    if (st.kind == SavedGraph::RegionStep::OutputAvg) {
+                        std::vector<const float *> srcs;
+                        for (const SavedGraph::Ref &r : st.main_refs) srcs.push_back(at(r));
+                        engines[0].link_average(srcs, final_out, BUF_SIZE);
+                        continue;
+                    }
+                    Engine &e = engines[(std::size_t)eng_of[k]];
+                    if (st.kind == SavedGraph::RegionStep::Region) {
+                        std::vector<const float *> ins;
+                        for (const SavedGraph::Ref &r : st.in_refs) ins.push_back(at(r));
+                        int rc = dspfx_process_io(e.raw(), ins.data(), (int)ins.size(), outs[k].data(), (int)outs[k].size(), nullptr, BUF_SIZE, nullptr);
+                        if (rc != DSPFX_OK) throw Error(rc, dspfx_last_error(e.raw()));
+                    } else {
+                        const float *src = zeros;
+                        if (st.main_refs.size() == 1) src = at(st.main_refs[0]);
+                        else if (st.main_refs.size() > 1) {
+                            std::vector<const float *> srcs;
+                            for (const SavedGraph::Ref &r : st.main_refs) srcs.push_back(at(r));
+                            e.link_average(srcs, scratch[k], BUF_SIZE);
+                            src = scratch[k];
+                        }
+                        std::vector<dspfx_ctl> ctl;
+                        for (const auto &kv : st.ctl_refs) ctl.push_back({0, kv.first, at(kv.second)});
+                        int rc = ctl.empty() ? dspfx_process(e.raw(), src, nullptr, outs[k][0], nullptr, BUF_SIZE, nullptr)
+                                             : dspfx_process_ctl(e.raw(), src, nullptr, outs[k][0], nullptr, BUF_SIZE, ctl.data(), (int)ctl.size(), nullptr);
+                        if (rc != DSPFX_OK) throw Error(rc, dspfx_last_error(e.raw()));
+                    }
+                }
+                dspfx_sync(engines[0].raw(), nullptr);
+                const float *yb = outs.back()[0];
+                for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                    for (uint32_t c = 0; c < N; ++c) {
+                        const float want = y[(f0 + f) * C + c % C];
+                        worst = std::max(worst, ulp(yb[f * N + c], want));
+                        max_abs = std::max(max_abs, (double)std::fabs(want));
+                        max_err = std::max(max_err, (double)std::fabs(yb[f * N + c] - want));
+                    }
+            }
+            std::printf("max ulp %d rel err %.3g steps %zu engines %zu (region plan)\n", worst, max_err / max_abs, rs.size(), engines.size());
+            const bool loose = argc > 7 && std::strcmp(argv[7], "--fir-tolerance") == 0;
+            return (loose ? max_err <= 1e-5 * max_abs : worst <= 1) ? 0 : 1;
+        }
         if (std::strcmp(argv[2], "--plan") == 0) {
             if (!one && !series) { std::printf("run by run\n"); return 0; }
             if (!one) {

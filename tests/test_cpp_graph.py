@@ -91,6 +91,74 @@ def test_cpp_importer_plans_what_the_python_mirror_plans(dspfx, tmp_path):
     assert r.returncode == 3 and "not JSON" in r.stdout
 
 
+def test_cpp_region_plan_equals_the_python_one(dspfx, tmp_path):
+    """SavedGraph::region_plan (any graph as a few generated kernels exchanging several blocks) against graph.py's."""
+    from dsp_stuff_amd import graph as G
+    E = dspfx
+    _build()
+    docs = [graphs.random_dag(s, n) for s, n in ((1, 40), (2, 40), (3, 30), (11, 23), (13, 5))] + \
+           [graphs.around_fir_and_fuzz(), graphs.cab_rig(bypass=True), graphs.cab_rig(cut="fuzz"), graphs.diamond(), graphs.routing("B", "A")]
+    for text in docs:
+        p = tmp_path / "doc.json"
+        p.write_text(text)
+        r = subprocess.run([EXE, str(p), "--plan-regions"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        got = r.stdout.strip().splitlines()
+        want = []
+
+        def rr(ref):
+            return (-1, 0) if ref == -1 else (-2, 0) if ref is None else tuple(ref)
+
+        for kind, *what in G.region_plan(G.Graph(text)):
+            if kind == "region":
+                specs, links, in_refs, n_out = what
+                want.append("step region %d" % n_out)
+                want += ["in %d %d" % rr(x) for x in in_refs]
+            elif kind == "node":
+                spec, main_refs, ctl_refs = what
+                specs, links = [spec], []
+                want.append("step node 0")
+                want += ["main %d %d" % rr(x) for x in main_refs]
+                want += ["ctl %d %d %d" % ((k,) + rr(x)) for k, x in sorted(ctl_refs.items())]
+            else:
+                specs, links = [], []
+                want.append("step output 0")
+                want += ["main %d %d" % rr(x) for x in what[0]]
+            for sp in specs:
+                want.append(("node", sp.kind, sp.mode, int(sp.delay_len), 0 if sp.taps_reversed is None else len(sp.taps_reversed)))
+            want += ["link %d %d %d" % tuple(l) for l in links]
+        assert len(got) == len(want), (got, want)
+        for a, b in zip(got, want):
+            if isinstance(b, tuple):
+                w = a.split()
+                assert w[0] == "node" and (int(w[1]), int(w[2]), int(w[4]), int(w[5])) == b[1:], (a, b)
+            else:
+                assert a == b, (a, b)
+
+
+@pytest.mark.gpu
+def test_cpp_region_plan_runs_on_the_gpu(dspfx, tmp_path):
+    """The region plan driven from C++ through dspfx_process_io (blocks in page-locked host memory): the golden graphs and
+    a 40-node random DAG against the oracle."""
+    import graph_eval
+    import oracle as O
+    from dsp_stuff_amd import graph as G
+    from test_graph_cpu import _graph_goldens
+    _build()
+    cases = [(name, doc, x, y) for name, doc, x, y in _graph_goldens()]
+    text = graphs.random_dag(2, 40)
+    x = O.noise(0x5EED0042, np.arange(3), np.arange(384))
+    cases.append(("random40", text, x, graph_eval.run_graph(G.Graph(text), x)))
+    for name, doc, x, y in cases:
+        (tmp_path / "doc.json").write_text(doc)
+        x.astype(np.float32).tofile(tmp_path / "x.f32")
+        y.astype(np.float32).tofile(tmp_path / "y.f32")
+        loose = ["--fir-tolerance"] if ("fir" in name or "cab" in name) else []
+        r = subprocess.run([EXE, str(tmp_path / "doc.json"), str(tmp_path / "x.f32"), str(tmp_path / "y.f32"), str(x.shape[1]),
+                            str(x.shape[0]), "--regions"] + loose, capture_output=True, text=True)
+        assert r.returncode == 0 and "region plan" in r.stdout, (name, r.stdout, r.stderr)
+
+
 @pytest.mark.gpu
 def test_cpp_importer_runs_the_golden_graphs(dspfx, tmp_path):
     from test_graph_cpu import _graph_goldens
