@@ -355,6 +355,10 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     es1.record()
     es1.synchronize()
     est_ms = max(es0.elapsed_time(es1) / 16, 1e-3)
+    if ctx.use_dist:     # every rank must run the SAME number of steps: the batched bus collectives are counted in steps
+        t_est = torch.tensor([est_ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_est, op=dist.ReduceOp.MAX)
+        est_ms = float(t_est.item())
     settle_steps = int(max(probe_steps + 8, min(20000, settle_s * 1e3 / est_ms)))
     es0.record()
     for k in range(settle_steps):

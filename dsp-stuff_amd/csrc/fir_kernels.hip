@@ -160,15 +160,21 @@ struct FirMfmaArgs {
     Layout lay;
 };
 
-template <bool WARM, bool FUSED>
+// NJT = output tiles of 32 frames per wave.  4: one wave sweeps a channel tile's whole 128-frame block (every history row
+// is loaded once; 240 registers = 2 waves per SIMD).  2: the block's two halves go to two waves of the SAME workgroup
+// (the second read of a row hits in cache a few chunks later); half the accumulators = 4 waves per SIMD to cover each
+// other's per-chunk bubbles, and a narrower Toeplitz band (K / T = 4159 / 4096 instead of 4223 / 4096).
+template <bool WARM, bool FUSED, int NJT>
 __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
+    static_assert(NJT == 4 || (NJT == 2 && !FUSED), "the fused append needs the wave that sweeps the whole block");
     extern __shared__ float tp[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntp = (int)(PAD_LO + a.T + PAD_HI);
     for (int i = tid; i < ntp; i += 256) tp[i] = a.taps[i];
     __syncthreads();
-    const uint32_t tile = blockIdx.x * 4 + wave;
-    if ((size_t)tile * TILE_C >= a.N) return;
+    const uint32_t tile = NJT == 4 ? blockIdx.x * 4 + wave : blockIdx.x * 2 + (wave >> 1);
+    const int j0 = NJT == 4 ? 0 : (wave & 1) * 64;        // first output frame of this wave
+    if ((size_t)tile * TILE_C >= a.N || (uint32_t)j0 >= a.nframes) return;
     const int cl = lane & 31, kh = lane >> 5;
     float *hbase = a.ring + (size_t)tile * a.R * TILE_C + cl;
     const uint32_t c = tile * TILE_C + cl;
@@ -177,10 +183,10 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     const bool dirty = a.nf_time[tile] > (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
 
     // per output-tile weight index: LDS index = wofs[jt] + k'   (the lane's kh folded in)
-    int wofs[4], whi[4];
+    int wofs[NJT], whi[NJT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt) {
-        const int j = jt * 32 + cl;
+    for (int jt = 0; jt < NJT; ++jt) {
+        const int j = j0 + jt * 32 + cl;
         if constexpr (WARM) {
             const long long first = a.n0 + j - (long long)a.T + 1;            // front of output j's deque ...
             const long long Fj = first >= a.tfront ? first : a.tfront;        // ... which never moves before tfront
@@ -193,9 +199,9 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         }
     }
 
-    f32x16 acc[4], tot[4];
+    f32x16 acc[NJT], tot[NJT];
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[jt][r] = 0.0f; tot[jt][r] = 0.0f; }
 
@@ -209,6 +215,9 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     // happens in `arrive`, when the chunk becomes the current one.  (Consuming a value right after its load -- or a
     // store between two loads, which the compiler must assume to alias -- serialises eight memory round trips per chunk:
     // measured +0.12 ms per block.)
+    // NJT == 4 streams every history row exactly once: nontemporal.  NJT == 2 reads each row twice (the two halves of the
+    // block, a few chunks apart): plain loads, so that the second read finds the line in L2.
+    auto hload = [](const float *q) { return NJT == 4 ? __builtin_nontemporal_load(q) : *q; };
     auto load_chunk = [&](uint32_t kc, float (&h)[KC / 2]) {
         if (FUSED && kc >= a.kring) {
             // the block itself: frame f of the slice is row k' = kring + f
@@ -224,13 +233,13 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         if (row0 + KC + 1 <= a.R && kc + KC <= a.kvalid) {
             const float *p = hlane + (size_t)row0 * TILE_C;
 #pragma unroll
-            for (int s = 0; s < KC / 2; ++s) h[s] = __builtin_nontemporal_load(p + (size_t)(2 * s) * TILE_C);
+            for (int s = 0; s < KC / 2; ++s) h[s] = hload(p + (size_t)(2 * s) * TILE_C);
         } else {
 #pragma unroll
             for (int s = 0; s < KC / 2; ++s) {
                 uint32_t row = row0 + 2 * s + kh;
                 row = row >= a.R ? row - a.R : row;
-                h[s] = kc + 2 * s + kh < a.kvalid ? __builtin_nontemporal_load(hbase + (size_t)row * TILE_C) : 0.0f;
+                h[s] = kc + 2 * s + kh < a.kvalid ? hload(hbase + (size_t)row * TILE_C) : 0.0f;
             }
         }
     };
@@ -258,15 +267,19 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         }
     };
 
+    // this wave's part of the sweep: outputs [j0, j0 + 32 NJT) have weights only for k in [j0, j0 + 32 NJT + T - 2]
+    const uint32_t kc0 = (uint32_t)j0;                   // a multiple of KC
+    uint32_t kc1 = (a.koff + (uint32_t)j0 + 32u * NJT + a.T - 1 + KC - 1) / KC * KC;
+    kc1 = kc1 < a.kpad ? kc1 : a.kpad;
     float h_cur[KC / 2], h_nxt[KC / 2];
-    load_chunk(0, h_nxt);
+    load_chunk(kc0, h_nxt);
 
     // One chunk for the output tiles [LO, HI] (compile-time: the loop body holds exactly those MFMAs).
     auto chunk = [&](auto lo_c, auto hi_c, uint32_t kc) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s];
-        if (kc + KC < a.kpad) load_chunk(kc + KC, h_nxt);
+        if (kc + KC < kc1) load_chunk(kc + KC, h_nxt);
         arrive(kc, h_cur);
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
@@ -288,7 +301,7 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     };
     auto flush = [&]() {
 #pragma unroll
-        for (int jt = 0; jt < 4; ++jt)
+        for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { tot[jt][r] = tot[jt][r] + acc[jt][r]; acc[jt][r] = 0.0f; }
     };
@@ -299,19 +312,19 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     // accumulators AGPR <-> VGPR, costing far more than the corners.  A fixed-trip inner sweep keeps the accumulators in
     // place; its f32 chain is <= FLUSH * KC terms.
     using I0 = std::integral_constant<int, 0>;
-    using I3 = std::integral_constant<int, 3>;
-    uint32_t kc = 0;
-    while (kc < a.kpad) {
-        const uint32_t kend = kc + FLUSH * KC < a.kpad ? kc + FLUSH * KC : a.kpad;
-        for (; kc < kend; kc += KC) chunk(I0{}, I3{}, kc);
+    using IL = std::integral_constant<int, NJT - 1>;
+    uint32_t kc = kc0;
+    while (kc < kc1) {
+        const uint32_t kend = kc + FLUSH * KC < kc1 ? kc + FLUSH * KC : kc1;
+        for (; kc < kend; kc += KC) chunk(I0{}, IL{}, kc);
         flush();
     }
     if (!c_ok) return;
 #pragma unroll
-    for (int jt = 0; jt < 4; ++jt)
+    for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (j < a.nframes) {
                 const float val = tot[jt][r] + 0.0f;                   // fir.rs:216 `a + b` (one f32 sum here: the MFMA path's bar is an RMS tolerance)
                 __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
@@ -362,9 +375,11 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
     const size_t lds = ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float);
     if (lds > 160 * 1024 - 1024) s.kernel = 0;         // tap table must fit the CU's LDS
     if (s.kernel == 1 && lds > 64 * 1024) {
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     return 0;
 }
@@ -533,14 +548,22 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.hop_div = hop_div;
             a.hop = hop;
             a.lay = lay;
-            const unsigned grid = (s.tiles + 3) / 4;
+            // two output tiles per wave (4 waves per SIMD, a narrower Toeplitz band) for short filters; DSPFX_FIR_NJT=2|4 forces either
+            const char *njt_env = getenv("DSPFX_FIR_NJT");
+            // (measured at 262144 channels, kernel ms: T = 256: 0.201 vs 0.214 with four tiles per wave; T = 1024: 0.611 vs 0.584;
+            //  T = 4096: 2.257 vs 2.072 -- reading every history row twice costs more than the occupancy gains)
+            const bool two = !fused && nf > 64 && (njt_env ? atoi(njt_env) == 2 : s.T <= 384);
+            const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
             const size_t lds = ((size_t)PAD_LO + s.T + PAD_HI) * sizeof(float);
-            if (!steady)
-                hipLaunchKernelGGL((fir_mfma_kernel<true, false>), dim3(grid), dim3(256), lds, stream, a);
-            else if (fused)
-                hipLaunchKernelGGL((fir_mfma_kernel<false, true>), dim3(grid), dim3(256), lds, stream, a);
-            else
-                hipLaunchKernelGGL((fir_mfma_kernel<false, false>), dim3(grid), dim3(256), lds, stream, a);
+            if (!steady) {
+                if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, false, 2>), dim3(grid), dim3(256), lds, stream, a);
+                else hipLaunchKernelGGL((fir_mfma_kernel<true, false, 4>), dim3(grid), dim3(256), lds, stream, a);
+            } else if (fused) {
+                hipLaunchKernelGGL((fir_mfma_kernel<false, true, 4>), dim3(grid), dim3(256), lds, stream, a);
+            } else {
+                if (two) hipLaunchKernelGGL((fir_mfma_kernel<false, false, 2>), dim3(grid), dim3(256), lds, stream, a);
+                else hipLaunchKernelGGL((fir_mfma_kernel<false, false, 4>), dim3(grid), dim3(256), lds, stream, a);
+            }
             if (ev_end && f0 + SLICE >= nframes) (void)hipEventRecord(ev_end, stream);
             // tiles holding a non-finite sample inside this slice's window are redone exactly (nothing to do otherwise)
             ex.only_dirty = 1;
