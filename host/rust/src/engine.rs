@@ -182,6 +182,37 @@ impl Engine {
         self.check(rc)
     }
 
+    /// Impulse-response reload (nodes/fir.rs:153-171): new taps, given in natural order h[0..T); the history is kept,
+    /// exactly like the reference's `state` deque.
+    pub fn set_taps(&mut self, node: usize, impulse_response: &[f64], mode: c_int) -> Result<(), Error> {
+        let rev: Vec<f64> = impulse_response.iter().rev().copied().collect();
+        let rc = unsafe { dspfx_set_taps(self.h, node as c_int, rev.as_ptr(), rev.len() as u32, mode) };
+        self.check(rc)
+    }
+
+    /// The mix bus across GPUs: sum this rank's un-normalised bus (device pointer, `n_frames` f32) over the
+    /// communicator's ranks -- ONE RCCL all-reduce, in place, asynchronous on `stream` -- then the Output node's hop
+    /// with the GLOBAL channel count (node.rs:189-191).
+    ///
+    /// # Safety
+    /// `mix` must be a device pointer to at least `n_frames` floats that stays valid until the stream has run the call.
+    pub unsafe fn mix_allreduce(&mut self, comm: &mut Comm, mix: *mut f32, n_frames: u32, n_channels_total: u64,
+                                stream: *mut std::os::raw::c_void) -> Result<(), Error> {
+        let rc = dspfx_mix_allreduce(self.h, comm.h, mix, n_frames, n_channels_total, stream);
+        self.check(rc)
+    }
+
+    /// A graph engine with several input / output blocks (a REGION of a graph cut into several kernels): device pointers,
+    /// `ins[k]` = input block k, `outs[m]` = output block m.
+    ///
+    /// # Safety
+    /// Every non-null pointer must address a whole block in the engine's layout and stay valid until the stream has run the call.
+    pub unsafe fn process_io(&mut self, ins: &[*const f32], outs: &[*mut f32], n_frames: u32,
+                             stream: *mut std::os::raw::c_void) -> Result<(), Error> {
+        let rc = dspfx_process_io(self.h, ins.as_ptr(), ins.len() as c_int, outs.as_ptr(), outs.len() as c_int, ptr::null_mut(), n_frames, stream);
+        self.check(rc)
+    }
+
     pub fn describe(&self) -> String {
         let mut buf = vec![0u8; 64 << 10];
         let rc = unsafe { dspfx_describe(self.h, buf.as_mut_ptr() as *mut _, buf.len()) };
@@ -190,5 +221,39 @@ impl Engine {
         }
         let end = buf.iter().position(|&b| b == 0).unwrap_or(buf.len());
         String::from_utf8_lossy(&buf[..end]).into_owned()
+    }
+}
+
+/// The mix bus' communicator: one per process / GPU (`dspfx_comm_create`).  Rank 0 calls `Comm::unique_id()` and hands the
+/// bytes to every rank over the host's own control channel; `Comm::new` is collective.
+pub struct Comm {
+    h: *mut dspfx_comm,
+}
+unsafe impl Send for Comm {}
+
+impl Comm {
+    pub fn unique_id() -> Result<[u8; DSPFX_COMM_ID_BYTES], Error> {
+        let mut id = [0u8; DSPFX_COMM_ID_BYTES];
+        let rc = unsafe { dspfx_comm_unique_id(id.as_mut_ptr() as *mut _) };
+        if rc != DSPFX_OK {
+            return Err(Error { status: rc, message: "dspfx_comm_unique_id".into() });
+        }
+        Ok(id)
+    }
+    pub fn new(device: i32, n_ranks: i32, rank: i32, id: Option<&[u8; DSPFX_COMM_ID_BYTES]>) -> Result<Self, Error> {
+        let mut h = ptr::null_mut();
+        let rc = unsafe { dspfx_comm_create(device, n_ranks, rank, id.map_or(ptr::null(), |b| b.as_ptr() as *const _), &mut h) };
+        if rc != DSPFX_OK {
+            return Err(Error { status: rc, message: "dspfx_comm_create".into() });
+        }
+        Ok(Comm { h })
+    }
+    pub fn size(&self) -> i32 { unsafe { dspfx_comm_size(self.h) } }
+    pub fn rank(&self) -> i32 { unsafe { dspfx_comm_rank(self.h) } }
+}
+
+impl Drop for Comm {
+    fn drop(&mut self) {
+        unsafe { dspfx_comm_destroy(self.h) }
     }
 }
