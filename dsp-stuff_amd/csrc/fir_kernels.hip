@@ -157,6 +157,7 @@ struct FirMfmaArgs {
     float hop_div;
     int hop;
     int pad_;
+    double hop_rc;         // RN_f64(1 / hop_div)
     Layout lay;
 };
 
@@ -245,20 +246,31 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     };
     auto arrive = [&](uint32_t kc, float (&h)[KC / 2]) {
         if (FUSED && kc >= a.kring) {
+            // branch-free per element (predicated store, selects): the hop as the exact product with RN_f64(1 / divisor) --
+            // exact for 1.0001f like every divisor that is not an even integer (chain_kernels.hip.h, div_c)
+            bool bad = false;
 #pragma unroll
             for (int s = 0; s < KC / 2; ++s) {
                 const uint32_t f = kc - a.kring + 2 * s + kh;
-                if (f < a.nframes && c_ok) {
-                    float v = h[s];
-                    if (a.hop) v = (0.0f + v) / a.hop_div;                    // node.rs:162-194, one pipe
-                    uint32_t row = a.row_new + f;
-                    row = row >= a.R ? row - a.R : row;
-                    hbase[(size_t)row * TILE_C] = v;                         // fir.rs:193 push_back
-                    if (!finite_f32(v)) {
-                        atomicMax(&a.nf_time[tile], (unsigned long long)(a.n0 + f + 1));
-                        v = 0.0f;
+                const bool ok = c_ok && f < a.nframes;
+                float v = h[s];
+                if (a.hop) v = (float)((double)(0.0f + v) * a.hop_rc);        // node.rs:162-194, one pipe
+                uint32_t row = a.row_new + f;
+                row = row >= a.R ? row - a.R : row;
+                if (ok) hbase[(size_t)row * TILE_C] = v;                      // fir.rs:193 push_back
+                const bool fin = finite_f32(v);
+                bad = bad || (ok && !fin);
+                h[s] = (ok && fin) ? v : 0.0f;
+            }
+            if (__builtin_amdgcn_ballot_w64(bad)) {                           // rare: flag the tile for the exact fix-up pass
+#pragma unroll
+                for (int s = 0; s < KC / 2; ++s) {
+                    const uint32_t f = kc - a.kring + 2 * s + kh;
+                    if (c_ok && f < a.nframes) {
+                        uint32_t row = a.row_new + f;
+                        row = row >= a.R ? row - a.R : row;
+                        if (!finite_f32(hbase[(size_t)row * TILE_C])) atomicMax(&a.nf_time[tile], (unsigned long long)(a.n0 + f + 1));
                     }
-                    h[s] = v;
                 }
             }
         } else if (dirty) {
@@ -546,6 +558,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.tfront = (long long)front0;
             a.divisor = divisor;
             a.hop_div = hop_div;
+            a.hop_rc = 1.0 / (double)hop_div;
             a.hop = hop;
             a.lay = lay;
             // two output tiles per wave (4 waves per SIMD, a narrower Toeplitz band) for short filters; DSPFX_FIR_NJT=2|4 forces either
