@@ -1,17 +1,16 @@
 // fir_kernels.h -- FIR convolution stage (nodes/fir.rs:179-225) over N channels.
 //
-// History lives in HBM as a ring of R rows, f32 (the reference widens f32 samples to f64, so f32 storage
-// is exact), tiled by 32 channels:
-//     ring[(c / 32) * R + (t mod R)][c % 32]
-// so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous HBM stream of 128-byte
-// rows.  Every output is a dot product over the samples the reference's VecDeque holds at that step:
+// History lives in HBM as a ring of R rows (R a multiple of 16), f32 (the reference widens f32 samples to f64, so f32
+// storage is exact), tiled by 32 channels and, inside a tile, by groups of 16 rows stored so that the eight rows an MFMA
+// lane feeds into one 16-row chunk are two 16-byte pieces (fir_kernels.hip, ring_in_tile):
+//     ring[c / 32][(t mod R) / 16][piece][row parity][c % 32][4]
+// so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous HBM stream of 2 KiB chunks.
+// Every output is a dot product over the samples the reference's VecDeque holds at that step:
+//   - fir_append_kernel: the block's samples (hop applied) go into the ring; non-finite ones raise the tile's flag;
 //   - fir_mfma_kernel : out^T[B x 32ch] = W[B x K] * H[K x 32ch] on v_mfma_f32_32x32x2_f32 (exact f32 FMA
 //     chain, flushed into a second accumulator every 512 terms); W is the Toeplitz matrix of the taps,
-//     generated on the fly from a zero-padded table in LDS.  In steady state the kernel also APPENDS the block:
-//     the newest B rows of its K sweep come straight from the caller's `in` (hop applied) and are written to
-//     the ring on the way -- no separate append pass.  Weight tiles that are entirely zero (the corners of the
-//     Toeplitz band) are skipped.  Non-finite samples are replaced by 0 in the MFMA operand (0 x inf in the
-//     band's zero corners would otherwise poison neighbouring outputs) and flagged per tile;
+//     generated on the fly from a zero-padded table in LDS.  Non-finite samples are replaced by 0 in the MFMA
+//     operand (0 x inf in the band's zero corners would otherwise poison neighbouring outputs);
 //   - fir_exact_kernel: sequential f64 accumulation in deque order, split at the deque's wrap point into the
 //     reference's two partial sums (`a`, `b`: fir.rs:201-216), bit-faithful; serves tiny filters, taps that do
 //     not fit LDS, cross-checks, and re-computes every tile flagged non-finite after the MFMA pass.
@@ -28,7 +27,7 @@
 namespace dspfx {
 
 struct FirState {
-    float *ring = nullptr;        // [ceil(N/32)][R][32]
+    float *ring = nullptr;        // [ceil(N/32)] tiles of R * 32 + 32 floats
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path
     unsigned long long *nf_time = nullptr;   // [tiles]: 1 + absolute time of the newest non-finite sample of the tile (0: none)
@@ -38,7 +37,6 @@ struct FirState {
     uint64_t front = 0;           // absolute index of the deque's oldest sample (deque length = n_seen - front)
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
-    int last_fused = 0;           // the last block ran the fused append (reporting)
 };
 
 int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,

@@ -26,43 +26,78 @@ const char *fir_last_error() { return g_fir_err.c_str(); }
         }                                                                         \
     } while (0)
 
+// Experiment builds only (make libdspfx_firexp<N>.so; results in profiles/r02_fir.txt): bit 0 = the A operand comes from a VALU
+// op instead of an LDS read, bit 1 = the history is loaded once and reused.  Wrong results by design; they show what the
+// matrix pipe delivers when one of its two feeds costs nothing.
+#ifndef DSPFX_FIR_EXP
+#define DSPFX_FIR_EXP 0
+#endif
 constexpr int TILE_C = 32;   // channels per MFMA tile == ring tile width
 constexpr int KC = 16;       // k per chunk (8 MFMA k-steps); history prefetched one chunk ahead
 constexpr int FLUSH = 32;    // chunks per accumulator flush (512 terms)
 constexpr uint32_t SLICE = 128;          // output frames per launch (4 MFMA tiles of 32)
 constexpr uint32_t PAD_LO = 160, PAD_HI = 160;   // zero pads of the LDS tap table: >= 127 + KC below, >= SLICE + KC above
 
-__device__ __forceinline__ size_t ring_at(uint32_t c, uint32_t row, uint32_t R) {
-    return ((size_t)(c >> 5) * R + row) * TILE_C + (c & 31);
+// History ring, chunk-transposed (R a multiple of KC = 16 rows; sample time t lives in row t mod R, so t mod 16 == row mod 16):
+//     ring[tile][row / 16][((row % 16) / 2) / 4][row & 1][channel in tile (32)][((row % 16) / 2) % 4]
+//     tile stride = R * 32 + 32 floats
+// The MFMA B operand of lane (c, kh) for one 16-row chunk is rows row0 + kh, row0 + 2 + kh, ..., row0 + 14 + kh of channel
+// c.  Here those eight floats are two 16-byte pieces and a wave's chunk is one 2 KiB extent read by two fully coalesced
+// dwordx4 loads per lane, whose only address arithmetic is the chunk's (scalar) offset -- instead of eight dword loads
+// with a wrap test each: the loads and their address arithmetic were the largest non-MFMA cost of the row-major sweep
+// (profiles/r02_fir.txt, experiment builds).  A chunk never straddles the ring's wrap.  The tile stride gets one odd
+// 128-byte pad so that concurrent waves, which walk their tiles at about the same row, spread over the HBM channels
+// (R * 128 B alone would be a multiple of 2 KiB).
+__host__ __device__ __forceinline__ size_t ring_tile_stride(uint32_t R) { return (size_t)R * TILE_C + TILE_C; }
+__host__ __device__ __forceinline__ size_t ring_in_tile(uint32_t row, uint32_t cl) {
+    const uint32_t s = (row & 15) >> 1;
+    return (size_t)(row >> 4) * (KC * TILE_C) + (s >> 2) * 256 + (row & 1) * 128 + cl * 4 + (s & 3);
 }
+__host__ __device__ __forceinline__ size_t ring_at(uint32_t c, uint32_t row, uint32_t R) {
+    return (size_t)(c >> 5) * ring_tile_stride(R) + ring_in_tile(row, c & 31);
+}
+static size_t ring_bytes_for(uint32_t tiles, uint32_t R) { return (size_t)tiles * ring_tile_stride(R) * sizeof(float); }
 __device__ __forceinline__ bool finite_f32(float v) { return __builtin_fabsf(v) < __builtin_inff(); }   // false for inf and NaN
 
 // ring[(row0 + f) mod R] <- port value of in[f][c]  (fir.rs:193 push_back, after the collect_and_average hop when
-// enabled).  Used when the MFMA kernel cannot append the block itself (warm-up, the delayed window after a tap reload,
-// the exact kernel).  blockIdx.y = group of 4 frames, x = channels: consecutive lanes take consecutive channels of
-// one frame in both layouts.  Non-finite samples raise the tile's flag.
-constexpr uint32_t APPEND_FRAMES = 4;
+// enabled).  One thread = one channel x one (16-row group, row parity, half): the four rows whose samples are one
+// 16-byte piece of the ring.  Consecutive lanes take consecutive channels: the reads are coalesced 256-byte row segments
+// in both I/O layouts, the writes 16 bytes per lane, contiguous over 32 lanes.  blockIdx.y = piece index from the
+// 16-row group that holds row0.  Non-finite samples raise the tile's flag.
 __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float *ring, unsigned long long *nf_time, uint32_t N,
                                                          uint32_t nframes, uint32_t row0, uint32_t R, unsigned long long t0,
                                                          int hop, float hop_div, const Layout lay) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
-    const uint32_t f0 = blockIdx.y * APPEND_FRAMES;
-    float x[APPEND_FRAMES];
+    const uint32_t piece = blockIdx.y, g = piece >> 2, kh = (piece >> 1) & 1, half = piece & 1;
+    // linear row (not yet wrapped) of the piece's first sample; frame f of the block is linear row row0 + f
+    const uint32_t lin0 = (row0 & ~15u) + g * KC + half * 8 + kh;
+    float x[4];
+    bool ok[4];
 #pragma unroll
-    for (uint32_t k = 0; k < APPEND_FRAMES; ++k)
-        if (f0 + k < nframes) x[k] = __builtin_nontemporal_load(in + lay.at(f0 + k, c));
+    for (uint32_t k = 0; k < 4; ++k) {
+        const int f = (int)(lin0 + 2 * k) - (int)row0;
+        ok[k] = f >= 0 && (uint32_t)f < nframes;
+        x[k] = ok[k] ? __builtin_nontemporal_load(in + lay.at((uint32_t)f, c)) : 0.0f;
+    }
+    uint32_t rg = (row0 & ~15u) + g * KC;                  // the group's first ring row: groups wrap as a whole
+    rg = rg >= R ? rg - R : rg;
+    float *dst = ring + ring_at(c, rg + half * 8 + kh, R);
 #pragma unroll
-    for (uint32_t k = 0; k < APPEND_FRAMES; ++k) {
-        if (f0 + k >= nframes) break;
-        float v = x[k];
-        if (hop) v = (0.0f + v) / hop_div;
-        uint32_t r = row0 + f0 + k;
-        r = r >= R ? r - R : r;
-        ring[ring_at(c, r, R)] = v;
-        if (!finite_f32(v)) atomicMax(&nf_time[c >> 5], t0 + f0 + k + 1);
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (hop) x[k] = (0.0f + x[k]) / hop_div;
+        if (ok[k] && !finite_f32(x[k])) atomicMax(&nf_time[c >> 5], t0 + (lin0 + 2 * k - row0) + 1);
+    }
+    if (ok[0] && ok[1] && ok[2] && ok[3]) {
+        *(float4 *)dst = make_float4(x[0], x[1], x[2], x[3]);
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k)
+            if (ok[k]) dst[k] = x[k];
     }
 }
+// pieces that can hold rows of a block of nframes starting anywhere in a 16-row group
+static uint32_t append_pieces(uint32_t row0, uint32_t nframes) { return (((row0 & 15u) + nframes + KC - 1) / KC) * 4; }
 
 // ---- exact path ---------------------------------------------------------------------------------------------
 // One lane per (frame, channel); a workgroup = one 32-channel tile x 8 frames.  Output f of the slice sees the
@@ -95,7 +130,7 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
     const uint32_t cl = threadIdx.x & 31, fi = threadIdx.x >> 5;
     const uint32_t c = tile * TILE_C + cl;
     if (c >= a.N) return;
-    const float *col = a.ring + (size_t)tile * a.R * TILE_C + cl;
+    const float *col = a.ring + (size_t)tile * ring_tile_stride(a.R);
     // blockIdx.y strides over groups of 8 frames (the fix-up pass launches ONE block per tile: most exit above)
     for (uint32_t f = blockIdx.y * 8 + fi; f < a.nframes; f += gridDim.y * 8) {
         const unsigned long long F = a.front0 + a.dfront[f], n = a.n0 + f;
@@ -104,7 +139,7 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
         const uint32_t la = na < a.T ? na : a.T;
         double acc = 0.0;
         for (uint32_t k = 0; k < la; ++k) {
-            acc += (double)col[(size_t)r * TILE_C] * a.taps[k];
+            acc += (double)col[ring_in_tile(r, cl)] * a.taps[k];
             r = r + 1 == a.R ? 0 : r + 1;
         }
         const float fa = (float)acc;
@@ -113,7 +148,7 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
             const uint32_t lb = (len - na) < (a.T - na) ? (len - na) : (a.T - na);
             double accb = 0.0;
             for (uint32_t k = 0; k < lb; ++k) {
-                accb += (double)col[(size_t)r * TILE_C] * a.taps[na + k];
+                accb += (double)col[ring_in_tile(r, cl)] * a.taps[na + k];
                 r = r + 1 == a.R ? 0 : r + 1;
             }
             fb = (float)accb;
@@ -129,35 +164,28 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
 //                                     B operand = H (lane: c = l&31, k = l>>5)
 //   C/D: lane holds column c = l&31, rows j = (r&3) + 8*(r>>2) + 4*(l>>5)  => each
 //   accumulator register is one coalesced 128-byte output row segment.
-// The sweep index k' runs over history rows from time t_k0 on; k = k' - koff is the row's distance from the oldest
-// sample of output 0 (koff < KC pads the front so that the block's own samples start on a chunk boundary).
+// The sweep index k' runs over history rows from time t_k0 on, t_k0 a multiple of KC (so every chunk is one 16-row
+// group of the ring); k = k' - koff is the row's distance from the oldest sample of output 0 (koff < KC).
 // W[j][k] = taps_rev[k - j] in steady state (Toeplitz).  While the deque is still filling the reference pairs
 // state[m - front] with taps[m - front] (fir.rs:204-206) and only samples m <= n exist: the WARM variant applies
-// that map.  FUSED (steady state, no extra delay): rows k' >= kring are the block itself -- read from `in`, hop
-// applied, written to the ring, flagged when non-finite.
+// that map.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FirMfmaArgs {
-    float *ring;
+    const float *ring;
     const float *taps;     // [pad_lo + T + pad_hi], zeros in the pads
-    const float *in;       // FUSED: the slice's input block
     float *out;
-    unsigned long long *nf_time;
+    const unsigned long long *nf_time;
     uint32_t N, nframes, T, R;
-    uint32_t rb;           // ring row of k' = 0
+    uint32_t rb;           // ring row of k' = 0 (a multiple of KC)
     uint32_t kpad;         // sweep length, multiple of KC
-    uint32_t kvalid;       // rows k' >= kvalid are not history (ring: not read)
-    uint32_t kring;        // FUSED: first k' that comes from `in` (multiple of KC); otherwise kpad
+    uint32_t kvalid;       // rows k' >= kvalid are not history (stale ring rows: masked)
     uint32_t koff;
-    uint32_t row_new;      // FUSED: ring row that receives frame 0
     long long n0;          // absolute index of the slice's first output
     long long t_k0;        // absolute time of row k' = 0 (may be negative)
     long long tfront;      // WARM: absolute index of the deque's front
     float divisor;
-    float hop_div;
-    int hop;
-    int pad_;
-    double hop_rc;         // RN_f64(1 / hop_div)
     Layout lay;
 };
 
@@ -165,9 +193,8 @@ struct FirMfmaArgs {
 // is loaded once; 240 registers = 2 waves per SIMD).  2: the block's two halves go to two waves of the SAME workgroup
 // (the second read of a row hits in cache a few chunks later); half the accumulators = 4 waves per SIMD to cover each
 // other's per-chunk bubbles, and a narrower Toeplitz band (K / T = 4159 / 4096 instead of 4223 / 4096).
-template <bool WARM, bool FUSED, int NJT>
+template <bool WARM, int NJT>
 __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
-    static_assert(NJT == 4 || (NJT == 2 && !FUSED), "the fused append needs the wave that sweeps the whole block");
     extern __shared__ float tp[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntp = (int)(PAD_LO + a.T + PAD_HI);
@@ -177,7 +204,6 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     const int j0 = NJT == 4 ? 0 : (wave & 1) * 64;        // first output frame of this wave
     if ((size_t)tile * TILE_C >= a.N || (uint32_t)j0 >= a.nframes) return;
     const int cl = lane & 31, kh = lane >> 5;
-    float *hbase = a.ring + (size_t)tile * a.R * TILE_C + cl;
     const uint32_t c = tile * TILE_C + cl;
     const bool c_ok = c < a.N;
     // a non-finite sample somewhere in this tile's sweep: the ring loads are sanitised (wave-uniform)
@@ -206,74 +232,31 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[jt][r] = 0.0f; tot[jt][r] = 0.0f; }
 
-    // History rows of one chunk.  The chunk's first row is wave-uniform (scalar); unless the chunk straddles the
-    // ring's wrap point (once per sweep) every load is base + immediate.
-    const float *hlane = hbase + (size_t)kh * TILE_C;
-    const float *pin = nullptr;
-    if constexpr (FUSED) pin = a.in + a.lay.at(0, c_ok ? c : 0);
-    // load_chunk only ISSUES the loads of a chunk (one chunk ahead of its use); whatever has to look at the values --
-    // the hop, the ring store and the non-finite check of the block's own rows, the sanitising of dirty history --
-    // happens in `arrive`, when the chunk becomes the current one.  (Consuming a value right after its load -- or a
-    // store between two loads, which the compiler must assume to alias -- serialises eight memory round trips per chunk:
-    // measured +0.12 ms per block.)
+    // History rows of one chunk: the lane's two 16-byte pieces of the chunk's 2 KiB extent (ring layout above); the
+    // chunk's offset is wave-uniform.  load_chunk only ISSUES the loads (one chunk ahead of their use); whatever has to
+    // look at the values -- masking the rows past the newest sample, sanitising dirty history -- happens in `arrive`,
+    // when the chunk becomes the current one.
     // NJT == 4 streams every history row exactly once: nontemporal.  NJT == 2 reads each row twice (the two halves of the
     // block, a few chunks apart): plain loads, so that the second read finds the line in L2.
-    auto hload = [](const float *q) { return NJT == 4 ? __builtin_nontemporal_load(q) : *q; };
-    auto load_chunk = [&](uint32_t kc, float (&h)[KC / 2]) {
-        if (FUSED && kc >= a.kring) {
-            // the block itself: frame f of the slice is row k' = kring + f
-#pragma unroll
-            for (int s = 0; s < KC / 2; ++s) {
-                const uint32_t f = kc - a.kring + 2 * s + kh;
-                h[s] = (f < a.nframes && c_ok) ? __builtin_nontemporal_load(pin + (size_t)f * a.lay.ld) : 0.0f;
-            }
-            return;
-        }
-        uint32_t row0 = a.rb + kc;                     // < 2R: rb < R, kc < kpad <= R
+    const float *hlane = a.ring + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
+    auto load_chunk = [&](uint32_t kc, f32x4 (&h)[2]) {
+        uint32_t row0 = a.rb + kc;                     // < 2R: rb < R, kc < kpad <= R; a multiple of KC
         row0 = row0 >= a.R ? row0 - a.R : row0;
-        if (row0 + KC + 1 <= a.R && kc + KC <= a.kvalid) {
-            const float *p = hlane + (size_t)row0 * TILE_C;
-#pragma unroll
-            for (int s = 0; s < KC / 2; ++s) h[s] = hload(p + (size_t)(2 * s) * TILE_C);
+        const f32x4 *p = (const f32x4 *)(hlane + (size_t)row0 * TILE_C);
+        if constexpr (NJT == 4) {
+            h[0] = __builtin_nontemporal_load(p);
+            h[1] = __builtin_nontemporal_load(p + 64);
         } else {
-#pragma unroll
-            for (int s = 0; s < KC / 2; ++s) {
-                uint32_t row = row0 + 2 * s + kh;
-                row = row >= a.R ? row - a.R : row;
-                h[s] = kc + 2 * s + kh < a.kvalid ? hload(hbase + (size_t)row * TILE_C) : 0.0f;
-            }
+            h[0] = p[0];
+            h[1] = p[64];
         }
     };
     auto arrive = [&](uint32_t kc, float (&h)[KC / 2]) {
-        if (FUSED && kc >= a.kring) {
-            // branch-free per element (predicated store, selects): the hop as the exact product with RN_f64(1 / divisor) --
-            // exact for 1.0001f like every divisor that is not an even integer (chain_kernels.hip.h, div_c)
-            bool bad = false;
+        if (kc + KC > a.kvalid) {                      // the sweep's last chunk: rows past the block's newest sample are stale
 #pragma unroll
-            for (int s = 0; s < KC / 2; ++s) {
-                const uint32_t f = kc - a.kring + 2 * s + kh;
-                const bool ok = c_ok && f < a.nframes;
-                float v = h[s];
-                if (a.hop) v = (float)((double)(0.0f + v) * a.hop_rc);        // node.rs:162-194, one pipe
-                uint32_t row = a.row_new + f;
-                row = row >= a.R ? row - a.R : row;
-                if (ok) hbase[(size_t)row * TILE_C] = v;                      // fir.rs:193 push_back
-                const bool fin = finite_f32(v);
-                bad = bad || (ok && !fin);
-                h[s] = (ok && fin) ? v : 0.0f;
-            }
-            if (__builtin_amdgcn_ballot_w64(bad)) {                           // rare: flag the tile for the exact fix-up pass
-#pragma unroll
-                for (int s = 0; s < KC / 2; ++s) {
-                    const uint32_t f = kc - a.kring + 2 * s + kh;
-                    if (c_ok && f < a.nframes) {
-                        uint32_t row = a.row_new + f;
-                        row = row >= a.R ? row - a.R : row;
-                        if (!finite_f32(hbase[(size_t)row * TILE_C])) atomicMax(&a.nf_time[tile], (unsigned long long)(a.n0 + f + 1));
-                    }
-                }
-            }
-        } else if (dirty) {
+            for (int s = 0; s < KC / 2; ++s) h[s] = kc + 2 * s + kh < a.kvalid ? h[s] : 0.0f;
+        }
+        if (dirty) {
 #pragma unroll
             for (int s = 0; s < KC / 2; ++s) h[s] = finite_f32(h[s]) ? h[s] : 0.0f;
         }
@@ -283,15 +266,16 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     const uint32_t kc0 = (uint32_t)j0;                   // a multiple of KC
     uint32_t kc1 = (a.koff + (uint32_t)j0 + 32u * NJT + a.T - 1 + KC - 1) / KC * KC;
     kc1 = kc1 < a.kpad ? kc1 : a.kpad;
-    float h_cur[KC / 2], h_nxt[KC / 2];
+    float h_cur[KC / 2];
+    f32x4 h_nxt[2];
     load_chunk(kc0, h_nxt);
 
     // One chunk for the output tiles [LO, HI] (compile-time: the loop body holds exactly those MFMAs).
     auto chunk = [&](auto lo_c, auto hi_c, uint32_t kc) {
         constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s];
-        if (kc + KC < kc1) load_chunk(kc + KC, h_nxt);
+        for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s >> 2][s & 3];
+        if ((DSPFX_FIR_EXP & 2) == 0 && kc + KC < kc1) load_chunk(kc + KC, h_nxt);
         arrive(kc, h_cur);
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
@@ -304,6 +288,8 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
                     const int ic = idx < lo ? lo : idx;
                     w = tp[ic];
                     w = idx <= whi[jt] ? w : 0.0f;
+                } else if constexpr ((DSPFX_FIR_EXP & 1) != 0) {
+                    w = __int_as_float(idx);
                 } else {
                     w = tp[idx];
                 }
@@ -351,9 +337,21 @@ __global__ void __launch_bounds__(256) fir_rebase_kernel(const float *src, float
     const size_t total = (size_t)(t_end - t_begin) * per_t;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const unsigned long long t = t_begin + i / per_t;
-        const size_t rem = i % per_t;
-        const uint32_t tile = (uint32_t)(rem / TILE_C), cl = (uint32_t)(rem % TILE_C);
-        dst[((size_t)tile * R_dst + (uint32_t)(t % R_dst)) * TILE_C + cl] = src[((size_t)tile * R_src + (uint32_t)(t % R_src)) * TILE_C + cl];
+        const uint32_t c = (uint32_t)(i % per_t);
+        dst[ring_at(c, (uint32_t)(t % R_dst), R_dst)] = src[ring_at(c, (uint32_t)(t % R_src), R_src)];
+    }
+}
+
+// dense[k][c] <-> ring row of time t0 + k (state export / import); times before 0 read as zeros
+__global__ void __launch_bounds__(256) fir_rows_kernel(float *ring, float *dense, uint32_t N, uint32_t R, long long t0, uint32_t nrows,
+                                                       int to_dense) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    for (uint32_t k = blockIdx.y; k < nrows; k += gridDim.y) {
+        const long long t = t0 + k;
+        float *cell = ring + ring_at(c, (uint32_t)((t % (long long)R + (long long)R) % (long long)R), R);
+        if (to_dense) dense[(size_t)k * N + c] = t < 0 ? 0.0f : *cell;
+        else if (t >= 0) *cell = dense[(size_t)k * N + c];
     }
 }
 
@@ -361,10 +359,9 @@ static uint32_t ring_rows_for(uint64_t held, uint32_t n_taps, uint32_t max_frame
     // rows the sweep may touch: the deque (held samples, at least T-1), the block, the alignment pad and one chunk of slack
     uint64_t need = std::max<uint64_t>(held + 1, n_taps) + max_frames + 2 * KC;
     if (need < 4 * KC) need = 4 * KC;
-    // an ODD row count: consecutive tiles are R * 128 bytes apart, and every wave of a launch walks its tile at about
-    // the same row, so the tile stride decides how the concurrent 128-byte reads spread over the HBM channels.  Odd R
-    // makes the stride an odd multiple of 128 B (measured: R = 4256 ran the 4096-tap sweep 3.4 % slower than R = 4223)
-    return (uint32_t)need | 1u;
+    // whole 16-row groups (ring layout above); the tile stride (R + 1) * 128 B is then an odd multiple of 128 B (measured
+    // on the row-major ring: a stride that is a multiple of 4 KiB ran the 4096-tap sweep 3.4 % slower)
+    return (uint32_t)((need + KC - 1) / KC * KC);
 }
 
 static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps) {
@@ -387,11 +384,10 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
     const size_t lds = ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float);
     if (lds > 160 * 1024 - 1024) s.kernel = 0;         // tap table must fit the CU's LDS
     if (s.kernel == 1 && lds > 64 * 1024) {
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     return 0;
 }
@@ -407,7 +403,7 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     s.front = 0;
     s.dq_cap = s.dq_head = 0;
     s.R = ring_rows_for(0, n_taps, max_frames);
-    const size_t ring_bytes = (size_t)s.tiles * s.R * TILE_C * sizeof(float);
+    const size_t ring_bytes = ring_bytes_for(s.tiles, s.R);
     FIRCHK(hipMalloc((void **)&s.ring, ring_bytes));
     FIRCHK(hipMemset(s.ring, 0, ring_bytes));
     FIRCHK(hipMalloc((void **)&s.nf_time, (size_t)s.tiles * sizeof(unsigned long long)));
@@ -426,7 +422,7 @@ int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int 
     const uint32_t need = ring_rows_for(held, n_taps, s.max_frames);
     if (need > s.R) {
         float *nr = nullptr;
-        const size_t bytes = (size_t)s.tiles * need * TILE_C * sizeof(float);
+        const size_t bytes = ring_bytes_for(s.tiles, need);
         FIRCHK(hipMalloc((void **)&nr, bytes));
         FIRCHK(hipMemset(nr, 0, bytes));
         if (held) {
@@ -454,7 +450,7 @@ void fir_free(FirState &s) {
 }
 
 void fir_reset(FirState &s) {
-    if (s.ring) (void)hipMemset(s.ring, 0, (size_t)s.tiles * s.R * TILE_C * sizeof(float));
+    if (s.ring) (void)hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R));
     if (s.nf_time) (void)hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long));
     s.n_seen = 0;
     s.front = 0;
@@ -492,11 +488,8 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
     }
     // fir.rs:187-190
     const float divisor = s.mode == DSPFX_FIR_AVERAGE ? 1.0f / (float)s.T : 1.0f;
-    // The MFMA kernel CAN append the block itself (FUSED: its newest rows come from `in`), which saves the append pass
-    // (43 us at config 4) -- but measured on MI355X the fused kernel runs 0.10 ms longer (2.155 vs 2.056 ms per block,
-    // profiles/r02_fir.txt), so the separate append pass stays the default; DSPFX_FIR_FUSE=1 selects the fused form.
-    const char *fuse_env = getenv("DSPFX_FIR_FUSE");     // read per call (tests flip it)
-    const bool no_fuse = !(fuse_env && atoi(fuse_env) == 1);
+    // (An MFMA kernel that appends the block itself -- its newest rows read from `in` -- saved the 43 us append pass but
+    // ran 0.10 ms longer per block at config 4: profiles/r02_fir.txt.  Removed; the append stays a pass of its own.)
     bool ev_open = false;
     // up to 128 output frames per launch (4 MFMA tiles); longer blocks go in slices
     for (uint32_t f0 = 0; f0 < nframes; f0 += SLICE) {
@@ -526,11 +519,11 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         const bool steady = len0 + 1 >= s.T;                 // the first output already sees T samples
         const uint64_t d = len0 > s.T ? len0 - s.T : 0;      // deque longer than the taps: a pure extra delay (fir.rs:195-197 pops one per step)
         const bool mfma = s.kernel == 1;
-        const bool fused = mfma && steady && d == 0 && !no_fuse;
-        s.last_fused = fused ? 1 : 0;
-        if (!fused)
-            hipLaunchKernelGGL(fir_append_kernel, dim3((s.N + 255) / 256, (nf + APPEND_FRAMES - 1) / APPEND_FRAMES), dim3(256), 0,
-                               stream, in_s, s.ring, s.nf_time, s.N, nf, (uint32_t)(n0 % s.R), s.R, (unsigned long long)n0, hop, hop_div, lay);
+        {
+            const uint32_t row0 = (uint32_t)(n0 % s.R);
+            hipLaunchKernelGGL(fir_append_kernel, dim3((s.N + 255) / 256, append_pieces(row0, nf)), dim3(256), 0, stream, in_s, s.ring,
+                               s.nf_time, s.N, nf, row0, s.R, (unsigned long long)n0, hop, hop_div, lay);
+        }
         if (ev_begin && !ev_open) {
             (void)hipEventRecord(ev_begin, stream);
             ev_open = true;
@@ -540,7 +533,6 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             FirMfmaArgs a{};
             a.ring = s.ring;
             a.taps = s.taps32;
-            a.in = in_s;
             a.out = out_s;
             a.nf_time = s.nf_time;
             a.N = s.N;
@@ -548,34 +540,28 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.T = s.T;
             a.R = s.R;
             a.n0 = (long long)n0;
-            a.koff = (KC - (s.T - 1) % KC) % KC;             // the block's own rows start on a chunk boundary
-            a.t_k0 = (long long)n0 - (long long)d - (long long)(s.T - 1) - (long long)a.koff;   // may be negative
+            const long long oldest = (long long)n0 - (long long)d - (long long)(s.T - 1);   // oldest sample of output 0; may be negative
+            a.koff = (uint32_t)(((oldest % KC) + KC) % KC);  // the sweep starts on the 16-row group that holds it
+            a.t_k0 = oldest - (long long)a.koff;
             a.rb = (uint32_t)(((a.t_k0 % (long long)s.R) + (long long)s.R) % (long long)s.R);
             a.kvalid = a.koff + s.T - 1 + nf;
             a.kpad = (a.kvalid + KC - 1) / KC * KC;
-            a.kring = fused ? a.koff + s.T - 1 : a.kpad;
-            a.row_new = (uint32_t)(n0 % s.R);
             a.tfront = (long long)front0;
             a.divisor = divisor;
-            a.hop_div = hop_div;
-            a.hop_rc = 1.0 / (double)hop_div;
-            a.hop = hop;
             a.lay = lay;
             // two output tiles per wave (4 waves per SIMD, a narrower Toeplitz band) for short filters; DSPFX_FIR_NJT=2|4 forces either
             const char *njt_env = getenv("DSPFX_FIR_NJT");
             // (measured at 262144 channels, kernel ms: T = 256: 0.201 vs 0.214 with four tiles per wave; T = 1024: 0.611 vs 0.584;
             //  T = 4096: 2.257 vs 2.072 -- reading every history row twice costs more than the occupancy gains)
-            const bool two = !fused && nf > 64 && (njt_env ? atoi(njt_env) == 2 : s.T <= 384);
+            const bool two = nf > 64 && (njt_env ? atoi(njt_env) == 2 : s.T <= 384);
             const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
             const size_t lds = ((size_t)PAD_LO + s.T + PAD_HI) * sizeof(float);
             if (!steady) {
-                if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, false, 2>), dim3(grid), dim3(256), lds, stream, a);
-                else hipLaunchKernelGGL((fir_mfma_kernel<true, false, 4>), dim3(grid), dim3(256), lds, stream, a);
-            } else if (fused) {
-                hipLaunchKernelGGL((fir_mfma_kernel<false, true, 4>), dim3(grid), dim3(256), lds, stream, a);
+                if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
+                else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
             } else {
-                if (two) hipLaunchKernelGGL((fir_mfma_kernel<false, false, 2>), dim3(grid), dim3(256), lds, stream, a);
-                else hipLaunchKernelGGL((fir_mfma_kernel<false, false, 4>), dim3(grid), dim3(256), lds, stream, a);
+                if (two) hipLaunchKernelGGL((fir_mfma_kernel<false, 2>), dim3(grid), dim3(256), lds, stream, a);
+                else hipLaunchKernelGGL((fir_mfma_kernel<false, 4>), dim3(grid), dim3(256), lds, stream, a);
             }
             if (ev_end && f0 + SLICE >= nframes) (void)hipEventRecord(ev_end, stream);
             // tiles holding a non-finite sample inside this slice's window are redone exactly (nothing to do otherwise)
@@ -594,37 +580,39 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
 // exported state: u64 n_seen, then the T-1 most recent samples [t][N], oldest first
 size_t fir_state_bytes(const FirState &s) { return 8 + (size_t)(s.T - 1) * s.N * sizeof(float); }
 
-// one history row (time t) <-> a dense [N] host row: N/32 segments of 128 B, pitch R*128 B
-static hipError_t copy_row(const FirState &s, uint32_t row, void *host, bool to_host) {
-    const size_t seg = TILE_C * sizeof(float);
-    const uint32_t full = s.N / TILE_C, rem = s.N % TILE_C;
-    float *dev = s.ring + (size_t)row * TILE_C;
-    hipError_t e = hipSuccess;
-    if (full) {
-        e = to_host ? hipMemcpy2D(host, seg, dev, (size_t)s.R * seg, seg, full, hipMemcpyDeviceToHost)
-                    : hipMemcpy2D(dev, (size_t)s.R * seg, host, seg, seg, full, hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
+// dense rows [t0, t0 + n) <-> host, through a device staging buffer in pieces of at most 64 MiB
+static int copy_rows(FirState &s, long long t0, uint64_t n, char *host, bool to_host) {
+    const size_t row = (size_t)s.N * sizeof(float);
+    const uint64_t per = std::max<uint64_t>(1, std::min<uint64_t>(n, ((size_t)64 << 20) / row));
+    float *stage = nullptr;
+    FIRCHK(hipMalloc((void **)&stage, (size_t)per * row));
+    int rc = 0;
+    for (uint64_t k = 0; k < n && rc == 0; k += per) {
+        const uint32_t m = (uint32_t)std::min<uint64_t>(per, n - k);
+        const dim3 grid((s.N + 255) / 256, std::min<uint32_t>(m, 256));
+        hipError_t e = hipSuccess;
+        if (!to_host) e = hipMemcpy(stage, host + (size_t)k * row, (size_t)m * row, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(fir_rows_kernel, grid, dim3(256), 0, nullptr, s.ring, stage, s.N, s.R, t0 + (long long)k, m, to_host ? 1 : 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess && to_host) e = hipMemcpy(host + (size_t)k * row, stage, (size_t)m * row, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            g_fir_err = std::string("FIR state copy: ") + hipGetErrorString(e);
+            rc = DSPFX_ERR_HIP;
+        }
     }
-    if (rem) {
-        float *d2 = dev + (size_t)full * s.R * TILE_C;
-        char *h2 = (char *)host + (size_t)full * seg;
-        e = to_host ? hipMemcpy(h2, d2, rem * sizeof(float), hipMemcpyDeviceToHost)
-                    : hipMemcpy(d2, h2, rem * sizeof(float), hipMemcpyHostToDevice);
-    }
-    return e;
+    (void)hipFree(stage);
+    return rc;
 }
 
 int fir_state_export(FirState &s, void *host_dst) {
     memcpy(host_dst, &s.n_seen, 8);
-    char *dst = (char *)host_dst + 8;
-    const size_t row = (size_t)s.N * sizeof(float);
-    for (uint32_t k = 0; k + 1 < s.T; ++k) {
-        // sample time n_seen - (T-1) + k ; before the start of time => zeros
-        const int64_t t = (int64_t)s.n_seen - (int64_t)(s.T - 1) + k;
-        if (t < 0) memset(dst + (size_t)k * row, 0, row);
-        else FIRCHK(copy_row(s, (uint32_t)((uint64_t)t % s.R), dst + (size_t)k * row, true));
-    }
-    return 0;
+    if (s.T < 2) return 0;
+    FIRCHK(hipDeviceSynchronize());
+    // sample times n_seen - (T-1) ... n_seen - 1 ; before the start of time => zeros
+    return copy_rows(s, (long long)s.n_seen - (long long)(s.T - 1), s.T - 1, (char *)host_dst + 8, true);
 }
 
 int fir_state_import(FirState &s, const void *host_src) {
@@ -632,13 +620,14 @@ int fir_state_import(FirState &s, const void *host_src) {
     memcpy(&seen, host_src, 8);
     const char *src = (const char *)host_src + 8;
     const size_t row = (size_t)s.N * sizeof(float);
-    FIRCHK(hipMemset(s.ring, 0, (size_t)s.tiles * s.R * TILE_C * sizeof(float)));
+    FIRCHK(hipDeviceSynchronize());
+    FIRCHK(hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R)));
     FIRCHK(hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long)));
     // re-base time so that the imported history occupies rows [0, hist): a deque of `hist` samples pushed from empty
     const uint64_t hist = seen < s.T - 1 ? seen : s.T - 1;
-    for (uint64_t k = 0; k < hist; ++k) {
-        const uint64_t srow = (s.T - 1) - hist + k;
-        FIRCHK(copy_row(s, (uint32_t)k, (void *)(src + (size_t)srow * row), false));
+    if (hist) {
+        const int rc = copy_rows(s, 0, hist, const_cast<char *>(src) + (size_t)((s.T - 1) - hist) * row, false);
+        if (rc) return rc;
     }
     s.n_seen = 0;
     s.front = 0;
