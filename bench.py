@@ -284,6 +284,10 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
         tune_log = {"ms_before": round(before, 4), "seconds": round(tune_s, 2)}
     for j, x_ in enumerate(xs):     # block j of the noise stream in input j
         eng.fill_noise(x_, B, j * B, SEED, stream)
+    if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1":     # diagnosis only (is a kernel power-limited? zeros toggle nothing); reported in config
+        with torch.cuda.stream(ctx.compute_stream):
+            for x_ in xs:
+                x_.zero_()
     if os.environ.get("DSPFX_BENCH_COMM_EARLY", "0") != "1":
         make_comm(ctx)              # after the engine's large allocations and the tuning (A/B: DSPFX_BENCH_COMM_EARLY=1)
     pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
@@ -430,7 +434,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     res = {
         "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
-                   "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags,
+                   "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags, **({"zero_input": True} if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1" else {}),
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
                    "collective": (None if not dist_run else "dspfx_mix_allreduce (RCCL behind the C ABI)" if ctx.comm is not None
                                   else "torch.distributed all_reduce"),

@@ -26,17 +26,11 @@ const char *fir_last_error() { return g_fir_err.c_str(); }
         }                                                                         \
     } while (0)
 
-// Experiment builds only (make libdspfx_firexp<N>.so; results in profiles/r02_fir.txt): bit 0 = the A operand comes from a VALU
-// op instead of an LDS read, bit 1 = the history is loaded once and reused.  Wrong results by design; they show what the
-// matrix pipe delivers when one of its two feeds costs nothing.
-#ifndef DSPFX_FIR_EXP
-#define DSPFX_FIR_EXP 0
-#endif
 constexpr int TILE_C = 32;   // channels per MFMA tile == ring tile width
 constexpr int KC = 16;       // k per chunk (8 MFMA k-steps); history prefetched one chunk ahead
 constexpr int FLUSH = 32;    // chunks per accumulator flush (512 terms)
 constexpr uint32_t SLICE = 128;          // output frames per launch (4 MFMA tiles of 32)
-constexpr uint32_t PAD_LO = 160, PAD_HI = 160;   // zero pads of the LDS tap table: >= 127 + KC below, >= SLICE + KC above
+constexpr uint32_t PAD_LO = 160, PAD_HI = 192;   // zero pads of the LDS tap table: >= 127 + KC below, >= SLICE + 3 KC above (weights are fetched one group ahead)
 
 // History ring, chunk-transposed (R a multiple of KC = 16 rows; sample time t lives in row t mod R, so t mod 16 == row mod 16):
 //     ring[tile][row / 16][((row % 16) / 2) / 4][row & 1][channel in tile (32)][((row % 16) / 2) % 4]
@@ -270,31 +264,40 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     f32x4 h_nxt[2];
     load_chunk(kc0, h_nxt);
 
-    // One chunk for the output tiles [LO, HI] (compile-time: the loop body holds exactly those MFMAs).
-    auto chunk = [&](auto lo_c, auto hi_c, uint32_t kc) {
-        constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+    // Weights of group g of chunk kc: the chunk's eight k-steps go in four groups of two (2 NJT MFMAs each).  The LDS
+    // reads of a group are issued one group ahead of their MFMAs -- the last group of a chunk fetches the first group of
+    // the NEXT chunk (the table's upper pad covers the read past the sweep's end) -- so that no MFMA waits for an LDS
+    // round trip issued just before it.
+    auto wload = [&](uint32_t kc, int g, float (&w)[NJT][2]) {
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s >> 2][s & 3];
-        if ((DSPFX_FIR_EXP & 2) == 0 && kc + KC < kc1) load_chunk(kc + KC, h_nxt);
-        arrive(kc, h_cur);
+        for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) {
-#pragma unroll
-            for (int jt = LO; jt <= HI; ++jt) {
-                const int idx = wofs[jt] + (int)kc + 2 * s;
-                float w;
+            for (int u = 0; u < 2; ++u) {
+                const int idx = wofs[jt] + (int)kc + 4 * g + 2 * u;
                 if constexpr (WARM) {
                     const int lo = (int)PAD_LO - 1;          // tp[PAD_LO-1] == 0
-                    const int ic = idx < lo ? lo : idx;
-                    w = tp[ic];
-                    w = idx <= whi[jt] ? w : 0.0f;
-                } else if constexpr ((DSPFX_FIR_EXP & 1) != 0) {
-                    w = __int_as_float(idx);
+                    w[jt][u] = tp[(idx < lo || idx > whi[jt]) ? lo : idx];
                 } else {
-                    w = tp[idx];
+                    w[jt][u] = tp[idx];
                 }
-                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w, h_cur[s], acc[jt], 0, 0, 0);
             }
+    };
+    float wq[2][NJT][2];
+    wload(kc0, 0, wq[0]);
+    auto chunk = [&](uint32_t kc) {
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) h_cur[s] = h_nxt[s >> 2][s & 3];
+        if (kc + KC < kc1) load_chunk(kc + KC, h_nxt);
+        arrive(kc, h_cur);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g < 3) wload(kc, g + 1, wq[(g + 1) & 1]);
+            else wload(kc + KC, 0, wq[0]);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int jt = 0; jt < NJT; ++jt)
+                    acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[g & 1][jt][u], h_cur[2 * g + u], acc[jt], 0, 0, 0);
         }
     };
     auto flush = [&]() {
@@ -309,12 +312,10 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     // both pushed the kernel past 256 registers (one wave per SIMD instead of two) and made the compiler shuttle the
     // accumulators AGPR <-> VGPR, costing far more than the corners.  A fixed-trip inner sweep keeps the accumulators in
     // place; its f32 chain is <= FLUSH * KC terms.
-    using I0 = std::integral_constant<int, 0>;
-    using IL = std::integral_constant<int, NJT - 1>;
     uint32_t kc = kc0;
     while (kc < kc1) {
         const uint32_t kend = kc + FLUSH * KC < kc1 ? kc + FLUSH * KC : kc1;
-        for (; kc < kend; kc += KC) chunk(I0{}, IL{}, kc);
+        for (; kc < kend; kc += KC) chunk(kc);
         flush();
     }
     if (!c_ok) return;
@@ -325,6 +326,154 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
             const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
             if (j < a.nframes) {
                 const float val = tot[jt][r] + 0.0f;                   // fir.rs:216 `a + b` (one f32 sum here: the MFMA path's bar is an RMS tolerance)
+                __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
+            }
+        }
+}
+
+// ---- steady state, skewed sweep -----------------------------------------------------------------------------
+// In steady state W is Toeplitz: W[j][k] = taps_rev[k - j].  Output tile jt (frames 32 jt ...) times history chunk
+// i + 2 jt needs the weights taps_rev[16 i + kk - jj] -- the SAME for every jt.  So iteration i of this kernel gives all
+// NJT output tiles one shared set of weights (8 LDS values per lane instead of 8 NJT) and tile jt its own history chunk
+// i + 2 jt, kept in a register window of 2 NJT chunks (slot = chunk mod 2 NJT; the loop is unrolled by the window so
+// that every slot is a fixed set of registers).  Every tile then sweeps exactly its own band: (T + 30 + koff) / 16 + 1
+// iterations instead of the (T + 32 NJT - 2 + koff) / 16 + 1 chunks of the rectangular sweep above, whose tiles
+// multiply the zero corners of the band (2.3 % of the MFMAs at T = 4096, NJT = 4).
+template <int P, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (P < N) {
+        f(std::integral_constant<int, P>{});
+        static_for<P + 1, N>(f);
+    }
+}
+
+template <int NJT, int D>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT == 4 ? 2 : 4))) fir_skew_kernel(const FirMfmaArgs a) {
+    // WIN chunks are in use by the NJT tiles of one iteration (every second one; the others belong to the next iteration),
+    // D more are in flight: a chunk is requested D iterations before its first use
+    constexpr int WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + D;
+    constexpr int FLUSH_S = SLOTS * ((FLUSH + SLOTS / 2) / SLOTS);      // iterations per flush: a whole number of unrolled bodies
+    static_assert(SLOTS % 2 == 0, "the weight registers alternate with the iteration's parity");
+    extern __shared__ float tp[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntp = (int)(PAD_LO + a.T + PAD_HI);
+    for (int i = tid; i < ntp; i += 256) tp[i] = a.taps[i];
+    __syncthreads();
+    const uint32_t tile = NJT == 4 ? blockIdx.x * 4 + wave : blockIdx.x * 2 + (wave >> 1);
+    const int j0 = NJT == 4 ? 0 : (wave & 1) * 64;        // first output frame of this wave
+    if ((size_t)tile * TILE_C >= a.N || (uint32_t)j0 >= a.nframes) return;
+    const int cl = lane & 31, kh = lane >> 5;
+    const uint32_t c = tile * TILE_C + cl;
+    const bool c_ok = c < a.N;
+    const bool dirty = a.nf_time[tile] > (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
+    const uint32_t cb = (uint32_t)j0 / KC;                // this wave's chunk 0 in sweep chunks
+    const int wofs = (int)PAD_LO + kh - (int)a.koff - cl;  // LDS index of (iteration i, step s) = wofs + 16 i + 2 s
+    const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
+
+    // acc: the running f32 chains (AGPRs).  Every FLUSH iterations they are added into the totals: tile 0's in
+    // registers, the other tiles' in LDS (touched once per FLUSH iterations; 12 KiB per wave) -- with all totals in
+    // registers the window would push the kernel past 256 registers, i.e. to one wave per SIMD.
+    f32x16 acc[NJT], tot0;
+    f32x4 *tl = (f32x4 *)(tp + (size_t)((ntp + 3) & ~3)) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot0[r] = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < (NJT - 1) * 4; ++q) tl[q * 64] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float *hlane = a.ring + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
+    f32x4 win[SLOTS][2];
+    // chunk m (relative to cb) -> window slot; the load is unconditional: past the sweep's end it fetches rows of the
+    // ring that nobody uses (the ring is sized for it: ring_rows_for)
+    auto load_chunk = [&](uint32_t m, f32x4 (&h)[2]) {
+        uint32_t row0 = a.rb + (cb + m) * KC;              // < 2R
+        row0 = row0 >= a.R ? row0 - a.R : row0;
+        const f32x4 *p = (const f32x4 *)(hlane + (size_t)row0 * TILE_C);
+        if constexpr (NJT == 4) {
+            h[0] = __builtin_nontemporal_load(p);
+            h[1] = __builtin_nontemporal_load(p + 64);
+        } else {
+            h[0] = p[0];
+            h[1] = p[64];
+        }
+    };
+    auto arrive = [&](uint32_t m, f32x4 (&h)[2]) {
+        const uint32_t kc = (cb + m) * KC;
+        if (kc + KC > a.kvalid) {                          // rows past the block's newest sample are stale
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) h[s >> 2][s & 3] = kc + 2 * s + kh < a.kvalid ? h[s >> 2][s & 3] : 0.0f;
+        }
+        if (dirty) {
+#pragma unroll
+            for (int s = 0; s < KC / 2; ++s) h[s >> 2][s & 3] = finite_f32(h[s >> 2][s & 3]) ? h[s >> 2][s & 3] : 0.0f;
+        }
+    };
+    auto wload = [&](uint32_t i, float (&w)[KC / 2]) {
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) w[s] = tp[wofs + (int)(i * KC) + 2 * s];
+    };
+    static_for<0, SLOTS - 1>([&](auto m) { load_chunk(m.value, win[m.value]); });
+    float wq[2][KC / 2];
+    wload(0, wq[0]);
+    static_for<0, WIN - 1>([&](auto m) { arrive(m.value, win[m.value]); });
+
+    // iteration i, i mod SLOTS == P.  The barriers keep the order written here: consecutive MFMAs on different
+    // accumulators (left alone, the scheduler groups the MFMAs of one tile, and four dependent MFMAs in a row leave the
+    // pipe idle between them), the global loads and the LDS reads of the next iteration's weights in the middle of the
+    // MFMA stream, a quarter / half an iteration after the waits that guard the registers they overwrite.
+    auto iter = [&](auto p_c, uint32_t i) {
+        constexpr int P = decltype(p_c)::value;
+        arrive(i + WIN - 1, win[(P + WIN - 1) % SLOTS]);              // requested D iterations ago, first used now
+#pragma unroll
+        for (int s = 0; s < KC / 2; ++s) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 2) load_chunk(i + SLOTS - 1, win[(P + SLOTS - 1) % SLOTS]);      // the slot chunk i - 1 has left
+            if (s == 4) wload(i + 1, wq[(P + 1) & 1]);                                // (reads the table's upper pad at the end)
+            if (s == 2 || s == 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wq[P & 1][s], win[(P + 2 * jt) % SLOTS][s >> 2][s & 3], acc[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 1; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
+                tl[((jt - 1) * 4 + q) * 64] = t;
+            }
+    };
+    uint32_t i = 0;
+    while (i < n_iter) {
+        const uint32_t iend = i + FLUSH_S < n_iter ? i + FLUSH_S : n_iter;
+        for (; i + SLOTS <= iend; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
+        if (i < iend) {                                    // fewer than SLOTS left: only the sweep's last segment
+            const uint32_t rest = iend - i;
+            static_for<0, SLOTS - 1>([&](auto p) {
+                if ((uint32_t)p.value < rest) iter(p, i + p.value);
+            });
+            i = iend;
+        }
+        flush();
+    }
+    if (!c_ok) return;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (j < a.nframes) {
+                const float t = jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3];
+                const float val = t + 0.0f;                            // fir.rs:216 `a + b`
                 __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
             }
         }
@@ -357,11 +506,19 @@ __global__ void __launch_bounds__(256) fir_rows_kernel(float *ring, float *dense
 
 static uint32_t ring_rows_for(uint64_t held, uint32_t n_taps, uint32_t max_frames) {
     // rows the sweep may touch: the deque (held samples, at least T-1), the block, the alignment pad and one chunk of slack
-    uint64_t need = std::max<uint64_t>(held + 1, n_taps) + max_frames + 2 * KC;
+    // (the skewed sweep prefetches up to eight chunks past the newest row of a full slice)
+    uint64_t need = std::max<uint64_t>(held + 1, n_taps) + std::max<uint32_t>(max_frames, SLICE) + 24 * KC;
     if (need < 4 * KC) need = 4 * KC;
     // whole 16-row groups (ring layout above); the tile stride (R + 1) * 128 B is then an odd multiple of 128 B (measured
     // on the row-major ring: a stride that is a multiple of 4 KiB ran the 4096-tap sweep 3.4 % slower)
     return (uint32_t)((need + KC - 1) / KC * KC);
+}
+
+constexpr size_t LDS_PER_CU = 160 * 1024;
+static size_t tap_table_bytes(uint32_t n_taps) { return ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float); }
+// the skewed kernel keeps the totals of its output tiles 1 .. NJT-1 in LDS behind the tap table: 4 waves x (NJT-1) x 4 KiB
+static size_t skew_lds_bytes(uint32_t n_taps, int njt) {
+    return ((tap_table_bytes(n_taps) + 15) & ~(size_t)15) + (size_t)4 * (njt - 1) * 4 * 64 * sizeof(f32x4);
 }
 
 static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps) {
@@ -381,13 +538,22 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
     // DSPFX_FIR_KERNEL: 0 = exact f64 VALU kernel, 1 = MFMA; default MFMA unless the filter is tiny
     const char *k = getenv("DSPFX_FIR_KERNEL");
     s.kernel = k ? atoi(k) : (n_taps >= 16 ? 1 : 0);
-    const size_t lds = ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float);
-    if (lds > 160 * 1024 - 1024) s.kernel = 0;         // tap table must fit the CU's LDS
-    if (s.kernel == 1 && lds > 64 * 1024) {
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t lds = tap_table_bytes(n_taps);
+    if (lds > LDS_PER_CU - 1024) s.kernel = 0;         // tap table must fit the CU's LDS
+    if (s.kernel == 1) {
+        const size_t sk4 = skew_lds_bytes(n_taps, 4), sk2 = skew_lds_bytes(n_taps, 2);
+        if (lds > 64 * 1024) {
+            FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_mfma_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        if (sk4 > 64 * 1024 && sk4 <= LDS_PER_CU) {
+            FIRCHK(hipFuncSetAttribute((const void *)fir_skew_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk4));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_skew_kernel<4, 5>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk4));
+        }
+        if (sk2 > 64 * 1024 && sk2 <= LDS_PER_CU)
+            FIRCHK(hipFuncSetAttribute((const void *)fir_skew_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk2));
     }
     return 0;
 }
@@ -549,16 +715,28 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.tfront = (long long)front0;
             a.divisor = divisor;
             a.lay = lay;
-            // two output tiles per wave (4 waves per SIMD, a narrower Toeplitz band) for short filters; DSPFX_FIR_NJT=2|4 forces either
+            // Tiles per wave: four (one wave sweeps the whole 128-frame slice: every history row is loaded once) unless the
+            // slice is at most 64 frames, which is one wave's two tiles.  DSPFX_FIR_NJT=2|4 forces either.  (With the
+            // rectangular sweep two tiles per wave were faster up to 384 taps -- a narrower band; the skewed sweep has no
+            // band overhead and four tiles win at every length: profiles/r02_fir.txt.)
             const char *njt_env = getenv("DSPFX_FIR_NJT");
-            // (measured at 262144 channels, kernel ms: T = 256: 0.201 vs 0.214 with four tiles per wave; T = 1024: 0.611 vs 0.584;
-            //  T = 4096: 2.257 vs 2.072 -- reading every history row twice costs more than the occupancy gains)
-            const bool two = nf > 64 && (njt_env ? atoi(njt_env) == 2 : s.T <= 384);
+            const bool two = nf <= 64 || (njt_env && atoi(njt_env) == 2);
+            const char *skew_env = getenv("DSPFX_FIR_SKEW");     // 0: the rectangular sweep in steady state too (A/B, cross-checks)
+            // (the skewed kernel wants its workgroup's LDS twice per CU for NJT = 4 -- two waves per SIMD -- else the rectangular sweep serves)
+            const size_t lds_skew = skew_lds_bytes(s.T, two ? 2 : 4);
+            const bool skew = steady && !(skew_env && atoi(skew_env) == 0) && lds_skew * 2 <= LDS_PER_CU;
             const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
-            const size_t lds = ((size_t)PAD_LO + s.T + PAD_HI) * sizeof(float);
+            const size_t lds = skew ? lds_skew : tap_table_bytes(s.T);
             if (!steady) {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
+            } else if (skew) {
+                // history chunks requested 5 iterations before their first use (11 in flight or in use per wave); with 1
+                // the sweep waits for HBM: 1.997 vs 1.949 ms at config 4, 3: 1.986, 7 / 9: 1.962-1.979 (DSPFX_FIR_DIST=1 for A/B)
+                const char *dist_env = getenv("DSPFX_FIR_DIST");
+                if (two) hipLaunchKernelGGL((fir_skew_kernel<2, 1>), dim3(grid), dim3(256), lds, stream, a);
+                else if (dist_env && atoi(dist_env) == 1) hipLaunchKernelGGL((fir_skew_kernel<4, 1>), dim3(grid), dim3(256), lds, stream, a);
+                else hipLaunchKernelGGL((fir_skew_kernel<4, 5>), dim3(grid), dim3(256), lds, stream, a);
             } else {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<false, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<false, 4>), dim3(grid), dim3(256), lds, stream, a);

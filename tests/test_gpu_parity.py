@@ -710,21 +710,37 @@ def test_fir_mfma_ragged_shapes(dspfx, torch_cuda, monkeypatch, N, block):
     assert np.abs(y - ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("fuse", ["0", "1"])
-def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, fuse):
+@pytest.mark.parametrize("skew", ["1", "0"])
+@pytest.mark.parametrize("T", [300, 17, 64, 500, 1000])
+def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
     """Integer taps and samples are exact in f32: the MFMA path must equal the oracle bit for bit,
     including every warm-up output (fir.rs:193-214 pairs state[k] with taps[k] while filling).
-    fuse = 1: the MFMA kernel appends the block itself (its newest rows come straight from `in`)."""
+    skew = 1 (default): the steady-state kernel whose output tiles share one set of weights per iteration
+    (fir_skew_kernel; two tiles per wave up to 384 taps, four above); 0: the rectangular sweep throughout."""
     monkeypatch.setenv("DSPFX_FIR_KERNEL", "1")
-    monkeypatch.setenv("DSPFX_FIR_FUSE", fuse)
+    monkeypatch.setenv("DSPFX_FIR_SKEW", skew)
     rng = np.random.default_rng(5)
-    T = 300
     h = rng.integers(-4, 5, T).astype(np.float64)
-    xi = rng.integers(-8, 9, (128 * 5, 96)).astype(F)
+    xi = rng.integers(-8, 9, (128 * 5 + (T // 128) * 128, 96)).astype(F)
     for mode in (dspfx.FIR_BALANCED, dspfx.FIR_AVERAGE):
         ch = [dspfx.Fir(h, mode)]
         y, ref = run_gpu(dspfx, torch_cuda, ch, xi, 0), run_oracle(ch, xi, 0)
         assert np.array_equal(y, ref)
+
+
+@pytest.mark.parametrize("block", [128, 256, 100, 64, 48, 16])
+@pytest.mark.parametrize("T", [33, 400])
+def test_fir_skewed_sweep_block_sizes_integer_exact(dspfx, torch_cuda, monkeypatch, T, block):
+    """Blocks that are not 128 frames: slices of 128 + a ragged rest, or short blocks (one wave's two tiles), at both
+    tiles-per-wave forms of the skewed kernel; integer data, bit for bit, ten blocks past the warm-up."""
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", "1")
+    rng = np.random.default_rng(11)
+    h = rng.integers(-4, 5, T).astype(np.float64)
+    n = ((T + block - 1) // block + 10) * block
+    xi = rng.integers(-8, 9, (n, 70)).astype(F)
+    ch = [dspfx.Fir(h)]
+    y, ref = run_gpu(dspfx, torch_cuda, ch, xi, 0, block=block), run_oracle(ch, xi, 0)
+    assert np.array_equal(y, ref)
 
 
 def test_fir_config4_taps_small_n(dspfx, torch_cuda):
@@ -793,14 +809,14 @@ def test_fir_exact_kernel_is_bit_exact_and_mfma_within_tolerance(dspfx, torch_cu
                 assert fir_rel_rms(y, ref) < FIR_RMS_TOL, (T, mode)
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "fused"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect"])
 def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel):
     """dspfx_set_taps = the impulse-response reload of fir.rs:153-171: the taps change, `state` does not.  A history
     longer than the new tap count stays longer (one pop per step, fir.rs:193-197): the output is the new convolution
     delayed by the difference; a shorter one goes on filling front-aligned.  Against the oracle, whose node takes the
     same reloads; integer data is exact on both kernels, random data exact on the f64 kernel."""
-    if kernel == "fused":
-        monkeypatch.setenv("DSPFX_FIR_FUSE", "1")
+    if kernel == "rect":        # the rectangular MFMA sweep in steady state too
+        monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     rng = np.random.default_rng(8)
@@ -834,15 +850,15 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
     assert eng.describe()
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "fused"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect"])
 def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cuda, monkeypatch, kernel):
     """inf / NaN samples: the reference's sums turn inf / NaN exactly while the sample is inside the deque (T outputs)
     and only in that channel.  The MFMA sweep multiplies the zero corners of its Toeplitz band with the history, where
     0 x inf would poison neighbouring outputs: non-finite samples are zeroed in the operand, flagged per tile, and the
     flagged tiles are recomputed by the exact kernel -- so the inf / NaN pattern equals the oracle's and every finite
     output stays within the FIR tolerance."""
-    if kernel == "fused":       # the MFMA kernel appends the block itself
-        monkeypatch.setenv("DSPFX_FIR_FUSE", "1")
+    if kernel == "rect":        # the rectangular MFMA sweep in steady state too
+        monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     T, N, nf = 200, 100, 128 * 8

@@ -1,10 +1,11 @@
 #!/bin/bash
 # rocprofv3 evidence for config 4 (262144 ch, 4096-tap FIR): kernel trace + PMC passes (each counter group in its own
-# pass, counters only with --kernel-trace).  FETCH/WRITE are calibrated on fir_append_kernel (DSPFX_FIR_FUSE=0 run):
-# it reads N*B*4 bytes and writes N*B*4 bytes with the same 4-byte-per-lane, 128-byte-row accesses the sweep uses.
+# pass, counters only with --kernel-trace).  FETCH/WRITE are calibrated on fir_append_kernel of the same run: it reads
+# N*B*4 bytes and writes N*B*4 bytes.  Summary: tools/fir_pmc_report.py <dir> <round>.  Extra environment (e.g.
+# DSPFX_FIR_SKEW=0) is inherited by the benchmark.
 set -u
 R=${1:-r02}
-OUT=/root/repo/gpurun_out/firpmc_$R; mkdir -p $OUT
+OUT=/root/repo/gpurun_out/firpmc_$R; rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python3 /root/repo/bench.py --config cfg4 --steps 20 --warmup 5 --no-cpu-baseline"
 rocprofv3 -L > $OUT/counters.txt 2>&1
@@ -18,7 +19,4 @@ pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 pass mops SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass fetch FETCH_SIZE
 pass write WRITE_SIZE
-export DSPFX_FIR_FUSE=0
-pass fetch_nofuse FETCH_SIZE
-pass write_nofuse WRITE_SIZE
 find $OUT -name "*.csv" | head -40
