@@ -522,22 +522,44 @@ __device__ __forceinline__ float *uniform_ptr(float *p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (float *)(((unsigned long long)hi << 32) | lo);
 }
-// wave-uniform base of ring row (pos + f0 + f) for this wave's first channel
-__device__ __forceinline__ float *ring_row(const SlotArgs &s, const Ctx &cx, int f) {
-    unsigned r = s.pos + cx.f0 + f;           // < 2*D: host keeps pos < D, nframes <= D
+// The group pointers a span of at most 128 consecutive ring rows starting at row pos + f0 can need: the group of its first
+// row, the one after it, and group 0 (rows after the wrap at D).  Three scalar loads issued together -- one table read PER
+// ROW, each waited for before the row's address could be formed, cost a wave 32 x ~90 ns before its first tap load was
+// even issued (tools/ts_timeline.py: 2.9 us at the head of the time-sliced kernel).
+struct RingGroups {
+    float *ga, *gb, *g0;
+    unsigned gia;
+};
+__device__ __forceinline__ RingGroups ring_groups(const SlotArgs &s, const Ctx &cx) {
+    unsigned r = s.pos + cx.f0;               // < 2*D: host keeps pos < D, nframes <= D
     r = r >= s.D ? r - s.D : r;
-    // the group table is never written by a kernel: read it through the constant address space so the load
-    // is a scalar one whatever stores precede it
+    // the group table is never written by a kernel: read it through the constant address space so the loads
+    // are scalar ones whatever stores precede them
     typedef float *fptr_t;
     const __attribute__((address_space(4))) fptr_t *tab = (const __attribute__((address_space(4))) fptr_t *)s.groups;
-    float *gb = tab[__builtin_amdgcn_readfirstlane(r >> 7)];
+    const unsigned gia = __builtin_amdgcn_readfirstlane(r >> 7), glast = __builtin_amdgcn_readfirstlane((s.D - 1) >> 7);
+    RingGroups g;
+    g.gia = gia;
+    g.ga = tab[gia];
+    g.gb = tab[gia < glast ? gia + 1 : glast];
+    g.g0 = tab[0];
+    return g;
+}
+// wave-uniform base of ring row (pos + f0 + f), f < 128, for this wave's first channel
+__device__ __forceinline__ float *ring_row(const SlotArgs &s, const Ctx &cx, const RingGroups &g, int f) {
+    unsigned r = s.pos + cx.f0 + f;
+    r = r >= s.D ? r - s.D : r;
+    const unsigned gi = __builtin_amdgcn_readfirstlane(r >> 7);
+    float *gb = gi == g.gia ? g.ga : (gi == g.gia + 1 ? g.gb : g.g0);
     return uniform_ptr(gb + cx.ring_base0 + (size_t)(r & 127u) * cx.ld);
 }
 template <int F, int CPL, bool GUARD>
 __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, RingPre<F, CPL> &pre) {
+    static_assert(F <= 128, "ring_groups covers spans of at most one group length");
+    const RingGroups g = ring_groups(s, cx);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-        pre.row[f] = ring_row(s, cx, f);
+        pre.row[f] = ring_row(s, cx, g, f);
         load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(pre.row[f], cx.ring_off), pre.tap[f], cx.active);
     }
 }
@@ -1145,16 +1167,31 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 // (biquad, one-pole, envelope, generator) is a recurrence over time, so the waves take turns at it -- wave q starts from
 // the state wave q-1 left in LDS -- and every recurrence still sees its frames in order: bit for bit chain_kernel's
 // results, with four times the waves per SIMD.
+// DSPFX_TS_TRACE (tools/ts_timeline.py, a debug build only): wall-clock stamps (100 MHz) per wave at the phase boundaries
+#ifdef DSPFX_TS_TRACE
+constexpr unsigned TS_TRACE_GROUPS = 4096, TS_TRACE_STAMPS = 16;
+static __device__ unsigned long long dspfx_ts_trace[TS_TRACE_GROUPS * 4 * TS_TRACE_STAMPS];
+#define DSPFX_TS_STAMP(k)                                                                                          \
+    if (lane == 0 && group < TS_TRACE_GROUPS) dspfx_ts_trace[((size_t)group * 4 + q) * TS_TRACE_STAMPS + (k)] = wall_clock64();
+#else
+#define DSPFX_TS_STAMP(k)
+#endif
 template <int S, int CPL, class SL>
 __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
+    // (Passing the state from slice to slice with an LDS flag instead of a workgroup barrier per turn -- so that the early
+    // slices store while the later ones still take their turns -- was tried: config 2 27.3 -> 30.2 us, the 5-node chain at
+    // 65536 channels 35.0 -> 32.7 us only at two channels per lane; reads and writes in separate phases suit the HBM better.)
     __shared__ float lds_st[4][CPL][64];           // the state rows of the node whose turns are being taken
     if (a.mp_stage) mixpipe_prologue(a);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
+    // (Rotating the slices over the waves per workgroup -- so that co-resident workgroups take their turns on different
+    // SIMDs -- changes nothing: profiles/r02_small_n.txt.)
     const unsigned group = work_block(a.xcd_remap);                        // channel group of 64*CPL channels
     const unsigned wave_global = a.wave_base + group;
     const size_t rel = ((size_t)group * 64 + lane) * CPL;
     if (rel >= a.n_launch) return;                 // uniform over the whole workgroup: no barrier is left waiting
+    DSPFX_TS_STAMP(0)
     const size_t c = a.c_base + rel;
     const WaveAddr w = wave_addr(a, c);
     const unsigned f_begin = (unsigned)q * S;
@@ -1165,19 +1202,23 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
 #define DSPFX_TAPS(I)                                                                                            \
     float tap##I[sig_is<K_REVERB>(SL::v[I]) ? S : 1][CPL];                                                       \
+    RingGroups rg##I{};        /* three pointers: the 32 row addresses are formed again for the stores */        \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
+        rg##I = ring_groups(a.slot[I], cx);                                                                      \
         _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
-            load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, f), cx.ring_off), tap##I[f], true);  \
+            load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], true); \
     }
     DSPFX_FOR_SLOTS(DSPFX_TAPS)
 #undef DSPFX_TAPS
+    DSPFX_TS_STAMP(1)
 #define DSPFX_RUN(I)                                                                                             \
+    if constexpr (SL::v[I] != SIG_NONE) { DSPFX_TS_STAMP(2 + I) }                                                \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         if constexpr (sig_hop(SL::v[I])) apply_hop<S, CPL, true>(v, cx.hop_div, cx.hop_rc);                      \
         const float decay = a.slot[I].p[0];                                                                      \
         _Pragma("unroll") for (int f = 0; f < S; ++f) {                                                          \
             _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
-            store_vec<CPL, false, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, f), cx.ring_off), v[f], true);     \
+            store_vec<CPL, false, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), v[f], true); \
         }                                                                                                        \
     } else if constexpr (SL::v[I] != SIG_NONE && kind_nstate(sig_kind(SL::v[I])) == 0) {                         \
         float none[4][CPL];                                                                                      \
@@ -1206,10 +1247,13 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     }
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
+    DSPFX_TS_STAMP(12)
 #pragma unroll
     for (int f = 0; f < S; ++f)
         if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+    DSPFX_TS_STAMP(13)
     if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
+    DSPFX_TS_STAMP(14)
 }
 
 // ---- the fused chain kernel, interpreting any chain ----------------------------------

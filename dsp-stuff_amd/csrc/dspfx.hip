@@ -672,7 +672,10 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
     int want = -1;
     if (const char *sv = getenv("DSPFX_VARIANT"))
         if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
-    if (want == 0 || (want < 0 && N > TS_MAX_CHANNELS) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    // Measured crossover against the standard kernels (profiles/r02_small_n.txt): 81920 channels for chains of up to three
+    // nodes, 65536 for longer ones (more registers per wave, fewer co-resident workgroups).
+    const uint32_t ts_max = st.count <= 3 ? TS_MAX_CHANNELS : 65536u;
+    if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     const Pref pref = read_pref();
     std::vector<const Variant *> all;
     collect_variants(all);
@@ -686,7 +689,9 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
             ok = v->sigs[i] == sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
         }
         if (!ok) continue;
-        const int want_cpl = pref.cpl > 0 ? pref.cpl : 1;
+        // two channels per lane (half the load / store instructions per byte) once there are still two workgroups per CU
+        // at that width and the chain is short enough for the doubled registers: 3-node chain at 65536 channels 29.0 -> 27.6 us
+        const int want_cpl = pref.cpl > 0 ? pref.cpl : (st.count <= 3 && N >= 57344u ? 2 : 1);
         if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
     }
     if (best) return best;

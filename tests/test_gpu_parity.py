@@ -1210,7 +1210,8 @@ def test_time_sliced_kernel_equals_the_standard_one(dspfx, torch_cuda, monkeypat
     recurrence still sees its frames in order: outputs, mix bus and carried state must equal the standard kernel bit
     for bit (and the oracle within the chain's bar), in both layouts, with a ragged channel count, across blocks."""
     chain = chain3(dspfx, 300) if which == "chain3" else chain5(dspfx, 300)
-    for N, tile in ((64 * 37 + 5, 0), (4096, 256), (8192, 0)):
+    # (65536 channels: the 3-node chain's time-sliced kernel runs two channels per lane there)
+    for N, tile in ((64 * 37 + 5, 0), (4096, 256), (8192, 0), (65536, 256)):
         x = noise_block(N, 128 * 5)
         outs = {}
         for ts in ("1", "0"):
@@ -1231,7 +1232,10 @@ def test_time_sliced_kernel_equals_the_standard_one(dspfx, torch_cuda, monkeypat
         for a, b in zip(outs["1"][0], outs["0"][0]):
             assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
         for a, b in zip(outs["1"][1], outs["0"][1]):
-            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            if N < 57344:
+                assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+            else:       # kernels of different channels-per-lane associate the bus' sum differently
+                assert np.allclose(a, b, rtol=2e-5, atol=2e-3)
         assert np.array_equal(outs["1"][2], outs["0"][2])
         monkeypatch.delenv("DSPFX_VARIANT")
         ref = run_oracle(chain, x[:256], 3)
@@ -1528,8 +1532,8 @@ def test_default_variant_selection_above_131072_channels_matches_small_engines(d
         a, am, sa = run(0, half)
         b, bm, _ = run(half, N - half)
         # the halves are small engines: one channel per lane; from 16384 channels on they too get a run-time specialised
-        # kernel (and the time-sliced one for whole 128-frame blocks) unless that is switched off
-        assert "_c2" not in sa.split(";")[0] and (("jit_" in sa and "time-sliced" in sa) if not tile else "jit_" not in sa), sa
+        # kernel unless that is switched off (66048 channels is past the time-sliced kernel's range for a 6-node chain)
+        assert "_c2" not in sa.split(";")[0] and (("jit_" in sa and "time-sliced" not in sa) if not tile else "jit_" not in sa), sa
         assert np.array_equal(big.view(np.uint32), np.concatenate([a, b], axis=1).view(np.uint32)), (N, tile)
         assert np.allclose(big_mix, am + bm, rtol=1e-5, atol=1e-2)
 
