@@ -1046,11 +1046,12 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
         lay.ld = N;
         lay.tile_stride = 0;
     }
+    bool bus_done = false;   // a FIR node that ends the chain left the mix bus' partial sums itself
     for (size_t si = 0; si < e->stages.size(); ++si) {
         const Stage &st = e->stages[si];
         const bool last = si + 1 == e->stages.size();
         if (st.type == ST_FUSED) {
-            if (st.count == 0 && !(last && (mix || e->partials_override || e->mp_building)) && src == out) continue;   // nothing to do
+            if (st.count == 0 && (bus_done || !(last && (mix || e->partials_override || e->mp_building))) && src == out) continue;   // nothing to do
             GraphArgs ga;                   // a graph kernel reads the slots beyond ChainArgs from it
             memset(&ga, 0, sizeof ga);
             if (e->graph_mode) {
@@ -1192,8 +1193,43 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 if (e->prof.size() <= si) e->prof.resize(si + 1);
                 e->prof[si].emplace_back(ea, eb);
             }
-            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream, ea, eb);
+            // The FIR node ends the chain and the Output node's mix bus is wanted: the sweep's epilogue leaves the bus'
+            // first-stage partials (one row per 32-channel tile) and the empty chain kernel that would otherwise read the
+            // whole FIR output again just to sum it is skipped.  Slice / final stages as after a chain kernel; in the
+            // pipelined form they run as the stand-alone kernels (the sweep does not host the prologue).
+            const bool ends_chain = si + 2 == e->stages.size() && e->stages[si + 1].type == ST_FUSED && e->stages[si + 1].count == 0 && !e->win_n;
+            const bool want_bus = ends_chain && (mix || e->partials_override || e->mp_building);
+            const uint32_t frows = (N + 31) / 32;
+            const bool deferred = want_bus && e->partials_override != nullptr;
+            float *fpart = nullptr;
+            if (want_bus) {
+                if (frows > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
+                fpart = deferred ? e->partials_override : e->mixpart;
+                if (e->mp_building) {
+                    const int cur = (int)(e->mp_count & 1), prev = cur ^ 1;
+                    fpart = e->mixpart2[cur];
+                    e->mp_rows[cur] = frows;
+                    const int stage = (e->mp_count >= 1 ? 1 : 0) | (e->mp_count >= 2 ? 2 : 0);
+                    float *b_cur = cur ? e->mixpart_b2 : e->mixpart_b, *b_prev = cur ? e->mixpart_b : e->mixpart_b2;
+                    if (stage & 2) {
+                        launch_mix_reduce_final(b_prev, e->mp_mix_now, nframes, stream);
+                        if (e->mp_div_now != 0.0f) launch_mix_finish(e->mp_mix_now, nframes, e->mp_div_now, stream);
+                    }
+                    if (stage & 1) launch_mix_reduce_slices(e->mixpart2[prev], b_cur, nframes, e->mp_rows[prev], stream);
+                }
+            }
+            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream, ea, eb, fpart);
             if (rc != 0) return fail(e, rc, "FIR: %s", fir_last_error());
+            if (want_bus) {
+                if (deferred) {
+                    e->part_stride[e->flip] = frows;
+                    e->part_frames[e->flip] = nframes;
+                } else if (!e->mp_building) {
+                    launch_mix_reduce(e->mixpart, e->mixpart_b, mix, nframes, frows, stream);
+                    HIPCHK(e, hipGetLastError());
+                }
+                bus_done = true;
+            }
         }
         src = out;
     }
@@ -1303,7 +1339,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
         else if (v->mod) (v->cpl == 2 ? e->dyn_mod2 : e->dyn_mod) = v;
         else if (v->f == 8 && v->cpl == 1 && v->libm) e->dyn = v;   // fallbacks handle every node kind
     }
-    e->mixpart_cols = (size_t)desc->channels / 64 + 8;
+    e->mixpart_cols = (size_t)desc->channels / 32 + 8;   // rows of first-stage partials: one per wave of a chain kernel, one per 32-channel tile of a FIR sweep
     if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&e->mixpart_b, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&e->mixpart_b2, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess) {
@@ -2435,6 +2471,8 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                 s += " ";
                 s += kn[e->nodes[(size_t)(st.first + k)].d.kind];
             }
+            if (st.count == 0 && i > 0 && e->stages[i - 1].type == ST_FIR)
+                s += " (mix bus only; not launched for whole blocks: the FIR sweep leaves the bus' partial sums)";
             s += "\n";
         } else if (st.type == ST_FUZZ) {
             snprintf(buf, sizeof buf, "stage %zu: fuzz kernel\n", i);

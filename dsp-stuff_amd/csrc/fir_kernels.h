@@ -37,6 +37,7 @@ struct FirState {
     uint64_t front = 0;           // absolute index of the deque's oldest sample (deque length = n_seen - front)
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
+    const char *last_kernel = nullptr;   // the sweep kernel of the last block (reporting)
 };
 
 int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,
@@ -45,9 +46,11 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
 int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode);
 void fir_free(FirState &s);
 void fir_reset(FirState &s);
-// ev_begin/ev_end (optional) are recorded around the compute kernel(s)
+// ev_begin/ev_end (optional) are recorded around the compute kernel(s).  mixpart (optional): [ceil(N/32)][nframes] floats
+// that receive, per 32-channel tile and frame, the sum of the block's outputs (the Output node's mix bus, first stage).
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr);
+                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
+                float *mixpart = nullptr);
 size_t fir_state_bytes(const FirState &s);
 int fir_state_export(FirState &s, void *host_dst);
 int fir_state_import(FirState &s, const void *host_src);

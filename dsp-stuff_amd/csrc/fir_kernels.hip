@@ -111,6 +111,8 @@ struct FirExactArgs {
     long long t_lo;
     float divisor;
     int only_dirty;
+    float *mixpart;        // mix-bus partials [tiles][mix_ld] like the sweep's (fir_epilogue), or null
+    uint32_t mix_ld;
     Layout lay;
     uint32_t n_a[SLICE];
     uint8_t dfront[SLICE];
@@ -123,32 +125,41 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
     }
     const uint32_t cl = threadIdx.x & 31, fi = threadIdx.x >> 5;
     const uint32_t c = tile * TILE_C + cl;
-    if (c >= a.N) return;
+    const bool c_ok = c < a.N;                 // (lanes past the last channel stay: they take part in the tile's sums)
     const float *col = a.ring + (size_t)tile * ring_tile_stride(a.R);
     // blockIdx.y strides over groups of 8 frames (the fix-up pass launches ONE block per tile: most exit above)
     for (uint32_t f = blockIdx.y * 8 + fi; f < a.nframes; f += gridDim.y * 8) {
-        const unsigned long long F = a.front0 + a.dfront[f], n = a.n0 + f;
-        const uint32_t len = (uint32_t)(n - F + 1), na = a.n_a[f];
-        uint32_t r = (uint32_t)(F % a.R);
-        const uint32_t la = na < a.T ? na : a.T;
-        double acc = 0.0;
-        for (uint32_t k = 0; k < la; ++k) {
-            acc += (double)col[ring_in_tile(r, cl)] * a.taps[k];
-            r = r + 1 == a.R ? 0 : r + 1;
-        }
-        const float fa = (float)acc;
-        float fb = 0.0f;
-        if (na < a.T) {
-            const uint32_t lb = (len - na) < (a.T - na) ? (len - na) : (a.T - na);
-            double accb = 0.0;
-            for (uint32_t k = 0; k < lb; ++k) {
-                accb += (double)col[ring_in_tile(r, cl)] * a.taps[na + k];
+        float o = 0.0f;
+        if (c_ok) {
+            const unsigned long long F = a.front0 + a.dfront[f], n = a.n0 + f;
+            const uint32_t len = (uint32_t)(n - F + 1), na = a.n_a[f];
+            uint32_t r = (uint32_t)(F % a.R);
+            const uint32_t la = na < a.T ? na : a.T;
+            double acc = 0.0;
+            for (uint32_t k = 0; k < la; ++k) {
+                acc += (double)col[ring_in_tile(r, cl)] * a.taps[k];
                 r = r + 1 == a.R ? 0 : r + 1;
             }
-            fb = (float)accb;
+            const float fa = (float)acc;
+            float fb = 0.0f;
+            if (na < a.T) {
+                const uint32_t lb = (len - na) < (a.T - na) ? (len - na) : (a.T - na);
+                double accb = 0.0;
+                for (uint32_t k = 0; k < lb; ++k) {
+                    accb += (double)col[ring_in_tile(r, cl)] * a.taps[na + k];
+                    r = r + 1 == a.R ? 0 : r + 1;
+                }
+                fb = (float)accb;
+            }
+            const float val = fa + fb;                                  // fir.rs:216
+            o = val * a.divisor;                                        // fir.rs:222
+            a.out[a.lay.at(f, c)] = o;
         }
-        const float val = fa + fb;                                  // fir.rs:216
-        a.out[a.lay.at(f, c)] = val * a.divisor;                    // fir.rs:222
+        if (a.mixpart) {                                                // the tile's sum over its channels for this frame
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) o = o + __shfl_xor(o, m, 32);
+            if (cl == 0) a.mixpart[(size_t)tile * a.mix_ld + f] = o;
+        }
     }
 }
 
@@ -180,8 +191,40 @@ struct FirMfmaArgs {
     long long t_k0;        // absolute time of row k' = 0 (may be negative)
     long long tfront;      // WARM: absolute index of the deque's front
     float divisor;
+    float *mixpart;        // mix-bus partials [tiles][mix_ld] (this slice's first frame at column 0), or null
+    uint32_t mix_ld;
     Layout lay;
 };
+
+// The end of a sweep: out = (a + b) * divisor (fir.rs:216-222), each accumulator register one coalesced 128-byte row of the
+// output -- and, when the FIR node ends the chain, the Output node's mix bus: the tile's per-frame sums over its 32 channels
+// (a reduce-scatter over the 32 lanes of each half-wave: 62 cross-lane adds for the 64 frames a half holds), one row of
+// partials per tile, reduced further by the engine's usual slice / final stages.  Without this the engine ran an
+// empty chain kernel over the FIR output just to sum it (32 us per block at config 4).
+template <int NJT, class Get>
+__device__ __forceinline__ void fir_epilogue(const FirMfmaArgs &a, uint32_t tile, uint32_t c, bool c_ok, int j0, int kh, int lane, Get get) {
+    constexpr int NV = NJT * 16;
+    float o[NV];
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float val = get(jt, r) + 0.0f;                       // fir.rs:216 `a + b` (one f32 sum here: the MFMA path's bar is an RMS tolerance)
+            o[jt * 16 + r] = val * a.divisor;                          // fir.rs:222
+            const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (c_ok && j < a.nframes) __builtin_nontemporal_store(o[jt * 16 + r], a.out + a.lay.at(j, c));
+        }
+    if (!a.mixpart) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) o[i] = c_ok ? o[i] : 0.0f;
+    rs_stage<NV, NV, 16>(o, lane);                 // lane (l & 31) of each half now holds the sums of values (NV/32) (l & 31) + i
+#pragma unroll
+    for (int i = 0; i < NV / 32; ++i) {
+        const int idx = (NV / 32) * (lane & 31) + i, jt = idx >> 4, r = idx & 15;
+        const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (j < a.nframes) a.mixpart[(size_t)tile * a.mix_ld + j] = o[i];
+    }
+}
 
 // NJT = output tiles of 32 frames per wave.  4: one wave sweeps a channel tile's whole 128-frame block (every history row
 // is loaded once; 240 registers = 2 waves per SIMD).  2: the block's two halves go to two waves of the SAME workgroup
@@ -318,17 +361,7 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         for (; kc < kend; kc += KC) chunk(kc);
         flush();
     }
-    if (!c_ok) return;
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (j < a.nframes) {
-                const float val = tot[jt][r] + 0.0f;                   // fir.rs:216 `a + b` (one f32 sum here: the MFMA path's bar is an RMS tolerance)
-                __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
-            }
-        }
+    fir_epilogue<NJT>(a, tile, c, c_ok, j0, kh, lane, [&](int jt, int r) { return tot[jt][r]; });
 }
 
 // ---- steady state, skewed sweep -----------------------------------------------------------------------------
@@ -465,18 +498,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
         }
         flush();
     }
-    if (!c_ok) return;
-#pragma unroll
-    for (int jt = 0; jt < NJT; ++jt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const uint32_t j = j0 + jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (j < a.nframes) {
-                const float t = jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3];
-                const float val = t + 0.0f;                            // fir.rs:216 `a + b`
-                __builtin_nontemporal_store(val * a.divisor, a.out + a.lay.at(j, c));   // fir.rs:222
-            }
-        }
+    fir_epilogue<NJT>(a, tile, c, c_ok, j0, kh, lane,
+                      [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
 }
 
 // old ring -> new ring for the sample times [t_begin, t_end): a tap reload that needs more rows
@@ -647,7 +670,7 @@ static uint32_t deque_step(FirState &s) {
 }
 
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end) {
+                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, float *mixpart) {
     if (nframes > s.max_frames) {
         g_fir_err = "nframes > max_frames";
         return DSPFX_ERR_INVALID;
@@ -681,6 +704,8 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         ex.front0 = front0;
         ex.t_lo = (long long)(front0 + ex.dfront[0]);
         ex.divisor = divisor;
+        ex.mixpart = mixpart ? mixpart + f0 : nullptr;       // rows of nframes floats; this slice starts at column f0
+        ex.mix_ld = nframes;
         ex.lay = lay;
         const bool steady = len0 + 1 >= s.T;                 // the first output already sees T samples
         const uint64_t d = len0 > s.T ? len0 - s.T : 0;      // deque longer than the taps: a pure extra delay (fir.rs:195-197 pops one per step)
@@ -714,6 +739,8 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.kpad = (a.kvalid + KC - 1) / KC * KC;
             a.tfront = (long long)front0;
             a.divisor = divisor;
+            a.mixpart = ex.mixpart;
+            a.mix_ld = nframes;
             a.lay = lay;
             // Tiles per wave: four (one wave sweeps the whole 128-frame slice: every history row is loaded once) unless the
             // slice is at most 64 frames, which is one wave's two tiles.  DSPFX_FIR_NJT=2|4 forces either.  (With the
@@ -727,6 +754,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             const bool skew = steady && !(skew_env && atoi(skew_env) == 0) && lds_skew * 2 <= LDS_PER_CU;
             const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
             const size_t lds = skew ? lds_skew : tap_table_bytes(s.T);
+            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
             if (!steady) {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
@@ -814,6 +842,8 @@ int fir_state_import(FirState &s, const void *host_src) {
     return 0;
 }
 
-const char *fir_kernel_name(const FirState &s) { return s.kernel == 1 ? "fir_mfma_kernel" : "fir_exact_kernel"; }
+const char *fir_kernel_name(const FirState &s) {
+    return s.kernel != 1 ? "fir_exact_kernel" : s.last_kernel ? s.last_kernel : "fir_skew_kernel";
+}
 
 }  // namespace dspfx

@@ -883,6 +883,51 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
             assert np.array_equal(y[fin].view(np.uint32), ref[fin].view(np.uint32))
 
 
+@pytest.mark.parametrize("kernel", ["1", "rect", "0"])
+@pytest.mark.parametrize("N,tile,B", [(70, 0, 128), (4096 + 256, 256, 128), (300, 0, 256), (96, 0, 48)])
+def test_fir_that_ends_the_chain_feeds_the_mix_bus_itself(dspfx, torch_cuda, monkeypatch, kernel, N, tile, B):
+    """When the FIR node ends the chain the sweep's epilogue (and the exact kernel) leave the Output node's mix-bus partials
+    per 32-channel tile, instead of an empty chain kernel re-reading the output.  The bus must equal the sum over the
+    channels of the block the engine returned -- all three forms (dspfx_process with mix, the pipelined form, flush), ragged
+    channel counts, blocks of two slices, short blocks, warm-up and steady state, both sweeps and the f64 kernel, and a
+    block with non-finite samples, where the fix-up pass recomputes the flagged tile's partials too."""
+    if kernel == "rect":
+        monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
+        kernel = "1"
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
+    T, blocks = 100, 6
+    x = noise_block(N, B * blocks)
+    x[B * 4 + 5, min(40, N - 1)] = np.inf
+    chain = [dspfx.Gain(0.7), dspfx.Fir(fir_taps(T))]
+    a, b = dspfx.Engine(N, B, tile_channels=tile), dspfx.Engine(N, B, tile_channels=tile)
+    a.set_chain(chain)
+    b.set_chain(chain)
+    assert "fir" in a.describe().lower()
+    mixes = [torch_cuda.full((B,), 7.0, device="cuda") for _ in range(blocks)]
+    outs, inline = [], []
+    for k in range(blocks):
+        dx = torch_cuda.from_numpy(dspfx.to_layout(x[k * B:(k + 1) * B], tile)).cuda()
+        y0, y1 = torch_cuda.empty_like(dx), torch_cuda.empty_like(dx)
+        m = torch_cuda.empty(B, device="cuda")
+        a.process(dx, out=y0, mix=m, n_frames=B)
+        b.process_mixpipe(dx, y1, mixes[k - 2] if k >= 2 else None, B)
+        torch_cuda.cuda.synchronize()
+        assert torch_cuda.equal(y0, y1) or np.array_equal(np.isnan(y0.cpu().numpy()), np.isnan(y1.cpu().numpy()))
+        outs.append(dspfx.from_layout(y0.cpu().numpy(), B, N, tile))
+        inline.append(m.cpu().numpy())
+    b.mixpipe_flush(mixes[blocks - 2], mixes[blocks - 1])
+    torch_cuda.cuda.synchronize()
+    for k in range(blocks):
+        want = outs[k].astype(np.float64).sum(axis=1)
+        scale = np.abs(outs[k][np.isfinite(outs[k])]).astype(np.float64).sum() / B + 1.0
+        for got in (inline[k], mixes[k].cpu().numpy()):
+            fin = np.isfinite(want)
+            assert np.array_equal(np.isfinite(got), fin), (k, "non-finite pattern")
+            assert not fin.any() or np.abs(got[fin] - want[fin]).max() <= 2e-6 * scale, (k, np.abs(got[fin] - want[fin]).max(), scale)
+        assert np.array_equal(inline[k].view(np.uint32)[np.isfinite(inline[k])], mixes[k].cpu().numpy().view(np.uint32)[np.isfinite(inline[k])])
+    assert not np.isfinite(np.concatenate(inline)).all()        # the inf really went through the bus
+
+
 # ---- SignalGen: the reference's control source (signal_gen.rs:55-129) ------------------------------
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
