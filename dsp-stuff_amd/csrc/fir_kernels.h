@@ -1,9 +1,9 @@
 // fir_kernels.h -- FIR convolution stage (nodes/fir.rs:179-225) over N channels.
 //
 // History lives in HBM as a ring of R rows (R a multiple of 16), f32 (the reference widens f32 samples to f64, so f32
-// storage is exact), tiled by 32 channels and, inside a tile, by groups of 16 rows stored so that the eight rows an MFMA
-// lane feeds into one 16-row chunk are two 16-byte pieces (fir_kernels.hip, ring_in_tile):
-//     ring[c / 32][(t mod R) / 16][piece][row parity][c % 32][4]
+// storage is exact), tiled by 32 channels and, inside a tile, by groups of 16 rows stored so that the eight consecutive rows
+// an MFMA lane feeds into one 16-row chunk are two 16-byte pieces (fir_kernels.hip, ring_in_tile):
+//     ring[c / 32][(t mod R) / 16][row / 4 % 2][row / 8 % 2][c % 32][row % 4]
 // so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous HBM stream of 2 KiB chunks.
 // Every output is a dot product over the samples the reference's VecDeque holds at that step:
 //   - fir_append_kernel: the block's samples (hop applied) go into the ring; non-finite ones raise the tile's flag;

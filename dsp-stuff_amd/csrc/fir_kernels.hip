@@ -33,19 +33,18 @@ constexpr uint32_t SLICE = 128;          // output frames per launch (4 MFMA til
 constexpr uint32_t PAD_LO = 160, PAD_HI = 192;   // zero pads of the LDS tap table: >= 127 + KC below, >= SLICE + 3 KC above (weights are fetched one group ahead)
 
 // History ring, chunk-transposed (R a multiple of KC = 16 rows; sample time t lives in row t mod R, so t mod 16 == row mod 16):
-//     ring[tile][row / 16][((row % 16) / 2) / 4][row & 1][channel in tile (32)][((row % 16) / 2) % 4]
-//     tile stride = R * 32 + 32 floats
-// The MFMA B operand of lane (c, kh) for one 16-row chunk is rows row0 + kh, row0 + 2 + kh, ..., row0 + 14 + kh of channel
-// c.  Here those eight floats are two 16-byte pieces and a wave's chunk is one 2 KiB extent read by two fully coalesced
-// dwordx4 loads per lane, whose only address arithmetic is the chunk's (scalar) offset -- instead of eight dword loads
-// with a wrap test each: the loads and their address arithmetic were the largest non-MFMA cost of the row-major sweep
-// (profiles/r02_fir.txt, experiment builds).  A chunk never straddles the ring's wrap.  The tile stride gets one odd
-// 128-byte pad so that concurrent waves, which walk their tiles at about the same row, spread over the HBM channels
-// (R * 128 B alone would be a multiple of 2 KiB).
+//     ring[tile][row / 16][(row / 4) % 2][(row / 8) % 2][channel in tile (32)][row % 4]          tile stride = R * 32 + 32 floats
+// MFMA lane (c, kh) feeds one 16-row chunk with the eight CONSECUTIVE rows row0 + 8 kh ... row0 + 8 kh + 7 of channel c (K
+// index of the lane's step s: 8 kh + s; the weights follow the same map).  Here those eight floats are two 16-byte
+// pieces and a wave's chunk is one 2 KiB extent read by two fully coalesced dwordx4 loads per lane, whose only address
+// arithmetic is the chunk's (scalar) offset -- instead of eight dword loads with a wrap test each: the loads and their
+// address arithmetic were the largest non-MFMA cost of the row-major sweep (profiles/r02_fir.txt, experiment builds).
+// The same eight consecutive rows are what one lane of the bf16 MFMAs (K = 16) of the split-precision sweep needs.
+// A chunk never straddles the ring's wrap.  The tile stride gets one odd 128-byte pad so that concurrent waves, which
+// walk their tiles at about the same row, spread over the HBM channels (R * 128 B alone would be a multiple of 2 KiB).
 __host__ __device__ __forceinline__ size_t ring_tile_stride(uint32_t R) { return (size_t)R * TILE_C + TILE_C; }
 __host__ __device__ __forceinline__ size_t ring_in_tile(uint32_t row, uint32_t cl) {
-    const uint32_t s = (row & 15) >> 1;
-    return (size_t)(row >> 4) * (KC * TILE_C) + (s >> 2) * 256 + (row & 1) * 128 + cl * 4 + (s & 3);
+    return (size_t)(row >> 4) * (KC * TILE_C) + ((row >> 2) & 1) * 256 + ((row >> 3) & 1) * 128 + cl * 4 + (row & 3);
 }
 __host__ __device__ __forceinline__ size_t ring_at(uint32_t c, uint32_t row, uint32_t R) {
     return (size_t)(c >> 5) * ring_tile_stride(R) + ring_in_tile(row, c & 31);
@@ -54,8 +53,7 @@ static size_t ring_bytes_for(uint32_t tiles, uint32_t R) { return (size_t)tiles 
 __device__ __forceinline__ bool finite_f32(float v) { return __builtin_fabsf(v) < __builtin_inff(); }   // false for inf and NaN
 
 // ring[(row0 + f) mod R] <- port value of in[f][c]  (fir.rs:193 push_back, after the collect_and_average hop when
-// enabled).  One thread = one channel x one (16-row group, row parity, half): the four rows whose samples are one
-// 16-byte piece of the ring.  Consecutive lanes take consecutive channels: the reads are coalesced 256-byte row segments
+// enabled).  One thread = one channel x four consecutive rows: the samples of one 16-byte piece of the ring.  Consecutive lanes take consecutive channels: the reads are coalesced 256-byte row segments
 // in both I/O layouts, the writes 16 bytes per lane, contiguous over 32 lanes.  blockIdx.y = piece index from the
 // 16-row group that holds row0.  Non-finite samples raise the tile's flag.
 __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float *ring, unsigned long long *nf_time, uint32_t N,
@@ -63,24 +61,24 @@ __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float 
                                                          int hop, float hop_div, const Layout lay) {
     const uint32_t c = blockIdx.x * 256 + threadIdx.x;
     if (c >= N) return;
-    const uint32_t piece = blockIdx.y, g = piece >> 2, kh = (piece >> 1) & 1, half = piece & 1;
+    const uint32_t piece = blockIdx.y, g = piece >> 2, q4 = piece & 3;      // q4: which four consecutive rows of the group
     // linear row (not yet wrapped) of the piece's first sample; frame f of the block is linear row row0 + f
-    const uint32_t lin0 = (row0 & ~15u) + g * KC + half * 8 + kh;
+    const uint32_t lin0 = (row0 & ~15u) + g * KC + q4 * 4;
     float x[4];
     bool ok[4];
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
-        const int f = (int)(lin0 + 2 * k) - (int)row0;
+        const int f = (int)(lin0 + k) - (int)row0;
         ok[k] = f >= 0 && (uint32_t)f < nframes;
         x[k] = ok[k] ? __builtin_nontemporal_load(in + lay.at((uint32_t)f, c)) : 0.0f;
     }
     uint32_t rg = (row0 & ~15u) + g * KC;                  // the group's first ring row: groups wrap as a whole
     rg = rg >= R ? rg - R : rg;
-    float *dst = ring + ring_at(c, rg + half * 8 + kh, R);
+    float *dst = ring + ring_at(c, rg + q4 * 4, R);
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k) {
         if (hop) x[k] = (0.0f + x[k]) / hop_div;
-        if (ok[k] && !finite_f32(x[k])) atomicMax(&nf_time[c >> 5], t0 + (lin0 + 2 * k - row0) + 1);
+        if (ok[k] && !finite_f32(x[k])) atomicMax(&nf_time[c >> 5], t0 + (lin0 + k - row0) + 1);
     }
     if (ok[0] && ok[1] && ok[2] && ok[3]) {
         *(float4 *)dst = make_float4(x[0], x[1], x[2], x[3]);
@@ -254,11 +252,11 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         if constexpr (WARM) {
             const long long first = a.n0 + j - (long long)a.T + 1;            // front of output j's deque ...
             const long long Fj = first >= a.tfront ? first : a.tfront;        // ... which never moves before tfront
-            wofs[jt] = (int)PAD_LO + kh + (int)(a.t_k0 - Fj);                 // idx = m - Fj, m = t_k0 + k'
+            wofs[jt] = (int)PAD_LO + 8 * kh + (int)(a.t_k0 - Fj);             // idx = m - Fj, m = t_k0 + k'
             const long long hi = a.n0 + j - Fj < (long long)a.T - 1 ? a.n0 + j - Fj : (long long)a.T - 1;
             whi[jt] = (int)PAD_LO + (int)hi;                                  // samples newer than n do not exist yet
         } else {
-            wofs[jt] = (int)PAD_LO + kh - (int)a.koff - j;
+            wofs[jt] = (int)PAD_LO + 8 * kh - (int)a.koff - j;
             whi[jt] = 0;
         }
     }
@@ -291,7 +289,7 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
     auto arrive = [&](uint32_t kc, float (&h)[KC / 2]) {
         if (kc + KC > a.kvalid) {                      // the sweep's last chunk: rows past the block's newest sample are stale
 #pragma unroll
-            for (int s = 0; s < KC / 2; ++s) h[s] = kc + 2 * s + kh < a.kvalid ? h[s] : 0.0f;
+            for (int s = 0; s < KC / 2; ++s) h[s] = kc + 8 * kh + s < a.kvalid ? h[s] : 0.0f;
         }
         if (dirty) {
 #pragma unroll
@@ -316,7 +314,7 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
         for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const int idx = wofs[jt] + (int)kc + 4 * g + 2 * u;
+                const int idx = wofs[jt] + (int)kc + 2 * g + u;
                 if constexpr (WARM) {
                     const int lo = (int)PAD_LO - 1;          // tp[PAD_LO-1] == 0
                     w[jt][u] = tp[(idx < lo || idx > whi[jt]) ? lo : idx];
@@ -400,7 +398,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     const bool c_ok = c < a.N;
     const bool dirty = a.nf_time[tile] > (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
     const uint32_t cb = (uint32_t)j0 / KC;                // this wave's chunk 0 in sweep chunks
-    const int wofs = (int)PAD_LO + kh - (int)a.koff - cl;  // LDS index of (iteration i, step s) = wofs + 16 i + 2 s
+    const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;  // LDS index of (iteration i, step s) = wofs + 16 i + s
     const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
 
     // acc: the running f32 chains (AGPRs).  Every FLUSH iterations they are added into the totals: tile 0's in
@@ -437,7 +435,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
         const uint32_t kc = (cb + m) * KC;
         if (kc + KC > a.kvalid) {                          // rows past the block's newest sample are stale
 #pragma unroll
-            for (int s = 0; s < KC / 2; ++s) h[s >> 2][s & 3] = kc + 2 * s + kh < a.kvalid ? h[s >> 2][s & 3] : 0.0f;
+            for (int s = 0; s < KC / 2; ++s) h[s >> 2][s & 3] = kc + 8 * kh + s < a.kvalid ? h[s >> 2][s & 3] : 0.0f;
         }
         if (dirty) {
 #pragma unroll
@@ -446,7 +444,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     };
     auto wload = [&](uint32_t i, float (&w)[KC / 2]) {
 #pragma unroll
-        for (int s = 0; s < KC / 2; ++s) w[s] = tp[wofs + (int)(i * KC) + 2 * s];
+        for (int s = 0; s < KC / 2; ++s) w[s] = tp[wofs + (int)(i * KC) + s];
     };
     static_for<0, SLOTS - 1>([&](auto m) { load_chunk(m.value, win[m.value]); });
     float wq[2][KC / 2];
