@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: f32-input MFMA dense peak
 SEED = 0x5EED0001
 
@@ -414,6 +415,19 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
         achieved = flops / (kern_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / MFMA_F32_PEAK_TFLOPS}
+        if kern_name == "fir_split_kernel":
+            # split precision: every f32 operand as three bf16, six bf16 MFMAs (32x32x16) per 16 taps and 32x32 tile.  The
+            # pipe it runs on is the bf16 one, so the fraction is EXECUTED bf16 flop/s over the dense bf16 peak; the
+            # algorithmic (2 T flop per sample) rate and its ratio to the f32 MFMA peak are given beside it.
+            T = cfg["taps"]
+            koff = (1 - T) % 16                                  # whole 128-frame blocks: n0 is a multiple of 16
+            n_iter = (koff + T + 30) // 16 + 1
+            executed = ((N + 31) // 32) * ((B + 127) // 128) * n_iter * 24 * 32768.0
+            ex_rate = executed / (kern_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "dtype": "bf16x3 (f32 operands split exactly into three bf16; f32 accumulation)",
+                    "achieved": ex_rate, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex_rate / MFMA_BF16_PEAK_TFLOPS,
+                    "algorithmic_tflops": achieved, "algorithmic_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
+                    "note": "power-limited: the shader clock sits near 1.8 GHz under this kernel (profiles/r02_fir_split_pmc.json)"}
     else:
         achieved = bps * N * B / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -425,7 +439,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
     if os.path.exists(tr):
         try:
             t = json.load(open(tr))
-            ent = t.get(f"{cfg_name}:{N}:{B}")
+            ent = t.get(f"{cfg_name}{'split' if kern_name == 'fir_split_kernel' else ''}:{N}:{B}")
             if ent:
                 roof["traffic"] = ent["hbm_bytes_per_launch"]
                 roof["traffic_source"] = ent.get("source")
@@ -519,6 +533,17 @@ def main():
                                 "settle": o["config"]["settle"], "placement_tuning": o["config"]["placement_tuning"]}
             except Exception as ex:   # never lose the headline line
                 others[name] = {"error": str(ex)[:300]}
+        # config 4 once more through the opt-in split-precision sweep (DSPFX_FIR_SPLIT=1: same accuracy class, bf16 pipe)
+        try:
+            os.environ["DSPFX_FIR_SPLIT"] = "1"
+            o = measure(ctx, args, "cfg4", args.steps, args.warmup)
+            others["cfg4_split"] = {"workload": o["config"]["workload"] + " [DSPFX_FIR_SPLIT=1]", "value": o["value"], "unit": "samples/s",
+                                    "ms_per_step": o["ms_per_step"], "block_budget_ms": o["block_budget_ms"],
+                                    "roofline": o["roofline"], "plan": o["config"]["plan"]}
+        except Exception as ex:
+            others["cfg4_split"] = {"error": str(ex)[:300]}
+        finally:
+            os.environ.pop("DSPFX_FIR_SPLIT", None)
 
     if rank != 0:
         if ctx.use_dist:

@@ -30,6 +30,7 @@ struct FirState {
     float *ring = nullptr;        // [ceil(N/32)] tiles of R * 32 + 32 floats
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path
+    unsigned *taps_split = nullptr;   // split-precision sweep: [3][ntp4] bf16 pair tables of the same padded taps (or null)
     unsigned long long *nf_time = nullptr;   // [tiles]: 1 + absolute time of the newest non-finite sample of the tile (0: none)
     uint32_t T = 0, R = 0, N = 0, max_frames = 0, pad_lo = 0, pad_hi = 0, tiles = 0;
     int mode = 0;                 // 0 Balanced, 1 Average (fir.rs:187-190)

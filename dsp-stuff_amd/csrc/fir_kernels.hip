@@ -3,6 +3,7 @@
 #include "fir_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <type_traits>
 #include <cstdlib>
@@ -50,7 +51,9 @@ __host__ __device__ __forceinline__ size_t ring_at(uint32_t c, uint32_t row, uin
     return (size_t)(c >> 5) * ring_tile_stride(R) + ring_in_tile(row, c & 31);
 }
 static size_t ring_bytes_for(uint32_t tiles, uint32_t R) { return (size_t)tiles * ring_tile_stride(R) * sizeof(float); }
-__device__ __forceinline__ bool finite_f32(float v) { return __builtin_fabsf(v) < __builtin_inff(); }   // false for inf and NaN
+// false for inf, NaN -- and for finite samples of 2^127 and more, whose bf16 part would round to inf in the split-precision
+// sweep: the MFMA sweeps treat all of them as zero and the tile is redone by the exact kernel
+__device__ __forceinline__ bool finite_f32(float v) { return __builtin_fabsf(v) < 0x1p127f; }
 
 // ring[(row0 + f) mod R] <- port value of in[f][c]  (fir.rs:193 push_back, after the collect_and_average hop when
 // enabled).  One thread = one channel x four consecutive rows: the samples of one 16-byte piece of the ring.  Consecutive lanes take consecutive channels: the reads are coalesced 256-byte row segments
@@ -178,6 +181,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct FirMfmaArgs {
     const float *ring;
     const float *taps;     // [pad_lo + T + pad_hi], zeros in the pads
+    const unsigned *taps_split;   // split-precision sweep: [3][ntp4] bf16 pair tables (entry m: parts of taps m, m + 1)
     float *out;
     const unsigned long long *nf_time;
     uint32_t N, nframes, T, R;
@@ -500,6 +504,168 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
                       [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
 }
 
+// ---- steady state, split precision: f32 operands as three bf16 each, products on the bf16 matrix pipe --------------
+// x = x1 + x2 + x3 and h = h1 + h2 + h3 EXACTLY (bf16 keeps f32's exponent and 8 of its 24 significant bits; each part is
+// the round-to-nearest bf16 of what the parts before it left), so x h = sum of nine bf16 x bf16 products, each exact in
+// f32.  The six products of order <= 2^-16 -- x1h1, x1h2, x2h1, x1h3, x3h1, x2h2 -- go through v_mfma_f32_32x32x16_bf16
+// into the f32 accumulators; the three that are dropped are below 2^-24 of |x h|, the size of one f32 rounding.  One
+// MFMA now covers sixteen taps where the f32 form covers two, so an output's sum sees an eighth of the f32 roundings per
+// term: measured against the f64 oracle this sweep is as accurate as the f32 one (tools/fir_accuracy.py), at six bf16
+// MFMAs of 32 cycles per 16 taps and tile instead of eight f32 MFMAs of 64 -- the sweep becomes HBM-bound.
+// Same skewed schedule as fir_skew_kernel (one set of weights per iteration, tile jt on history chunk i + 2 jt); the
+// window holds the chunks already split (3 x 4 registers each, eight slots), the f32 loads stay in flight in a ring of
+// their own and are split when they arrive, between MFMA groups.  Weights: three LDS tables of bf16 PAIRS (entry m =
+// parts of taps m, m + 1), so that a lane's eight consecutive taps from any start are four aligned dwords.  A workgroup
+// is eight waves (two per SIMD) sharing one set of tables.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {     // v_cvt_pk_bf16_f32: round to nearest even
+    const bf16x2 p = __builtin_convertvector(f32x2{a, b}, bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &p, 4);
+    return u;
+}
+// eight f32 (K order) -> three vectors of eight bf16
+__device__ __forceinline__ void split8(const f32x4 (&v)[2], u32x4 (&p)[3]) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = v[e >> 1][(e & 1) * 2], b = v[e >> 1][(e & 1) * 2 + 1];
+        const unsigned p0 = pack_bf16(a, b);
+        const float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);       // exact
+        const unsigned p1 = pack_bf16(ra, rb);
+        const float sa = ra - __uint_as_float(p1 << 16), sb = rb - __uint_as_float(p1 & 0xffff0000u);     // exact, <= 8 bits left
+        p[0][e] = p0;
+        p[1][e] = p1;
+        p[2][e] = pack_bf16(sa, sb);
+    }
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &u) {
+    bf16x8 r;
+    __builtin_memcpy(&r, &u, 16);
+    return r;
+}
+
+constexpr int SPLIT_WAVES = 8;                 // waves per workgroup of fir_split_kernel
+__global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) fir_split_kernel(const FirMfmaArgs a) {
+    constexpr int NJT = 4, WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + 1, D = 4;       // SLOTS % D == 0: both rings repeat with the unrolled body
+    static_assert(FLUSH % SLOTS == 0 && SLOTS % D == 0, "unroll period");
+    extern __shared__ unsigned tps[];          // [3][ntp4] pair tables, then the totals of tiles 1..3 per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntp = (int)(PAD_LO + a.T + PAD_HI), ntp4 = (ntp + 3) & ~3;
+    for (int i = tid; i < 3 * ntp4; i += 64 * SPLIT_WAVES) tps[i] = a.taps_split[i];
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * SPLIT_WAVES + wave;
+    if ((size_t)tile * TILE_C >= a.N) return;
+    const int cl = lane & 31, kh = lane >> 5;
+    const uint32_t c = tile * TILE_C + cl;
+    const bool c_ok = c < a.N;
+    const bool dirty = a.nf_time[tile] > (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
+    const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;      // table index of (iteration i, K element e) = wofs + 16 i + e
+    const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
+
+    f32x16 acc[NJT], tot0;
+    f32x4 *tl = (f32x4 *)(tps + 3 * (size_t)ntp4) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot0[r] = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < (NJT - 1) * 4; ++q) tl[q * 64] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float *hlane = a.ring + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
+    auto load_chunk = [&](uint32_t m, f32x4 (&h)[2]) {     // unconditional: past the sweep's end some unused rows of the ring
+        uint32_t row0 = a.rb + m * KC;                     // < 2R
+        row0 = row0 >= a.R ? row0 - a.R : row0;
+        const f32x4 *p = (const f32x4 *)(hlane + (size_t)row0 * TILE_C);
+        h[0] = __builtin_nontemporal_load(p);
+        h[1] = __builtin_nontemporal_load(p + 64);
+    };
+    auto arrive = [&](uint32_t m, f32x4 (&h)[2]) {
+        const uint32_t kc = m * KC;
+        if (kc + KC > a.kvalid) {                          // rows past the block's newest sample are stale
+#pragma unroll
+            for (int e = 0; e < KC / 2; ++e) h[e >> 2][e & 3] = kc + 8 * kh + e < a.kvalid ? h[e >> 2][e & 3] : 0.0f;
+        }
+        if (dirty) {                                       // (non-finite or huge samples: zero here, the tile is redone exactly)
+#pragma unroll
+            for (int e = 0; e < KC / 2; ++e) h[e >> 2][e & 3] = finite_f32(h[e >> 2][e & 3]) ? h[e >> 2][e & 3] : 0.0f;
+        }
+    };
+    auto wload = [&](uint32_t i, u32x4 (&w)[3]) {
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[sp][e] = tps[sp * ntp4 + wofs + (int)(i * KC) + 2 * e];
+    };
+    u32x4 win[SLOTS][3];
+    f32x4 fly[D][2];
+    {   // chunks 0 .. WIN-1 split into the window, WIN .. WIN+D-1 in flight
+        f32x4 t[WIN][2];
+        static_for<0, WIN>([&](auto m) { load_chunk(m.value, t[m.value]); });
+        static_for<0, D>([&](auto m) { load_chunk(WIN + m.value, fly[(WIN + m.value) % D]); });
+        static_for<0, WIN>([&](auto m) {
+            arrive(m.value, t[m.value]);
+            split8(t[m.value], win[m.value]);
+        });
+    }
+    u32x4 wq[2][3];
+    wload(0, wq[0]);
+
+    // iteration i, i mod SLOTS == P: six groups of NJT MFMAs (one per product term), the other work pinned between them
+    auto iter = [&](auto p_c, uint32_t i) {
+        constexpr int P = decltype(p_c)::value;
+        constexpr int TX[6] = {0, 0, 1, 0, 2, 1}, TH[6] = {0, 1, 0, 2, 0, 1};      // x part, h part of the six terms
+        f32x4 (&in)[2] = fly[(P + WIN) % D];                                       // chunk i + WIN: lands in window slot (P + WIN) % SLOTS
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 0) arrive(i + WIN, in);
+            if (t == 1) split8(in, win[(P + WIN) % SLOTS]);
+            if (t == 3) load_chunk(i + WIN + D, in);
+            if (t == 4) wload(i + 1, wq[(P + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_bf16x8(wq[P & 1][TH[t]]), as_bf16x8(win[(P + 2 * jt) % SLOTS][TX[t]]),
+                                                                  acc[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto flush = [&]() {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 1; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
+                tl[((jt - 1) * 4 + q) * 64] = t;
+            }
+    };
+    uint32_t i = 0;
+    while (i < n_iter) {
+        const uint32_t iend = i + FLUSH < n_iter ? i + FLUSH : n_iter;
+        for (; i + SLOTS <= iend; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
+        if (i < iend) {                                    // fewer than SLOTS left: only the sweep's last segment
+            const uint32_t rest = iend - i;
+            static_for<0, SLOTS - 1>([&](auto p) {
+                if ((uint32_t)p.value < rest) iter(p, i + p.value);
+            });
+            i = iend;
+        }
+        flush();
+    }
+    fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
+                      [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
+}
+
 // old ring -> new ring for the sample times [t_begin, t_end): a tap reload that needs more rows
 __global__ void __launch_bounds__(256) fir_rebase_kernel(const float *src, float *dst, uint32_t tiles, uint32_t R_src, uint32_t R_dst,
                                                          unsigned long long t_begin, unsigned long long t_end) {
@@ -536,6 +702,22 @@ static uint32_t ring_rows_for(uint64_t held, uint32_t n_taps, uint32_t max_frame
 }
 
 constexpr size_t LDS_PER_CU = 160 * 1024;
+// round-to-nearest-even bf16 of a finite f32, as its 16 bits
+static uint32_t bf16_bits(float v) {
+    uint32_t u;
+    memcpy(&u, &v, 4);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+static float bf16_value(uint32_t b) {
+    const uint32_t u = b << 16;
+    float v;
+    memcpy(&v, &u, 4);
+    return v;
+}
+static size_t split_lds_bytes(uint32_t n_taps) {
+    const size_t ntp4 = ((size_t)PAD_LO + n_taps + PAD_HI + 3) & ~(size_t)3;
+    return 3 * ntp4 * sizeof(unsigned) + (size_t)SPLIT_WAVES * 3 * 4 * 64 * sizeof(f32x4);
+}
 static size_t tap_table_bytes(uint32_t n_taps) { return ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float); }
 // the skewed kernel keeps the totals of its output tiles 1 .. NJT-1 in LDS behind the tap table: 4 waves x (NJT-1) x 4 KiB
 static size_t skew_lds_bytes(uint32_t n_taps, int njt) {
@@ -545,8 +727,10 @@ static size_t skew_lds_bytes(uint32_t n_taps, int njt) {
 static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps) {
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
+    if (s.taps_split) (void)hipFree(s.taps_split);
     s.taps64 = nullptr;
     s.taps32 = nullptr;
+    s.taps_split = nullptr;
     s.T = n_taps;
     s.pad_lo = PAD_LO;
     s.pad_hi = PAD_HI;
@@ -556,6 +740,27 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
     for (uint32_t i = 0; i < n_taps; ++i) t32[PAD_LO + i] = (float)taps_reversed[i];
     FIRCHK(hipMalloc((void **)&s.taps32, t32.size() * sizeof(float)));
     FIRCHK(hipMemcpy(s.taps32, t32.data(), t32.size() * sizeof(float), hipMemcpyHostToDevice));
+    // split-precision tables: each padded tap as three bf16 parts (exact: tap == p0 + p1 + p2), stored as pairs (m, m + 1)
+    bool tame = true;
+    for (float t : t32) tame = tame && std::fabs(t) < 0x1p127f;
+    if (tame && split_lds_bytes(n_taps) <= LDS_PER_CU) {
+        const size_t ntp = t32.size(), ntp4 = (ntp + 3) & ~(size_t)3;
+        std::vector<uint32_t> part[3];
+        for (auto &v : part) v.assign(ntp + 1, 0);
+        for (size_t m = 0; m < ntp; ++m) {
+            float r = t32[m];
+            for (int k = 0; k < 3; ++k) {
+                part[k][m] = bf16_bits(r);
+                r -= bf16_value(part[k][m]);               // exact
+            }
+        }
+        std::vector<uint32_t> tab(3 * ntp4, 0);
+        for (int k = 0; k < 3; ++k)
+            for (size_t m = 0; m < ntp; ++m) tab[k * ntp4 + m] = part[k][m] | (part[k][m + 1] << 16);
+        FIRCHK(hipMalloc((void **)&s.taps_split, tab.size() * sizeof(uint32_t)));
+        FIRCHK(hipMemcpy(s.taps_split, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes(n_taps)));
+    }
     // DSPFX_FIR_KERNEL: 0 = exact f64 VALU kernel, 1 = MFMA; default MFMA unless the filter is tiny
     const char *k = getenv("DSPFX_FIR_KERNEL");
     s.kernel = k ? atoi(k) : (n_taps >= 16 ? 1 : 0);
@@ -629,10 +834,12 @@ void fir_free(FirState &s) {
     if (s.ring) (void)hipFree(s.ring);
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
+    if (s.taps_split) (void)hipFree(s.taps_split);
     if (s.nf_time) (void)hipFree(s.nf_time);
     s.ring = nullptr;
     s.taps64 = nullptr;
     s.taps32 = nullptr;
+    s.taps_split = nullptr;
     s.nf_time = nullptr;
 }
 
@@ -722,6 +929,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             FirMfmaArgs a{};
             a.ring = s.ring;
             a.taps = s.taps32;
+            a.taps_split = s.taps_split;
             a.out = out_s;
             a.nf_time = s.nf_time;
             a.N = s.N;
@@ -752,10 +960,15 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             const bool skew = steady && !(skew_env && atoi(skew_env) == 0) && lds_skew * 2 <= LDS_PER_CU;
             const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
             const size_t lds = skew ? lds_skew : tap_table_bytes(s.T);
-            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
+            // split precision (bf16 x 3 on the bf16 matrix pipe): whole 128-frame slices in steady state; DSPFX_FIR_SPLIT=0|1
+            const char *split_env = getenv("DSPFX_FIR_SPLIT");
+            const bool split = steady && nf > 64 && s.taps_split && (split_env ? atoi(split_env) == 1 : false);
+            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
             if (!steady) {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
+            } else if (split) {
+                hipLaunchKernelGGL(fir_split_kernel, dim3((s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES), dim3(64 * SPLIT_WAVES), split_lds_bytes(s.T), stream, a);
             } else if (skew) {
                 // history chunks requested 5 iterations before their first use (11 in flight or in use per wave); with 1
                 // the sweep waits for HBM: 1.997 vs 1.949 ms at config 4, 3: 1.986, 7 / 9: 1.962-1.979 (DSPFX_FIR_DIST=1 for A/B)

@@ -710,15 +710,19 @@ def test_fir_mfma_ragged_shapes(dspfx, torch_cuda, monkeypatch, N, block):
     assert np.abs(y - ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("skew", ["1", "0"])
+@pytest.mark.parametrize("skew", ["1", "0", "split"])
 @pytest.mark.parametrize("T", [300, 17, 64, 500, 1000])
 def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
     """Integer taps and samples are exact in f32: the MFMA path must equal the oracle bit for bit,
     including every warm-up output (fir.rs:193-214 pairs state[k] with taps[k] while filling).
     skew = 1 (default): the steady-state kernel whose output tiles share one set of weights per iteration
-    (fir_skew_kernel; two tiles per wave up to 384 taps, four above); 0: the rectangular sweep throughout."""
+    (fir_skew_kernel); 0: the rectangular sweep throughout; split: the split-precision sweep (fir_split_kernel: every
+    operand as three bf16 parts, six bf16 MFMAs per 16 taps -- small integers have one part, so it is exact too)."""
     monkeypatch.setenv("DSPFX_FIR_KERNEL", "1")
-    monkeypatch.setenv("DSPFX_FIR_SKEW", skew)
+    if skew == "split":
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    else:
+        monkeypatch.setenv("DSPFX_FIR_SKEW", skew)
     rng = np.random.default_rng(5)
     h = rng.integers(-4, 5, T).astype(np.float64)
     xi = rng.integers(-8, 9, (128 * 5 + (T // 128) * 128, 96)).astype(F)
@@ -753,6 +757,28 @@ def test_fir_config4_taps_small_n(dspfx, torch_cuda):
     assert fir_rel_rms(y, ref) < FIR_RMS_TOL
     assert fir_rel_rms(y[-512:], ref[-512:]) < FIR_RMS_TOL      # steady state alone
     assert fir_rel_rms(y[:2048], ref[:2048]) < FIR_RMS_TOL      # warm-up alone
+
+
+def test_fir_split_precision_sweep_config4_accuracy(dspfx, torch_cuda, monkeypatch):
+    """The opt-in split-precision sweep (DSPFX_FIR_SPLIT=1) on config 4's filter: within the same stated tolerance as the
+    f32 sweep (measured 2.9e-7 against 3.3e-7), it really is the kernel that ran, huge finite samples (whose bf16 part
+    would round to inf) are routed to the exact kernel like non-finite ones."""
+    monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    T, N, blocks = 4096, 32, 40
+    x = noise_block(N, 128 * blocks)
+    x[128 * 36 + 7, 5] = 3.0e38
+    ch = [dspfx.Fir(fir_taps(T))]
+    eng = dspfx.Engine(N, 128, link_flags=3)
+    eng.set_chain(ch)
+    y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
+    assert "fir_split_kernel" in eng.describe(), eng.describe()
+    ref = run_oracle(ch, x, 3)
+    ok = np.ones(N, bool)
+    ok[5] = False
+    assert fir_rel_rms(y[-512:, ok], ref[-512:, ok]) < FIR_RMS_TOL / 2
+    assert np.array_equal(np.isfinite(y), np.isfinite(ref))
+    fin = np.isfinite(ref[:, 5])
+    assert np.allclose(y[fin, 5], ref[fin, 5], rtol=1e-5, atol=1e-5 * np.abs(ref[fin, 5]).max())
 
 
 def test_fir_state_export_import(dspfx, torch_cuda):
@@ -809,7 +835,7 @@ def test_fir_exact_kernel_is_bit_exact_and_mfma_within_tolerance(dspfx, torch_cu
                 assert fir_rel_rms(y, ref) < FIR_RMS_TOL, (T, mode)
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "rect"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split"])
 def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel):
     """dspfx_set_taps = the impulse-response reload of fir.rs:153-171: the taps change, `state` does not.  A history
     longer than the new tap count stays longer (one pop per step, fir.rs:193-197): the output is the new convolution
@@ -817,6 +843,9 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
     same reloads; integer data is exact on both kernels, random data exact on the f64 kernel."""
     if kernel == "rect":        # the rectangular MFMA sweep in steady state too
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
+        kernel = "1"
+    if kernel == "split":       # the split-precision sweep in steady state
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     rng = np.random.default_rng(8)
@@ -850,7 +879,7 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
     assert eng.describe()
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "rect"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split"])
 def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cuda, monkeypatch, kernel):
     """inf / NaN samples: the reference's sums turn inf / NaN exactly while the sample is inside the deque (T outputs)
     and only in that channel.  The MFMA sweep multiplies the zero corners of its Toeplitz band with the history, where
@@ -859,6 +888,9 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
     output stays within the FIR tolerance."""
     if kernel == "rect":        # the rectangular MFMA sweep in steady state too
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
+        kernel = "1"
+    if kernel == "split":       # the split-precision sweep in steady state
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     T, N, nf = 200, 100, 128 * 8
@@ -883,7 +915,7 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
             assert np.array_equal(y[fin].view(np.uint32), ref[fin].view(np.uint32))
 
 
-@pytest.mark.parametrize("kernel", ["1", "rect", "0"])
+@pytest.mark.parametrize("kernel", ["1", "rect", "0", "split"])
 @pytest.mark.parametrize("N,tile,B", [(70, 0, 128), (4096 + 256, 256, 128), (300, 0, 256), (96, 0, 48)])
 def test_fir_that_ends_the_chain_feeds_the_mix_bus_itself(dspfx, torch_cuda, monkeypatch, kernel, N, tile, B):
     """When the FIR node ends the chain the sweep's epilogue (and the exact kernel) leave the Output node's mix-bus partials
@@ -893,6 +925,9 @@ def test_fir_that_ends_the_chain_feeds_the_mix_bus_itself(dspfx, torch_cuda, mon
     block with non-finite samples, where the fix-up pass recomputes the flagged tile's partials too."""
     if kernel == "rect":
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
+        kernel = "1"
+    if kernel == "split":
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     T, blocks = 100, 6
