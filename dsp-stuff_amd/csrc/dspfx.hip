@@ -1196,12 +1196,13 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             // The FIR node ends the chain and the Output node's mix bus is wanted: the sweep's epilogue leaves the bus'
             // first-stage partials (one row per 32-channel tile) and the empty chain kernel that would otherwise read the
             // whole FIR output again just to sum it is skipped.  Slice / final stages as after a chain kernel; in the
-            // pipelined form they run as the stand-alone kernels (the sweep does not host the prologue).
+            // pipelined form the sweep's first workgroups host them like a chain kernel's do.
             const bool ends_chain = si + 2 == e->stages.size() && e->stages[si + 1].type == ST_FUSED && e->stages[si + 1].count == 0 && !e->win_n;
             const bool want_bus = ends_chain && (mix || e->partials_override || e->mp_building);
             const uint32_t frows = (N + 31) / 32;
             const bool deferred = want_bus && e->partials_override != nullptr;
             float *fpart = nullptr;
+            FirMixPipe fmp;      // the pipelined bus' stages of earlier blocks: hosted by the sweep or launched by fir_process
             if (want_bus) {
                 if (frows > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
                 fpart = deferred ? e->partials_override : e->mixpart;
@@ -1211,14 +1212,16 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     e->mp_rows[cur] = frows;
                     const int stage = (e->mp_count >= 1 ? 1 : 0) | (e->mp_count >= 2 ? 2 : 0);
                     float *b_cur = cur ? e->mixpart_b2 : e->mixpart_b, *b_prev = cur ? e->mixpart_b : e->mixpart_b2;
-                    if (stage & 2) {
-                        launch_mix_reduce_final(b_prev, e->mp_mix_now, nframes, stream);
-                        if (e->mp_div_now != 0.0f) launch_mix_finish(e->mp_mix_now, nframes, e->mp_div_now, stream);
-                    }
-                    if (stage & 1) launch_mix_reduce_slices(e->mixpart2[prev], b_cur, nframes, e->mp_rows[prev], stream);
+                    fmp.stage = stage;
+                    fmp.rows_a = e->mp_rows[prev];
+                    fmp.prev_a = e->mixpart2[prev];
+                    fmp.cur_b = b_cur;
+                    fmp.prev_b = b_prev;
+                    fmp.mix = e->mp_mix_now;
+                    fmp.div = e->mp_div_now;
                 }
             }
-            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream, ea, eb, fpart);
+            const int rc = fir_process(n.fir, src, out, nframes, node_hop(e, st.first), e->hop_div, lay, stream, ea, eb, fpart, &fmp);
             if (rc != 0) return fail(e, rc, "FIR: %s", fir_last_error());
             if (want_bus) {
                 if (deferred) {

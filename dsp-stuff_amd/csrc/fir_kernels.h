@@ -41,6 +41,19 @@ struct FirState {
     const char *last_kernel = nullptr;   // the sweep kernel of the last block (reporting)
 };
 
+// The pipelined mix bus' work of EARLIER blocks (chain_kernels.hip.h, mixpipe_prologue) for a block whose last launch is a
+// FIR sweep: the sweep's first workgroups host it when it has enough of them, else fir_process launches the stand-alone
+// kernels.  stage bit 0: slice-reduce prev_a into cur_b; bit 1: final-reduce prev_b into mix (/ div when non-zero).
+struct FirMixPipe {
+    int stage = 0;
+    unsigned rows_a = 0;
+    const float *prev_a = nullptr;
+    float *cur_b = nullptr;
+    const float *prev_b = nullptr;
+    float *mix = nullptr;
+    float div = 0.0f;
+};
+
 int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,
                   uint32_t max_frames);
 // Impulse-response reload (fir.rs:153-171): new taps, the history and the deque's length are KEPT.
@@ -51,7 +64,7 @@ void fir_reset(FirState &s);
 // that receive, per 32-channel tile and frame, the sum of the block's outputs (the Output node's mix bus, first stage).
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
                 const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
-                float *mixpart = nullptr);
+                float *mixpart = nullptr, const FirMixPipe *mixpipe = nullptr);
 size_t fir_state_bytes(const FirState &s);
 int fir_state_export(FirState &s, void *host_dst);
 int fir_state_import(FirState &s, const void *host_src);

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/dspfx.h"
+#include "aux_kernels.h"
 
 namespace dspfx {
 
@@ -195,8 +196,14 @@ struct FirMfmaArgs {
     float divisor;
     float *mixpart;        // mix-bus partials [tiles][mix_ld] (this slice's first frame at column 0), or null
     uint32_t mix_ld;
+    FirMixPipe mp;         // earlier blocks' mix-bus stages hosted by this launch's first workgroups (stage == 0: none)
     Layout lay;
 };
+__device__ __forceinline__ void fir_mixpipe_prologue(const FirMfmaArgs &a) {      // = mixpipe_prologue of the chain kernels
+    const unsigned b = blockIdx.x;
+    if ((a.mp.stage & 1) && b < MIX_SLICES) mix_slice_reduce(a.mp.prev_a, a.mp.cur_b, a.mp.rows_a, a.mix_ld, b, threadIdx.x, blockDim.x);
+    else if ((a.mp.stage & 2) && b == MIX_SLICES) mix_final_reduce(a.mp.prev_b, a.mp.mix, a.mix_ld, a.mp.div, threadIdx.x, blockDim.x);
+}
 
 // The end of a sweep: out = (a + b) * divisor (fir.rs:216-222), each accumulator register one coalesced 128-byte row of the
 // output -- and, when the FIR node ends the chain, the Output node's mix bus: the tile's per-frame sums over its 32 channels
@@ -389,6 +396,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     constexpr int WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + D;
     constexpr int FLUSH_S = SLOTS * ((FLUSH + SLOTS / 2) / SLOTS);      // iterations per flush: a whole number of unrolled bodies
     static_assert(SLOTS % 2 == 0, "the weight registers alternate with the iteration's parity");
+    if (a.mp.stage) fir_mixpipe_prologue(a);
     extern __shared__ float tp[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntp = (int)(PAD_LO + a.T + PAD_HI);
@@ -552,6 +560,7 @@ constexpr int SPLIT_WAVES = 8;                 // waves per workgroup of fir_spl
 __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) fir_split_kernel(const FirMfmaArgs a) {
     constexpr int NJT = 4, WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + 1, D = 4;       // SLOTS % D == 0: both rings repeat with the unrolled body
     static_assert(FLUSH % SLOTS == 0 && SLOTS % D == 0, "unroll period");
+    if (a.mp.stage) fir_mixpipe_prologue(a);
     extern __shared__ unsigned tps[];          // [3][ntp4] pair tables, then the totals of tiles 1..3 per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntp = (int)(PAD_LO + a.T + PAD_HI), ntp4 = (ntp + 3) & ~3;
@@ -874,8 +883,16 @@ static uint32_t deque_step(FirState &s) {
     return std::min(len, s.dq_cap - s.dq_head);
 }
 
+static void fir_mixpipe_standalone(const FirMixPipe &mp, uint32_t nframes, hipStream_t stream) {
+    if (mp.stage & 2) {
+        launch_mix_reduce_final(mp.prev_b, mp.mix, nframes, stream);
+        if (mp.div != 0.0f) launch_mix_finish(mp.mix, nframes, mp.div, stream);
+    }
+    if (mp.stage & 1) launch_mix_reduce_slices(mp.prev_a, mp.cur_b, nframes, mp.rows_a, stream);
+}
+
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
-                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, float *mixpart) {
+                const Layout &lay, hipStream_t stream, hipEvent_t ev_begin, hipEvent_t ev_end, float *mixpart, const FirMixPipe *mixpipe) {
     if (nframes > s.max_frames) {
         g_fir_err = "nframes > max_frames";
         return DSPFX_ERR_INVALID;
@@ -948,6 +965,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             a.mixpart = ex.mixpart;
             a.mix_ld = nframes;
             a.lay = lay;
+            const bool mp_pending = mixpipe && mixpipe->stage && f0 == 0;      // the block's first slice carries it
             // Tiles per wave: four (one wave sweeps the whole 128-frame slice: every history row is loaded once) unless the
             // slice is at most 64 frames, which is one wave's two tiles.  DSPFX_FIR_NJT=2|4 forces either.  (With the
             // rectangular sweep two tiles per wave were faster up to 384 taps -- a narrower band; the skewed sweep has no
@@ -964,6 +982,11 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             const char *split_env = getenv("DSPFX_FIR_SPLIT");
             const bool split = steady && nf > 64 && s.taps_split && (split_env ? atoi(split_env) == 1 : false);
             s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
+            const unsigned grid_sweep = split ? (s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES : grid;
+            if (mp_pending) {
+                if (steady && (split || skew) && grid_sweep > MIX_SLICES) a.mp = *mixpipe;     // rides in the sweep's first workgroups
+                else fir_mixpipe_standalone(*mixpipe, nframes, stream);
+            }
             if (!steady) {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
@@ -985,6 +1008,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             ex.only_dirty = 1;
             hipLaunchKernelGGL(fir_exact_kernel, dim3(s.tiles, 1), dim3(256), 0, stream, ex);
         } else {
+            if (mixpipe && mixpipe->stage && f0 == 0) fir_mixpipe_standalone(*mixpipe, nframes, stream);
             ex.only_dirty = 0;
             hipLaunchKernelGGL(fir_exact_kernel, ex_grid, dim3(256), 0, stream, ex);
             if (ev_end && f0 + SLICE >= nframes) (void)hipEventRecord(ev_end, stream);
