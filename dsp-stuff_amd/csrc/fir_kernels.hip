@@ -108,7 +108,7 @@ struct FirExactArgs {
     const double *taps;
     float *out;
     const unsigned long long *nf_time;
-    uint32_t N, nframes, T, R;
+    uint32_t N, nframes, T, R, tiles;
     unsigned long long n0, front0;
     long long t_lo;
     float divisor;
@@ -120,16 +120,17 @@ struct FirExactArgs {
     uint8_t dfront[SLICE];
 };
 __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
-    const uint32_t tile = blockIdx.x;
+  // (the fix-up pass behind a sweep launches a few hundred workgroups that walk the tiles and skip the clean ones)
+  for (uint32_t tile = blockIdx.x; tile < a.tiles; tile += gridDim.x) {
     if (a.only_dirty) {
         const unsigned long long lo = a.t_lo > 0 ? (unsigned long long)a.t_lo : 0ull;
-        if (a.nf_time[tile] <= lo) return;
+        if (a.nf_time[tile] <= lo) continue;
     }
     const uint32_t cl = threadIdx.x & 31, fi = threadIdx.x >> 5;
     const uint32_t c = tile * TILE_C + cl;
     const bool c_ok = c < a.N;                 // (lanes past the last channel stay: they take part in the tile's sums)
     const float *col = a.ring + (size_t)tile * ring_tile_stride(a.R);
-    // blockIdx.y strides over groups of 8 frames (the fix-up pass launches ONE block per tile: most exit above)
+    // blockIdx.y strides over groups of 8 frames (one group per block in the fix-up pass: all of the tile in this block)
     for (uint32_t f = blockIdx.y * 8 + fi; f < a.nframes; f += gridDim.y * 8) {
         float o = 0.0f;
         if (c_ok) {
@@ -163,6 +164,7 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
             if (cl == 0) a.mixpart[(size_t)tile * a.mix_ld + f] = o;
         }
     }
+  }
 }
 
 // ---- MFMA path ------------------------------------------------------------------------
@@ -922,6 +924,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         ex.nframes = nf;
         ex.T = s.T;
         ex.R = s.R;
+        ex.tiles = s.tiles;
         ex.n0 = n0;
         ex.front0 = front0;
         ex.t_lo = (long long)(front0 + ex.dfront[0]);
@@ -1006,7 +1009,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             if (ev_end && f0 + SLICE >= nframes) (void)hipEventRecord(ev_end, stream);
             // tiles holding a non-finite sample inside this slice's window are redone exactly (nothing to do otherwise)
             ex.only_dirty = 1;
-            hipLaunchKernelGGL(fir_exact_kernel, dim3(s.tiles, 1), dim3(256), 0, stream, ex);
+            hipLaunchKernelGGL(fir_exact_kernel, dim3(std::min<uint32_t>(s.tiles, 512), 1), dim3(256), 0, stream, ex);
         } else {
             if (mixpipe && mixpipe->stage && f0 == 0) fir_mixpipe_standalone(*mixpipe, nframes, stream);
             ex.only_dirty = 0;
