@@ -174,13 +174,42 @@ def make_comm(ctx):
     """The mix bus' own communicator behind the C ABI (rank 0 makes the id, torch.distributed only carries the bytes)."""
     import torch
     import torch.distributed as dist
-    if ctx.comm is not None or not ctx.use_dist or os.environ.get("DSPFX_BENCH_COMM", "abi") != "abi":
+    if ctx.comm is not None or getattr(ctx, "comm_fallback", None) or not ctx.use_dist or os.environ.get("DSPFX_BENCH_COMM", "abi") != "abi":
         return
+    # Any failure on any rank (the library could not find RCCL, ncclCommInitRank refused ...) sends ALL ranks back to
+    # torch.distributed's all_reduce -- the same RCCL collective, called from Python -- and the line says so in
+    # config.collective: a run on N GPUs must not die on the plumbing of an alternative call path.
+    err = ""
     idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=ctx.dev)
-    if ctx.rank == 0:
-        idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
+    try:
+        if ctx.rank == 0:
+            idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
+    except Exception as ex:
+        err = "unique id: %s" % ex
     dist.broadcast(idt, 0)
-    ctx.comm = ctx.pkg.Comm(ctx.local_rank, ctx.world, ctx.rank, bytes(idt.cpu().tolist()))
+    comm = None
+    if os.environ.get("DSPFX_BENCH_COMM_FAIL") == "1":       # exercise the fallback below
+        err = "forced by DSPFX_BENCH_COMM_FAIL"
+    elif not bool(idt.any().item()):
+        err = err or "rank 0 could not make a unique id"
+    else:
+        try:
+            comm = ctx.pkg.Comm(ctx.local_rank, ctx.world, ctx.rank, bytes(idt.cpu().tolist()))
+        except Exception as ex:
+            err = "comm create: %s" % ex
+    okt = torch.tensor([0.0 if err else 1.0], device=ctx.dev)
+    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+    if okt.item() >= 1.0:
+        ctx.comm = comm
+    else:
+        if comm is not None:
+            try:
+                comm.close()
+            except Exception:
+                pass
+        ctx.comm_fallback = err or "another rank failed to create its communicator"
+        print("bench.py rank %d: C-ABI communicator unavailable (%s); using torch.distributed all_reduce" % (ctx.rank, ctx.comm_fallback),
+              file=sys.stderr)
     dist.barrier()
     torch.cuda.synchronize()
 
@@ -451,7 +480,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags, **({"zero_input": True} if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1" else {}),
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
                    "collective": (None if not dist_run else "dspfx_mix_allreduce (RCCL behind the C ABI)" if ctx.comm is not None
-                                  else "torch.distributed all_reduce"),
+                                  else "torch.distributed all_reduce" + (" (fallback: %s)" % ctx.comm_fallback if getattr(ctx, "comm_fallback", None) else "")),
                    "placement_probe": probe_log, "placement_tuning": tune_log,
                    "settle": {"steps": settle_steps, "ms_per_step": round(settle_ms, 4)},
                    "layout": f"channel-tiled [N/{args.tile}][B][{args.tile}]" if args.tile else "frame-major [B][N]",
