@@ -7,10 +7,15 @@
 // so the K = T-1+B rows one 32-channel MFMA tile needs per block form ONE contiguous HBM stream of 2 KiB chunks.
 // Every output is a dot product over the samples the reference's VecDeque holds at that step:
 //   - fir_append_kernel: the block's samples (hop applied) go into the ring; non-finite ones raise the tile's flag;
-//   - fir_mfma_kernel : out^T[B x 32ch] = W[B x K] * H[K x 32ch] on v_mfma_f32_32x32x2_f32 (exact f32 FMA
-//     chain, flushed into a second accumulator every 512 terms); W is the Toeplitz matrix of the taps,
-//     generated on the fly from a zero-padded table in LDS.  Non-finite samples are replaced by 0 in the MFMA
-//     operand (0 x inf in the band's zero corners would otherwise poison neighbouring outputs);
+//   - the sweeps: out^T[B x 32ch] = W[B x K] * H[K x 32ch] on the matrix pipe, W the Toeplitz matrix of the taps generated
+//     on the fly from zero-padded tables in LDS, f32 chains flushed into separate totals every ~512 terms:
+//       fir_skew_kernel   steady state, v_mfma_f32_32x32x2_f32 (exact f32 FMA chain); the four output tiles of a wave share
+//                         one set of weights per iteration, each on its own history chunk out of a register window;
+//       fir_mfma_kernel   the rectangular form (one history chunk per step shared by the tiles, per-tile weights): while the
+//                         deque fills (WARM: the reference's front-aligned pairing) and as the steady-state fallback;
+//       fir_split_kernel  opt-in: f32 operands as three bf16 parts each, six v_mfma_f32_32x32x16_bf16 per 16 taps and tile;
+//     non-finite (and huge) samples are replaced by 0 in the MFMA operands and their tiles redone by the exact kernel;
+//     when the FIR node ends the chain the sweeps' epilogue also leaves the Output node's mix-bus partials;
 //   - fir_exact_kernel: sequential f64 accumulation in deque order, split at the deque's wrap point into the
 //     reference's two partial sums (`a`, `b`: fir.rs:201-216), bit-faithful; serves tiny filters, taps that do
 //     not fit LDS, cross-checks, and re-computes every tile flagged non-finite after the MFMA pass.

@@ -29,8 +29,8 @@ const char *fir_last_error() { return g_fir_err.c_str(); }
     } while (0)
 
 constexpr int TILE_C = 32;   // channels per MFMA tile == ring tile width
-constexpr int KC = 16;       // k per chunk (8 MFMA k-steps); history prefetched one chunk ahead
-constexpr int FLUSH = 32;    // chunks per accumulator flush (512 terms)
+constexpr int KC = 16;       // k per chunk: 8 k-steps of the f32 MFMA (K = 2), one bf16 MFMA (K = 16)
+constexpr int FLUSH = 32;    // chunks per accumulator flush (about 512 terms per f32 chain)
 constexpr uint32_t SLICE = 128;          // output frames per launch (4 MFMA tiles of 32)
 constexpr uint32_t PAD_LO = 160, PAD_HI = 192;   // zero pads of the LDS tap table: >= 127 + KC below, >= SLICE + 3 KC above (weights are fetched one group ahead)
 
@@ -57,8 +57,10 @@ static size_t ring_bytes_for(uint32_t tiles, uint32_t R) { return (size_t)tiles 
 __device__ __forceinline__ bool finite_f32(float v) { return __builtin_fabsf(v) < 0x1p127f; }
 
 // ring[(row0 + f) mod R] <- port value of in[f][c]  (fir.rs:193 push_back, after the collect_and_average hop when
-// enabled).  One thread = one channel x four consecutive rows: the samples of one 16-byte piece of the ring.  Consecutive lanes take consecutive channels: the reads are coalesced 256-byte row segments
-// in both I/O layouts, the writes 16 bytes per lane, contiguous over 32 lanes.  blockIdx.y = piece index from the
+// enabled).  One thread = one channel x four consecutive rows: the samples of one 16-byte piece of the ring.  Consecutive
+// lanes take consecutive channels: the reads are coalesced 256-byte row segments in both I/O layouts, the writes 16 bytes
+// per lane, contiguous over 32 lanes.  (Four channels x four rows per thread -- 16-byte loads, a 4 x 4 transpose in
+// registers, 64 contiguous bytes of stores per lane -- was slower: every store instruction then touches a quarter of each line.)  blockIdx.y = piece index from the
 // 16-row group that holds row0.  Non-finite samples raise the tile's flag.
 __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float *ring, unsigned long long *nf_time, uint32_t N,
                                                          uint32_t nframes, uint32_t row0, uint32_t R, unsigned long long t0,
@@ -415,7 +417,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;  // LDS index of (iteration i, step s) = wofs + 16 i + s
     const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
 
-    // acc: the running f32 chains (AGPRs).  Every FLUSH iterations they are added into the totals: tile 0's in
+    // acc: the running f32 chains.  Every FLUSH_S iterations they are added into the totals: tile 0's in
     // registers, the other tiles' in LDS (touched once per FLUSH iterations; 12 KiB per wave) -- with all totals in
     // registers the window would push the kernel past 256 registers, i.e. to one wave per SIMD.
     f32x16 acc[NJT], tot0;
