@@ -417,19 +417,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;  // LDS index of (iteration i, step s) = wofs + 16 i + s
     const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
 
-    // acc: the running f32 chains.  Every FLUSH_S iterations they are added into the totals: tile 0's in
-    // registers, the other tiles' in LDS (touched once per FLUSH iterations; 12 KiB per wave) -- with all totals in
-    // registers the window would push the kernel past 256 registers, i.e. to one wave per SIMD.
-    f32x16 acc[NJT], tot0;
-    f32x4 *tl = (f32x4 *)(tp + (size_t)((ntp + 3) & ~3)) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) tot0[r] = 0.0f;
+    // acc: the running f32 chains; every FLUSH_S iterations they are added into the totals (244 registers with the
+    // window: two waves per SIMD)
+    f32x16 acc[NJT], tot[NJT];
 #pragma unroll
     for (int jt = 0; jt < NJT; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
-#pragma unroll
-    for (int q = 0; q < (NJT - 1) * 4; ++q) tl[q * 64] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int r = 0; r < 16; ++r) { acc[jt][r] = 0.0f; tot[jt][r] = 0.0f; }
 
     const float *hlane = a.ring + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
     f32x4 win[SLOTS][2];
@@ -471,8 +465,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
     // accumulators (left alone, the scheduler groups the MFMAs of one tile, and four dependent MFMAs in a row leave the
     // pipe idle between them), the global loads and the LDS reads of the next iteration's weights in the middle of the
     // MFMA stream, a quarter / half an iteration after the waits that guard the registers they overwrite.
-    auto iter = [&](auto p_c, uint32_t i) {
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { tot[jt][r] = tot[jt][r] + acc[jt][r]; acc[jt][r] = 0.0f; }
+    };
+    auto iter = [&](auto p_c, uint32_t i) __attribute__((always_inline)) {
         constexpr int P = decltype(p_c)::value;
+        // The flush sits INSIDE the unrolled body (first iteration of every FLUSH_S / SLOTS-th body), behind a uniform
+        // branch both of whose sides leave the same loads in flight.  As the end of an outer loop over segments it cost
+        // 5.6 % of the sweep: at that join the paths (whole bodies, the conditional tail) have different numbers of loads
+        // pending, so the compiler's counter pass made the wave wait for ALL of them -- the whole prefetch pipeline drained
+        // eight times per sweep (s_waitcnt vmcnt(0); profiles/r02_fir.txt).
+        if constexpr (P == 0) {
+            if (i != 0 && i % FLUSH_S == 0) flush();
+        }
         arrive(i + WIN - 1, win[(P + WIN - 1) % SLOTS]);              // requested D iterations ago, first used now
 #pragma unroll
         for (int s = 0; s < KC / 2; ++s) {
@@ -486,34 +494,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NJT ==
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto flush = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
-#pragma unroll
-        for (int jt = 1; jt < NJT; ++jt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
-                tl[((jt - 1) * 4 + q) * 64] = t;
-            }
-    };
     uint32_t i = 0;
-    while (i < n_iter) {
-        const uint32_t iend = i + FLUSH_S < n_iter ? i + FLUSH_S : n_iter;
-        for (; i + SLOTS <= iend; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
-        if (i < iend) {                                    // fewer than SLOTS left: only the sweep's last segment
-            const uint32_t rest = iend - i;
-            static_for<0, SLOTS - 1>([&](auto p) {
-                if ((uint32_t)p.value < rest) iter(p, i + p.value);
-            });
-            i = iend;
-        }
-        flush();
+    for (; i + SLOTS <= n_iter; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
+    if (i < n_iter) {                                      // fewer than SLOTS left
+        const uint32_t rest = n_iter - i;
+        static_for<0, SLOTS - 1>([&](auto p) {
+            if ((uint32_t)p.value < rest) iter(p, i + p.value);
+        });
     }
+    flush();
     fir_epilogue<NJT>(a, tile, c, c_ok, j0, kh, lane,
-                      [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
+                      [&](int jt, int r) { return tot[jt][r]; });
 }
 
 // ---- steady state, split precision: f32 operands as three bf16 each, products on the bf16 matrix pipe --------------
@@ -630,8 +621,24 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
     wload(0, wq[0]);
 
     // iteration i, i mod SLOTS == P: six groups of NJT MFMAs (one per product term), the other work pinned between them
-    auto iter = [&](auto p_c, uint32_t i) {
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 1; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
+                tl[((jt - 1) * 4 + q) * 64] = t;
+            }
+    };
+    auto iter = [&](auto p_c, uint32_t i) __attribute__((always_inline)) {
         constexpr int P = decltype(p_c)::value;
+        if constexpr (P == 0) {                            // the flush inside the unrolled body: see fir_skew_kernel
+            if (i != 0 && i % FLUSH == 0) flush();
+        }
         constexpr int TX[6] = {0, 0, 1, 0, 2, 1}, TH[6] = {0, 1, 0, 2, 0, 1};      // x part, h part of the six terms
         f32x4 (&in)[2] = fly[(P + WIN) % D];                                       // chunk i + WIN: lands in window slot (P + WIN) % SLOTS
 #pragma unroll
@@ -649,32 +656,15 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto flush = [&]() {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
-#pragma unroll
-        for (int jt = 1; jt < NJT; ++jt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
-                tl[((jt - 1) * 4 + q) * 64] = t;
-            }
-    };
     uint32_t i = 0;
-    while (i < n_iter) {
-        const uint32_t iend = i + FLUSH < n_iter ? i + FLUSH : n_iter;
-        for (; i + SLOTS <= iend; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
-        if (i < iend) {                                    // fewer than SLOTS left: only the sweep's last segment
-            const uint32_t rest = iend - i;
-            static_for<0, SLOTS - 1>([&](auto p) {
-                if ((uint32_t)p.value < rest) iter(p, i + p.value);
-            });
-            i = iend;
-        }
-        flush();
+    for (; i + SLOTS <= n_iter; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
+    if (i < n_iter) {                                      // fewer than SLOTS left
+        const uint32_t rest = n_iter - i;
+        static_for<0, SLOTS - 1>([&](auto p) {
+            if ((uint32_t)p.value < rest) iter(p, i + p.value);
+        });
     }
+    flush();
     fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
                       [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
 }
@@ -732,10 +722,7 @@ static size_t split_lds_bytes(uint32_t n_taps) {
     return 3 * ntp4 * sizeof(unsigned) + (size_t)SPLIT_WAVES * 3 * 4 * 64 * sizeof(f32x4);
 }
 static size_t tap_table_bytes(uint32_t n_taps) { return ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float); }
-// the skewed kernel keeps the totals of its output tiles 1 .. NJT-1 in LDS behind the tap table: 4 waves x (NJT-1) x 4 KiB
-static size_t skew_lds_bytes(uint32_t n_taps, int njt) {
-    return ((tap_table_bytes(n_taps) + 15) & ~(size_t)15) + (size_t)4 * (njt - 1) * 4 * 64 * sizeof(f32x4);
-}
+static size_t skew_lds_bytes(uint32_t n_taps, int) { return tap_table_bytes(n_taps); }
 
 static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps) {
     if (s.taps64) (void)hipFree(s.taps64);
