@@ -1176,40 +1176,47 @@ static __device__ unsigned long long dspfx_ts_trace[TS_TRACE_GROUPS * 4 * TS_TRA
 #else
 #define DSPFX_TS_STAMP(k)
 #endif
-template <int S, int CPL, class SL>
-__global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
-    // (Passing the state from slice to slice with an LDS flag instead of a workgroup barrier per turn -- so that the early
-    // slices store while the later ones still take their turns -- was tried: config 2 27.3 -> 30.2 us, the 5-node chain at
-    // 65536 channels 35.0 -> 32.7 us only at two channels per lane; reads and writes in separate phases suit the HBM better.)
-    __shared__ float lds_st[4][CPL][64];           // the state rows of the node whose turns are being taken
-    if (a.mp_stage) mixpipe_prologue(a);
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
-    // (Rotating the slices over the waves per workgroup -- so that co-resident workgroups take their turns on different
-    // SIMDs -- changes nothing: profiles/r02_small_n.txt.)
-    const unsigned group = work_block(a.xcd_remap);                        // channel group of 64*CPL channels
-    const unsigned wave_global = a.wave_base + group;
-    const size_t rel = ((size_t)group * 64 + lane) * CPL;
-    if (rel >= a.n_launch) return;                 // uniform over the whole workgroup: no barrier is left waiting
-    DSPFX_TS_STAMP(0)
-    const size_t c = a.c_base + rel;
-    const WaveAddr w = wave_addr(a, c);
-    const unsigned f_begin = (unsigned)q * S;
-    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
-    float v[S][CPL];
-#pragma unroll
-    for (int f = 0; f < S; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+// first slot with per-channel state (a recurrence: turns) / first delay slot of a chain shape, or MAX_SLOTS
+template <class SL> constexpr int ts_first_stateful() {
+    for (int i = 0; i < MAX_SLOTS; ++i)
+        if (SL::v[i] != SIG_NONE && !sig_is<K_REVERB>(SL::v[i]) && kind_nstate(sig_kind(SL::v[i])) > 0) return i;
+    return MAX_SLOTS;
+}
+template <class SL> constexpr int ts_slot_count() {
+    int n = 0;
+    for (int i = 0; i < MAX_SLOTS; ++i) n += SL::v[i] != SIG_NONE ? 1 : 0;
+    return n;
+}
+template <class SL> constexpr int ts_first_reverb() {
+    for (int i = 0; i < MAX_SLOTS; ++i)
+        if (sig_is<K_REVERB>(SL::v[i])) return i;
+    return MAX_SLOTS;
+}
+// The chain on one wave's slice.  LATE (slice 0 only): the delay taps are requested AFTER the wave's turn at the first stateful
+// node instead of right behind the block's samples.  A wave issues in order, and under the memory system's back-pressure
+// the 32 tap loads take microseconds to ISSUE: behind them slice 0 could not start the chain of turns -- which every other
+// slice waits for -- before the whole workgroup's reads were served.  The other slices request their taps first: they
+// have to wait for their turn anyway.  (Two copies of the body rather than one with conditional loads: at a join of
+// paths with different loads in flight the compiler's counter pass waits for all of them.)
+template <int S, int CPL, class SL, bool LATE>
+__device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CPL][64], const Ctx &cx, const WaveAddr &w, float (&v)[S][CPL],
+                                       int q, int lane, size_t c, unsigned group, unsigned wave_global, unsigned f_begin) {
+    constexpr int FS = ts_first_stateful<SL>(), FR = ts_first_reverb<SL>();
+    constexpr bool late = LATE && FS < FR && FR < MAX_SLOTS;
     // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
-#define DSPFX_TAPS(I)                                                                                            \
+#define DSPFX_TAPS_DECL(I)                                                                                       \
     float tap##I[sig_is<K_REVERB>(SL::v[I]) ? S : 1][CPL];                                                       \
-    RingGroups rg##I{};        /* three pointers: the 32 row addresses are formed again for the stores */        \
+    RingGroups rg##I{};        /* three pointers: the 32 row addresses are formed again for the stores */
+    DSPFX_FOR_SLOTS(DSPFX_TAPS_DECL)
+#undef DSPFX_TAPS_DECL
+#define DSPFX_TAPS(I)                                                                                            \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         rg##I = ring_groups(a.slot[I], cx);                                                                      \
         _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
             load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], true); \
     }
-    DSPFX_FOR_SLOTS(DSPFX_TAPS)
-#undef DSPFX_TAPS
+    auto load_taps = [&]() __attribute__((always_inline)) { DSPFX_FOR_SLOTS(DSPFX_TAPS) };
+    if constexpr (!late) load_taps();
     DSPFX_TS_STAMP(1)
 #define DSPFX_RUN(I)                                                                                             \
     if constexpr (SL::v[I] != SIG_NONE) { DSPFX_TS_STAMP(2 + I) }                                                \
@@ -1241,12 +1248,14 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
                     _Pragma("unroll") for (int k = 0; k < NS; ++k)                                               \
                         _Pragma("unroll") for (int j = 0; j < CPL; ++j) lds_st[k][j][lane] = st[k][j];           \
                 }                                                                                                \
+                if constexpr (late && I == FS) load_taps();      /* slice 0, its first turn done */             \
             }                                                                                                    \
             __syncthreads();                                                                                     \
         }                                                                                                        \
     }
     DSPFX_FOR_SLOTS(DSPFX_RUN)
 #undef DSPFX_RUN
+#undef DSPFX_TAPS
     DSPFX_TS_STAMP(12)
 #pragma unroll
     for (int f = 0; f < S; ++f)
@@ -1254,6 +1263,44 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     DSPFX_TS_STAMP(13)
     if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
     DSPFX_TS_STAMP(14)
+}
+
+template <int S, int CPL, class SL>
+__global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
+    // (Passing the state from slice to slice with an LDS flag instead of a workgroup barrier per turn -- so that the early
+    // slices store while the later ones still take their turns -- was tried: config 2 27.3 -> 30.2 us, the 5-node chain at
+    // 65536 channels 35.0 -> 32.7 us only at two channels per lane; reads and writes in separate phases suit the HBM better.)
+    __shared__ float lds_st[4][CPL][64];           // the state rows of the node whose turns are being taken
+    if (a.mp_stage) mixpipe_prologue(a);
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
+    // (Rotating the slices over the waves per workgroup -- so that co-resident workgroups take their turns on different
+    // SIMDs -- changes nothing: profiles/r02_small_n.txt.)
+    const unsigned group = work_block(a.xcd_remap);                        // channel group of 64*CPL channels
+    const unsigned wave_global = a.wave_base + group;
+    const size_t rel = ((size_t)group * 64 + lane) * CPL;
+    if (rel >= a.n_launch) return;                 // uniform over the whole workgroup: no barrier is left waiting
+    DSPFX_TS_STAMP(0)
+    const size_t c = a.c_base + rel;
+    const WaveAddr w = wave_addr(a, c);
+    const unsigned f_begin = (unsigned)q * S;
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    float v[S][CPL];
+#pragma unroll
+    for (int f = 0; f < S; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+    // slice 0's late taps cost registers (the second copy of the body): 3-node chain 119 -> 153 (one channel per lane, still
+    // three workgroups per CU where that form is used), 218 -> 243 (two); the 5-node chain would drop from four workgroups
+    // per CU to three (108 -> 155) and ran 36 -> 42 us at 65536 channels: short chains only.  (Late taps for EVERY slice --
+    // one copy of the body -- expose the taps' latency in the later slices: config 2 33.4 us.)
+    if constexpr (ts_slot_count<SL>() <= 3) {
+#ifndef DSPFX_TS_LATE_Q
+#define DSPFX_TS_LATE_Q 1
+#endif
+        if (q < DSPFX_TS_LATE_Q) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+        else ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+    } else {
+        ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+    }
 }
 
 // ---- the fused chain kernel, interpreting any chain ----------------------------------
