@@ -381,8 +381,8 @@ __global__ void __launch_bounds__(256) fir_mfma_kernel(const FirMfmaArgs a) {
 // In steady state W is Toeplitz: W[j][k] = taps_rev[k - j].  Output tile jt (frames 32 jt ...) times history chunk
 // i + 2 jt needs the weights taps_rev[16 i + kk - jj] -- the SAME for every jt.  So iteration i of this kernel gives all
 // NJT output tiles one shared set of weights (8 LDS values per lane instead of 8 NJT) and tile jt its own history chunk
-// i + 2 jt, kept in a register window of 2 NJT chunks (slot = chunk mod 2 NJT; the loop is unrolled by the window so
-// that every slot is a fixed set of registers).  Every tile then sweeps exactly its own band: (T + 30 + koff) / 16 + 1
+// i + 2 jt, kept in a register window of 2 NJT - 1 + D chunks (the ones in use plus D requested ahead; slot = chunk mod
+// window; the loop is unrolled by the window so that every slot is a fixed set of registers).  Every tile then sweeps exactly its own band: (T + 30 + koff) / 16 + 1
 // iterations instead of the (T + 32 NJT - 2 + koff) / 16 + 1 chunks of the rectangular sweep above, whose tiles
 // multiply the zero corners of the band (2.3 % of the MFMAs at T = 4096, NJT = 4).
 template <int P, int N, class F>
