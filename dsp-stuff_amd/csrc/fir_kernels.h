@@ -16,6 +16,10 @@
 //       fir_split_kernel  opt-in: f32 operands as three bf16 parts each, six v_mfma_f32_32x32x16_bf16 per 16 taps and tile;
 //     non-finite (and huge) samples are replaced by 0 in the MFMA operands and their tiles redone by the exact kernel;
 //     when the FIR node ends the chain the sweeps' epilogue also leaves the Output node's mix-bus partials;
+//   - fir_warm_scan_kernel: while a deque that started empty is still filling, state[k] pairs with taps[k] (fir.rs:193-214)
+//     and nothing is popped, so output n is the PREFIX sum over samples 0..n of x[m] taps[m] -- one running f64 sum per
+//     channel, the same sequence of f64 additions as the reference's fresh sum: bit-exact, and O(1) per sample where the
+//     warm-up sweep costs more than a steady-state block;
 //   - fir_exact_kernel: sequential f64 accumulation in deque order, split at the deque's wrap point into the
 //     reference's two partial sums (`a`, `b`: fir.rs:201-216), bit-faithful; serves tiny filters, taps that do
 //     not fit LDS, cross-checks, and re-computes every tile flagged non-finite after the MFMA pass.
@@ -44,6 +48,8 @@ struct FirState {
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
     const char *last_kernel = nullptr;   // the sweep kernel of the last block (reporting)
+    double *warm_acc = nullptr;   // [N] running f64 sums of the fill phase (fir_warm_scan_kernel)
+    bool warm_ok = false;         // warm_acc holds the sums of everything pushed since the deque was last empty
 };
 
 // The pipelined mix bus' work of EARLIER blocks (chain_kernels.hip.h, mixpipe_prologue) for a block whose last launch is a

@@ -169,6 +169,35 @@ __global__ void __launch_bounds__(256) fir_exact_kernel(const FirExactArgs a) {
   }
 }
 
+// ---- fill phase of a deque that started empty ------------------------------------------------------------------
+// fir.rs:193-214 with front == 0 and no pop yet: out[n] = (sum_{m <= n} state[m] * taps[m]) as f32 + 0.0, times the divisor.
+// The reference forms that sum afresh for every output, sequentially in f64 from m = 0: exactly the running sum kept
+// here per channel, so the outputs are the reference's bit for bit.  One thread per channel walks the slice's frames; the
+// 32 channels of a tile are the lanes of one half-wave (mix-bus partials like fir_exact_kernel's).
+__global__ void __launch_bounds__(256) fir_warm_scan_kernel(const float *in, float *out, double *acc, const double *taps, uint32_t N,
+                                                            uint32_t nframes, uint32_t n0, int hop, float hop_div, float divisor,
+                                                            float *mixpart, uint32_t mix_ld, const Layout lay) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    const bool c_ok = c < N;
+    double a = c_ok ? acc[c] : 0.0;
+    for (uint32_t f = 0; f < nframes; ++f) {
+        float o = 0.0f;
+        if (c_ok) {
+            float x = __builtin_nontemporal_load(in + lay.at(f, c));
+            if (hop) x = (0.0f + x) / hop_div;                         // node.rs:162-194, one pipe (as in fir_append_kernel)
+            a += (double)x * taps[n0 + f];                             // fir.rs:204-206
+            o = ((float)a + 0.0f) * divisor;                           // fir.rs:216 (`b` is the empty second slice), 222
+            __builtin_nontemporal_store(o, out + lay.at(f, c));
+        }
+        if (mixpart) {
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) o = o + __shfl_xor(o, m, 32);
+            if ((threadIdx.x & 31) == 0 && c_ok) mixpart[(size_t)(c >> 5) * mix_ld + f] = o;
+        }
+    }
+    if (c_ok) acc[c] = a;
+}
+
 // ---- MFMA path ------------------------------------------------------------------------
 // One wave = one 32-channel tile x up to 128 output frames (4 MFMA tiles of 32).
 //   D[j][c] += W[j][k] * H[k][c]      A operand = W (lane: j = l&31, k = l>>5)
@@ -800,6 +829,9 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     FIRCHK(hipMemset(s.ring, 0, ring_bytes));
     FIRCHK(hipMalloc((void **)&s.nf_time, (size_t)s.tiles * sizeof(unsigned long long)));
     FIRCHK(hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long)));
+    FIRCHK(hipMalloc((void **)&s.warm_acc, (size_t)N * sizeof(double)));
+    FIRCHK(hipMemset(s.warm_acc, 0, (size_t)N * sizeof(double)));
+    s.warm_ok = true;
     return upload_taps(s, taps_reversed, n_taps);
 }
 
@@ -810,6 +842,7 @@ int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int 
     }
     FIRCHK(hipDeviceSynchronize());                      // blocks in flight still read the old taps / ring
     s.mode = mode;
+    s.warm_ok = s.warm_ok && s.n_seen == 0;              // running sums of the old taps are worthless
     const uint64_t held = s.n_seen - s.front;            // the deque survives the reload (fir.rs:153-171 touches `taps` only)
     const uint32_t need = ring_rows_for(held, n_taps, s.max_frames);
     if (need > s.R) {
@@ -836,6 +869,9 @@ void fir_free(FirState &s) {
     if (s.taps32) (void)hipFree(s.taps32);
     if (s.taps_split) (void)hipFree(s.taps_split);
     if (s.nf_time) (void)hipFree(s.nf_time);
+    if (s.warm_acc) (void)hipFree(s.warm_acc);
+    s.warm_acc = nullptr;
+    s.warm_ok = false;
     s.ring = nullptr;
     s.taps64 = nullptr;
     s.taps32 = nullptr;
@@ -846,6 +882,8 @@ void fir_free(FirState &s) {
 void fir_reset(FirState &s) {
     if (s.ring) (void)hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R));
     if (s.nf_time) (void)hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long));
+    if (s.warm_acc) (void)hipMemset(s.warm_acc, 0, (size_t)s.N * sizeof(double));
+    s.warm_ok = s.warm_acc != nullptr;
     s.n_seen = 0;
     s.front = 0;
     s.dq_cap = s.dq_head = 0;
@@ -934,6 +972,18 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             ev_open = true;
         }
         const dim3 ex_grid(s.tiles, (nf + 7) / 8);
+        // the fill phase of a deque that started empty: running sums (exact); DSPFX_FIR_SCAN=0 keeps the warm-up sweep (A/B, tests)
+        const char *scan_env = getenv("DSPFX_FIR_SCAN");
+        const bool fill = mfma && s.warm_ok && front0 == 0 && s.front == 0 && n0 + nf <= s.T && !(scan_env && atoi(scan_env) == 0);
+        if (!steady && !fill) s.warm_ok = false;             // a filling slice the running sums did not see
+        if (fill) {
+            s.last_kernel = "fir_warm_scan_kernel";
+            hipLaunchKernelGGL(fir_warm_scan_kernel, dim3((s.N + 255) / 256), dim3(256), 0, stream, in_s, out_s, s.warm_acc, s.taps64, s.N, nf,
+                               (uint32_t)n0, hop, hop_div, divisor, ex.mixpart, nframes, lay);
+            if (mixpipe && mixpipe->stage && f0 == 0) fir_mixpipe_standalone(*mixpipe, nframes, stream);
+            if (ev_end && f0 + SLICE >= nframes) (void)hipEventRecord(ev_end, stream);
+            continue;
+        }
         if (mfma) {
             FirMfmaArgs a{};
             a.ring = s.ring;
@@ -1066,6 +1116,8 @@ int fir_state_import(FirState &s, const void *host_src) {
     s.front = 0;
     s.dq_cap = s.dq_head = 0;
     for (uint64_t k = 0; k < hist; ++k) (void)deque_step(s);
+    FIRCHK(hipMemset(s.warm_acc, 0, (size_t)s.N * sizeof(double)));
+    s.warm_ok = hist == 0;                               // imported history: its running sums are not known
     return 0;
 }
 

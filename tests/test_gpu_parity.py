@@ -781,6 +781,42 @@ def test_fir_split_precision_sweep_config4_accuracy(dspfx, torch_cuda, monkeypat
     assert np.allclose(y[fin, 5], ref[fin, 5], rtol=1e-5, atol=1e-5 * np.abs(ref[fin, 5]).max())
 
 
+@pytest.mark.parametrize("tile", [0, 256])
+def test_fir_fill_phase_is_bit_exact(dspfx, torch_cuda, monkeypatch, tile):
+    """While a deque that started empty fills, output n is the prefix sum over samples 0..n of state[m] * taps[m]
+    (fir.rs:193-214: nothing is popped, state[k] pairs with taps[k]): fir_warm_scan_kernel keeps that running f64 sum per
+    channel -- the same additions as the reference's fresh sum, so the first T outputs equal the oracle's bit for bit on the
+    default (MFMA) path, noise data, mix bus included; the blocks after them are the sweeps' (tolerance).  A tap reload
+    or DSPFX_FIR_SCAN=0 sends the fill phase to the warm-up sweep instead."""
+    T, N, B = 1000, 512 if tile else 70, 128
+    x = noise_block(N, B * 12)
+    ch = [dspfx.Fir(fir_taps(T), dspfx.FIR_AVERAGE)]
+    eng = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
+    eng.set_chain(ch)
+    ys, kinds, mixes = [], [], []
+    for k in range(12):
+        dx = torch_cuda.from_numpy(dspfx.to_layout(x[k * B:(k + 1) * B], tile)).cuda()
+        dy, dm = torch_cuda.empty_like(dx), torch_cuda.empty(B, device="cuda")
+        eng.process(dx, out=dy, mix=dm, n_frames=B)
+        torch_cuda.cuda.synchronize()
+        ys.append(dspfx.from_layout(dy.cpu().numpy(), B, N, tile))
+        mixes.append(dm.cpu().numpy())
+        kinds.append([l for l in eng.describe().splitlines() if l.startswith("stage 0")][0])
+    y, ref = np.concatenate(ys), run_oracle(ch, x, 3)
+    full = (T // B) * B                                              # whole blocks inside the fill phase
+    assert all("fir_warm_scan_kernel" in k for k in kinds[:T // B]) and "fir_warm_scan_kernel" not in kinds[-1], kinds
+    assert np.array_equal(y[:full].view(np.uint32), ref[:full].view(np.uint32))
+    assert fir_rel_rms(y[full:], ref[full:]) < FIR_RMS_TOL
+    want = y.astype(np.float64).sum(axis=1)
+    assert np.allclose(np.concatenate(mixes), want, rtol=1e-5, atol=1e-4 * np.abs(want).max())
+    monkeypatch.setenv("DSPFX_FIR_SCAN", "0")
+    eng2 = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
+    eng2.set_chain(ch)
+    y2 = _run_fir_blocks(dspfx, torch_cuda, eng2, x[:B * 2]) if not tile else None
+    if y2 is not None:
+        assert "fir_mfma_kernel" in eng2.describe() and fir_rel_rms(y2, ref[:B * 2]) < FIR_RMS_TOL
+
+
 def test_fir_state_export_import(dspfx, torch_cuda):
     T, N = 130, 70
     x = noise_block(N, 128 * 6)
