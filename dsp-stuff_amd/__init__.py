@@ -33,6 +33,7 @@ SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
 DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"]
 FIR_BALANCED, FIR_AVERAGE = 0, 1
+FIR_PRECISION_DEFAULT, FIR_PRECISION_F32, FIR_PRECISION_SPLIT = 0, 1, 2
 LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
 GRAPH_MAX_NODES = 16
@@ -47,7 +48,7 @@ PORT_RAW = 256
 EXPORTS = [
     "dspfx_abi_version", "dspfx_strerror", "dspfx_device_count", "dspfx_node_defaults", "dspfx_delay_len",
     "dspfx_link_divisor", "dspfx_engine_create", "dspfx_engine_destroy", "dspfx_last_error", "dspfx_chain_set",
-    "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps",
+    "dspfx_chain_len", "dspfx_set_param", "dspfx_set_mode", "dspfx_set_delay_len", "dspfx_set_taps", "dspfx_set_fir_precision",
     "dspfx_reset", "dspfx_tune_placement", "dspfx_process", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_mix_finish", "dspfx_process_mixpipe", "dspfx_mixpipe_flush", "dspfx_link_average", "dspfx_graph_set", "dspfx_graph_source", "dspfx_state_size",
     "dspfx_state_export", "dspfx_state_import", "dspfx_fill_noise", "dspfx_sync", "dspfx_describe",
     "dspfx_algorithmic_bytes_per_sample", "dspfx_profile_enable", "dspfx_profile_read", "dspfx_verify_fast_division", "dspfx_verify_libm",
@@ -127,6 +128,7 @@ def lib():
     L.dspfx_set_mode.argtypes = [vp, C.c_int, C.c_int]
     L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
     L.dspfx_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.c_int]
+    L.dspfx_set_fir_precision.argtypes = [vp, C.c_int, C.c_int]
     L.dspfx_reset.argtypes = [vp]
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
@@ -421,6 +423,10 @@ class Engine:
     def set_taps(self, node: int, impulse_response, mode: int = FIR_BALANCED):
         t = np.ascontiguousarray(np.asarray(impulse_response, np.float64)[::-1])
         self._chk(self.L.dspfx_set_taps(self.h, node, t.ctypes.data_as(C.POINTER(C.c_double)), len(t), mode))
+
+    def set_fir_precision(self, node: int, precision: int):
+        """FIR_PRECISION_DEFAULT / _F32 / _SPLIT (dspfx_set_fir_precision): how the node's steady-state sweep multiplies."""
+        self._chk(self.L.dspfx_set_fir_precision(self.h, node, precision))
 
     def reset(self):
         self._chk(self.L.dspfx_reset(self.h))

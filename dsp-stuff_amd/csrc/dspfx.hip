@@ -1577,6 +1577,16 @@ extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reve
     return rc ? fail(e, rc, "FIR tap reload failed: %s", fir_last_error()) : DSPFX_OK;
 }
 
+extern "C" int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_FIR)
+        return fail(e, DSPFX_ERR_INVALID, "node %d is not a FIR node", node);
+    if (precision < DSPFX_FIR_PRECISION_DEFAULT || precision > DSPFX_FIR_PRECISION_SPLIT)
+        return fail(e, DSPFX_ERR_INVALID, "unknown FIR precision %d", precision);
+    e->nodes[(size_t)node].fir.precision = precision;
+    return DSPFX_OK;
+}
+
 extern "C" int dspfx_reset(dspfx_engine *e) {
     if (!e) return DSPFX_ERR_INVALID;
     HIPCHK(e, hipSetDevice(e->device));

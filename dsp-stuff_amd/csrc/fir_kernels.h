@@ -47,6 +47,7 @@ struct FirState {
     uint64_t front = 0;           // absolute index of the deque's oldest sample (deque length = n_seen - front)
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
+    int precision = 0;            // dspfx_fir_precision: 0 environment / f32, 1 f32, 2 split (bf16 x 3)
     const char *last_kernel = nullptr;   // the sweep kernel of the last block (reporting)
     double *warm_acc = nullptr;   // [N] running f64 sums of the fill phase (fir_warm_scan_kernel)
     bool warm_ok = false;         // warm_acc holds the sums of everything pushed since the deque was last empty

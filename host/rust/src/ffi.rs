@@ -124,6 +124,10 @@ pub const DSPFX_SIG_CONSTANT: c_int = 3;
 // dspfx_fir_mode (nodes/fir.rs)
 pub const DSPFX_FIR_BALANCED: c_int = 0;
 pub const DSPFX_FIR_AVERAGE: c_int = 1;
+/// dspfx_fir_precision (dspfx.h): how a FIR node's steady-state sweep multiplies
+pub const DSPFX_FIR_PRECISION_DEFAULT: c_int = 0;
+pub const DSPFX_FIR_PRECISION_F32: c_int = 1;
+pub const DSPFX_FIR_PRECISION_SPLIT: c_int = 2;
 
 #[link(name = "dspfx")]
 extern "C" {
@@ -144,6 +148,7 @@ extern "C" {
     pub fn dspfx_set_mode(e: *mut dspfx_engine, node: c_int, mode: c_int) -> c_int;
     pub fn dspfx_set_delay_len(e: *mut dspfx_engine, node: c_int, delay_len: u32) -> c_int;
     pub fn dspfx_set_taps(e: *mut dspfx_engine, node: c_int, taps_reversed: *const f64, n_taps: u32, mode: c_int) -> c_int;
+    pub fn dspfx_set_fir_precision(e: *mut dspfx_engine, node: c_int, precision: c_int) -> c_int;
     pub fn dspfx_reset(e: *mut dspfx_engine) -> c_int;
 
     pub fn dspfx_tune_placement(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;

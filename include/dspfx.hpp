@@ -156,6 +156,8 @@ class Engine {
     void set_param(int node, int param, float v) { chk(dspfx_set_param(e_, node, param, v)); }
     void set_mode(int node, Mode m) { chk(dspfx_set_mode(e_, node, static_cast<int>(m))); }
     void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }
+    /// DSPFX_FIR_PRECISION_DEFAULT / _F32 / _SPLIT: how a FIR node's steady-state sweep multiplies (dspfx.h)
+    void set_fir_precision(int node, dspfx_fir_precision p) { chk(dspfx_set_fir_precision(e_, node, static_cast<int>(p))); }
     void reset() { chk(dspfx_reset(e_)); }
     // device buffers, asynchronous on `stream`
     void process(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr,

@@ -763,15 +763,20 @@ def test_fir_split_precision_sweep_config4_accuracy(dspfx, torch_cuda, monkeypat
     """The opt-in split-precision sweep (DSPFX_FIR_SPLIT=1) on config 4's filter: within the same stated tolerance as the
     f32 sweep (measured 2.9e-7 against 3.3e-7), it really is the kernel that ran, huge finite samples (whose bf16 part
     would round to inf) are routed to the exact kernel like non-finite ones."""
-    monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
     T, N, blocks = 4096, 32, 40
     x = noise_block(N, 128 * blocks)
     x[128 * 36 + 7, 5] = 3.0e38
     ch = [dspfx.Fir(fir_taps(T))]
     eng = dspfx.Engine(N, 128, link_flags=3)
     eng.set_chain(ch)
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_SPLIT)           # through the C ABI (dspfx_set_fir_precision), not the environment
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_fir_precision(0, 7)
     y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
     assert "fir_split_kernel" in eng.describe(), eng.describe()
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_F32)
+    _run_fir_blocks(dspfx, torch_cuda, eng, x[:128])
+    assert "fir_skew_kernel" in eng.describe(), eng.describe()
     ref = run_oracle(ch, x, 3)
     ok = np.ones(N, bool)
     ok[5] = False
