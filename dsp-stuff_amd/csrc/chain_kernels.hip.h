@@ -1293,10 +1293,7 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     // per CU to three (108 -> 155) and ran 36 -> 42 us at 65536 channels: short chains only.  (Late taps for EVERY slice --
     // one copy of the body -- expose the taps' latency in the later slices: config 2 33.4 us.)
     if constexpr (ts_slot_count<SL>() <= 3) {
-#ifndef DSPFX_TS_LATE_Q
-#define DSPFX_TS_LATE_Q 1
-#endif
-        if (q < DSPFX_TS_LATE_Q) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+        if (q == 0) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
         else ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
     } else {
         ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
