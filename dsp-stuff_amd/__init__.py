@@ -55,6 +55,7 @@ EXPORTS = [
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
     "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
+    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted",
 ]
 COMM_ID_BYTES = 128
 
@@ -78,6 +79,11 @@ class _NodeDesc(C.Structure):
 
 class _GraphLink(C.Structure):
     _fields_ = [("src", C.c_int32), ("dst", C.c_int32), ("port", C.c_int32)]
+
+
+class _ParamEvent(C.Structure):
+    _fields_ = [("seq", C.c_uint64), ("frame", C.c_uint64), ("node", C.c_int32), ("param", C.c_int32),
+                ("value", C.c_float), ("reserved", C.c_int32)]
 
 
 class _Ctl(C.Structure):
@@ -126,6 +132,10 @@ def lib():
     L.dspfx_graph_source.argtypes = [C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int, C.c_char_p, C.c_size_t]
     L.dspfx_set_param.argtypes = [vp, C.c_int, C.c_int, C.c_float]
     L.dspfx_set_mode.argtypes = [vp, C.c_int, C.c_int]
+    L.dspfx_set_param_seq.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.POINTER(C.c_uint64)]
+    L.dspfx_param_log.argtypes = [vp, C.POINTER(_ParamEvent), C.c_int, C.c_uint64]
+    L.dspfx_frames_submitted.restype = C.c_uint64
+    L.dspfx_frames_submitted.argtypes = [vp]
     L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
     L.dspfx_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.c_int]
     L.dspfx_set_fir_precision.argtypes = [vp, C.c_int, C.c_int]
@@ -417,6 +427,25 @@ class Engine:
     def set_mode(self, node: int, mode: int):
         self._chk(self.L.dspfx_set_mode(self.h, node, int(mode)))
 
+    def set_param_seq(self, node: int, param: int, value: float) -> int:
+        """set_param that also returns the store's sequence number (safe from any thread: the store is queued and
+        applied at the next block boundary, dspfx.h)."""
+        seq = C.c_uint64()
+        self._chk(self.L.dspfx_set_param_seq(self.h, node, param, float(value), C.byref(seq)))
+        return int(seq.value)
+
+    def param_log(self, after_seq: int = 0, cap: int = 4096):
+        """The stores applied so far with seq > after_seq: [(seq, frame, node, param, value)], oldest first; `frame` =
+        frames submitted when the store took effect (param -1: a mode store)."""
+        arr = (_ParamEvent * cap)()
+        n = self.L.dspfx_param_log(self.h, arr, cap, int(after_seq))
+        if n < 0:
+            self._chk(n)
+        return [(int(a.seq), int(a.frame), int(a.node), int(a.param), float(a.value)) for a in arr[:n]]
+
+    def frames_submitted(self) -> int:
+        return int(self.L.dspfx_frames_submitted(self.h))
+
     def set_delay_len(self, node: int, d: int):
         self._chk(self.L.dspfx_set_delay_len(self.h, node, int(d)))
 
@@ -496,7 +525,7 @@ class Engine:
                                              C.c_void_p(stream) if stream else None))
 
     def tune_placement(self, x, out, n_frames: int, side=None, stream: int = 0):
-        """Re-tune the delay rings' placement with the real chain kernels on the caller's buffers (resets DSP state)."""
+        """Re-tune the delay rings' placement with the real chain kernels on the caller's buffers (DSP state is kept)."""
         self._chk(self.L.dspfx_tune_placement(self.h, _ptr(x), _ptr(side), _ptr(out), int(n_frames),
                                               C.c_void_p(stream) if stream else None))
 

@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -119,6 +120,24 @@ struct dspfx_engine {
     bool profiling = false;
     std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;   // [stage][launch]
     std::vector<hipEvent_t> ev_pool;
+    // ---- threads and streams (include/dspfx.h, "Threads and streams") ----------------------------------------------
+    // api_mu serialises every entry point that touches the engine; a slider store from another thread never waits
+    // for it: it is queued under pend_mu and applied by whoever holds api_mu next, at a block boundary.
+    mutable std::recursive_mutex api_mu;
+    int api_depth = 0;                        // nesting of entry points (dspfx_process_ctl -> dspfx_process): only the outermost drains
+    mutable std::mutex pend_mu;               // pending, pub_kinds, log, next_seq
+    struct Store { uint64_t seq; int node, param; float value; };   // param -1: a mode store (value = the mode)
+    std::deque<Store> pending;
+    std::vector<int> pub_kinds;               // node kinds as of the last chain / graph set: validation without api_mu
+    std::deque<dspfx_param_event> log;        // the stores already applied, oldest first (bounded)
+    uint64_t next_seq = 1;
+    uint64_t frames_submitted = 0;            // frames handed to the process calls so far
+    // the stream the DSP state was last touched on: every state write (biquad reset, dspfx_reset, ...) is queued on
+    // it, and a call on a different stream first waits for an event recorded there
+    hipStream_t cur_stream = nullptr;
+    bool cur_stream_set = true;               // the null stream to begin with: setup-time writes go there
+    hipEvent_t ev_order = nullptr;
+    mutable std::mutex err_mu;                        // err (also kept per calling thread: dspfx_last_error)
 };
 
 namespace {
@@ -153,6 +172,11 @@ struct ProfScope {   // brackets one kernel launch with events on its own stream
     }
 };
 
+// The last error text is kept per engine AND per calling thread: a GUI thread whose slider store failed reads its own
+// message, not the one the audio thread produced a microsecond later.
+thread_local const dspfx_engine *tl_err_engine = nullptr;
+thread_local std::string tl_err;
+
 int fail(dspfx_engine *e, int code, const char *fmt, ...) {
     if (e) {
         char buf[512];
@@ -160,6 +184,9 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
         va_start(ap, fmt);
         vsnprintf(buf, sizeof buf, fmt, ap);
         va_end(ap);
+        tl_err = buf;
+        tl_err_engine = e;
+        std::lock_guard<std::mutex> lk(e->err_mu);
         e->err = buf;
     }
     return code;
@@ -1060,7 +1087,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     const int blk = graph_input_block(l.src);
                     if (blk == 1 && !side) return fail(e, DSPFX_ERR_INVALID, "this graph reads a second block (DSPFX_GRAPH_INPUT2): side must not be null");
                     if (blk >= 2 && !e->io_in[blk]) return fail(e, DSPFX_ERR_INVALID, "this graph reads input block %d: pass it with dspfx_process_io", blk);
-                    if (l.dst > n_nodes && !e->io_out[l.dst - n_nodes]) return fail(e, DSPFX_ERR_INVALID, "this graph writes output block %d: pass it with dspfx_process_io", l.dst - n_nodes);
+                    if (l.dst > n_nodes && !e->io_out[l.dst - n_nodes]) return fail(e, DSPFX_ERR_INVALID, "this graph writes output block %d: pass it with dspfx_process_io", l.dst - n_nodes);   // (blocks are contiguous: validate_graph)
                 }
                 for (int k = 2; k < GRAPH_IO; ++k) ga.xin[k - 2] = e->io_in[k] ? e->io_in[k] + e->io_off : nullptr;
                 for (int m = 1; m < GRAPH_IO; ++m) ga.xout[m - 1] = e->io_out[m] ? e->io_out[m] + e->io_off : nullptr;
@@ -1246,6 +1273,131 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
     return DSPFX_OK;
 }
 
+// ---- threads and streams ------------------------------------------------------------------------------------------
+// The engine's DSP state is read at the start of a block's kernels and written at their end, so everything that writes
+// that state must be ordered with the blocks in flight.  Two rules do it:
+//   * every state write is queued on the stream the state was last used on (cur_stream), never on the null stream;
+//   * a call that uses the state on ANOTHER stream first makes that stream wait for an event recorded on cur_stream.
+// Callers' streams are usually non-blocking (torch's, the bench's): the null stream orders nothing against them.
+int bind_stream(dspfx_engine *e, hipStream_t s) {
+    if (e->cur_stream_set && e->cur_stream != s) {
+        bool ok = true;
+        if (!e->ev_order) ok = hipEventCreateWithFlags(&e->ev_order, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventRecord(e->ev_order, e->cur_stream) == hipSuccess && hipStreamWaitEvent(s, e->ev_order, 0) == hipSuccess;
+        if (!ok) {                      // the old stream may be gone (its owner destroyed it): everything it held has run or never will
+            (void)hipGetLastError();
+            HIPCHK(e, hipDeviceSynchronize());
+        }
+    }
+    e->cur_stream = s;
+    e->cur_stream_set = true;
+    return DSPFX_OK;
+}
+
+// Setup-time calls that free or re-allocate state (chain / graph set, delay length, tap reload, state import / export):
+// nothing of this engine may be in flight, on any stream.
+int quiesce(dspfx_engine *e) {
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipDeviceSynchronize());
+    return DSPFX_OK;
+}
+// ... and what they queued on the null stream has finished before a non-blocking stream can touch the new state.
+int settle_null_stream(dspfx_engine *e) {
+    HIPCHK(e, hipStreamSynchronize(nullptr));
+    return DSPFX_OK;
+}
+
+void publish_kinds(dspfx_engine *e) {
+    std::lock_guard<std::mutex> lk(e->pend_mu);
+    e->pub_kinds.clear();
+    for (const Node &n : e->nodes) e->pub_kinds.push_back(n.d.kind);
+    e->pending.clear();                 // stores aimed at the nodes that no longer exist
+}
+
+// One slider / mode store takes effect (api_mu held).  State writes go to `s` in stream order.  *replan: the stage split or a
+// stage's division verdict changed.
+int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char> &biquad_reset, bool &replan) {
+    if (st.node < 0 || st.node >= (int)e->nodes.size()) return DSPFX_OK;   // the chain was replaced since
+    Node &n = e->nodes[(size_t)st.node];
+    if (st.param < 0) {                                  // dspfx_set_mode
+        n.d.mode = (int)st.value;
+        if (n.d.kind == DSPFX_FIR) n.fir.mode = n.d.mode;
+        replan = true;                                   // Fuzz <-> other modes changes the stage split
+        return DSPFX_OK;
+    }
+    n.d.params[st.param] = st.value;
+    if (st.param < 3) n.latch_valid &= ~(1 << st.param);   // a slider store overwrites the latched values
+    if (n.d.kind == DSPFX_BIQUAD) {   // after_settings_change: renormalise + reset_state (biquad.rs:62-76)
+        biquad_regenerate(n);
+        biquad_reset[(size_t)st.node] = 1;
+    }
+    if (n.d.kind == DSPFX_DISTORT) {
+        // A new clip level is a new constant divisor.  Whether its fast form is exact is decided on the host (see
+        // divisor_is_fast) for everything but the even integers, so a slider store launches nothing and keeps the
+        // kernel it has; only a store that flips the verdict of the node's stage (to or from an even integer that
+        // failed its check) re-plans, and that picks among kernels that already exist.
+        for (const Stage &sg : e->stages)
+            if (sg.type == ST_FUSED && st.node >= sg.first && st.node < sg.first + sg.count) {
+                HIPCHK(e, hipSetDevice(e->device));
+                if (stage_fast_div(e, sg) != sg.fast_div) replan = true;
+            }
+    }
+    return DSPFX_OK;
+}
+
+// Apply every queued store, in order, at this block boundary (api_mu held); biquad resets are queued on `s` -- the
+// stream of the block about to be launched, or the stream the state was last used on.
+int drain_pending(dspfx_engine *e, hipStream_t s) {
+    std::deque<dspfx_engine::Store> todo;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (e->pending.empty()) return DSPFX_OK;
+        todo.swap(e->pending);
+    }
+    std::vector<char> biquad_reset(e->nodes.size(), 0);
+    bool replan = false;
+    int rc = DSPFX_OK;
+    for (const auto &st : todo) {
+        const int r = apply_store(e, st, biquad_reset, replan);
+        if (r && !rc) rc = r;
+    }
+    HIPCHK(e, hipSetDevice(e->device));
+    for (size_t i = 0; i < biquad_reset.size(); ++i)
+        if (biquad_reset[i] && e->nodes[i].state)
+            HIPCHK(e, hipMemsetAsync(e->nodes[i].state, 0, e->nodes[i].state_bytes, s));
+    if (replan) {
+        const int r = plan(e);
+        if (r && !rc) rc = r;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        for (const auto &st : todo) {
+            e->log.push_back(dspfx_param_event{st.seq, e->frames_submitted, st.node, st.param, st.value, 0});
+            if (e->log.size() > 4096) e->log.pop_front();
+        }
+    }
+    return rc;
+}
+
+// Every entry point that touches an engine: take api_mu; the outermost one applies the queued stores first.  With a
+// stream (the process calls, tuning) the state is bound to it before anything is queued.
+struct ApiScope {
+    dspfx_engine *e;
+    int rc = DSPFX_OK;
+    bool outer = false;
+    ApiScope(dspfx_engine *e_, bool has_stream = false, hipStream_t s = nullptr) : e(e_) {
+        e->api_mu.lock();
+        outer = e->api_depth++ == 0;
+        if (hipSetDevice(e->device) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+        if (has_stream && rc == DSPFX_OK) rc = bind_stream(e, s);
+        if (outer && rc == DSPFX_OK) rc = drain_pending(e, e->cur_stream_set ? e->cur_stream : nullptr);
+    }
+    ~ApiScope() {
+        --e->api_depth;
+        e->api_mu.unlock();
+    }
+};
+
 }  // namespace
 
 // ------------------------------------------------------------------ library
@@ -1380,16 +1532,26 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
             (void)hipEventDestroy(p.second);
         }
     for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+    if (e->ev_order) (void)hipEventDestroy(e->ev_order);
     delete e;
 }
 
-extern "C" const char *dspfx_last_error(const dspfx_engine *e) { return e ? e->err.c_str() : "null engine"; }
+extern "C" const char *dspfx_last_error(const dspfx_engine *e) {
+    if (!e) return "null engine";
+    if (tl_err_engine != e) {           // this thread has not failed on this engine: the engine's most recent message
+        std::lock_guard<std::mutex> lk(e->err_mu);
+        tl_err = e->err;
+        tl_err_engine = e;
+    }
+    return tl_err.c_str();              // valid until this thread's next failing call
+}
 
 namespace {
 int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
 }
 extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
     e->graph_mode = false;
     e->wiring.clear();
     e->no_long = false;
@@ -1404,20 +1566,35 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
         const int rc = validate_node(e, nodes[i]);
         if (rc) return rc;
     }
+    {   // blocks still in flight read the state about to be freed
+        const int rc = quiesce(e);
+        if (rc) return rc;
+    }
     for (Node &n : e->nodes) free_node(n);
     e->nodes.clear();
     e->nodes.resize((size_t)n_nodes);
-    for (int i = 0; i < n_nodes; ++i) {
+    e->mp_count = 0;
+    int rc = DSPFX_OK;
+    for (int i = 0; i < n_nodes && rc == DSPFX_OK; ++i) {
         Node &n = e->nodes[(size_t)i];
         n.d = nodes[i];
         n.d.taps = nullptr;
         if (n.d.kind == DSPFX_BIQUAD) biquad_regenerate(n);
         if (n.d.kind == DSPFX_REVERB) n.D = nodes[i].delay_len;
         if (n.d.kind == DSPFX_FIR) n.taps.assign(nodes[i].taps, nodes[i].taps + nodes[i].n_taps);
-        const int rc = alloc_node_state(e, n);
-        if (rc) return rc;
+        rc = alloc_node_state(e, n);
     }
-    return plan(e);
+    if (rc != DSPFX_OK) {               // leave no half-built chain behind
+        for (Node &n : e->nodes) free_node(n);
+        e->nodes.clear();
+        (void)plan(e);
+        publish_kinds(e);
+        return rc;
+    }
+    rc = plan(e);
+    publish_kinds(e);
+    const int rs = settle_null_stream(e);
+    return rc ? rc : rs;
 }
 }  // namespace
 
@@ -1449,6 +1626,13 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
         if (++fan_in[{l.dst, port}] > DSPFX_MAX_LINKS)
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: more than %d links into one port", i, DSPFX_MAX_LINKS);
     }
+    {   // output blocks are stored by the generated kernel for every m < n_out: each of them needs a signal (and a buffer)
+        int n_out = 1;
+        for (int i = 0; i < n_links; ++i) n_out = std::max(n_out, links[i].dst - n_nodes + 1);
+        for (int m = 1; m < n_out; ++m)
+            if (!fan_in.count({n_nodes + m, DSPFX_PORT_MAIN}))
+                return fail(e, DSPFX_ERR_INVALID, "graph: output block %d has no link although block %d has (output blocks must be contiguous)", m, n_out - 1);
+    }
     for (int i = 0; i < n_links; ++i)   // a RAW link is its port's only link, and it carries a signal
         if ((links[i].port & DSPFX_PORT_RAW) && (fan_in[{links[i].dst, links[i].port & ~DSPFX_PORT_RAW}] != 1 || links[i].src == DSPFX_GRAPH_ZERO))
             return fail(e, DSPFX_ERR_INVALID, "graph link %d: a RAW link must be the only link into its port", i);
@@ -1462,6 +1646,7 @@ int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, c
 extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
                                int n_links) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
     const uint32_t N = e->desc.channels;
     if (N % 64u) return fail(e, DSPFX_ERR_UNSUPPORTED, "graph kernel needs whole waves: channels %% 64 == 0");
     const int vrc = validate_graph(e, nodes, n_nodes, links, n_links);
@@ -1505,80 +1690,135 @@ extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, con
     return DSPFX_OK;
 }
 
-extern "C" int dspfx_chain_len(const dspfx_engine *e) { return e ? (int)e->nodes.size() : DSPFX_ERR_INVALID; }
+extern "C" int dspfx_chain_len(const dspfx_engine *e) {
+    if (!e) return DSPFX_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
+    return (int)e->nodes.size();
+}
+
+// Slider / mode stores.  The reference's GUI thread stores into an atomic while the node's task runs process()
+// (dsp-stuff-derive/src/lib.rs:487-492) and runs after_settings_change under the node's mutex (biquad.rs:62-76): the
+// store lands between two blocks.  Here: the store is queued (never waiting for a process call in progress) and applied
+// by the next entry point that holds the engine -- at once when the engine is idle, else at the next block boundary --
+// with its state write (the biquad reset) queued in stream order behind the blocks already in flight.
+namespace {
+int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *seq_out) {
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (node < 0 || node >= (int)e->pub_kinds.size() || param < -1 || param >= 8)
+            return fail(e, DSPFX_ERR_INVALID, param < 0 ? "node %d out of range" : "set_param(%d,%d) out of range", node, param);
+        if (param < 0) {                                // a mode store: validate against the node's kind
+            dspfx_node_desc d{};
+            d.kind = e->pub_kinds[(size_t)node];
+            d.mode = (int)value;
+            d.delay_len = DSPFX_BUF_SIZE;
+            d.n_taps = 1;
+            static const double one = 1.0;
+            d.taps = &one;
+            const int rc = validate_node(e, d);
+            if (rc) return rc;
+        }
+        const uint64_t seq = e->next_seq++;
+        e->pending.push_back(dspfx_engine::Store{seq, node, param, value});
+        if (seq_out) *seq_out = seq;
+    }
+    if (e->api_mu.try_lock()) {                         // nobody is inside the engine: the store takes effect now
+        std::lock_guard<std::recursive_mutex> lk(e->api_mu, std::adopt_lock);
+        if (e->api_depth == 0) {                        // (not this thread re-entering from inside an entry point)
+            ++e->api_depth;
+            int rc = hipSetDevice(e->device) == hipSuccess ? DSPFX_OK : fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+            if (rc == DSPFX_OK) rc = drain_pending(e, e->cur_stream_set ? e->cur_stream : nullptr);
+            --e->api_depth;
+            return rc;
+        }
+    }
+    return DSPFX_OK;                                    // applied at the next block boundary
+}
+}  // namespace
 
 extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value) {
     if (!e) return DSPFX_ERR_INVALID;
-    if (node < 0 || node >= (int)e->nodes.size() || param < 0 || param >= 8)
-        return fail(e, DSPFX_ERR_INVALID, "set_param(%d,%d) out of range", node, param);
-    Node &n = e->nodes[(size_t)node];
-    n.d.params[param] = value;
-    if (param < 3) n.latch_valid &= ~(1 << param);   // a slider store overwrites the latched values
-    if (n.d.kind == DSPFX_BIQUAD) {   // after_settings_change: renormalise + reset_state (biquad.rs:62-76)
-        biquad_regenerate(n);
-        HIPCHK(e, hipSetDevice(e->device));
-        HIPCHK(e, hipMemset(n.state, 0, n.state_bytes));
-    }
-    if (n.d.kind == DSPFX_DISTORT) {
-        // A new clip level is a new constant divisor.  Whether its fast form is exact is decided on the host (see
-        // divisor_is_fast) for everything but the even integers, so a slider store launches nothing and keeps the
-        // kernel it has; only a store that flips the verdict of the node's stage (to or from an even integer that
-        // failed its check) re-plans, and that picks among kernels that already exist.
-        for (const Stage &st : e->stages)
-            if (st.type == ST_FUSED && node >= st.first && node < st.first + st.count) {
-                HIPCHK(e, hipSetDevice(e->device));
-                if (stage_fast_div(e, st) != st.fast_div) return plan(e);
-            }
-    }
-    return DSPFX_OK;
+    if (param < 0) return fail(e, DSPFX_ERR_INVALID, "set_param(%d,%d) out of range", node, param);
+    return enqueue_store(e, node, param, value, nullptr);
+}
+
+extern "C" int dspfx_set_param_seq(dspfx_engine *e, int node, int param, float value, uint64_t *seq) {
+    if (!e) return DSPFX_ERR_INVALID;
+    if (param < 0) return fail(e, DSPFX_ERR_INVALID, "set_param(%d,%d) out of range", node, param);
+    return enqueue_store(e, node, param, value, seq);
 }
 
 extern "C" int dspfx_set_mode(dspfx_engine *e, int node, int mode) {
     if (!e) return DSPFX_ERR_INVALID;
-    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
-    Node &n = e->nodes[(size_t)node];
-    dspfx_node_desc d = n.d;
-    d.mode = mode;
-    d.taps = n.taps.data();
-    const int rc = validate_node(e, d);
-    if (rc) return rc;
-    n.d.mode = mode;
-    if (n.d.kind == DSPFX_FIR) n.fir.mode = mode;
-    return plan(e);   // Fuzz <-> other modes changes the stage split
+    return enqueue_store(e, node, -1, (float)mode, nullptr);
+}
+
+extern "C" int dspfx_param_log(dspfx_engine *e, dspfx_param_event *dst, int cap, uint64_t after_seq) {
+    if (!e || cap < 0 || (cap > 0 && !dst)) return DSPFX_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(e->pend_mu);
+    int n = 0;
+    for (const dspfx_param_event &ev : e->log)
+        if (ev.seq > after_seq && n < cap) dst[n++] = ev;
+    return n;
+}
+
+extern "C" uint64_t dspfx_frames_submitted(const dspfx_engine *e) {
+    if (!e) return 0;
+    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
+    return e->frames_submitted;
 }
 
 extern "C" int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_REVERB)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a REVERB node", node);
     if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
-    HIPCHK(e, hipSetDevice(e->device));
+    {   // the old ring is freed: nothing may still be reading it
+        const int rc = quiesce(e);
+        if (rc) return rc;
+    }
     Node &n = e->nodes[(size_t)node];
     n.D = delay_len;   // reverb.rs:55-71: a brand-new zero-filled ring
     n.d.delay_len = delay_len;
-    const int rc = alloc_node_state(e, n);
+    int rc = alloc_node_state(e, n);
     if (rc) return rc;
-    return plan(e);
+    rc = plan(e);
+    const int rs = settle_null_stream(e);
+    return rc ? rc : rs;
 }
 
 extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_FIR)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a FIR node", node);
     if (!taps_reversed || n_taps == 0) return fail(e, DSPFX_ERR_INVALID, "FIR node needs taps");
-    HIPCHK(e, hipSetDevice(e->device));
+    {   // blocks in flight still read the old tap tables (and the ring, should it have to grow)
+        const int rc = quiesce(e);
+        if (rc) return rc;
+    }
     Node &n = e->nodes[(size_t)node];
     n.taps.assign(taps_reversed, taps_reversed + n_taps);
     n.d.n_taps = n_taps;
     n.d.mode = mode;
-    if (!n.fir.ring) return alloc_node_state(e, n);
-    // fir.rs:153-171 replaces `taps` only: `state` (fir.rs:64-65) is never cleared, so the history survives
-    const int rc = fir_set_taps(n.fir, n.taps.data(), n_taps, mode);
-    return rc ? fail(e, rc, "FIR tap reload failed: %s", fir_last_error()) : DSPFX_OK;
+    int rc;
+    if (!n.fir.ring) rc = alloc_node_state(e, n);
+    else {
+        // fir.rs:153-171 replaces `taps` only: `state` (fir.rs:64-65) is never cleared, so the history survives
+        rc = fir_set_taps(n.fir, n.taps.data(), n_taps, mode);
+        if (rc) rc = fail(e, rc, "FIR tap reload failed: %s", fir_last_error());
+    }
+    const int rs = settle_null_stream(e);
+    return rc ? rc : rs;
 }
 
 extern "C" int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_FIR)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a FIR node", node);
     if (precision < DSPFX_FIR_PRECISION_DEFAULT || precision > DSPFX_FIR_PRECISION_SPLIT)
@@ -1587,18 +1827,26 @@ extern "C" int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision)
     return DSPFX_OK;
 }
 
-extern "C" int dspfx_reset(dspfx_engine *e) {
-    if (!e) return DSPFX_ERR_INVALID;
-    HIPCHK(e, hipSetDevice(e->device));
+namespace {
+// Zero every node's DSP state, queued on `s`: ordered behind the blocks in flight there, ahead of the next one.
+int reset_on(dspfx_engine *e, hipStream_t s) {
     for (Node &n : e->nodes) {
-        if (n.state) HIPCHK(e, hipMemset(n.state, 0, n.d.kind == DSPFX_BIQUAD ? 4 * (size_t)e->desc.channels * sizeof(float)
-                                                                              : (size_t)e->desc.channels * sizeof(float)));
-        for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, n.group_floats * sizeof(float)));
+        if (n.state) HIPCHK(e, hipMemsetAsync(n.state, 0, n.d.kind == DSPFX_BIQUAD ? 4 * (size_t)e->desc.channels * sizeof(float)
+                                                                                   : (size_t)e->desc.channels * sizeof(float), s));
+        for (float *g : n.groups) HIPCHK(e, hipMemsetAsync(g, 0, n.group_floats * sizeof(float), s));
         n.pos = 0;
-        if (n.d.kind == DSPFX_FIR) fir_reset(n.fir);
+        if (n.d.kind == DSPFX_FIR) fir_reset(n.fir, s);
     }
     e->mp_count = 0;   // blocks still in the mix pipeline are dropped
     return DSPFX_OK;
+}
+}  // namespace
+
+extern "C" int dspfx_reset(dspfx_engine *e) {
+    if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
+    return reset_on(e, e->cur_stream_set ? e->cur_stream : nullptr);
 }
 
 // ------------------------------------------------------------- the hot path
@@ -1606,42 +1854,62 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
 // Placement tuning against the caller's own buffers (see include/dspfx.h).  Every candidate 128-row group of every
 // large delay ring is timed with the REAL chain (all stages, the engine's chosen kernels) reading `in` and writing
 // `out`: the node temporarily becomes a 128-row ring made of that one group.  The fastest groups are kept.
-// The engine's DSP state survives: filter / generator state is snapshotted and restored around the probes, every ring
-// group's rows are parked in a scratch group while it is probed and put back (or moved into the candidate that
-// replaces it, at the same ring position), the ring position is untouched.  (Engines with a FIR node still reset:
-// its history cannot be parked that cheaply.)
+// The engine's DSP state survives.  The probes run whole blocks through EVERY node, so everything a block writes is
+// parked first and put back afterwards:
+//   * filter / generator / envelope rows: snapshotted, restored at the end;
+//   * every delay ring (the probed one, the small ones, the ones probed earlier or later): its position is put back
+//     before every probe run, so all probes overwrite the same n_frames rows -- parked once, restored at the end;
+//   * the ring being probed: each of its groups is parked in a scratch group while it stands in as the one-group ring,
+//     and put back (or moved into the candidate that replaces it, at the same ring position);
+//   * FIR nodes: the rows the probes' samples land in, the non-finite flags, the fill-phase sums and the host-side
+//     deque model (fir_park / fir_rewind / fir_unpark).
 namespace {
-struct TuneGuard {   // whatever happens inside the probe loop, the node gets its real ring geometry back and nothing leaks
+struct TuneGuard {   // whatever happens inside the probe loop, every node gets its real geometry / position back and nothing leaks
     dspfx_engine *e;
     Node *n = nullptr;
-    uint32_t D0 = 0, pos0 = 0, min0 = 0;
+    uint32_t D0 = 0, min0 = 0;
     float **table0 = nullptr, **d_one = nullptr;
     float *park = nullptr;
     hipEvent_t ea = nullptr, eb = nullptr;
     std::vector<float *> extras;            // candidates allocated here and not (yet) adopted by the ring
     std::vector<std::pair<float *, size_t>> snaps;   // device copies of node state: (copy, node index)
-    explicit TuneGuard(dspfx_engine *e_) : e(e_) {}
+    std::vector<uint32_t> pos0;             // ring position of every node on entry
+    std::vector<float *> rows;              // per node: the parked rows [n_frames][N] of its delay ring (or null)
+    std::vector<FirPark> firs;              // per node
+    explicit TuneGuard(dspfx_engine *e_) : e(e_), pos0(e_->nodes.size(), 0), rows(e_->nodes.size(), nullptr), firs(e_->nodes.size()) {
+        for (size_t i = 0; i < e->nodes.size(); ++i) pos0[i] = e->nodes[i].pos;
+    }
     void arm(Node &node) {
         n = &node;
         D0 = node.D;
-        pos0 = node.pos;
         min0 = e->min_delay;
         table0 = node.d_groups;
     }
     void disarm() {
         if (!n) return;
         n->D = D0;
-        n->pos = pos0;
         n->d_groups = table0;
         e->min_delay = min0;
         n = nullptr;
     }
+    // host-side positions as on entry (the node being probed: a one-group ring at position 0)
+    void rewind() {
+        for (size_t i = 0; i < e->nodes.size(); ++i) {
+            Node &m = e->nodes[i];
+            if (m.d.kind == DSPFX_REVERB) m.pos = &m == n ? 0 : pos0[i];
+            if (m.d.kind == DSPFX_FIR && firs[i].rows) fir_rewind(m.fir, firs[i]);
+        }
+    }
     ~TuneGuard() {
         disarm();
+        rewind();
         for (float *g : extras)
             if (g) (void)hipFree(g);
         for (auto &sn : snaps)
             if (sn.first) (void)hipFree(sn.first);
+        for (float *r : rows)
+            if (r) (void)hipFree(r);
+        for (FirPark &f : firs) fir_park_free(f);
         if (d_one) (void)hipFree(d_one);
         if (park) (void)hipFree(park);
         if (ea) (void)hipEventDestroy(ea);
@@ -1654,29 +1922,35 @@ struct TuneGuard {   // whatever happens inside the probe loop, the node gets it
 extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                                     void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    ApiScope api(e, true, s);
+    if (api.rc) return api.rc;
     if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
     if (n_frames == 0 || n_frames > e->desc.max_frames || n_frames > RING_GROUP_ROWS)
         return fail(e, DSPFX_ERR_INVALID, "n_frames must be 1..%u here", std::min<uint32_t>(e->desc.max_frames, RING_GROUP_ROWS));
     if (e->collect_due || e->mp_count) return fail(e, DSPFX_ERR_STATE, "flush the mix pipeline before tuning");
-    HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t s = (hipStream_t)stream;
-    bool has_fir = false, any = false;
-    for (const Node &n : e->nodes) {
-        has_fir = has_fir || n.d.kind == DSPFX_FIR;
-        any = any || (n.d.kind == DSPFX_REVERB && n.group_floats * sizeof(float) >= ((size_t)64 << 20));
-    }
+    bool any = false;
+    for (const Node &n : e->nodes) any = any || (n.d.kind == DSPFX_REVERB && n.group_floats * sizeof(float) >= ((size_t)64 << 20));
     if (!any) return DSPFX_OK;               // nothing large enough to be placement-sensitive: state untouched
     if (e->graph_mode)                       // a region kernel with extra blocks: its buffers are not all known here
         for (const dspfx_graph_link &l : e->wiring)
             if (graph_input_block(l.src) >= 2 || l.dst > (int)e->nodes.size()) return DSPFX_OK;
+    const uint32_t N = e->desc.channels;
+    const uint32_t W = e->desc.tile_channels ? e->desc.tile_channels : N;
     TuneGuard tg(e);
     if (hipEventCreate(&tg.ea) != hipSuccess || hipEventCreate(&tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventCreate failed");
-    // snapshot the small per-channel state (biquad / one-pole / generator / envelope rows): the probes run the real chain
-    if (!has_fir) {
-        HIPCHK(e, hipStreamSynchronize(s));
-        for (size_t i = 0; i < e->nodes.size(); ++i) {
-            Node &n = e->nodes[i];
-            if (!n.state || !n.state_bytes || n.d.kind == DSPFX_REVERB) continue;
+    HIPCHK(e, hipStreamSynchronize(s));
+    // park what a block writes: small per-channel state rows, the block's rows of every delay ring, FIR histories
+    for (size_t i = 0; i < e->nodes.size(); ++i) {
+        Node &n = e->nodes[i];
+        if (n.d.kind == DSPFX_REVERB) {
+            if (hipMalloc((void **)&tg.rows[i], (size_t)n_frames * N * sizeof(float)) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "no room to park ring rows");
+            launch_ring_copy(n.d_groups, tg.rows[i], N, W, n.D, n.pos, n_frames, true, s);
+            HIPCHK(e, hipGetLastError());
+        } else if (n.d.kind == DSPFX_FIR) {
+            const int rc = fir_park(n.fir, n_frames, s, tg.firs[i]);
+            if (rc) return fail(e, rc, "FIR: %s", fir_last_error());
+        } else if (n.state && n.state_bytes) {
             float *copy = nullptr;
             if (hipMalloc((void **)&copy, n.state_bytes) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "no room for a state snapshot");
             tg.snaps.emplace_back(copy, i);
@@ -1694,7 +1968,7 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipMemGetInfo failed");
         const size_t reserve = ((size_t)8 << 30) + gbytes;             // room for the caller + the parking group
         size_t extra = free_b > reserve ? std::min(G, (free_b - reserve) / gbytes) : 0;
-        if (!tg.park && !has_fir && big_alloc((void **)&tg.park, gbytes) != hipSuccess) {
+        if (!tg.park && big_alloc((void **)&tg.park, gbytes) != hipSuccess) {
             (void)hipGetLastError();
             return fail(e, DSPFX_ERR_OOM, "no room to park a ring group (%zu MiB)", gbytes >> 20);
         }
@@ -1713,12 +1987,12 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         n.d_groups = tg.d_one;
         std::vector<float> t(cand.size(), 0.0f);
         for (size_t g = 0; g < cand.size() && rc == DSPFX_OK; ++g) {
-            const bool live = g < G && !has_fir;        // holds ring rows that must survive
+            const bool live = g < G;                    // holds ring rows that must survive
             if (live && hipMemcpyAsync(tg.park, cand[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
             if (rc == DSPFX_OK && hipMemcpyAsync(tg.d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
             float best = 1e30f;
             for (int rep = 0; rep < 3 && rc == DSPFX_OK; ++rep) {
-                n.pos = 0;
+                tg.rewind();
                 (void)hipEventRecord(tg.ea, s);
                 rc = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
                 (void)hipEventRecord(tg.eb, s);
@@ -1733,6 +2007,7 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
                 rc = fail(e, DSPFX_ERR_HIP, "restoring a ring group failed");
         }
         tg.disarm();
+        tg.rewind();
         if (rc) return rc;
         if (getenv("DSPFX_RING_TUNE_DEBUG")) {
             fprintf(stderr, "placement tuning ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
@@ -1753,7 +2028,7 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         for (size_t p = 0; p < G; ++p) {
             if (keep[p]) continue;
             const size_t x = spare[next_spare++];
-            if (!has_fir && hipMemcpyAsync(cand[x], cand[p], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "moving a ring group failed");
+            if (hipMemcpyAsync(cand[x], cand[p], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "moving a ring group failed");
             std::swap(cand[p], cand[x]);              // cand[p] is the ring's group now, cand[x] the dropped allocation
             ++replaced;
         }
@@ -1763,13 +2038,26 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
         cand.resize(G);
         n.groups = cand;
         n.ring_replaced = replaced;
-        HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpyAsync(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice, s));
+        HIPCHK(e, hipStreamSynchronize(s));
     }
-    if (has_fir) return dspfx_reset(e);   // probing ran blocks through the FIR history: start clean
+    // put back what the probes' blocks overwrote
+    tg.rewind();
+    for (size_t i = 0; i < e->nodes.size(); ++i) {
+        Node &n = e->nodes[i];
+        if (n.d.kind == DSPFX_REVERB && tg.rows[i]) {
+            launch_ring_copy(n.d_groups, tg.rows[i], N, W, n.D, n.pos, n_frames, false, s);
+            HIPCHK(e, hipGetLastError());
+        } else if (n.d.kind == DSPFX_FIR) {
+            const int r = fir_unpark(n.fir, tg.firs[i], s);
+            if (r) return fail(e, r, "FIR: %s", fir_last_error());
+        }
+    }
     for (auto &sn : tg.snaps) {
         Node &n = e->nodes[sn.second];
         if (hipMemcpyAsync(n.state, sn.first, n.state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "restoring node state failed");
     }
+    // control-port latches are only written while a port is connected: the probes connect none
     HIPCHK(e, hipStreamSynchronize(s));
     return DSPFX_OK;
 }
@@ -1777,14 +2065,15 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
 extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                              uint32_t n_frames, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    ApiScope api(e, true, s);            // queued slider stores take effect here, at the block boundary
+    if (api.rc) return api.rc;
     if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
     if (n_frames == 0) return DSPFX_OK;
     if (n_frames > e->desc.max_frames)
         return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
     if (e->has_fuzz && n_frames % DSPFX_BUF_SIZE)
         return fail(e, DSPFX_ERR_INVALID, "Fuzz is block-global over 128 frames: n_frames %u %% 128 != 0", n_frames);
-    HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t s = (hipStream_t)stream;
     // a block's delay taps must not depend on the same launch's outputs: split at min delay
     uint32_t sub = std::min(n_frames, e->min_delay);
     if (e->has_fuzz || e->has_siggen) sub = std::max<uint32_t>(DSPFX_BUF_SIZE, sub / DSPFX_BUF_SIZE * DSPFX_BUF_SIZE);
@@ -1798,6 +2087,7 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
                                     nf, e->ctl_tile_frames ? e->ctl_tile_frames : n_frames, s);
         e->io_off = 0;
         if (rc) return rc;
+        e->frames_submitted += nf;
     }
     return DSPFX_OK;
 }
@@ -1805,6 +2095,8 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
 extern "C" int dspfx_process_io(dspfx_engine *e, const float *const *ins, int n_ins, float *const *outs, int n_outs, float *mix,
                                 uint32_t n_frames, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e, true, (hipStream_t)stream);
+    if (api.rc) return api.rc;
     if (n_ins < 0 || n_ins > DSPFX_GRAPH_MAX_IO || n_outs < 1 || n_outs > DSPFX_GRAPH_MAX_IO || (n_ins > 0 && !ins) || !outs || !outs[0])
         return fail(e, DSPFX_ERR_INVALID, "process_io: 0..%d input blocks, 1..%d output blocks (the first one non-null)", DSPFX_GRAPH_MAX_IO, DSPFX_GRAPH_MAX_IO);
     if (!e->graph_mode && (n_ins > 2 || n_outs > 1)) return fail(e, DSPFX_ERR_INVALID, "only a graph engine (dspfx_graph_set) takes extra blocks");
@@ -1825,9 +2117,10 @@ extern "C" int dspfx_process_io(dspfx_engine *e, const float *const *ins, int n_
 extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                                  uint32_t n_frames, const dspfx_ctl *ctl, int n_ctl, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e, true, (hipStream_t)stream);
+    if (api.rc) return api.rc;
     if (n_ctl < 0 || (n_ctl > 0 && !ctl)) return fail(e, DSPFX_ERR_INVALID, "bad control-port list");
     if (n_ctl > 0 && e->graph_mode) return fail(e, DSPFX_ERR_INVALID, "a fused graph's control ports are links of the graph");
-    HIPCHK(e, hipSetDevice(e->device));
     if (n_ctl > 0 && !e->no_long) {   // control ports are evaluated by the chain kernels: cut long stages back to their size
         bool has_long = false;
         for (const Stage &st : e->stages) has_long = has_long || (st.type == ST_FUSED && st.count > MAX_SLOTS);
@@ -1909,10 +2202,11 @@ bool is_pinned_host(const void *p) {
 extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                                   uint32_t n_frames) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
     if (n_frames > e->desc.max_frames)
         return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
-    HIPCHK(e, hipSetDevice(e->device));
     const size_t cap = (size_t)e->desc.max_frames * e->desc.channels * sizeof(float);
     const size_t bytes = (size_t)n_frames * e->desc.channels * sizeof(float);
     if (!e->h_in) HIPCHK(e, hipMalloc((void **)&e->h_in, cap));
@@ -1933,6 +2227,10 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
             HIPCHK(e, hipStreamCreateWithFlags(&e->hs_in, hipStreamNonBlocking));
             HIPCHK(e, hipStreamCreateWithFlags(&e->hs_out, hipStreamNonBlocking));
             HIPCHK(e, hipStreamCreateWithFlags(&e->hs_run, hipStreamNonBlocking));
+        }
+        {   // the parts run on the engine's own stream: order it behind whatever used the state last
+            const int brc = bind_stream(e, e->hs_run);
+            if (brc) return brc;
         }
         const uint32_t n_parts = (N + part - 1) / part;
         while (e->hev.size() < 2 * (size_t)n_parts) {
@@ -1970,6 +2268,7 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
         (void)hipStreamSynchronize(e->hs_in);
         (void)hipStreamSynchronize(e->hs_run);
         HIPCHK(e, hipStreamSynchronize(e->hs_out));
+        if (rc == DSPFX_OK) e->frames_submitted += n_frames;
         return rc;
     }
     HIPCHK(e, hipMemcpy(e->h_in, in, bytes, hipMemcpyHostToDevice));
@@ -1986,12 +2285,13 @@ extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float 
 extern "C" int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, float *out,
                                       uint32_t n_frames, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    hipStream_t s = (hipStream_t)stream;
+    ApiScope api(e, true, s);
+    if (api.rc) return api.rc;
     if (e->collect_due) return fail(e, DSPFX_ERR_STATE, "dspfx_mix_collect must follow dspfx_process_partials");
     if (n_frames == 0 || n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "bad n_frames %u", n_frames);
     if (n_frames > e->min_delay)
         return fail(e, DSPFX_ERR_UNSUPPORTED, "deferred mix needs n_frames <= shortest delay line (%u)", e->min_delay);
-    HIPCHK(e, hipSetDevice(e->device));
-    hipStream_t s = (hipStream_t)stream;
     const int b = e->flip;
     if (!e->mixpart2[b]) {
         HIPCHK(e, hipMalloc((void **)&e->mixpart2[b], e->mixpart_cols * e->desc.max_frames * sizeof(float)));
@@ -2014,6 +2314,8 @@ extern "C" int dspfx_process_partials(dspfx_engine *e, const float *in, const fl
 
 extern "C" int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stream) {
     if (!e || !mix) return DSPFX_ERR_INVALID;
+    ApiScope api(e);                     // (its stream only reads the partial sums: the DSP state stays bound to the chain's stream)
+    if (api.rc) return api.rc;
     if (!e->collect_due) return fail(e, DSPFX_ERR_STATE, "no partials pending: call dspfx_process_partials first");
     const int b = e->flip;
     if (n_frames != e->part_frames[b]) return fail(e, DSPFX_ERR_INVALID, "n_frames %u != %u of the pending block", n_frames, e->part_frames[b]);
@@ -2032,6 +2334,8 @@ extern "C" int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames,
 extern "C" int dspfx_process_mixpipe(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                                      uint32_t n_frames, uint64_t n_connected, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e, true, (hipStream_t)stream);
+    if (api.rc) return api.rc;
     if (e->collect_due) return fail(e, DSPFX_ERR_STATE, "dspfx_mix_collect must follow dspfx_process_partials");
     if (n_frames == 0 || n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "bad n_frames %u", n_frames);
     if (n_frames > e->min_delay)
@@ -2067,6 +2371,8 @@ extern "C" int dspfx_process_mixpipe(dspfx_engine *e, const float *in, const flo
 
 extern "C" int dspfx_mixpipe_flush(dspfx_engine *e, float *mix_older, float *mix_newer, uint64_t n_connected, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e, true, (hipStream_t)stream);
+    if (api.rc) return api.rc;
     if (e->mp_count == 0) return DSPFX_OK;
     if (!mix_newer || (e->mp_count >= 2 && !mix_older)) return fail(e, DSPFX_ERR_INVALID, "mix buffers must not be null");
     HIPCHK(e, hipSetDevice(e->device));
@@ -2096,6 +2402,8 @@ extern "C" int dspfx_mixpipe_flush(dspfx_engine *e, float *mix_older, float *mix
 
 extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_connected, void *stream) {
     if (!e || !mix) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     HIPCHK(e, hipSetDevice(e->device));
     if (e->div_n != n_connected || e->div_v == 0.0f) {   // the literal f32 increment loop is O(n): cache it
         e->div_v = dspfx_link_divisor(n_connected);
@@ -2121,7 +2429,8 @@ struct Rccl {
     int (*CommDestroy)(void *) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
-    std::string err;
+    std::string err;          // why RCCL is unavailable, or the last failure that left no communicator behind
+    std::mutex err_mu;
 };
 Rccl *rccl() {
     static Rccl r;
@@ -2164,7 +2473,13 @@ extern "C" int dspfx_comm_unique_id(void *id_out) {
     Rccl *r = rccl();
     if (!r->lib) return DSPFX_ERR_UNSUPPORTED;
     static_assert(sizeof(IdBlob) == DSPFX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-    return r->GetUniqueId(id_out) == 0 ? DSPFX_OK : DSPFX_ERR_HIP;
+    const int rc = r->GetUniqueId(id_out);
+    if (rc != 0) {
+        std::lock_guard<std::mutex> lk(r->err_mu);
+        r->err = std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed");
+        return DSPFX_ERR_HIP;
+    }
+    return DSPFX_OK;
 }
 
 extern "C" int dspfx_comm_create(int device, int n_ranks, int rank, const void *id, dspfx_comm **out) {
@@ -2192,6 +2507,10 @@ extern "C" int dspfx_comm_create(int device, int n_ranks, int rank, const void *
         memcpy(blob.bytes, id, sizeof blob.bytes);
         const int rc = r->CommInitRank(&c->comm, n_ranks, blob, rank);
         if (rc != 0) {
+            {   // dspfx_comm_last_error(NULL) reports it: there is no communicator to ask
+                std::lock_guard<std::mutex> lk(r->err_mu);
+                r->err = std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed");
+            }
             delete c;
             return DSPFX_ERR_HIP;
         }
@@ -2211,11 +2530,20 @@ extern "C" void dspfx_comm_destroy(dspfx_comm *c) {
 
 extern "C" int dspfx_comm_size(const dspfx_comm *c) { return c ? c->n_ranks : DSPFX_ERR_INVALID; }
 extern "C" int dspfx_comm_rank(const dspfx_comm *c) { return c ? c->rank : DSPFX_ERR_INVALID; }
-extern "C" const char *dspfx_comm_last_error(const dspfx_comm *c) { return c ? c->err.c_str() : rccl()->err.c_str(); }
+extern "C" const char *dspfx_comm_last_error(const dspfx_comm *c) {
+    if (c) return c->err.c_str();
+    static thread_local std::string copy;
+    Rccl *r = rccl();
+    std::lock_guard<std::mutex> lk(r->err_mu);
+    copy = r->err;
+    return copy.c_str();
+}
 
 extern "C" int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, uint32_t n_frames, uint64_t n_connected,
                                    void *stream) {
     if (!e || !c || !mix) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (n_frames == 0) return DSPFX_OK;
     if (c->device != e->device) return fail(e, DSPFX_ERR_INVALID, "communicator lives on device %d, engine on %d", c->device, e->device);
     HIPCHK(e, hipSetDevice(e->device));
@@ -2235,6 +2563,8 @@ extern "C" int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, u
 extern "C" int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
                                   void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (!dst || n_srcs < 0 || (n_srcs > 0 && !srcs)) return fail(e, DSPFX_ERR_INVALID, "bad link list");
     if (n_srcs > DSPFX_MAX_LINKS) return fail(e, DSPFX_ERR_UNSUPPORTED, "more than %d links into one port", DSPFX_MAX_LINKS);
     if (n_frames == 0) return DSPFX_OK;
@@ -2255,7 +2585,9 @@ extern "C" int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int
 }
 
 extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
-    if (!e || node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;
+    if (!e) return DSPFX_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
+    if (node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;
     const Node &n = e->nodes[(size_t)node];
     if (n.d.kind == DSPFX_FIR) return (int64_t)fir_state_bytes(n.fir);
     if (n.d.kind == DSPFX_REVERB) return (int64_t)n.D * e->desc.channels * (int64_t)sizeof(float);   // canonical [D][N]
@@ -2264,6 +2596,8 @@ extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
 
 extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, size_t size) {
     if (!e || !host_dst) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
     Node &n = e->nodes[(size_t)node];
     const int64_t need = dspfx_state_size(e, node);
@@ -2282,9 +2616,12 @@ extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, siz
 
 extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_src, size_t size) {
     if (!e || !host_src) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
     Node &n = e->nodes[(size_t)node];
-    const int64_t need = dspfx_state_size(e, node);
+    // a FIR node's blob carries its own length (the deque's, which need not be this engine's current one)
+    const int64_t need = n.d.kind == DSPFX_FIR ? fir_state_import_bytes(n.fir, host_src, size) : dspfx_state_size(e, node);
     if ((int64_t)size != need) return fail(e, DSPFX_ERR_INVALID, "state size %zu != %lld", size, (long long)need);
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipDeviceSynchronize());
@@ -2299,7 +2636,7 @@ extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_sr
         HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
     }
     n.pos = 0;
-    return DSPFX_OK;
+    return settle_null_stream(e);
 }
 
 // ---------------------------------------------------------------- utilities
@@ -2307,7 +2644,8 @@ extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_sr
 extern "C" int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, uint32_t n_abs0, uint32_t seed,
                                 void *stream) {
     if (!e || !dst) return DSPFX_ERR_INVALID;
-    HIPCHK(e, hipSetDevice(e->device));
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     Layout lay{};
     if (e->desc.tile_channels) {
         const uint32_t W = e->desc.tile_channels;
@@ -2365,6 +2703,8 @@ extern "C" int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uin
 
 extern "C" int dspfx_profile_enable(dspfx_engine *e, int enable) {
     if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     e->profiling = enable != 0;
     if (enable > 0) {   // `enable` doubles as a hint: events for that many launches are created now,
         HIPCHK(e, hipSetDevice(e->device));   // outside the timed region (hipEventCreate is slow)
@@ -2380,7 +2720,8 @@ extern "C" int dspfx_profile_enable(dspfx_engine *e, int enable) {
 extern "C" int dspfx_profile_read(dspfx_engine *e, double *total_ms, uint32_t *launches, char *kernel_name,
                                   size_t cap, int reset) {
     if (!e) return DSPFX_ERR_INVALID;
-    HIPCHK(e, hipSetDevice(e->device));
+    ApiScope api(e);
+    if (api.rc) return api.rc;
     double best = -1.0;
     uint32_t best_n = 0;
     size_t best_stage = 0;
@@ -2426,6 +2767,7 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
     // + per-block state traffic / n_frames, + 4 B side input for ADD/MIX,
     // FIR: + 4 B history write + 4*(T-1)/n_frames history re-read.
     if (!e || n_frames == 0) return 0.0;
+    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
     double b = 8.0;
     bool side = false;
     for (const Node &n : e->nodes) {
@@ -2458,6 +2800,7 @@ extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint
 
 extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
     if (!e || !dst || cap == 0) return DSPFX_ERR_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
     static const char *kn[] = {"gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "overdrive",
                                "chebyshev", "fir", "add", "mix", "signal_gen", "envelope"};
     std::string s;

@@ -71,15 +71,38 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
 // Impulse-response reload (fir.rs:153-171): new taps, the history and the deque's length are KEPT.
 int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode);
 void fir_free(FirState &s);
-void fir_reset(FirState &s);
+// Empty history; the device writes are queued on `stream` (ordered with the blocks in flight there).
+void fir_reset(FirState &s, hipStream_t stream);
 // ev_begin/ev_end (optional) are recorded around the compute kernel(s).  mixpart (optional): [ceil(N/32)][nframes] floats
 // that receive, per 32-channel tile and frame, the sum of the block's outputs (the Output node's mix bus, first stage).
 int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int hop, float hop_div,
                 const Layout &lay, hipStream_t stream, hipEvent_t ev_begin = nullptr, hipEvent_t ev_end = nullptr,
                 float *mixpart = nullptr, const FirMixPipe *mixpipe = nullptr);
+// Exported state: a FIR_STATE_HEADER-byte header (n_seen, deque length, VecDeque capacity / head, tap count) + the deque's
+// samples [held][N] f32, oldest first (fir_kernels.hip, fir_state_export).
+constexpr size_t FIR_STATE_HEADER = 32;
 size_t fir_state_bytes(const FirState &s);
 int fir_state_export(FirState &s, void *host_dst);
+// bytes the blob at host_src must have (read from its header), or -1 when `size` cannot even hold a header
+int64_t fir_state_import_bytes(const FirState &s, const void *host_src, size_t size);
 int fir_state_import(FirState &s, const void *host_src);
+// Placement tuning runs real blocks through the node.  fir_park snapshots what up to `nframes` more samples overwrite (the
+// ring rows they land in, the non-finite flags, the fill phase's running sums, the host-side deque model), fir_rewind
+// puts the host-side counters back before each probe run, fir_unpark restores everything.
+struct FirPark {
+    float *rows = nullptr;
+    unsigned long long *nf = nullptr;
+    double *acc = nullptr;
+    uint32_t nframes = 0;
+    uint64_t n_seen = 0, front = 0;
+    uint32_t dq_cap = 0, dq_head = 0;
+    bool warm_ok = false;
+    const char *last_kernel = nullptr;
+};
+int fir_park(FirState &s, uint32_t nframes, hipStream_t stream, FirPark &p);
+void fir_rewind(FirState &s, const FirPark &p);
+int fir_unpark(FirState &s, FirPark &p, hipStream_t stream);
+void fir_park_free(FirPark &p);
 const char *fir_kernel_name(const FirState &s);
 const char *fir_last_error();
 

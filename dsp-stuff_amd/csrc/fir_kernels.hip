@@ -723,6 +723,19 @@ __global__ void __launch_bounds__(256) fir_rows_kernel(float *ring, float *dense
     }
 }
 
+// nf_time[tile] = 1 + time of the newest non-finite sample among the times [0, held) (an imported history)
+__global__ void __launch_bounds__(256) fir_flag_scan_kernel(const float *ring, unsigned long long *nf_time, uint32_t N, uint32_t R,
+                                                            unsigned long long held) {
+    const uint32_t tile = blockIdx.x;
+    unsigned long long best = 0;
+    for (unsigned long long i = threadIdx.x; i < held * TILE_C; i += 256) {
+        const unsigned long long t = i / TILE_C;
+        const uint32_t c = tile * TILE_C + (uint32_t)(i % TILE_C);
+        if (c < N && !finite_f32(ring[ring_at(c, (uint32_t)(t % R), R)])) best = t + 1 > best ? t + 1 : best;
+    }
+    if (best) atomicMax(&nf_time[tile], best);
+}
+
 static uint32_t ring_rows_for(uint64_t held, uint32_t n_taps, uint32_t max_frames) {
     // rows the sweep may touch: the deque (held samples, at least T-1), the block, the alignment pad and one chunk of slack
     // (the skewed sweep prefetches up to eight chunks past the newest row of a full slice)
@@ -835,6 +848,26 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     return upload_taps(s, taps_reversed, n_taps);
 }
 
+// A ring of at least `need` rows that still holds the deque (sample times [front, n_seen)).
+static int grow_ring(FirState &s, uint32_t need) {
+    if (need <= s.R) return 0;
+    const uint64_t held = s.n_seen - s.front;
+    float *nr = nullptr;
+    const size_t bytes = ring_bytes_for(s.tiles, need);
+    FIRCHK(hipMalloc((void **)&nr, bytes));
+    FIRCHK(hipMemset(nr, 0, bytes));
+    if (held) {
+        hipLaunchKernelGGL(fir_rebase_kernel, dim3(1024), dim3(256), 0, nullptr, s.ring, nr, s.tiles, s.R, need, (unsigned long long)s.front,
+                           (unsigned long long)s.n_seen);
+        FIRCHK(hipGetLastError());
+    }
+    FIRCHK(hipDeviceSynchronize());
+    (void)hipFree(s.ring);
+    s.ring = nr;
+    s.R = need;
+    return 0;
+}
+
 int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode) {
     if (!s.ring) {
         g_fir_err = "FIR node has no state yet";
@@ -844,22 +877,8 @@ int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int 
     s.mode = mode;
     s.warm_ok = s.warm_ok && s.n_seen == 0;              // running sums of the old taps are worthless
     const uint64_t held = s.n_seen - s.front;            // the deque survives the reload (fir.rs:153-171 touches `taps` only)
-    const uint32_t need = ring_rows_for(held, n_taps, s.max_frames);
-    if (need > s.R) {
-        float *nr = nullptr;
-        const size_t bytes = ring_bytes_for(s.tiles, need);
-        FIRCHK(hipMalloc((void **)&nr, bytes));
-        FIRCHK(hipMemset(nr, 0, bytes));
-        if (held) {
-            hipLaunchKernelGGL(fir_rebase_kernel, dim3(1024), dim3(256), 0, nullptr, s.ring, nr, s.tiles, s.R, need, (unsigned long long)s.front,
-                               (unsigned long long)s.n_seen);
-            FIRCHK(hipGetLastError());
-            FIRCHK(hipDeviceSynchronize());
-        }
-        (void)hipFree(s.ring);
-        s.ring = nr;
-        s.R = need;
-    }
+    const int rc = grow_ring(s, ring_rows_for(held, n_taps, s.max_frames));
+    if (rc) return rc;
     return upload_taps(s, taps_reversed, n_taps);
 }
 
@@ -879,10 +898,11 @@ void fir_free(FirState &s) {
     s.nf_time = nullptr;
 }
 
-void fir_reset(FirState &s) {
-    if (s.ring) (void)hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R));
-    if (s.nf_time) (void)hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long));
-    if (s.warm_acc) (void)hipMemset(s.warm_acc, 0, (size_t)s.N * sizeof(double));
+void fir_reset(FirState &s, hipStream_t stream) {
+    // queued on the caller's stream: behind the blocks in flight there, ahead of the next one
+    if (s.ring) (void)hipMemsetAsync(s.ring, 0, ring_bytes_for(s.tiles, s.R), stream);
+    if (s.nf_time) (void)hipMemsetAsync(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long), stream);
+    if (s.warm_acc) (void)hipMemsetAsync(s.warm_acc, 0, (size_t)s.N * sizeof(double), stream);
     s.warm_ok = s.warm_acc != nullptr;
     s.n_seen = 0;
     s.front = 0;
@@ -1063,8 +1083,15 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
     return 0;
 }
 
-// exported state: u64 n_seen, then the T-1 most recent samples [t][N], oldest first
-size_t fir_state_bytes(const FirState &s) { return 8 + (size_t)(s.T - 1) * s.N * sizeof(float); }
+// Exported state = the reference's `state: VecDeque<f64>` (fir.rs:64-65) as it stands: a 32-byte header
+//   u64 n_seen   samples pushed since the deque was last empty (informational)
+//   u64 held     the deque's length: < T while it fills, T in steady state, > T after a reload with a shorter
+//                impulse response (fir.rs:153-171 keeps `state`; fir.rs:193-197 pops one sample per step)
+//   u32 dq_cap, u32 dq_head   std VecDeque's buffer capacity and head index: they decide where as_slices() splits the
+//                deque, i.e. which terms go into the partial sums `a` and `b` (fir.rs:201-216)
+//   u32 n_taps, u32 reserved
+// then the `held` samples [held][N] f32, oldest first (f32 is exact: the reference widens f32 samples).
+size_t fir_state_bytes(const FirState &s) { return FIR_STATE_HEADER + (size_t)(s.n_seen - s.front) * s.N * sizeof(float); }
 
 // dense rows [t0, t0 + n) <-> host, through a device staging buffer in pieces of at most 64 MiB
 static int copy_rows(FirState &s, long long t0, uint64_t n, char *host, bool to_host) {
@@ -1094,34 +1121,116 @@ static int copy_rows(FirState &s, long long t0, uint64_t n, char *host, bool to_
 }
 
 int fir_state_export(FirState &s, void *host_dst) {
+    const uint64_t held = s.n_seen - s.front;
+    const uint32_t hdr32[4] = {s.dq_cap, s.dq_head, s.T, 0};
     memcpy(host_dst, &s.n_seen, 8);
-    if (s.T < 2) return 0;
+    memcpy((char *)host_dst + 8, &held, 8);
+    memcpy((char *)host_dst + 16, hdr32, 16);
+    if (!held) return 0;
     FIRCHK(hipDeviceSynchronize());
-    // sample times n_seen - (T-1) ... n_seen - 1 ; before the start of time => zeros
-    return copy_rows(s, (long long)s.n_seen - (long long)(s.T - 1), s.T - 1, (char *)host_dst + 8, true);
+    return copy_rows(s, (long long)s.front, held, (char *)host_dst + FIR_STATE_HEADER, true);
+}
+
+int64_t fir_state_import_bytes(const FirState &s, const void *host_src, size_t size) {
+    if (size < FIR_STATE_HEADER) return -1;
+    uint64_t held;
+    memcpy(&held, (const char *)host_src + 8, 8);
+    if (held > ((uint64_t)1 << 32)) return -1;
+    return (int64_t)(FIR_STATE_HEADER + held * s.N * sizeof(float));
 }
 
 int fir_state_import(FirState &s, const void *host_src) {
-    uint64_t seen;
+    uint64_t seen, held;
+    uint32_t hdr32[4];
     memcpy(&seen, host_src, 8);
-    const char *src = (const char *)host_src + 8;
-    const size_t row = (size_t)s.N * sizeof(float);
+    memcpy(&held, (const char *)host_src + 8, 8);
+    memcpy(hdr32, (const char *)host_src + 16, 16);
+    const char *src = (const char *)host_src + FIR_STATE_HEADER;
     FIRCHK(hipDeviceSynchronize());
-    FIRCHK(hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R)));
-    FIRCHK(hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long)));
-    // re-base time so that the imported history occupies rows [0, hist): a deque of `hist` samples pushed from empty
-    const uint64_t hist = seen < s.T - 1 ? seen : s.T - 1;
-    if (hist) {
-        const int rc = copy_rows(s, 0, hist, const_cast<char *>(src) + (size_t)((s.T - 1) - hist) * row, false);
-        if (rc) return rc;
-    }
+    // time is re-based so that the imported deque occupies the sample times [0, held)
     s.n_seen = 0;
     s.front = 0;
-    s.dq_cap = s.dq_head = 0;
-    for (uint64_t k = 0; k < hist; ++k) (void)deque_step(s);
+    {
+        const int rc = grow_ring(s, ring_rows_for(held, s.T, s.max_frames));
+        if (rc) return rc;
+    }
+    FIRCHK(hipMemset(s.ring, 0, ring_bytes_for(s.tiles, s.R)));
+    FIRCHK(hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long)));
+    if (held) {
+        const int rc = copy_rows(s, 0, held, const_cast<char *>(src), false);
+        if (rc) return rc;
+        // non-finite samples of the imported history must raise their tiles' flags like appended ones do
+        hipLaunchKernelGGL(fir_flag_scan_kernel, dim3(s.tiles), dim3(256), 0, nullptr, s.ring, s.nf_time, s.N, s.R, (unsigned long long)held);
+        FIRCHK(hipGetLastError());
+    }
+    s.n_seen = held;
+    // the VecDeque's own bookkeeping: as exported when it is consistent with the length, else that of a deque that was
+    // pushed `held` times from empty
+    uint32_t cap = hdr32[0], head = hdr32[1];
+    const bool cap_ok = cap >= held && cap >= (held ? 4u : 0u) && (cap & (cap - 1)) == 0 && (cap == 0 ? head == 0 : head < cap);
+    if (cap_ok) {
+        s.dq_cap = cap;
+        s.dq_head = head;
+    } else {
+        s.dq_cap = s.dq_head = 0;
+        const uint32_t T0 = s.T;
+        s.T = 0xffffffffu;                                 // no pops while rebuilding
+        s.n_seen = 0;
+        for (uint64_t k = 0; k < held; ++k) (void)deque_step(s);
+        s.T = T0;
+    }
     FIRCHK(hipMemset(s.warm_acc, 0, (size_t)s.N * sizeof(double)));
-    s.warm_ok = hist == 0;                               // imported history: its running sums are not known
+    s.warm_ok = held == 0;                               // imported history: its running sums are not known
+    FIRCHK(hipDeviceSynchronize());
+    (void)seen;
     return 0;
+}
+
+// ---- placement tuning runs real blocks through the node: park what they overwrite, put it back afterwards ---------
+int fir_park(FirState &s, uint32_t nframes, hipStream_t stream, FirPark &p) {
+    p.n_seen = s.n_seen;
+    p.front = s.front;
+    p.dq_cap = s.dq_cap;
+    p.dq_head = s.dq_head;
+    p.warm_ok = s.warm_ok;
+    p.last_kernel = s.last_kernel;
+    p.nframes = nframes;
+    FIRCHK(hipMalloc((void **)&p.rows, (size_t)nframes * s.N * sizeof(float)));
+    FIRCHK(hipMalloc((void **)&p.nf, (size_t)s.tiles * sizeof(unsigned long long)));
+    FIRCHK(hipMalloc((void **)&p.acc, (size_t)s.N * sizeof(double)));
+    // the rows the next `nframes` samples land in still hold the oldest part of the ring (sample times n_seen - R ...)
+    hipLaunchKernelGGL(fir_rows_kernel, dim3((s.N + 255) / 256, std::min<uint32_t>(nframes, 256)), dim3(256), 0, stream, s.ring, p.rows, s.N, s.R,
+                       (long long)s.n_seen + (long long)s.R * 4, nframes, 1);   // + 4 R: the same rows, a time that is never negative
+    FIRCHK(hipGetLastError());
+    FIRCHK(hipMemcpyAsync(p.nf, s.nf_time, (size_t)s.tiles * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    FIRCHK(hipMemcpyAsync(p.acc, s.warm_acc, (size_t)s.N * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+void fir_rewind(FirState &s, const FirPark &p) {
+    s.n_seen = p.n_seen;
+    s.front = p.front;
+    s.dq_cap = p.dq_cap;
+    s.dq_head = p.dq_head;
+    s.warm_ok = p.warm_ok;
+    s.last_kernel = p.last_kernel;
+}
+int fir_unpark(FirState &s, FirPark &p, hipStream_t stream) {
+    fir_rewind(s, p);
+    if (!p.rows) return 0;
+    hipLaunchKernelGGL(fir_rows_kernel, dim3((s.N + 255) / 256, std::min<uint32_t>(p.nframes, 256)), dim3(256), 0, stream, s.ring, p.rows, s.N, s.R,
+                       (long long)s.n_seen + (long long)s.R * 4, p.nframes, 0);
+    FIRCHK(hipGetLastError());
+    FIRCHK(hipMemcpyAsync(s.nf_time, p.nf, (size_t)s.tiles * sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+    FIRCHK(hipMemcpyAsync(s.warm_acc, p.acc, (size_t)s.N * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    return 0;
+}
+void fir_park_free(FirPark &p) {
+    if (p.rows) (void)hipFree(p.rows);
+    if (p.nf) (void)hipFree(p.nf);
+    if (p.acc) (void)hipFree(p.acc);
+    p.rows = nullptr;
+    p.nf = nullptr;
+    p.acc = nullptr;
 }
 
 const char *fir_kernel_name(const FirState &s) {

@@ -152,6 +152,22 @@ impl Engine {
         let rc = unsafe { dspfx_set_mode(self.h, node as c_int, mode) };
         self.check(rc)
     }
+    /// A handle the GUI thread keeps for its slider stores while the node's task owns the `Engine` (behind its
+    /// `Mutex`) and is inside `process`: the reference's widgets store into atomics from the GUI thread
+    /// (dsp-stuff-derive/src/lib.rs:487-492).  The C side queues the store and applies it at the next block boundary.
+    pub fn params(&self) -> ParamHandle {
+        ParamHandle { h: self.h }
+    }
+    /// The stores applied so far with a sequence number above `after_seq`, oldest first.
+    pub fn param_log(&mut self, after_seq: u64) -> Vec<dspfx_param_event> {
+        let mut ev = vec![dspfx_param_event { seq: 0, frame: 0, node: 0, param: 0, value: 0.0, reserved: 0 }; 4096];
+        let n = unsafe { dspfx_param_log(self.h, ev.as_mut_ptr(), ev.len() as c_int, after_seq) };
+        ev.truncate(n.max(0) as usize);
+        ev
+    }
+    pub fn frames_submitted(&self) -> u64 {
+        unsafe { dspfx_frames_submitted(self.h) }
+    }
     pub fn set_delay_seconds(&mut self, node: usize, seconds: f32) -> Result<(), Error> {
         let rc = unsafe { dspfx_set_delay_len(self.h, node as c_int, dspfx_delay_len(seconds, 0)) };
         self.check(rc)
@@ -262,5 +278,27 @@ impl Comm {
 impl Drop for Comm {
     fn drop(&mut self) {
         unsafe { dspfx_comm_destroy(self.h) }
+    }
+}
+
+/// Slider / mode stores from a thread that does not own the `Engine` (see `Engine::params`).  Sound because
+/// `dspfx_set_param` / `dspfx_set_mode` are thread-safe by contract (include/dspfx.h, "threads"): they only queue.
+/// The handle must not outlive its engine (the node owns both).
+#[derive(Clone, Copy)]
+pub struct ParamHandle {
+    h: *mut dspfx_engine,
+}
+unsafe impl Send for ParamHandle {}
+unsafe impl Sync for ParamHandle {}
+impl ParamHandle {
+    /// Returns the store's sequence number.
+    pub fn set_param(&self, node: usize, param: usize, value: f32) -> Result<u64, c_int> {
+        let mut seq = 0u64;
+        let rc = unsafe { dspfx_set_param_seq(self.h, node as c_int, param as c_int, value, &mut seq) };
+        if rc == 0 { Ok(seq) } else { Err(rc) }
+    }
+    pub fn set_mode(&self, node: usize, mode: c_int) -> Result<(), c_int> {
+        let rc = unsafe { dspfx_set_mode(self.h, node as c_int, mode) };
+        if rc == 0 { Ok(()) } else { Err(rc) }
     }
 }

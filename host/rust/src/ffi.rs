@@ -55,6 +55,18 @@ pub struct dspfx_graph_link {
     pub port: i32,
 }
 
+/// Where a slider / mode store took effect (`dspfx_param_log`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct dspfx_param_event {
+    pub seq: u64,
+    pub frame: u64,
+    pub node: i32,
+    pub param: i32,
+    pub value: f32,
+    pub reserved: i32,
+}
+
 pub const DSPFX_ABI_VERSION: u32 = 1;
 pub const DSPFX_BUF_SIZE: u32 = 128; // dsp-stuff/src/node.rs:257
 pub const DSPFX_MAX_NODES: u32 = 32;
@@ -145,7 +157,10 @@ extern "C" {
     pub fn dspfx_chain_set(e: *mut dspfx_engine, nodes: *const dspfx_node_desc, n_nodes: c_int) -> c_int;
     pub fn dspfx_chain_len(e: *const dspfx_engine) -> c_int;
     pub fn dspfx_set_param(e: *mut dspfx_engine, node: c_int, param: c_int, value: f32) -> c_int;
+    pub fn dspfx_set_param_seq(e: *mut dspfx_engine, node: c_int, param: c_int, value: f32, seq: *mut u64) -> c_int;
     pub fn dspfx_set_mode(e: *mut dspfx_engine, node: c_int, mode: c_int) -> c_int;
+    pub fn dspfx_param_log(e: *mut dspfx_engine, dst: *mut dspfx_param_event, cap: c_int, after_seq: u64) -> c_int;
+    pub fn dspfx_frames_submitted(e: *const dspfx_engine) -> u64;
     pub fn dspfx_set_delay_len(e: *mut dspfx_engine, node: c_int, delay_len: u32) -> c_int;
     pub fn dspfx_set_taps(e: *mut dspfx_engine, node: c_int, taps_reversed: *const f64, n_taps: u32, mode: c_int) -> c_int;
     pub fn dspfx_set_fir_precision(e: *mut dspfx_engine, node: c_int, precision: c_int) -> c_int;

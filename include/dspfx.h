@@ -21,8 +21,21 @@
  *     ("[B][N]"): for every frame the N channels are contiguous, so one
  *     wavefront reads 64 consecutive channels as one coalesced burst
  *     (dspfx_engine_desc.tile_channels selects the channel-tiled form).
- *   - one engine is driven by one thread at a time (like one node task,
- *     runtime.rs:718-728); distinct engines are independent.
+ *   - threads: every entry point may be called from any thread; calls on one engine are
+ *     serialised by the engine (distinct engines are independent).  The reference's split is
+ *     kept: ONE thread drives the process calls (one node task, runtime.rs:718-728) while
+ *     another -- the GUI -- stores sliders and modes (dsp-stuff-derive/src/lib.rs:487-492,
+ *     biquad.rs:62-76).  dspfx_set_param / dspfx_set_mode NEVER wait for a process call in
+ *     progress: the store is queued and takes effect at the next block boundary (at once when
+ *     the engine is idle), in the order the stores were made.
+ *   - streams: the process calls are asynchronous on the caller's stream.  Everything that
+ *     writes DSP state outside a block (a biquad's reset on a coefficient store, dspfx_reset)
+ *     is queued on the stream the state was last used on, so it is ordered behind the blocks
+ *     in flight and ahead of the next one -- with any kind of stream (torch's and most hosts'
+ *     streams are non-blocking: the null stream orders nothing against them).  A process call
+ *     on a DIFFERENT stream first waits (on the device) for the previous stream.  Calls that
+ *     free or re-allocate state (dspfx_chain_set, dspfx_graph_set, dspfx_set_delay_len,
+ *     dspfx_set_taps, dspfx_state_import / _export) wait for the device first.
  *   - there is NO CPU fallback: without a HIP device every entry point that
  *     needs one fails with DSPFX_ERR_NO_DEVICE.
  */
@@ -175,9 +188,31 @@ int dspfx_chain_len(const dspfx_engine *e);
  * 560-568): BIQUAD renormalises by a0 and ZEROES its state (biquad.rs:62-76);
  * other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
  * exactness of a DISTORT level as a constant divisor is decided on the host; only a level that is an even integer
- * other than a power of two runs the 2 ms device check, once per value and process). */
+ * other than a power of two runs the 2 ms device check, once per value and process).
+ * Safe from a second thread while another one is inside a process call (the reference's GUI thread does exactly
+ * that): the store is validated, queued and returns; it is applied -- with its stores before it, in order -- by the
+ * next entry point that holds the engine: immediately when the engine is idle, else at the next block boundary.  The
+ * biquad reset is queued on the stream of the blocks in flight, behind them.  dspfx_set_param_seq also returns the
+ * store's sequence number; dspfx_param_log tells where each store took effect. */
 int dspfx_set_param(dspfx_engine *e, int node, int param, float value);
+int dspfx_set_param_seq(dspfx_engine *e, int node, int param, float value, uint64_t *seq);
+/* Mode store (the `mode` atomics of distort.rs:46-50, fir.rs, signal_gen.rs): queued like a slider store. */
 int dspfx_set_mode(dspfx_engine *e, int node, int mode);
+/* Where the stores took effect.  `frame` = frames the engine had been handed (dspfx_frames_submitted) when the store
+ * was applied: the store governs every frame from that one on -- always a boundary between two process calls.
+ * Copies the applied stores with seq > after_seq, oldest first, into dst[cap]; returns how many (the engine keeps the
+ * most recent 4096). */
+typedef struct dspfx_param_event {
+    uint64_t seq;     /* 1, 2, ... in the order the stores were made on this engine */
+    uint64_t frame;
+    int32_t node;
+    int32_t param;    /* -1: a mode store (value = the mode) */
+    float value;
+    int32_t reserved;
+} dspfx_param_event;
+int dspfx_param_log(dspfx_engine *e, dspfx_param_event *dst, int cap, uint64_t after_seq);
+/* Frames handed to the process calls since the engine was created (all sub-blocks counted). */
+uint64_t dspfx_frames_submitted(const dspfx_engine *e);
 /* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring. */
 int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
 /* Fir tap reload (fir.rs:153-171).  Like the reference it replaces the taps ONLY: the history is kept (`state`,
@@ -201,7 +236,8 @@ typedef enum dspfx_fir_precision {
     DSPFX_FIR_PRECISION_SPLIT = 2
 } dspfx_fir_precision;
 int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision);
-/* Zero every node's DSP state (fresh nodes); parameters are kept. */
+/* Zero every node's DSP state (fresh nodes); parameters are kept.  Asynchronous: the clears are queued on the stream
+ * the engine was last driven on, behind the blocks in flight there. */
 int dspfx_reset(dspfx_engine *e);
 
 /* ---- the hot path ------------------------------------------------------ */
@@ -241,9 +277,9 @@ int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *side, float
  * `in` and writing `out` -- the buffers the host will keep using -- and keeps the fastest groups again.
  * `in` / `out` are laid out like a block of max_frames frames; n_frames <= 128 of it are streamed per probe (`out` is
  * overwritten).  About 3 s at 94 GiB.  DSP state is PRESERVED -- filter state is snapshotted and restored, every ring
- * group's rows are parked while it is probed and end up at the same ring position -- so a live host can call it again
- * after it re-allocated its buffers (flush the mix pipeline first; engines with a FIR node still reset).  Results never
- * change, only speed. */
+ * group's rows are parked while it is probed and end up at the same ring position, the rows the probe blocks overwrite
+ * in every OTHER delay ring and in FIR histories are parked and put back -- so a live host can call it again after it
+ * re-allocated its buffers (flush the mix pipeline first).  Results never change, only speed. */
 int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
                          void *stream);
 /* Page-locked host memory for the blocks handed to dspfx_process_host.  From ordinary (pageable) buffers the two
@@ -380,8 +416,12 @@ int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, const dspfx_gr
 /* ---- DSP state (parity tests; the reference never saves it) --- */
 /* Size in bytes of node `node`'s exported state:
  *   BIQUAD 4*N f32 [x1|x2|y1|y2][N]; LOW/HIGH_PASS N f32; REVERB D*N f32
- *   [D][N] oldest sample first; FIR (n_taps-1)*N f32 [t][N] oldest first + the
- *   warm-up count; others 0. */
+ *   [D][N] oldest sample first; others 0;
+ *   FIR: the reference's `state: VecDeque<f64>` (fir.rs:64-65) as it stands -- a 32-byte header {u64 samples pushed
+ *   since empty, u64 held = the deque's length, u32 VecDeque capacity, u32 VecDeque head, u32 n_taps, u32 0} followed
+ *   by the held samples [held][N] f32, oldest first.  held < n_taps while the deque fills, == n_taps in steady state,
+ *   > n_taps after a reload with a shorter impulse response: the size changes with the node's history, so ask right
+ *   before exporting.  dspfx_state_import takes such a blob of any length (the size must match the blob's own header). */
 int64_t dspfx_state_size(const dspfx_engine *e, int node);
 int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, size_t size);
 int dspfx_state_import(dspfx_engine *e, int node, const void *host_src, size_t size);

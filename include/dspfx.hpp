@@ -153,8 +153,24 @@ class Engine {
         for (const Node &n : nodes) d.push_back(n.d);
         chk(dspfx_graph_set(e_, d.data(), static_cast<int>(d.size()), links.data(), static_cast<int>(links.size())));
     }
+    // Slider / mode stores are safe from another thread while this one is inside process(): queued, applied at the next
+    // block boundary in order (dspfx.h, "threads").  set_param_seq returns the store's sequence number, param_log where
+    // the stores took effect.
     void set_param(int node, int param, float v) { chk(dspfx_set_param(e_, node, param, v)); }
+    std::uint64_t set_param_seq(int node, int param, float v) {
+        std::uint64_t seq = 0;
+        chk(dspfx_set_param_seq(e_, node, param, v, &seq));
+        return seq;
+    }
     void set_mode(int node, Mode m) { chk(dspfx_set_mode(e_, node, static_cast<int>(m))); }
+    std::vector<dspfx_param_event> param_log(std::uint64_t after_seq = 0) {
+        std::vector<dspfx_param_event> ev(4096);
+        const int n = dspfx_param_log(e_, ev.data(), static_cast<int>(ev.size()), after_seq);
+        if (n < 0) chk(n);
+        ev.resize(static_cast<std::size_t>(n));
+        return ev;
+    }
+    std::uint64_t frames_submitted() const { return dspfx_frames_submitted(e_); }
     void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }
     /// DSPFX_FIR_PRECISION_DEFAULT / _F32 / _SPLIT: how a FIR node's steady-state sweep multiplies (dspfx.h)
     void set_fir_precision(int node, dspfx_fir_precision p) { chk(dspfx_set_fir_precision(e_, node, static_cast<int>(p))); }
@@ -177,7 +193,7 @@ class Engine {
     void mix_allreduce(dspfx_comm *comm, float *mix, std::uint32_t n_frames, std::uint64_t n_connected, void *stream = nullptr) {
         chk(dspfx_mix_allreduce(e_, comm, mix, n_frames, n_connected, stream));
     }
-    // re-tune the delay rings' placement against the buffers the host will keep using (resets DSP state)
+    // re-tune the delay rings' placement against the buffers the host will keep using (DSP state is kept)
     void tune_placement(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr, void *stream = nullptr) {
         chk(dspfx_tune_placement(e_, in, side, out, n_frames, stream));
     }

@@ -834,9 +834,10 @@ def test_fir_state_export_import(dspfx, torch_cuda):
     for f0 in range(0, 384, 128):
         a.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
     st = a.state_export(0)
-    assert len(st) == 8 + (T - 1) * N * 4
-    hist = st[8:].view(np.float32).reshape(T - 1, N)
-    assert np.array_equal(hist, x[384 - (T - 1):384])            # oldest first
+    assert len(st) == 32 + T * N * 4                             # header + the deque as it stands (steady state: T samples)
+    assert st[:16].view(np.uint64).tolist() == [384, T]
+    hist = st[32:].view(np.float32).reshape(T, N)
+    assert np.array_equal(hist, x[384 - T:384])                  # oldest first
     b = dspfx.Engine(N, 128, link_flags=0)
     b.set_chain(ch)
     b.state_import(0, st)

@@ -1,0 +1,284 @@
+"""Threads and streams at the C-ABI boundary (include/dspfx.h, "threads" / "streams").
+
+In the reference the GUI thread stores sliders into atomics while the node's task is inside process()
+(dsp-stuff-derive/src/lib.rs:487-492) and `regenerate_filter` swaps coefficients and zeroes the state under the node's
+mutex (nodes/biquad.rs:62-76): the store lands between two blocks.  Here the process calls are ASYNCHRONOUS on the
+caller's (non-blocking) stream, so "between two blocks" has to hold against blocks that are queued but have not run:
+the store is queued, applied at the next block boundary, and its state reset travels in stream order.  Every test
+below keeps the stream busy behind a long spin kernel so that nothing has executed when the host-side calls are made;
+the oracle takes the same stores at the block the engine's own log reports."""
+import threading
+
+import numpy as np
+import pytest
+
+import oracle as O
+from chains import chain5, fir_taps, ulp_diff
+
+pytestmark = pytest.mark.gpu
+F = np.float32
+B = 128
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch
+
+
+def _noise(N, nf, seed=0x5EED0001):
+    return O.noise(seed, np.arange(N), np.arange(nf))
+
+
+def _oracle_blocks(chain, x, stores, link_flags=3, resets=()):
+    """x [nf][C] through per-channel oracle node lists; stores = {block: [(node, param, value)]} applied BEFORE that
+    block (the reference's after_settings_change included: O.Node.set_param regenerates + zeroes a biquad's state);
+    resets = blocks before which every node is replaced by a fresh one with its current parameters."""
+    descs = [n.oracle_desc() for n in chain]
+    nodes = []
+    out = np.empty_like(x)
+    for k in range(x.shape[0] // B):
+        if k in resets:
+            nodes = []
+        seg = x[k * B:(k + 1) * B]
+        if not nodes:
+            for _ in range(x.shape[1]):
+                nodes.append([O.node_from_desc(d) for d in descs])
+        for node, param, value in stores.get(k, []):
+            descs[node]["params"][param] = value
+            for per_channel in nodes:
+                per_channel[node].set_param(param, value)
+        for c in range(x.shape[1]):
+            out[k * B:(k + 1) * B, c] = O.chain_run(nodes[c], seg[:, c], link_flags)
+    return out
+
+
+_CYCLES_PER_MS = []
+
+
+def _hold(torch, stream, ms=60):
+    """Keep `stream` busy for about `ms` milliseconds: everything queued behind it is in flight, nothing has run."""
+    if not _CYCLES_PER_MS:                          # the spin kernel counts a clock whose rate is the platform's business
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda._sleep(1000)
+        torch.cuda.synchronize()
+        a.record()
+        torch.cuda._sleep(2_000_000)
+        b.record()
+        torch.cuda.synchronize()
+        _CYCLES_PER_MS.append(2_000_000 / max(a.elapsed_time(b), 1e-3))
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(int(ms * _CYCLES_PER_MS[0]))
+
+
+def test_slider_store_from_another_thread_with_blocks_in_flight(dspfx, torch_cuda):
+    torch = torch_cuda
+    N, blocks, sample = 16384, 96, [0, 1, 63, 64, 4097, 16383]
+    chain = chain5(dspfx, 256)
+    x = _noise(N, B * blocks)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(chain)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty_like(dx)
+    s = torch.cuda.Stream()                         # a non-blocking stream, like any host's
+    submitted = threading.Event()
+    result = {}
+
+    def gui_thread():
+        submitted.wait()
+        result["seq"] = [eng.set_param_seq(0, 1, -1.7),      # biquad 0: a1 (state reset, biquad.rs:74)
+                         eng.set_param_seq(4, 0, 0.25),      # gain
+                         eng.set_param_seq(3, 3, 0.9)]       # biquad 3: b0
+        result["busy"] = not s.query()
+
+    t = threading.Thread(target=gui_thread)
+    t.start()
+    torch.cuda.synchronize()
+    _hold(torch, s)
+    for k in range(blocks):
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B, stream=s.cuda_stream)
+        if k == 63:
+            submitted.set()                         # 64 blocks queued, none has run: now the other thread stores
+    t.join()
+    assert result["busy"], "the stream drained before the store: nothing was in flight"
+    s.synchronize()
+    log = eng.param_log()
+    assert [ev[0] for ev in log] == result["seq"] == [1, 2, 3]           # applied in the order they were made
+    stores = {}
+    for seq, frame, node, param, value in log:
+        assert frame % B == 0 and 64 * B <= frame <= blocks * B, frame   # a block boundary after the 64 queued blocks
+        stores.setdefault(frame // B, []).append((node, param, value))
+    assert eng.frames_submitted() == blocks * B
+    got = dy.cpu().numpy()[:, sample]
+    ref = _oracle_blocks(chain, x[:, sample], stores)
+    assert ulp_diff(got, ref).max() <= 1, (stores, ulp_diff(got, ref).max())
+    # ... and it is not the same as ignoring the stores or resetting early
+    assert ulp_diff(got, _oracle_blocks(chain, x[:, sample], {})).max() > 1000
+
+
+def test_store_made_while_idle_is_ordered_behind_the_blocks_in_flight(dspfx, torch_cuda):
+    """The single-threaded form of the same hazard: process ... set_param ... process on a non-blocking stream without a
+    host synchronisation in between.  The store is applied at once on the host, its state reset must still run AFTER the
+    blocks already queued."""
+    torch = torch_cuda
+    N, blocks = 4096, 12
+    chain = chain5(dspfx, 128)
+    x = _noise(N, B * blocks)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(chain)
+    dx, s = torch.from_numpy(x).cuda(), torch.cuda.Stream()
+    dy = torch.empty_like(dx)
+    torch.cuda.synchronize()
+    _hold(torch, s)
+    for k in range(blocks):
+        if k == 5:
+            eng.set_param(0, 2, 0.5)
+            eng.set_param(3, 1, -1.5)
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B, stream=s.cuda_stream)
+    assert not s.query()
+    s.synchronize()
+    assert [(ev[1], ev[2], ev[3]) for ev in eng.param_log()] == [(5 * B, 0, 2), (5 * B, 3, 1)]
+    ref = _oracle_blocks(chain, x[:, :64], {5: [(0, 2, 0.5), (3, 1, -1.5)]})
+    assert ulp_diff(dy.cpu().numpy()[:, :64], ref).max() <= 1
+
+
+@pytest.mark.parametrize("which", ["chain5", "fir"])
+def test_reset_is_ordered_with_blocks_in_flight(dspfx, torch_cuda, which):
+    torch = torch_cuda
+    N, blocks = 2048, 10
+    chain = chain5(dspfx, 384) if which == "chain5" else [dspfx.Gain(0.7), dspfx.Fir(fir_taps(96))]
+    x = _noise(N, B * blocks)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(chain)
+    dx, s = torch.from_numpy(x).cuda(), torch.cuda.Stream()
+    dy = torch.empty_like(dx)
+    torch.cuda.synchronize()
+    _hold(torch, s)
+    for k in range(blocks):
+        if k == 6:
+            eng.reset()
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B, stream=s.cuda_stream)
+    assert not s.query()
+    s.synchronize()
+    got = dy.cpu().numpy()[:, :48]
+    ref = _oracle_blocks(chain, x[:, :48], {}, resets=(6,))
+    if which == "chain5":
+        assert ulp_diff(got, ref).max() <= 1
+    else:
+        assert np.sqrt(np.mean((got - ref) ** 2)) <= 1e-6 * np.sqrt(np.mean(ref ** 2))
+
+
+def test_blocks_on_alternating_streams_stay_in_order(dspfx, torch_cuda):
+    """A host that moves an engine from one stream to another (or alternates) need not synchronise: the engine makes
+    the new stream wait for the one its state was last used on."""
+    torch = torch_cuda
+    N, blocks = 8192, 16
+    chain = chain5(dspfx, 256)
+    x = _noise(N, B * blocks)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(chain)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty_like(dx)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    _hold(torch, streams[0], 30)
+    for k in range(blocks):
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B, stream=streams[k % 3].cuda_stream)
+    torch.cuda.synchronize()
+    ref = _oracle_blocks(chain, x[:, :32], {})
+    assert ulp_diff(dy.cpu().numpy()[:, :32], ref).max() <= 1
+
+
+def test_mode_store_is_queued_like_a_slider_store(dspfx, torch_cuda):
+    torch = torch_cuda
+    N, blocks = 1024, 6
+    chain = [dspfx.Gain(0.9), dspfx.Distort(3.0, dspfx.SOFT_CLIP), dspfx.LowPass(0.4)]
+    x = _noise(N, B * blocks)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(chain)
+    dx, s = torch.from_numpy(x).cuda(), torch.cuda.Stream()
+    dy = torch.empty_like(dx)
+    torch.cuda.synchronize()
+    _hold(torch, s, 20)
+    for k in range(blocks):
+        if k == 2:
+            eng.set_mode(1, dspfx.HARD_CLIP)
+        if k == 4:
+            eng.set_mode(1, dspfx.SQUARE)
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B, stream=s.cuda_stream)
+    s.synchronize()
+    got = dy.cpu().numpy()[:, :16]
+    ref = np.empty_like(got)
+    nodes = [[O.node_from_desc(n.oracle_desc()) for n in chain] for _ in range(16)]
+    for k in range(blocks):
+        mode = dspfx.SOFT_CLIP if k < 2 else dspfx.HARD_CLIP if k < 4 else dspfx.SQUARE
+        for c in range(16):
+            nodes[c][1].L.orc_node_set_mode(nodes[c][1].h, mode)
+            ref[k * B:(k + 1) * B, c] = O.chain_run(nodes[c], x[k * B:(k + 1) * B, c], 3)
+    assert ulp_diff(got, ref).max() <= 1
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_mode(1, 99)                         # validated when it is made, not when it is applied
+    with pytest.raises(dspfx.DspfxError):
+        eng.set_param(7, 0, 1.0)
+
+
+def test_tune_placement_keeps_the_state_of_every_delay_line_and_fir_history(dspfx, torch_cuda):
+    """Two large delay rings, a small one and a FIR node in one chain: the probes run whole blocks through ALL of them
+    while one ring is being timed.  Outputs before, between and after tuning calls equal those of an engine that was
+    never tuned, bit for bit."""
+    torch = torch_cuda
+    N, blocks = 131072, 6                           # 64 MiB ring groups: the tuner engages
+    chain = [dspfx.Reverb(delay_samples=300, decay=0.5), dspfx.BiQuad(), dspfx.Reverb(delay_samples=128, decay=0.3),
+             dspfx.Fir(fir_taps(40)), dspfx.Reverb(delay_samples=257, decay=0.4), dspfx.LowPass(0.3)]
+    x = _noise(N, B * blocks)
+    eng, ref = dspfx.Engine(N, B), dspfx.Engine(N, B)
+    eng.set_chain(chain)
+    ref.set_chain(chain)
+    dx = torch.from_numpy(x).cuda()
+    y, y_ref, scratch = torch.empty((B, N), device="cuda"), torch.empty((B, N), device="cuda"), torch.empty((B, N), device="cuda")
+    for k in range(blocks):
+        eng.process(dx[k * B:(k + 1) * B], out=y, n_frames=B)
+        ref.process(dx[k * B:(k + 1) * B], out=y_ref, n_frames=B)
+        torch.cuda.synchronize()
+        assert torch.equal(y, y_ref), k
+        if k in (0, 2, 3):
+            eng.tune_placement(dx[((k + 3) % blocks) * B:((k + 3) % blocks + 1) * B], scratch, B)
+    for i in (0, 2, 3, 4):
+        assert np.array_equal(eng.state_export(i), ref.state_export(i)), i
+
+
+def test_fir_state_round_trip_after_tap_reloads(dspfx, torch_cuda, monkeypatch):
+    """dspfx_state_export / _import carry the deque as it stands: longer than the taps after a reload with a shorter
+    impulse response (a pure extra delay that must survive the round trip), still filling after a reload with a longer
+    one -- and the VecDeque's capacity / head, which decide the a/b split of the exact kernel's sums."""
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", "0")     # the bit-faithful kernel: any difference in the deque model shows
+    torch = torch_cuda
+    rng = np.random.default_rng(21)
+    N = 70
+    x = _noise(N, 128 * 12)
+    for T0, T1 in ((150, 9), (12, 300), (64, 64)):
+        h0, h1 = rng.uniform(-1, 1, T0), rng.uniform(-1, 1, T1)
+        a = dspfx.Engine(N, 128, link_flags=0)
+        a.set_chain([dspfx.Fir(h0)])
+        dx = torch.from_numpy(x).cuda()
+        ya, yb = torch.empty_like(dx), torch.empty_like(dx)
+        for k in range(4):
+            a.process(dx[k * B:(k + 1) * B], out=ya[k * B:(k + 1) * B], n_frames=B)
+        a.set_taps(0, h1)
+        a.process(dx[4 * B:5 * B], out=ya[4 * B:5 * B], n_frames=B)
+        st = a.state_export(0)
+        held = int(st[8:16].view(np.uint64)[0])
+        assert held == (T0 if T1 < T0 else min(T1, T0 + B)) and len(st) == 32 + held * N * 4
+        assert np.array_equal(st[32:].view(F).reshape(held, N), x[5 * B - held:5 * B])      # oldest first
+        b = dspfx.Engine(N, 128, link_flags=0)
+        b.set_chain([dspfx.Fir(h1)])
+        b.state_import(0, st)
+        assert np.array_equal(b.state_export(0), st)
+        for k in range(5, 12):
+            a.process(dx[k * B:(k + 1) * B], out=ya[k * B:(k + 1) * B], n_frames=B)
+            b.process(dx[k * B:(k + 1) * B], out=yb[k * B:(k + 1) * B], n_frames=B)
+        torch.cuda.synchronize()
+        assert torch.equal(ya[5 * B:], yb[5 * B:]), (T0, T1)
+        with pytest.raises(dspfx.DspfxError):
+            b.state_import(0, st[:-4])

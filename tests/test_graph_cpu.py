@@ -292,3 +292,16 @@ def test_region_plan_covers_any_graph(dspfx, tmp_path):
     assert len(mid[3]) >= 3 and mid[4] >= 2
     src = _compile_generated(E, mid[1], mid[2], tmp_path, "region")
     assert "xs[2]" in src and "ys[1]" in src and "static constexpr int n_out = %d" % mid[4] in src
+
+
+def test_output_blocks_must_be_contiguous(dspfx):
+    """A generated kernel stores every output block below the highest one a link names; a graph that writes block 2 but
+    not block 1 would store through the NULL entry the header allows for unused blocks.  Rejected when the graph is
+    validated (dspfx_graph_set / dspfx_graph_source), no device needed."""
+    nodes = [dspfx.Gain(0.5), dspfx.LowPass(0.3)]
+    ok = [(dspfx.GRAPH_INPUT, 0, dspfx.PORT_MAIN), (0, 1, dspfx.PORT_MAIN), (1, 2, dspfx.PORT_MAIN), (0, 3, dspfx.PORT_MAIN)]
+    assert "n_out = 2" in dspfx.graph_source(nodes, ok)
+    gap = [(dspfx.GRAPH_INPUT, 0, dspfx.PORT_MAIN), (0, 1, dspfx.PORT_MAIN), (1, 2, dspfx.PORT_MAIN), (0, 4, dspfx.PORT_MAIN)]
+    with pytest.raises(dspfx.DspfxError) as ei:
+        dspfx.graph_source(nodes, gap)
+    assert ei.value.status == -1
