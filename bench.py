@@ -69,6 +69,9 @@ def parse():
     ap.add_argument("--link-flags", type=int, default=3)
     ap.add_argument("--probe", type=int, default=1,
                     help="also rate 3 x K candidate sample buffers before the timed region (default 1 = off)")
+    ap.add_argument("--paced-seconds", type=float, default=5.0,
+                    help="length of the paced real-time run of the headline config (0 = skip; --paced runs nothing else)")
+    ap.add_argument("--paced", action="store_true", help="only the paced real-time run (plus the short settle before it)")
     ap.add_argument("--tile", type=int, default=256,
                     help="channel-tiled HBM layout [N/W][B][W] (engine-native, default 256); 0 = frame-major [B][N]")
     return ap.parse_args()
@@ -99,14 +102,40 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_topology():
+    """(physical cores, logical CPUs, sockets) of this host from /proc/cpuinfo."""
+    cores, sockets = set(), set()
+    phys = core = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                    sockets.add(phys)
+                phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return (len(cores) or logical), logical, (len(sockets) or 1)
+
+
 def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
     """The reference CPU path stand-in: the C restatement (oracle/), built -O3
     -march=native -ffp-contract=off ON THIS BOX, channel-at-a-time / node-at-a-time /
-    128-frame blocks like node.rs:267-352 (gather, /1.0001, process, scatter per node):
-    (i) one thread, (ii) threaded over channels on all host cores."""
+    128-frame blocks like node.rs:267-352 (gather, /1.0001, process, scatter per node), threaded
+    over channels.  Timed inside the C function (orc_bench_chain) between a start barrier
+    and the last thread's finish; node state is cloned once per thread and reset per channel, the input
+    is a per-thread table of noise blocks made before the barrier: nothing but the chain is timed.
+    Legs: 1, 16, 64, ... threads up to every logical CPU, each sized from a probe for an equal share of
+    target_s; `value` is the best leg (all the box can do), `scaling` lists them all."""
     from __graft_entry__ import load_oracle
+    import ctypes as C
     O = load_oracle()
-    cores = os.cpu_count() or 1
+    physical, logical, sockets = cpu_topology()
     native = False
     try:   # rebuild for this host's ISA (the in-tree native .so was built elsewhere)
         tmp = tempfile.mkdtemp(prefix="dspfx_cpu_")
@@ -114,59 +143,52 @@ def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
         subprocess.check_call(["gcc", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-fPIC",
                                "-std=c11", "-shared", "-o", so, os.path.join(ROOT, "oracle", "dspfx_oracle.c"),
                                "-lm", "-lpthread"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        import ctypes
-        L = O._bind(ctypes.CDLL(so))
+        L = O._bind(C.CDLL(so))
         native = True
     except Exception:
         L = O.lib()
     descs = [n.oracle_desc() for n in chain]
     block = 128
+    is_fir = cfg["chain"] == "fir"
+    # blocks per channel: more than one revolution of the delay ring (188 blocks at D = 24000), so the ring is read
+    # back and not only written; FIR: 48 blocks = 6144 samples, most of them past the 4096-sample fill phase
+    nb = 48 if is_fir else 256
 
-    def run(n_channels, n_blocks, threads):
-        import ctypes as C
+    def run(n_channels, threads):
         protos = [O.node_from_desc(d, _lib=L) for d in descs]
         hs = (C.c_void_p * len(protos))(*[p.h for p in protos])
-        t0 = time.perf_counter()
-        L.orc_run_noise_channels(hs, len(protos), link_flags, SEED, 0, n_channels, 0, n_blocks, block, None, None, threads)
-        return time.perf_counter() - t0
+        w = C.c_double()
+        L.orc_bench_chain(hs, len(protos), link_flags, SEED, n_channels, nb, block, threads, C.byref(w))
+        return max(w.value, 1e-9)
 
-    is_fir = cfg["chain"] == "fir"
-    # FIR: 48 blocks = 6144 samples, so most of the sample is past the 4096-sample warm-up (whose
-    # shorter dot products are cheaper); the probe uses the same block count so the rate transfers
-    ch, nb = (cores, 48) if is_fir else (cores * 64, 64)
-    run(cores, 1, cores)                              # touch code/pages
-    t = run(ch, nb, cores)                            # probe
-    rate = ch * nb * block / max(t, 1e-6)
-    # scale the sample to ~target_s of CPU work: >= 1 ring period of blocks for the delay chains,
-    # channels capped so the per-channel delay rings (96 KB each at D=24000) stay within ~6 GB of host RAM
-    if is_fir:
-        # keep the per-channel f64 history (64 KB at 4096 taps) cache-resident like the probe and
-        # spend the time budget on more (steady-state) blocks
-        ch2 = cores * 4
-        nb2 = int(max(nb, min(4096, rate * target_s / (ch2 * block))))
-    else:
-        nb2 = 256
-        ch2 = int(max(cores, min(1 << 16, rate * target_s / (nb2 * block))))
-        ch2 -= ch2 % cores or 0
-        ch2 = max(ch2, cores)
-        nb2 = int(max(nb2, min(1 << 14, rate * target_s / (ch2 * block))))
-    t2 = run(ch2, nb2, cores)
-    res = {"value": ch2 * nb2 * block / t2, "unit": "samples/s", "cores": cores, "cpu_model": cpu_model(),
-           "kind": "port",
-           "sample": f"{ch2} channels x {nb2} blocks of 128 frames, same chain/params/noise, {t2:.1f} s; "
+    legs = sorted({t for t in (1, 16, 64, physical, logical) if 1 <= t <= logical})
+    share = target_s / (len(legs) + 0.5)
+    scaling = []
+    for t in legs:
+        probe_ch = t * (1 if is_fir else 2)
+        tp = run(probe_ch, t)                                   # >= one ring period per channel: the rate transfers
+        ch = int(max(t, min(1 << 20, probe_ch * share / tp)))
+        ch -= ch % t
+        ch = max(ch, t)
+        tw = run(ch, t)
+        scaling.append({"threads": t, "value": ch * nb * block / tw, "channels": ch, "seconds": round(tw, 2)})
+    one = scaling[0]["value"]
+    for e in scaling:
+        e["speedup"] = round(e["value"] / one, 2)
+    best = max(scaling, key=lambda e: e["value"])
+    res = {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "physical_cores": physical,
+           "threads": logical, "sockets": sockets, "cpu_model": cpu_model(), "kind": "port",
+           "sample": f"{best['channels']} channels x {nb} blocks of 128 frames on {best['threads']} threads, same chain/params, "
+                     f"hashed-noise input table made before the timed region, {best['seconds']} s; "
                      f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
-                     f"pthreads over channels; excludes the reference's tokio/ring/pool overhead"}
+                     f"pthreads over channels (orc_bench_chain); excludes the reference's tokio/ring/pool overhead",
+           "scaling": scaling,
+           "scaling_note": "speedup over one thread; the one-thread leg runs at the single-core boost clock with the whole "
+                           "L2/L3 to itself, the all-core legs at the all-core clock with two SMT threads sharing a core's "
+                           "execution units: cores x single-thread is not reachable"}
     if with_single:
-        # (i) ONE thread, reference-structured: what one tokio worker of the reference could do at best
-        ch1, nb1 = (1, 48) if is_fir else (16, 256)
-        t1 = run(ch1, nb1, 1)
-        r1 = ch1 * nb1 * block / max(t1, 1e-6)
-        scale = int(max(1, min(256, 0.3 * target_s * r1 / (ch1 * nb1 * block))))
-        if scale > 1:
-            ch1 *= scale
-            t1 = run(ch1, nb1, 1)
-        res["single_thread"] = {"value": ch1 * nb1 * block / t1, "unit": "samples/s", "cores": 1,
-                                "sample": f"{ch1} channels x {nb1} blocks, one thread, {t1:.1f} s"}
+        res["single_thread"] = {"value": one, "unit": "samples/s", "cores": 1,
+                                "sample": f"{scaling[0]['channels']} channels x {nb} blocks, one thread, {scaling[0]['seconds']} s"}
     return res
 
 
@@ -219,8 +241,52 @@ class Ctx:
     pass
 
 
-def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
-    """One configuration: build the engine, settle, W warm-up steps, K timed steps.  Returns a dict."""
+def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
+    """Real-time operation: ONE block every block period (B / 48 kHz = 2.667 ms at B = 128) from a host timer, each block
+    with the Output node's bus of the SAME block (dspfx_process_bus).  Per block: host time from the submit call to the
+    moment the host sees the block's `out` AND `mix` complete (an event polled right behind the launch), and the GPU time
+    between two events around the launch.  The chip idles 2.3 ms between blocks: this is the pattern north_star's
+    '<128-sample block latency' is about, not the back-to-back throughput of the timed region."""
+    import numpy as np
+    period = B / 48000.0
+    n = max(8, int(seconds / period))
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    lat = np.empty(n)
+    lag = np.empty(n)
+    n_in = len(xs)
+    torch.cuda.synchronize()
+    t_next = time.perf_counter() + 0.005
+    t_begin = t_next
+    for k in range(n):
+        while True:                                   # sleep most of the gap, spin the last 300 us
+            now = time.perf_counter()
+            if now >= t_next:
+                break
+            if t_next - now > 3e-4:
+                time.sleep(1e-4)
+        t_sub = time.perf_counter()
+        ev[k][0].record()
+        eng.process_bus(xs[k % n_in], y, mixes[k & 3], B, n_connected=total_channels, stream=stream)
+        ev[k][1].record()
+        while not ev[k][1].query():
+            pass
+        lat[k] = time.perf_counter() - t_sub
+        lag[k] = t_sub - t_next
+        t_next += period
+    wall = time.perf_counter() - t_begin
+    gpu = np.array([a.elapsed_time(b) for a, b in ev])
+    q = lambda v, p: float(np.percentile(v, p))
+    return {"what": "one block per block period from a host timer; bus of the same block (dspfx_process_bus); latency = submit call -> host sees out and mix complete",
+            "period_ms": period * 1e3, "blocks": n, "seconds": wall,
+            "latency_ms": {"p50": q(lat, 50) * 1e3, "p99": q(lat, 99) * 1e3, "max": float(lat.max()) * 1e3},
+            "gpu_ms": {"p50": q(gpu, 50), "p99": q(gpu, 99), "max": float(gpu.max())},
+            "timer_lag_ms": {"p50": q(lag, 50) * 1e3, "p99": q(lag, 99) * 1e3, "max": float(lag.max()) * 1e3},
+            "deadline_misses": int((lat > period).sum())}
+
+
+def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
+    """One configuration: build the engine, settle, W warm-up steps, K timed steps.  Returns a dict.
+    extras: also the cold figure (first launches after an idle gap) and the paced real-time run (one block per block period)."""
     import torch
     import torch.distributed as dist
     pkg, P, dev, world = ctx.pkg, ctx.P, ctx.dev, ctx.world
@@ -336,9 +402,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
             eng.process_mixpipe(xs[k % n_in], y, m, B, n_connected=total_channels, stream=stream)
             pipe_fill[0] += 1
             return
-        if mix_mode == "inline" and not dist_run:
-            eng.process(xs[k % n_in], out=y, mix=m, n_frames=B, stream=stream)
-            eng.mix_finish(m, B, total_channels, stream)
+        if mix_mode == "inline" and not dist_run:        # the bus of THIS block, finished inside its own launch
+            eng.process_bus(xs[k % n_in], y, m, B, n_connected=total_channels, stream=stream)
             return
         eng.process_partials(xs[k % n_in], out=y, n_frames=B, stream=stream)
         eng.mix_collect(m, B, stream=ms)
@@ -474,8 +539,27 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None):
                 roof["traffic_source"] = ent.get("source")
         except Exception:
             pass
+    # ---- cold: the first launches after an idle gap, which the settle phase above deliberately keeps out of the timed region
+    # (the socket's power management answers an idle of >= 10 ms with ~50 slower launches: profiles/r02_idle_transient.txt)
+    cold = None
+    paced = None
+    if extras and not dist_run:
+        idle_s = float(os.environ.get("DSPFX_BENCH_COLD_IDLE", "0.15"))
+        ec0, ec1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        time.sleep(idle_s)
+        ec0.record()
+        for k in range(20):
+            step(k)
+        ec1.record()
+        drain()
+        fence()
+        cold = {"idle_ms": idle_s * 1e3, "steps": 20, "ms_per_step": ec0.elapsed_time(ec1) / 20,
+                "note": "first 20 launches after the idle gap, one event pair; the settled figure is ms_per_step"}
+        if use_mix and args.paced_seconds > 0:
+            paced = paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, args.paced_seconds)
     res = {
-        "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg,
+        "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags, **({"zero_input": True} if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1" else {}),
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
@@ -546,7 +630,10 @@ def main():
     torch.cuda.synchronize()
 
     over = {k: getattr(args, k) for k in ("channels", "frames", "delay", "taps") if getattr(args, k) is not None}
-    r = measure(ctx, args, args.config, args.steps, args.warmup, over)
+    if args.paced:
+        args.no_others = True
+        args.no_cpu_baseline = True
+    r = measure(ctx, args, args.config, args.steps, args.warmup, over, extras=(world == 1))
 
     # The other single-GPU BASELINE configs, timed in the same run with the same K / W (extra key; the line's
     # `value` stays the headline config's).  Default invocation on one GPU only.
@@ -592,6 +679,10 @@ def main():
         "block_latency_ms": r["ms_per_step"], "block_budget_ms": r["block_budget_ms"],
         "gpu_event_ms_per_step": r["gpu_event_ms_per_step"], "host_submit_ms_per_step": r["host_submit_ms_per_step"],
     }
+    if r.get("cold") is not None:
+        line["cold"] = r["cold"]
+    if r.get("paced") is not None:
+        line["paced"] = r["paced"]
     if others is not None:
         line["other_configs"] = others
     if world == 1 and not args.no_cpu_baseline:

@@ -55,7 +55,7 @@ EXPORTS = [
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
     "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
-    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted",
+    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus",
 ]
 COMM_ID_BYTES = 128
 
@@ -142,6 +142,7 @@ def lib():
     L.dspfx_reset.argtypes = [vp]
     L.dspfx_process.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, vp]
     L.dspfx_process_host.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32]
+    L.dspfx_process_bus.argtypes = [vp, f32p, f32p, f32p, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_mix_finish.argtypes = [vp, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_host_alloc.argtypes = [C.c_size_t, C.POINTER(C.c_void_p)]
     L.dspfx_host_free.argtypes = [C.c_void_p]
@@ -477,6 +478,12 @@ class Engine:
         else:
             self._chk(self.L.dspfx_process(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames), st))
         return out
+
+    def process_bus(self, x, out, mix, n_frames: int, n_connected: int = 0, side=None, stream: int = 0):
+        """One block with the Output node complete (dspfx_process_bus): `mix` = this block's bus, summed inside the chain
+        launch and divided by link_divisor(n_connected) when n_connected != 0."""
+        self._chk(self.L.dspfx_process_bus(self.h, _ptr(x), _ptr(side), _ptr(out), _ptr(mix), int(n_frames),
+                                           int(n_connected), C.c_void_p(stream) if stream else None))
 
     def process_io(self, ins, outs, n_frames: int, mix=None, stream: int = 0):
         """A graph engine with several input / output blocks (dspfx_process_io): ins[k] = input block k, outs[m] = output

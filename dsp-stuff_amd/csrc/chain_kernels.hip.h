@@ -64,16 +64,16 @@ struct ChainArgs {
     const float *in;
     const float *side;   // port "b" of ADD/MIX, or nullptr
     float *out;
-    float *mixpart;      // [mix_stride waves][nframes] per-wave partial sums (a wave's row is contiguous), or nullptr
+    float *mixpart;      // [mix_stride rows][nframes] partial sums of the mix bus, one row per WORKGROUP (contiguous), or nullptr
     unsigned N;
     unsigned nframes;
     float hop_div;       // f32(0.0001 + 1.0)  (node.rs:166,179)
     int n_slots;
     int side_hop;
-    unsigned mix_stride; // rows of mixpart = number of waves over all launches of this block
+    unsigned mix_stride; // rows of mixpart = number of workgroups over all launches of this block
     unsigned c_base;     // first channel of this launch
     unsigned n_launch;   // channels covered by this launch
-    unsigned wave_base;  // mixpart row of this launch's first wave
+    unsigned wave_base;  // mixpart row of this launch's first workgroup
     // sample layout: channel c, frame f lives at  (c >> w_shift) * tile_stride + f * ld + (c & w_mask)
     //   frame-major [B][N]      : w_shift = 31, w_mask = ~0u>>1, ld = N, tile strides unused
     //   channel-tiled [N/W][B][W]: w_shift = log2 W, w_mask = W-1, ld = W, tile_stride = B*W
@@ -96,35 +96,43 @@ struct ChainArgs {
     const float *mp_prev_b;  // slice sums of the block before that (written by the previous launch)
     float *mp_mix;           // [nframes] mix bus of the block two launches back
     float mp_div;            // Output-node divisor f32(0.0001 + n), or 0 to leave the sums un-normalised
+    // Same-block mix bus (mix_tail): the slice and final stages of THIS block run inside this launch -- the workgroup
+    // that completes a slice of rows reduces it, the one that completes the last slice finishes the bus.
+    float mt_div;            // Output-node divisor, or 0
+    unsigned *mt_tickets;    // [MIX_SLICES + 1] arrival counters, zero between launches; nullptr: no tail
+    float *mt_part2;         // [MIX_SLICES][nframes] slice sums
+    float *mt_mix;           // [nframes] the bus of this block
     SlotArgs slot[MAX_SLOTS];
 };
 
 // ---- mix bus, second and third stage (shared by the stand-alone kernels and the in-kernel pipeline) --------
-// part is [waves][nframes] (each wave wrote its own contiguous row).  Slice stage: slice b sums a fixed range of
-// waves for every frame (lane = frame: coalesced row reads) into part2[b][frame]; final stage: the slices are
-// summed in fixed order.  Fixed association => run-to-run deterministic, and identical in both forms.
-constexpr unsigned MIX_SLICES = 128;
+// part is [rows][nframes] (one contiguous row per workgroup of a chain kernel / per 32-channel tile of a FIR sweep).  Slice
+// stage: slice b sums a fixed range of rows for every frame (lane = frame: coalesced row reads) into part2[b][frame]; final
+// stage: the slices are summed in fixed order.  Fixed association => run-to-run deterministic, and identical in every form
+// (stand-alone kernels, pipelined in later launches, in the tail of the same launch).
+constexpr unsigned MIX_SLICES = 64;
+__device__ __forceinline__ float mix_rows_sum(const float *src, unsigned n, unsigned nframes, unsigned f) {
+    float a0 = 0.0f, a1 = 0.0f;
+    unsigned r = 0;
+    for (; r + 1 < n; r += 2) {
+        const float x0 = src[(size_t)r * nframes + f], x1 = src[(size_t)(r + 1) * nframes + f];
+        a0 = a0 + x0;
+        a1 = a1 + x1;
+    }
+    if (r < n) a0 = a0 + src[(size_t)r * nframes + f];
+    return a0 + a1;
+}
 __device__ __forceinline__ void mix_slice_reduce(const float *part, float *part2, unsigned waves, unsigned nframes,
                                                  unsigned b, unsigned tid, unsigned nthreads) {
     const unsigned per = (waves + MIX_SLICES - 1) / MIX_SLICES;
-    const unsigned w0 = b * per, w1 = min(waves, w0 + per);
-    for (unsigned f = tid; f < nframes; f += nthreads) {
-        float a0 = 0.0f, a1 = 0.0f;
-        unsigned w = w0;
-        for (; w + 1 < w1; w += 2) {
-            const float x0 = part[(size_t)w * nframes + f], x1 = part[(size_t)(w + 1) * nframes + f];
-            a0 = a0 + x0;
-            a1 = a1 + x1;
-        }
-        if (w < w1) a0 = a0 + part[(size_t)w * nframes + f];
-        part2[(size_t)b * nframes + f] = a0 + a1;
-    }
+    const unsigned w0 = min(waves, b * per), w1 = min(waves, w0 + per);
+    for (unsigned f = tid; f < nframes; f += nthreads) part2[(size_t)b * nframes + f] = mix_rows_sum(part + (size_t)w0 * nframes, w1 - w0, nframes, f);
 }
+// (slices that hold no rows were written as +0 by the slice stage and are added like the others)
 __device__ __forceinline__ void mix_final_reduce(const float *part2, float *mix, unsigned nframes, float div,
                                                  unsigned tid, unsigned nthreads) {
     for (unsigned f = tid; f < nframes; f += nthreads) {
-        float acc = 0.0f;
-        for (unsigned b = 0; b < MIX_SLICES; ++b) acc = acc + part2[(size_t)b * nframes + f];
+        const float acc = mix_rows_sum(part2, MIX_SLICES, nframes, f);
         mix[f] = div != 0.0f ? acc / div : acc;     // node.rs:189-191 (the Output node's hop)
     }
 }
@@ -134,6 +142,122 @@ __device__ __forceinline__ void mixpipe_prologue(const ChainArgs &a) {
     const unsigned b = blockIdx.x;
     if ((a.mp_stage & 1) && b < MIX_SLICES) mix_slice_reduce(a.mp_prev_a, a.mp_cur_b, a.mp_rows_a, a.nframes, b, threadIdx.x, blockDim.x);
     else if ((a.mp_stage & 2) && b == MIX_SLICES) mix_final_reduce(a.mp_prev_b, a.mp_mix, a.nframes, a.mp_div, threadIdx.x, blockDim.x);
+}
+
+// The kernel's arguments as they lie in the kernarg segment (every chain / graph kernel takes its ChainArgs first), for code
+// that runs once or twice per launch: read there, at the point of use, the fields it needs do not sit in scalar registers
+// across the chunk loop (the by-value argument's loads are loop-invariant and get hoisted: with the bus' tail fields the
+// 5-node kernel went from 18 to 154 scalar spills and lost a wave of occupancy to the spill registers).
+struct ColdArgs {
+    float *mixpart;
+    unsigned nframes, mix_stride, wave_base, n_launch;
+    int xcd_remap;
+    float mt_div;
+    unsigned *mt_tickets;
+    float *mt_part2, *mt_mix;
+};
+__device__ __forceinline__ ColdArgs cold_args() {
+    typedef const __attribute__((address_space(4))) ChainArgs *KernArgPtr;      // constant address space: scalar loads, wave-uniform values
+    KernArgPtr ka = (KernArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));               // opaque: nothing read through it can be hoisted above this point
+    ColdArgs c;
+    c.mixpart = ka->mixpart;
+    c.nframes = ka->nframes;
+    c.mix_stride = ka->mix_stride;
+    c.wave_base = ka->wave_base;
+    c.n_launch = ka->n_launch;
+    c.xcd_remap = ka->xcd_remap;
+    c.mt_div = ka->mt_div;
+    c.mt_tickets = ka->mt_tickets;
+    c.mt_part2 = ka->mt_part2;
+    c.mt_mix = ka->mt_mix;
+    return c;
+}
+// ---- same-block mix bus: the slice and final stages in the tail of the launch that produced the rows --------------
+// Rows are handed between workgroups INSIDE a launch, across XCDs whose L2s are not coherent with each other: the rows
+// and slice sums are written through (sc1 stores), every writing wave drains its stores (s_waitcnt vmcnt(0)) before
+// ONE lane bumps an agent-scope counter, and the workgroup that draws the last ticket reads them back with sc1 loads
+// (which the caches cannot serve stale).  No fences: a release fence would write back the XCD's whole L2, which at
+// this point is full of freshly stored samples.  Counters are reset by the last arriver, so they are zero between launches.
+typedef __attribute__((address_space(1))) unsigned dspfx_gu32;   // every shared word is a GLOBAL agent-scope access, never flat
+__device__ __forceinline__ float ld_sc1(const float *p) {
+    return __uint_as_float(__hip_atomic_load((const dspfx_gu32 *)reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void st_sc1(float *p, float v) {
+    __hip_atomic_store((dspfx_gu32 *)reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned ticket_take(unsigned *t, int lane) {
+    unsigned v = 0;
+    if (lane == 0) v = __hip_atomic_fetch_add((dspfx_gu32 *)t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// dst[f] = fixed-order sum over rows r of src[r][f], r in [0, n): rows of even index (counted from the first) are
+// added one after another into one accumulator, rows of odd index into a second one, the result is their sum -- the
+// association of mix_slice_reduce / mix_final_reduce.  ONE wave; the rows are read with sc1 loads, TAIL_BATCH of them in
+// flight per lane (a dependent chain of single loads would cost a memory round trip per row: the whole tail is latency).
+#ifndef DSPFX_TAIL_BATCH
+#define DSPFX_TAIL_BATCH 32
+#endif
+constexpr int TAIL_BATCH = DSPFX_TAIL_BATCH;   // even
+typedef unsigned dspfx_u32x2 __attribute__((ext_vector_type(2)));
+// sc1 loads through a buffer descriptor (`buffer_load_dwordx2 v, v_off, s[rsrc], 0 offen sc1`): one running 32-bit offset
+// register instead of a 64-bit vector address per row (the atomic-load builtin's global sc1 loads: 64 VGPRs of addresses for
+// 32 rows in flight), and the descriptor's bounds check returns 0 for rows past n_valid -- no branches in the batch.
+// nf is even (the host takes this path for even block lengths only): a lane takes the frames 2 lane, 2 lane + 1.
+constexpr int BUF_AUX_SC1 = 16;
+__device__ __forceinline__ void tail_reduce_rows(const float *src, unsigned n, unsigned n_valid, unsigned nf, float *dst, float div, bool write_through, int lane) {
+    const unsigned stride = nf * (unsigned)sizeof(float);           // n * stride stays far below 4 GiB (<= 8192 rows of <= a few thousand frames)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)(n_valid * stride), 0x00020000);
+    for (unsigned f = (unsigned)lane * 2; f < nf; f += 128) {
+        float a00 = 0.0f, a01 = 0.0f, a10 = 0.0f, a11 = 0.0f;       // a<parity of the row><frame>
+#pragma unroll 1                                                     // one batch in flight: two would double the registers of the whole kernel
+        for (unsigned r0 = 0; r0 < n; r0 += TAIL_BATCH) {
+            dspfx_u32x2 x[TAIL_BATCH];
+            unsigned off = r0 * stride + f * (unsigned)sizeof(float);
+#pragma unroll
+            for (int k = 0; k < TAIL_BATCH; ++k, off += stride) x[k] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, BUF_AUX_SC1);
+#pragma unroll
+            for (int k = 0; k < TAIL_BATCH; k += 2) {               // TAIL_BATCH is even: the parity of k is the row's
+                const bool in0 = r0 + k < n, in1 = r0 + k + 1 < n;  // uniform
+                const float s00 = a00 + __uint_as_float(x[k].x), s01 = a01 + __uint_as_float(x[k].y);
+                const float s10 = a10 + __uint_as_float(x[k + 1].x), s11 = a11 + __uint_as_float(x[k + 1].y);
+                a00 = in0 ? s00 : a00;
+                a01 = in0 ? s01 : a01;
+                a10 = in1 ? s10 : a10;
+                a11 = in1 ? s11 : a11;
+            }
+        }
+        float t0 = a00 + a10, t1 = a01 + a11;
+        if (div != 0.0f) {                                          // node.rs:189-191 (the Output node's hop)
+            t0 = t0 / div;
+            t1 = t1 / div;
+        }
+        if (write_through) {
+            st_sc1(dst + f, t0);
+            st_sc1(dst + f + 1, t1);
+        } else {
+            dst[f] = t0;
+            dst[f + 1] = t1;
+        }
+    }
+}
+// Called by ONE wave per row (the wave that stored the row), all 64 lanes alive, after the row's last store.
+__device__ __forceinline__ void mix_tail(unsigned row, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the row has left this wave and is in memory
+    const ColdArgs a = cold_args();
+    const unsigned rows = a.mix_stride, nf = a.nframes;
+    const unsigned per = (rows + MIX_SLICES - 1) / MIX_SLICES;
+    const unsigned b = row / per, w0 = b * per, w1 = min(rows, w0 + per);
+    if (ticket_take(a.mt_tickets + b, lane) + 1 != w1 - w0) return;
+    // last row of slice b: the same sums in the same order as mix_slice_reduce
+    tail_reduce_rows(a.mixpart + (size_t)w0 * nf, w1 - w0, w1 - w0, nf, a.mt_part2 + (size_t)b * nf, 0.0f, true, lane);
+    if (lane == 0) __hip_atomic_store((dspfx_gu32 *)(a.mt_tickets + b), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned live = (rows + per - 1) / per;                     // slices that hold rows; the others count as the +0 their stage would have written
+    if (ticket_take(a.mt_tickets + MIX_SLICES, lane) + 1 != live) return;
+    // last slice: the same sums in the same order as mix_final_reduce
+    tail_reduce_rows(a.mt_part2, MIX_SLICES, live, nf, a.mt_mix, a.mt_div, false, lane);
+    if (lane == 0) __hip_atomic_store((dspfx_gu32 *)(a.mt_tickets + MIX_SLICES), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Sample layout shared by every kernel: channel c, frame f lives at
@@ -1089,9 +1213,19 @@ template <int... SIGS> struct SigList {
     static constexpr int v[MAX_SLOTS] = {SIGS...};
 };
 
+// The bus' first stage.  Every wave reduces its chunk over its 64 lanes (reduce-scatter: one total per frame) and parks the
+// totals in LDS; once a 128-frame segment of the block is complete in all waves of the workgroup, wave 0 adds the waves'
+// rows in fixed order -- (w0 + w1) + (w2 + w3) -- and writes ONE row segment per workgroup (mixbus_flush).  A quarter
+// of the rows for the later stages to read, and no global stores inside the chunk loop.  Two buffers, used in turn, so one
+// barrier per segment suffices: nobody writes segment s + 2 before the barrier of segment s + 1, which wave 0 reaches
+// only after it has read segment s.
+constexpr unsigned MIX_SEG = 128;
+struct MixStage {
+    float row[2][WG / 64][MIX_SEG];
+};
 template <int F, int CPL>
-__device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (&v)[F][CPL], bool live,
-                                               unsigned f0, int lane, unsigned wave_global) {
+__device__ __forceinline__ void mixbus_partial(MixStage &ms, const float (&v)[F][CPL], bool live, unsigned f0, int lane, int wave) {
+    static_assert(MIX_SEG % F == 0, "a chunk never straddles two segments");
     float r[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -1101,13 +1235,53 @@ __device__ __forceinline__ void mixbus_partial(const ChainArgs &a, const float (
         r[f] = live ? sacc : 0.0f;
     }
     wave_reduce_scatter<F>(r, lane);
-    if (mixbus_lane_writes<F>(lane))
-        a.mixpart[(size_t)wave_global * a.nframes + f0 + mixbus_frame_of_lane<F>(lane)] = r[0];
+    if (mixbus_lane_writes<F>(lane)) {
+        const unsigned f = f0 + mixbus_frame_of_lane<F>(lane);
+        ms.row[(f / MIX_SEG) & 1][wave][f % MIX_SEG] = r[0];
+    }
+}
+// Frames [seg0, seg0 + len) are parked by every wave of the workgroup (nw of them are alive; they all call this).
+template <class ARGS>
+__device__ __forceinline__ void mixbus_flush(const ARGS &a, MixStage &ms, unsigned seg0, unsigned len, unsigned row, int nw, int wave, int lane) {
+    __syncthreads();
+    if (wave != 0) return;
+    const int buf = (seg0 / MIX_SEG) & 1;
+    float *dst = a.mixpart + (size_t)row * a.nframes + seg0;
+    for (unsigned f = lane; f < len; f += 64) {
+        float t = ms.row[buf][0][f];
+        if (nw > 1) t = t + ms.row[buf][1][f];
+        if (nw > 2) {
+            float u = ms.row[buf][2][f];
+            if (nw > 3) u = u + ms.row[buf][3][f];
+            t = t + u;
+        }
+        if (a.mt_tickets) st_sc1(dst + f, t);        // handed to another workgroup inside this launch: written through
+        else dst[f] = t;
+    }
+}
+// waves of this workgroup that cover channels (the others returned at once): wg_rel = first channel of the workgroup, relative
+template <int CPL, class ARGS>
+__device__ __forceinline__ int mixbus_live_waves(const ARGS &a, size_t wg_rel, int waves) {
+    const size_t left = a.n_launch > wg_rel ? a.n_launch - wg_rel : 0;
+    const size_t n = (left + 64 * CPL - 1) / (64 * CPL);
+    return n < (size_t)waves ? (int)n : waves;
+}
+// after chunk [f0, f0 + F): flush the segment it completed, if any (uniform over the workgroup).  Everything the flush
+// needs is derived here from the block / thread index rather than carried through the chunk loop in registers.
+template <int F, int CPL>
+__device__ __forceinline__ void mixbus_after_chunk(const ChainArgs &hot, MixStage &ms, unsigned f0) {
+    const unsigned end = f0 + F;
+    if (end % MIX_SEG != 0 && end != hot.nframes) return;
+    const ColdArgs a = cold_args();
+    const unsigned len = end % MIX_SEG ? end % MIX_SEG : MIX_SEG;
+    const unsigned wb = blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x;   // guarded tail launches use 64-lane blocks
+    const int nw = mixbus_live_waves<CPL>(a, (size_t)wb * blockDim.x * CPL, (int)(blockDim.x / 64));
+    mixbus_flush(a, ms, end - len, len, a.wave_base + wb, nw, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
 }
 
 template <int F, int CPL, class SL, bool MOD = false>
 __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_SLOTS][4][CPL], size_t c, const WaveAddr &w,
-                                            unsigned f0, int lane, unsigned wave_global) {
+                                            unsigned f0, int lane, MixStage &ms, int wave) {
     float v[F][CPL];
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
@@ -1129,18 +1303,19 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 #pragma unroll
     for (int f = 0; f < F; ++f)
         if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
-    if (a.mixpart) mixbus_partial<F, CPL>(a, v, true, f0, lane, wave_global);
+    if (a.mixpart) mixbus_partial<F, CPL>(ms, v, true, f0, lane, wave);
 }
 
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
 template <int F, int CPL, class SL, bool MOD = false>
 __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
+    __shared__ MixStage ms;
     if (a.mp_stage) mixpipe_prologue(a);
-    const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const unsigned wb = work_block(a.xcd_remap);
+    const unsigned tid = wb * WG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t rel = (size_t)tid * CPL;
-    if (rel >= a.n_launch) return;                 // whole-wave uniform by construction
+    if (rel >= a.n_launch) return;                 // whole-wave uniform by construction (a finished wave holds up no barrier)
     const size_t c = a.c_base + rel;
     float st[MAX_SLOTS][4][CPL];
 #define DSPFX_LD(I) load_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
@@ -1148,14 +1323,21 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
 #undef DSPFX_LD
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) chain_chunk<F, CPL, SL, MOD>(a, st, c, w, f0, lane, wave_global);
+    for (; f0 + F <= a.nframes; f0 += F) {
+        chain_chunk<F, CPL, SL, MOD>(a, st, c, w, f0, lane, ms, wave);
+        if (a.mixpart) mixbus_after_chunk<F, CPL>(a, ms, f0);
+    }
     if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) chain_chunk<1, CPL, SL, MOD>(a, st, c, w, f0, lane, wave_global);
+        for (; f0 < a.nframes; ++f0) {
+            chain_chunk<1, CPL, SL, MOD>(a, st, c, w, f0, lane, ms, wave);
+            if (a.mixpart) mixbus_after_chunk<1, CPL>(a, ms, f0);
+        }
 #define DSPFX_ST(I)                                                                              \
     if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st[I], a.nframes); \
     store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_ST)
 #undef DSPFX_ST
+    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + work_block(a.xcd_remap), lane);
 }
 
 // ---- the fused chain kernel, time-sliced: few channels ------------------------------------------------
@@ -1200,7 +1382,7 @@ template <class SL> constexpr int ts_first_reverb() {
 // paths with different loads in flight the compiler's counter pass waits for all of them.)
 template <int S, int CPL, class SL, bool LATE>
 __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CPL][64], const Ctx &cx, const WaveAddr &w, float (&v)[S][CPL],
-                                       int q, int lane, size_t c, unsigned group, unsigned wave_global, unsigned f_begin) {
+                                       int q, int lane, size_t c, unsigned group, MixStage &ms, unsigned f_begin) {
     constexpr int FS = ts_first_stateful<SL>(), FR = ts_first_reverb<SL>();
     constexpr bool late = LATE && FS < FR && FR < MAX_SLOTS;
     // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
@@ -1261,7 +1443,7 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     for (int f = 0; f < S; ++f)
         if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
     DSPFX_TS_STAMP(13)
-    if (a.mixpart) mixbus_partial<S, CPL>(a, v, true, f_begin, lane, wave_global);
+    if (a.mixpart) mixbus_partial<S, CPL>(ms, v, true, f_begin, lane, 0);      // the four slices of ONE row
     DSPFX_TS_STAMP(14)
 }
 
@@ -1271,6 +1453,7 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     // slices store while the later ones still take their turns -- was tried: config 2 27.3 -> 30.2 us, the 5-node chain at
     // 65536 channels 35.0 -> 32.7 us only at two channels per lane; reads and writes in separate phases suit the HBM better.)
     __shared__ float lds_st[4][CPL][64];           // the state rows of the node whose turns are being taken
+    __shared__ MixStage ms;
     if (a.mp_stage) mixpipe_prologue(a);
     const int lane = threadIdx.x & 63;
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // time slice of this wave
@@ -1293,10 +1476,14 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     // per CU to three (108 -> 155) and ran 36 -> 42 us at 65536 channels: short chains only.  (Late taps for EVERY slice --
     // one copy of the body -- expose the taps' latency in the later slices: config 2 33.4 us.)
     if constexpr (ts_slot_count<SL>() <= 3) {
-        if (q == 0) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
-        else ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+        if (q == 0) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
+        else ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
     } else {
-        ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, wave_global, f_begin);
+        ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
+    }
+    if (a.mixpart) {                               // 4 S frames == one segment; the workgroup's row is the four slices side by side
+        mixbus_flush(a, ms, 0, 4 * S, wave_global, 1, q, lane);
+        if (a.mt_tickets && q == 0) mix_tail(wave_global, lane);
     }
 }
 
@@ -1309,7 +1496,7 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
 // separate instantiation because those paths nearly double the register footprint (it runs at F=4).
 template <int F, int CPL, bool GUARD, bool FAST, bool MOD, bool LIBM>
 __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t c, const WaveAddr &w, bool active, unsigned f0,
-                                          int lane, unsigned wave_global) {
+                                          int lane, MixStage &ms, int wave) {
     float v[F][CPL];
 #pragma unroll
     for (int f = 0; f < F; ++f) load_vec<CPL, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
@@ -1338,17 +1525,18 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
 #pragma unroll
     for (int f = 0; f < F; ++f)
         if (!a.skip_store) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
-    if (a.mixpart) mixbus_partial<F, CPL>(a, v, !GUARD || active, f0, lane, wave_global);
+    if (a.mixpart) mixbus_partial<F, CPL>(ms, v, !GUARD || active, f0, lane, wave);
 }
 
 // LDS: [state rows][CPL][WG] floats (conflict-free: consecutive lanes, consecutive banks)
 template <int F, int CPL, bool GUARD, bool MOD, bool LIBM>
 __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     extern __shared__ float lds[];
+    __shared__ MixStage ms;
     if (a.mp_stage) mixpipe_prologue(a);
-    const unsigned tid = (blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x) * blockDim.x + threadIdx.x;   // tail launches use 64-lane blocks
-    const int lane = threadIdx.x & 63;
-    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const unsigned wb = blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x;   // tail launches use 64-lane blocks
+    const unsigned tid = wb * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t rel = (size_t)tid * CPL;
     const bool active = rel < a.n_launch;
     if (!GUARD && !active) return;                 // whole-wave uniform by construction
@@ -1372,13 +1560,25 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
     if (a.fast_div) {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) {
+            dyn_chunk<F, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, ms, wave);
+            if (a.mixpart) mixbus_after_chunk<F, CPL>(a, ms, f0);
+        }
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) {
+                dyn_chunk<1, CPL, GUARD, true, MOD, LIBM>(a, lds, c, w, active, f0, lane, ms, wave);
+                if (a.mixpart) mixbus_after_chunk<1, CPL>(a, ms, f0);
+            }
     } else {
-        for (; f0 + F <= a.nframes; f0 += F) dyn_chunk<F, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+        for (; f0 + F <= a.nframes; f0 += F) {
+            dyn_chunk<F, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, ms, wave);
+            if (a.mixpart) mixbus_after_chunk<F, CPL>(a, ms, f0);
+        }
         if constexpr (F > 1)
-            for (; f0 < a.nframes; ++f0) dyn_chunk<1, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, wave_global);
+            for (; f0 < a.nframes; ++f0) {
+                dyn_chunk<1, CPL, GUARD, false, MOD, LIBM>(a, lds, c, w, active, f0, lane, ms, wave);
+                if (a.mixpart) mixbus_after_chunk<1, CPL>(a, ms, f0);
+            }
     }
     {
         int row = 0;
@@ -1407,6 +1607,7 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
             row += ns;
         }
     }
+    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + wb, lane);
 }
 
 }  // namespace dspfx

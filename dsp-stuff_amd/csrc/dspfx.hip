@@ -81,6 +81,7 @@ struct dspfx_engine {
     float *mixpart = nullptr;
     float *mixpart_b = nullptr;   // second-stage scratch [128][max_frames] (one per stream of use: inline / deferred)
     float *mixpart_b2 = nullptr;
+    unsigned *mt_tickets = nullptr;   // same-block bus inside the chain launch: [MIX_SLICES + 1] arrival counters, zero between launches
     size_t mixpart_cols = 0;
     // pipelined mix bus (dspfx_process_partials / dspfx_mix_collect): double-buffered partials
     float *mixpart2[2] = {nullptr, nullptr};
@@ -96,6 +97,7 @@ struct dspfx_engine {
     float *mp_mix_now = nullptr;          // where the launch being built delivers block k-2's bus
     float mp_div_now = 0.0f;
     bool mp_building = false;
+    float bus_div_now = 0.0f;             // dspfx_process_bus: the Output hop's divisor for the block being launched (0: none)
     // channel window of the current run_subblock call (pipelined host path): channels [win_c0, win_c0 + win_n), 0 = all;
     // win_last marks the call that finishes the block (ring positions advance once)
     uint32_t win_c0 = 0, win_n = 0;
@@ -1143,9 +1145,22 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             const uint32_t waves_main = n_main / per_wave;
             const bool deferred = last && e->partials_override != nullptr;
             a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
-            a.mix_stride = waves_main + (N - n_main + 63) / 64;
-            if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
             const unsigned grid_main = v->ts ? waves_main : (waves_main * 64 + WG - 1) / WG;   // time-sliced: one workgroup per channel group
+            // the bus' first stage leaves one row of partial sums per WORKGROUP (chain_kernels.hip.h, mixbus_flush); the
+            // guarded tail launch runs one-wave workgroups
+            a.mix_stride = grid_main + (N - n_main + 63) / 64;
+            if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
+            // Same-block bus: the slice and final stages ride in the tail of this very launch (mix_tail) instead of two more
+            // kernels behind it.  DSPFX_MIX_TAIL=0: the stand-alone kernels (A/B runs, tests: bit-identical).
+            // (even block lengths: the tail reads two frames per lane with one 8-byte load)
+            const bool tail_bus = last && mix && !deferred && !e->mp_building && e->mt_tickets && nframes % 2u == 0 &&
+                                  !(getenv("DSPFX_MIX_TAIL") && atoi(getenv("DSPFX_MIX_TAIL")) == 0);
+            if (tail_bus) {
+                a.mt_tickets = e->mt_tickets;
+                a.mt_part2 = e->mixpart_b;
+                a.mt_mix = mix;
+                a.mt_div = e->bus_div_now;
+            }
             if (e->mp_building && last) {   // pipelined mix bus: earlier blocks' reductions ride in this launch
                 const int cur = (int)(e->mp_count & 1), prev = cur ^ 1;
                 a.mixpart = e->mixpart2[cur];
@@ -1174,7 +1189,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 if (w1 > w0) {
                     a.c_base = w0;
                     a.n_launch = w1 - w0;
-                    a.wave_base = w0 / per_wave;
+                    a.wave_base = v->ts ? w0 / per_wave : w0 / (per_wave * (WG / 64));   // rows of the windows before this one
                     ProfScope ps(e, si, stream);
                     if (launch_variant(v, a, v->ts ? (w1 - w0) / per_wave : ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream))
                         return fail(e, DSPFX_ERR_HIP, "kernel launch failed");
@@ -1193,15 +1208,16 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 const uint32_t n_tail = N - n_main;
                 a.c_base = n_main;
                 a.n_launch = n_tail;
-                a.wave_base = waves_main;
+                a.wave_base = grid_main;
                 (void)launch_variant(tail, a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
             }
             HIPCHK(e, hipGetLastError());
             if (deferred) {
                 e->part_stride[e->flip] = a.mix_stride;
                 e->part_frames[e->flip] = nframes;
-            } else if (a.mixpart && !e->mp_building) {
+            } else if (a.mixpart && !e->mp_building && !tail_bus) {
                 launch_mix_reduce(e->mixpart, e->mixpart_b, mix, nframes, a.mix_stride, stream);
+                if (e->bus_div_now != 0.0f) launch_mix_finish(mix, nframes, e->bus_div_now, stream);
                 HIPCHK(e, hipGetLastError());
             }
         } else if (st.type == ST_FUZZ) {
@@ -1256,6 +1272,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     e->part_frames[e->flip] = nframes;
                 } else if (!e->mp_building) {
                     launch_mix_reduce(e->mixpart, e->mixpart_b, mix, nframes, frows, stream);
+                    if (e->bus_div_now != 0.0f) launch_mix_finish(mix, nframes, e->bus_div_now, stream);
                     HIPCHK(e, hipGetLastError());
                 }
                 bus_done = true;
@@ -1497,7 +1514,9 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     e->mixpart_cols = (size_t)desc->channels / 32 + 8;   // rows of first-stage partials: one per wave of a chain kernel, one per 32-channel tile of a FIR sweep
     if (hipMalloc((void **)&e->mixpart, e->mixpart_cols * desc->max_frames * sizeof(float)) != hipSuccess ||
         hipMalloc((void **)&e->mixpart_b, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess ||
-        hipMalloc((void **)&e->mixpart_b2, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess) {
+        hipMalloc((void **)&e->mixpart_b2, (size_t)128 * desc->max_frames * sizeof(float)) != hipSuccess ||
+        hipMalloc((void **)&e->mt_tickets, (MIX_SLICES + 1) * sizeof(unsigned)) != hipSuccess ||
+        hipMemset(e->mt_tickets, 0, (MIX_SLICES + 1) * sizeof(unsigned)) != hipSuccess) {
         dspfx_engine_destroy(e);
         return DSPFX_ERR_OOM;
     }
@@ -1513,6 +1532,7 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);
     if (e->mixpart_b2) (void)hipFree(e->mixpart_b2);
+    if (e->mt_tickets) (void)hipFree(e->mt_tickets);
     for (int i = 0; i < 2; ++i) {
         if (e->mixpart2[i]) (void)hipFree(e->mixpart2[i]);
         if (e->ev_chain[i]) (void)hipEventDestroy(e->ev_chain[i]);
@@ -2090,6 +2110,28 @@ extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side
         e->frames_submitted += nf;
     }
     return DSPFX_OK;
+}
+
+// The Output node in the same launch: nodes/output.rs:215-249 feeds every channel's pipe into one port, and
+// collect_and_average (node.rs:162-194) sums them and divides by f32(0.0001 + n).
+extern "C" int dspfx_process_bus(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
+                                 uint32_t n_frames, uint64_t n_connected, void *stream) {
+    if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e, true, (hipStream_t)stream);
+    if (api.rc) return api.rc;
+    if (!mix) return fail(e, DSPFX_ERR_INVALID, "mix must not be null");
+    float div = 0.0f;
+    if (n_connected) {
+        if (e->div_n != n_connected || e->div_v == 0.0f) {
+            e->div_v = dspfx_link_divisor(n_connected);
+            e->div_n = n_connected;
+        }
+        div = e->div_v;
+    }
+    e->bus_div_now = div;
+    const int rc = dspfx_process(e, in, side, out, mix, n_frames, stream);
+    e->bus_div_now = 0.0f;
+    return rc;
 }
 
 extern "C" int dspfx_process_io(dspfx_engine *e, const float *const *ins, int n_ins, float *const *outs, int n_outs, float *mix,

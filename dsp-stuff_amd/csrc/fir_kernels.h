@@ -45,6 +45,7 @@ struct FirState {
     int mode = 0;                 // 0 Balanced, 1 Average (fir.rs:187-190)
     uint64_t n_seen = 0;          // samples consumed since the history was last empty
     uint64_t front = 0;           // absolute index of the deque's oldest sample (deque length = n_seen - front)
+    uint64_t seen_bias = 0;       // samples the deque had seen before a state import re-based time (reporting only)
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
     int precision = 0;            // dspfx_fir_precision: 0 environment / f32, 1 f32, 2 split (bf16 x 3)

@@ -835,6 +835,7 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     s.tiles = (N + TILE_C - 1) / TILE_C;
     s.n_seen = 0;
     s.front = 0;
+    s.seen_bias = 0;
     s.dq_cap = s.dq_head = 0;
     s.R = ring_rows_for(0, n_taps, max_frames);
     const size_t ring_bytes = ring_bytes_for(s.tiles, s.R);
@@ -906,6 +907,7 @@ void fir_reset(FirState &s, hipStream_t stream) {
     s.warm_ok = s.warm_acc != nullptr;
     s.n_seen = 0;
     s.front = 0;
+    s.seen_bias = 0;
     s.dq_cap = s.dq_head = 0;
 }
 
@@ -1123,7 +1125,8 @@ static int copy_rows(FirState &s, long long t0, uint64_t n, char *host, bool to_
 int fir_state_export(FirState &s, void *host_dst) {
     const uint64_t held = s.n_seen - s.front;
     const uint32_t hdr32[4] = {s.dq_cap, s.dq_head, s.T, 0};
-    memcpy(host_dst, &s.n_seen, 8);
+    const uint64_t seen = s.n_seen + s.seen_bias;
+    memcpy(host_dst, &seen, 8);
     memcpy((char *)host_dst + 8, &held, 8);
     memcpy((char *)host_dst + 16, hdr32, 16);
     if (!held) return 0;
@@ -1181,8 +1184,8 @@ int fir_state_import(FirState &s, const void *host_src) {
     }
     FIRCHK(hipMemset(s.warm_acc, 0, (size_t)s.N * sizeof(double)));
     s.warm_ok = held == 0;                               // imported history: its running sums are not known
+    s.seen_bias = seen >= held ? seen - held : 0;
     FIRCHK(hipDeviceSynchronize());
-    (void)seen;
     return 0;
 }
 

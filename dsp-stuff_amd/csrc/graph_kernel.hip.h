@@ -132,7 +132,7 @@ __device__ __forceinline__ void g_mix_mod(float (&v)[F][CPL], const float (&b)[F
 //                    template <int F, int CPL> static void run(g, xs, ys, st, cx)   xs[k] = input block k, ys[m] = output block m
 template <int F, int CPL, class PROG>
 __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAPH_SLOTS][4][CPL], size_t c, const WaveAddr &w,
-                                            unsigned f0, int lane, unsigned wave_global) {
+                                            unsigned f0, int lane, MixStage &ms, int wave) {
     const ChainArgs &a = g.c;
     float xs[GRAPH_IO][F][CPL], ys[GRAPH_IO][F][CPL];
 #pragma unroll
@@ -156,17 +156,18 @@ __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAP
                 store_vec<CPL, false, S_OUT>(lane_ptr(dst + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), ys[m][f], true);
         }
     }
-    if (a.mixpart) mixbus_partial<F, CPL>(a, ys[0], true, f0, lane, wave_global);
+    if (a.mixpart) mixbus_partial<F, CPL>(ms, ys[0], true, f0, lane, wave);
 }
 
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves), like chain_kernel.
 template <int F, int CPL, class PROG>
 __global__ void __launch_bounds__(WG) graph_kernel(const GraphArgs g) {
     const ChainArgs &a = g.c;
+    __shared__ MixStage ms;
     if (a.mp_stage) mixpipe_prologue(a);
-    const unsigned tid = work_block(a.xcd_remap) * WG + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const unsigned wave_global = a.wave_base + (tid >> 6);
+    const unsigned wb = work_block(a.xcd_remap);
+    const unsigned tid = wb * WG + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const size_t rel = (size_t)tid * CPL;
     if (rel >= a.n_launch) return;                 // whole-wave uniform by construction
     const size_t c = a.c_base + rel;
@@ -176,14 +177,21 @@ __global__ void __launch_bounds__(WG) graph_kernel(const GraphArgs g) {
 #undef DSPFX_LD
     const WaveAddr w = wave_addr(a, c);
     unsigned f0 = 0;
-    for (; f0 + F <= a.nframes; f0 += F) graph_chunk<F, CPL, PROG>(g, st, c, w, f0, lane, wave_global);
+    for (; f0 + F <= a.nframes; f0 += F) {
+        graph_chunk<F, CPL, PROG>(g, st, c, w, f0, lane, ms, wave);
+        if (a.mixpart) mixbus_after_chunk<F, CPL>(a, ms, f0);
+    }
     if constexpr (F > 1)
-        for (; f0 < a.nframes; ++f0) graph_chunk<1, CPL, PROG>(g, st, c, w, f0, lane, wave_global);
+        for (; f0 < a.nframes; ++f0) {
+            graph_chunk<1, CPL, PROG>(g, st, c, w, f0, lane, ms, wave);
+            if (a.mixpart) mixbus_after_chunk<1, CPL>(a, ms, f0);
+        }
 #define DSPFX_ST(I)                                                                              \
     if constexpr (sig_is<K_SIGNAL_GEN>(PROG::sigs[I])) signal_gen_close_block<CPL>(gslot<I>(g), st[I], a.nframes); \
     store_state<PROG::sigs[I], CPL, false>(gslot<I>(g), st[I], c, a.N, true);
     DSPFX_FOR_GSLOTS(DSPFX_ST)
 #undef DSPFX_ST
+    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + wb, lane);
 }
 
 }  // namespace dspfx

@@ -89,62 +89,112 @@ class MixBus:
         self._complete_pending()
 
 
-class PipelinedMixBus:
-    """Cross-rank mix bus on top of the in-kernel pipeline (`Engine.process_mixpipe`).
+class StreamOrder:
+    """The ordering PipelinedMixBus needs between its two streams, on real HIP streams (torch wraps them).  Split out so
+    that the ring / batch / drain logic can be driven without a GPU (HostOrder) in the world-size-2 gloo tests."""
 
-    The chain kernels of a rank run back to back on the compute stream; each launch delivers the rank-local,
-    un-normalised bus of the block submitted two calls earlier into a row of a ring buffer.  Every `batch`
-    blocks ONE event marker is put on the compute stream, and the second stream all-reduces the `batch` rows in
-    one RCCL call and applies the Output-node hop with the global channel count (`MixBus` over a
-    [batch * n_frames] buffer).  Three rings decouple the streams: a ring is reused two submits after its own,
-    when its collective and division have long finished (checked with an event query, no stall in steady state).
-    `results()` after `drain()` returns {block index: tensor view} for the blocks still held in the rings.
+    def __init__(self, torch, compute_stream, mix_stream):
+        self.torch, self.cs, self.ms = torch, compute_stream, mix_stream
+        self.compute_handle, self.mix_handle = compute_stream.cuda_stream, mix_stream.cuda_stream
+
+    def mix_after_compute(self):
+        """Everything queued on the compute stream so far happens before what the mix stream is given next (one event)."""
+        ev = self.torch.cuda.Event()
+        ev.record(self.cs)
+        self.ms.wait_event(ev)
+
+    def on_mix(self):
+        return self.torch.cuda.stream(self.ms)
+
+    def mark_mix(self):
+        ev = self.torch.cuda.Event()
+        ev.record(self.ms)
+        return ev
+
+    def compute_after(self, ev):
+        """The compute stream waits for a mark of the mix stream (no packet when it has long passed)."""
+        if not ev.query():
+            self.cs.wait_event(ev)
+
+
+class HostOrder:
+    """StreamOrder for a host-only run: every call completes before it returns, so there is nothing to order."""
+    compute_handle = mix_handle = 0
+
+    def mix_after_compute(self):
+        pass
+
+    def on_mix(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def mark_mix(self):
+        return None
+
+    def compute_after(self, ev):
+        pass
+
+
+class PipelinedMixBus:
+    """Cross-rank mix bus behind the chain kernels of a rank, which run back to back on the compute stream.
+
+    Each launch leaves a rank-local, un-normalised bus in a row of a ring buffer: the bus of ITS OWN block when
+    `same_block` (Engine.process_bus: the launch's last workgroups finish the sum), else of the block submitted two calls
+    earlier (Engine.process_mixpipe, the in-kernel pipeline).  Every `batch` blocks ONE event marker is put on the compute
+    stream, and the second stream all-reduces the `batch` rows in one RCCL call and applies the Output-node hop with the
+    global channel count (`MixBus` over a [batch * n_frames] buffer).  Three rings decouple the streams: a ring is reused
+    two submits after its own, when its collective and division have long finished (checked with an event query, no stall
+    in steady state).  `results()` after `drain()` returns {block index: tensor view} for the blocks still in the rings.
+    `order` = StreamOrder (GPU) or HostOrder (tests); `engine` needs process_bus / process_mixpipe / mixpipe_flush /
+    mix_finish (/ mix_allreduce with a `comm`).
     """
 
     def __init__(self, engine, total_channels: int, n_frames: int, compute_stream, mix_stream, world: int,
-                 batch: int = 8, device=None, comm=None):
+                 batch: int = 8, device=None, comm=None, same_block: bool = False, order=None, group=None):
         import torch
         self.torch, self.eng = torch, engine
         self.nf, self.batch = int(n_frames), int(batch)
-        self.cs, self.ms = compute_stream, mix_stream
+        self.order = order if order is not None else StreamOrder(torch, compute_stream, mix_stream)
+        self.same_block = bool(same_block)
+        self.lag = 0 if self.same_block else 2       # calls between a block's submission and its bus
         self.rings = [torch.zeros(self.batch * self.nf, dtype=torch.float32, device=device) for _ in range(3)]
+        mh = self.order.mix_handle
         # comm (dsp_stuff_amd.Comm): the collective goes through the C ABI (dspfx_mix_allreduce: RCCL + Output hop on the
         # second stream); without one, torch.distributed's all_reduce on that stream
-        allreduce = (lambda m, nf, n: engine.mix_allreduce(comm, m, nf, n, mix_stream.cuda_stream)) if comm is not None else None
+        allreduce = (lambda m, nf, n: engine.mix_allreduce(comm, m, nf, n, mh)) if comm is not None else None
         self.bus = MixBus(total_channels, self.batch * self.nf,
-                          lambda m, nf, n: engine.mix_finish(m, nf, n, mix_stream.cuda_stream), world=world,
-                          allreduce=allreduce)
+                          lambda m, nf, n: engine.mix_finish(m, nf, n, mh), world=world,
+                          allreduce=allreduce, group=group)
         self.count = 0            # blocks submitted since the last drain
         self.submitted = 0        # batches handed to the second stream
-        self.events = {}          # batch index -> event recorded on the second stream after its submit
+        self.events = {}          # batch index -> mark of the second stream after its submit
+        self.held = 0             # blocks of the last drain that results() can still serve
 
     def _row(self, j):
         q, r = divmod(j, self.batch)
         return self.rings[q % 3][r * self.nf:(r + 1) * self.nf]
 
     def _submit(self, q):
-        torch = self.torch
-        ev = torch.cuda.Event()
-        ev.record(self.cs)
-        self.ms.wait_event(ev)
-        with torch.cuda.stream(self.ms):
+        self.order.mix_after_compute()
+        with self.order.on_mix():
             self.bus.submit(self.rings[q % 3])       # also completes batch q-1 (wait + Output hop)
-            done = torch.cuda.Event()
-            done.record(self.ms)
+            done = self.order.mark_mix()
         self.events[q] = done
         self.events.pop(q - 3, None)
         self.submitted = q + 1
 
     def step(self, x, out, side=None):
-        j = self.count - 2                           # this call delivers the bus of block j
+        j = self.count - self.lag                    # this call delivers the bus of block j
         row = None
         if j >= 0:
             q, r = divmod(j, self.batch)
             if r == 0 and (q - 2) in self.events:    # ring q % 3 last held batch q-3, finished by submit q-2
-                if not self.events[q - 2].query():
-                    self.cs.wait_event(self.events[q - 2])
+                self.order.compute_after(self.events[q - 2])
             row = self._row(j)
-        self.eng.process_mixpipe(x, out, row, self.nf, n_connected=0, side=side, stream=self.cs.cuda_stream)
+        if self.same_block:
+            self.eng.process_bus(x, out, row, self.nf, n_connected=0, side=side, stream=self.order.compute_handle)
+        else:
+            self.eng.process_mixpipe(x, out, row, self.nf, n_connected=0, side=side, stream=self.order.compute_handle)
         self.count += 1
         if j >= 0 and (j + 1) % self.batch == 0:
             self._submit(j // self.batch)
@@ -152,11 +202,20 @@ class PipelinedMixBus:
     def drain(self):
         n = self.count
         if n:
-            self.eng.mixpipe_flush(self._row(n - 2) if n >= 2 else None, self._row(n - 1), n_connected=0,
-                                   stream=self.cs.cuda_stream)
+            if not self.same_block:
+                self.eng.mixpipe_flush(self._row(n - 2) if n >= 2 else None, self._row(n - 1), n_connected=0,
+                                       stream=self.order.compute_handle)
             for q in range(self.submitted, (n - 1) // self.batch + 1):    # partly filled rings: unused rows ride along
                 self._submit(q)
-        with self.torch.cuda.stream(self.ms):
+        with self.order.on_mix():
             self.bus.drain()
+        self.held = n
         self.count, self.submitted = 0, 0
         self.events.clear()
+
+    def results(self):
+        """After drain(): {block index: view of its finished bus} for the blocks the three rings still hold (the last
+        2 * batch + the partly filled batch at least)."""
+        n = self.held
+        first_batch = max(0, (n - 1) // self.batch - 2) if n else 0
+        return {j: self._row(j) for j in range(first_batch * self.batch, n)}

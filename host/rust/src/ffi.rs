@@ -168,6 +168,7 @@ extern "C" {
 
     pub fn dspfx_tune_placement(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
     pub fn dspfx_process(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, stream: *mut c_void) -> c_int;
+    pub fn dspfx_process_bus(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
     pub fn dspfx_process_ctl(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, ctl: *const dspfx_ctl, n_ctl: c_int, stream: *mut c_void) -> c_int;
     pub fn dspfx_host_alloc(bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn dspfx_host_free(p: *mut c_void) -> c_int;

@@ -256,6 +256,14 @@ int dspfx_reset(dspfx_engine *e);
  * block-global over BUF_SIZE, distort.rs:146-172). */
 int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                   uint32_t n_frames, void *stream);
+/* dspfx_process with the Output node complete: mix[f] = (sum over this engine's channels of out[f][c]) /
+ * dspfx_link_divisor(n_connected) -- nodes/output.rs:215-249 feeding collect_and_average (node.rs:162-194); n_connected
+ * = 0 leaves the un-normalised sum (what a rank hands to dspfx_mix_allreduce).  The bus of THIS block, ready when the
+ * block's samples are: the chain launch itself finishes the sum in its last workgroups (the workgroup that completes a
+ * slice of partial sums reduces it, the one that completes the last slice writes the bus), no further kernel runs.
+ * Fixed summation order: bit-identical from run to run and to every other form of the bus in this header. */
+int dspfx_process_bus(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t n_frames,
+                      uint64_t n_connected, void *stream);
 /* One connected control port (`as_input` slider, dsp-stuff-derive/src/lib.rs:122-161): `param` is
  * the slider's index in dspfx_node_desc.params (GAIN level 0; DISTORT level 0; OVERDRIVE boost 0,
  * drive 1, level 2; MIX ratio 0; SIGNAL_GEN amplitude 0, frequency 1); `signal` is a device buffer in the sample layout.  Per sample the
@@ -292,8 +300,10 @@ int dspfx_host_free(void *p);
  * H2D copy, process, D2H copy, synchronous. */
 int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                        uint32_t n_frames);
-/* Pipelined mix bus.  dspfx_process(mix != NULL) runs the second reduction stage on the same
- * stream, i.e. on the critical path of the next block.  The split form takes it off that path:
+/* Pipelined mix bus.  dspfx_process(mix != NULL) / dspfx_process_bus finish the bus inside the chain launch (a few
+ * microseconds at its tail; a chain that ends in a FIR node, an odd block length or DSPFX_MIX_TAIL=0 take two small
+ * kernels behind it instead).  The forms below move even that off the block's own launch, at the price of delivering
+ * the bus late:
  *   dspfx_process_partials(stream A): the chain, leaving per-wavefront partial sums in one of two
  *       engine-owned buffers (n_frames must not exceed the shortest delay line);
  *   dspfx_mix_collect(stream B): B waits for that chain kernel, reduces the partials into

@@ -180,6 +180,11 @@ class Engine {
                  float *mix = nullptr, void *stream = nullptr) {
         chk(dspfx_process(e_, in, side, out, mix, n_frames, stream));
     }
+    // the Output node in the same launch: mix = this block's bus / link_divisor(n_connected) (0: the un-normalised sum)
+    void process_bus(const float *in, float *out, float *mix, std::uint32_t n_frames, std::uint64_t n_connected,
+                     const float *side = nullptr, void *stream = nullptr) {
+        chk(dspfx_process_bus(e_, in, side, out, mix, n_frames, n_connected, stream));
+    }
     // host buffers ([n_frames][channels]), synchronous
     void process_host(const float *in, float *out, std::uint32_t n_frames, const float *side = nullptr,
                       float *mix = nullptr) {

@@ -4,12 +4,14 @@
  * Every function cites the reference lines it follows (paths relative to
  * /root/reference/).  f32 everywhere except Fir's f64 accumulation; no FMA.
  */
+#define _POSIX_C_SOURCE 200809L /* pthread barriers, clock_gettime (the CPU timing leg at the end of this file) */
 #include "dspfx_oracle.h"
 
 #include <math.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 /* ------------------------------------------------------------------ utils */
 
@@ -720,3 +722,89 @@ int orc_run_noise_channels(orc_node **proto, int n_nodes, int link_flags, uint32
     free(th);
     return 0;
 }
+
+/* ---------------------------------------------------------- CPU timing leg (bench.py: cpu_baseline, kind "port")
+ * The reference-structured chain (orc_chain_run: gather, /1.0001, process, scatter per node, 128-frame blocks,
+ * node.rs:267-352) over n_channels independent channels on n_threads threads, timed INSIDE this function between a
+ * start barrier and the last thread's finish.  Nothing but the chain is in the timed loops: every thread clones the
+ * nodes once before the barrier and resets them per channel (orc_node_reset: the zeroing a fresh node's state costs
+ * anyway, without the allocator), and the input is a per-thread table of hashed noise blocks filled before the barrier
+ * (the GPU path reads pre-materialised input too).  *wall_seconds = barrier release -> last thread done. */
+enum { ORC_BENCH_TABLE_BLOCKS = 61 }; /* prime: channel ci starts at block (7 ci) mod 61 of its thread's table */
+typedef struct {
+    orc_node **proto;
+    int n_nodes, link_flags;
+    uint32_t seed, c_begin, c_end, n_blocks, block;
+    pthread_barrier_t *bar;
+    double sink;
+} bench_job;
+
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *bench_worker(void *arg) {
+    bench_job *j = (bench_job *)arg;
+    const uint32_t B = j->block;
+    float *tab = (float *)malloc(sizeof(float) * B * ORC_BENCH_TABLE_BLOCKS);
+    float y[ORC_BUF_SIZE];
+    orc_node **nodes = (orc_node **)malloc(sizeof(orc_node *) * (size_t)j->n_nodes);
+    for (int k = 0; k < j->n_nodes; k++) nodes[k] = orc_node_clone(j->proto[k]);
+    for (uint32_t i = 0; i < B * ORC_BENCH_TABLE_BLOCKS; i++) tab[i] = orc_noise(j->seed, j->c_begin, i);
+    double sink = 0.0;
+    pthread_barrier_wait(j->bar);
+    for (uint32_t ci = j->c_begin; ci < j->c_end; ci++) {
+        for (int k = 0; k < j->n_nodes; k++) orc_node_reset(nodes[k]);
+        uint32_t tb = (7u * ci) % ORC_BENCH_TABLE_BLOCKS;
+        for (uint32_t b = 0; b < j->n_blocks; b++) {
+            orc_chain_run(nodes, j->n_nodes, j->link_flags, tab + (size_t)tb * B, NULL, y, B, B);
+            sink += (double)y[B - 1];
+            tb = tb + 1 == ORC_BENCH_TABLE_BLOCKS ? 0 : tb + 1;
+        }
+    }
+    j->sink = sink;
+    for (int k = 0; k < j->n_nodes; k++) orc_node_free(nodes[k]);
+    free(nodes);
+    free(tab);
+    return NULL;
+}
+
+int orc_bench_chain(orc_node **proto, int n_nodes, int link_flags, uint32_t seed, uint32_t n_channels,
+                    uint32_t n_blocks, uint32_t block, int n_threads, double *wall_seconds) {
+    if (n_threads < 1) n_threads = 1;
+    if ((uint32_t)n_threads > n_channels) n_threads = (int)(n_channels ? n_channels : 1);
+    if (block == 0 || block > ORC_BUF_SIZE) block = ORC_BUF_SIZE;
+    bench_job *jobs = (bench_job *)calloc((size_t)n_threads, sizeof(bench_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)n_threads + 1u);
+    for (int t = 0; t < n_threads; t++) {
+        bench_job *j = &jobs[t];
+        j->proto = proto;
+        j->n_nodes = n_nodes;
+        j->link_flags = link_flags;
+        j->seed = seed;
+        j->c_begin = (uint32_t)((uint64_t)n_channels * (uint64_t)t / (uint64_t)n_threads);
+        j->c_end = (uint32_t)((uint64_t)n_channels * (uint64_t)(t + 1) / (uint64_t)n_threads);
+        j->n_blocks = n_blocks;
+        j->block = block;
+        j->bar = &bar;
+        pthread_create(&th[t], NULL, bench_worker, j);
+    }
+    pthread_barrier_wait(&bar); /* every thread has its nodes and its input table */
+    const double t0 = now_seconds();
+    double sink = 0.0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        sink += jobs[t].sink;
+    }
+    const double t1 = now_seconds();
+    if (wall_seconds) *wall_seconds = t1 - t0;
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(th);
+    return sink == 12345.678 ? 1 : 0; /* keeps the outputs observable */
+}
+

@@ -183,6 +183,10 @@ float orc_noise(uint32_t seed, uint32_t channel, uint32_t n_abs);
  * frame-major f32.  If mix != NULL it receives the f64-accumulated per-frame sum
  * over channels of the final output (caller applies the link divisor).
  * n_threads<=1 => scalar single thread. Returns 0. */
+/* CPU timing leg of bench.py (cpu_baseline): the reference-structured chain over n_channels channels on n_threads
+ * threads; node clones and the input noise table are set up before the timed region (dspfx_oracle.c). */
+int orc_bench_chain(orc_node **proto, int n_nodes, int link_flags, uint32_t seed, uint32_t n_channels,
+                    uint32_t n_blocks, uint32_t block, int n_threads, double *wall_seconds);
 int orc_run_noise_channels(orc_node **proto, int n_nodes, int link_scale, uint32_t seed,
                            uint32_t c0, uint32_t n_channels, uint32_t n_abs0,
                            uint32_t n_blocks, uint32_t block, float *out, double *mix,

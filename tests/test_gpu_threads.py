@@ -282,3 +282,100 @@ def test_fir_state_round_trip_after_tap_reloads(dspfx, torch_cuda, monkeypatch):
         assert torch.equal(ya[5 * B:], yb[5 * B:]), (T0, T1)
         with pytest.raises(dspfx.DspfxError):
             b.state_import(0, st[:-4])
+
+
+# ---- the same-block mix bus inside the chain launch (chain_kernels.hip.h, mix_tail) ---------------------------------
+
+def _bus_blocks(dspfx, torch, N, chain, nf, blocks, tile=0, graph=None, seed=3):
+    """`blocks` blocks of nf frames with the mix bus requested in the same call; returns (outputs, buses)."""
+    eng = dspfx.Engine(N, nf, link_flags=3, tile_channels=tile)
+    if graph is None:
+        eng.set_chain(chain)
+    else:
+        eng.set_graph(chain, graph)
+    x = O.noise(seed, np.arange(N), np.arange(nf * blocks))
+    s = torch.cuda.Stream()
+    dx = [torch.from_numpy(dspfx.to_layout(x[k * nf:(k + 1) * nf], tile)).cuda() for k in range(blocks)]
+    dy = [torch.empty_like(d) for d in dx]
+    dm = torch.zeros((blocks, nf), device="cuda")
+    torch.cuda.synchronize()
+    for k in range(blocks):                          # back to back, no host synchronisation: the arrival counters must be
+        eng.process(dx[k], out=dy[k], mix=dm[k], n_frames=nf, stream=s.cuda_stream)   # back at zero when the next launch starts
+    s.synchronize()
+    ys = np.stack([dspfx.from_layout(d.cpu().numpy(), nf, N, tile) for d in dy])
+    return ys, dm.cpu().numpy(), eng.describe()
+
+
+@pytest.mark.parametrize("N,nf,tile,which", [
+    (1048576, 128, 256, "chain5"),      # the headline shard: s5h_f8_c2, 2048 rows
+    (131072 + 256, 128, 256, "chain5"),
+    (65536, 128, 0, "chain3"),          # the time-sliced kernel: one row per workgroup of four slices
+    (70000, 128, 0, "chain3"),          # ragged: the guarded one-wave tail launch arrives too
+    (4096 + 37, 256, 0, "chain5"),      # two 128-frame segments per launch
+    (8192, 192, 0, "mixed"),            # a segment and a half, the interpreter
+    (3000, 64, 0, "chain5"),            # 47 waves: fewer rows than slices
+    (1024, 100, 0, "chain5"),           # a short block
+    (1024, 77, 0, "chain5"),            # an odd block length: the stand-alone kernels serve (the tail reads frame pairs)
+    (262144, 128, 256, "graph"),        # a generated graph kernel
+])
+def test_the_bus_inside_the_launch_equals_the_stand_alone_reduction(dspfx, torch_cuda, monkeypatch, N, nf, tile, which):
+    """dspfx_process(mix) finishes the Output node's sum inside the chain launch: the workgroup that completes a slice of
+    partial rows reduces it, the one that completes the last slice writes the bus.  Same rows, same association as the
+    two stand-alone kernels it replaces (DSPFX_MIX_TAIL=0): identical bits, block after block with no host synchronisation
+    in between; and the bus is the sum of the outputs."""
+    from chains import chain3
+    links = None
+    if which == "chain3":
+        chain = chain3(dspfx, 256)
+    elif which == "chain5":
+        chain = chain5(dspfx, 384)
+    elif which == "mixed":
+        chain = [dspfx.Gain(0.8), dspfx.Distort(2.0, dspfx.TANH), dspfx.LowPass(0.2), dspfx.Reverb(delay_samples=200, decay=0.3)]
+    else:
+        chain = [dspfx.Gain(0.9), dspfx.LowPass(0.4), dspfx.HighPass(0.7), dspfx.Add()]
+        links = [(dspfx.GRAPH_INPUT, 0, dspfx.PORT_MAIN), (0, 1, dspfx.PORT_MAIN), (0, 2, dspfx.PORT_MAIN), (1, 3, dspfx.PORT_MAIN),
+                 (2, 3, dspfx.PORT_SIDE), (3, 4, dspfx.PORT_MAIN), (1, 4, dspfx.PORT_MAIN)]
+    blocks = 12
+    monkeypatch.setenv("DSPFX_MIX_TAIL", "1")
+    y1, m1, desc = _bus_blocks(dspfx, torch_cuda, N, chain, nf, blocks, tile, links)
+    monkeypatch.setenv("DSPFX_MIX_TAIL", "0")
+    y0, m0, _ = _bus_blocks(dspfx, torch_cuda, N, chain, nf, blocks, tile, links)
+    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+    assert np.array_equal(m1.view(np.uint32), m0.view(np.uint32)), (desc, np.abs(m1 - m0).max())
+    want = y1.astype(np.float64).sum(axis=2)
+    assert np.allclose(m1, want, rtol=1e-5, atol=1e-4 * np.abs(want).max())
+
+
+def test_the_bus_inside_the_launch_under_uneven_load(dspfx, torch_cuda, monkeypatch):
+    """The hand-off between workgroups crosses XCDs whose L2s are not coherent: rows written through, drained, one agent-scope
+    ticket per row, read back past the caches.  A stale read shows as a wrong bus; make the arrival order as uneven as a
+    test can: other kernels hammering HBM on a second stream while 300 blocks run back to back."""
+    torch = torch_cuda
+    N, nf, blocks = 262144, 128, 300
+    eng = dspfx.Engine(N, nf, link_flags=3, tile_channels=256)
+    eng.set_chain(chain5(dspfx, 256))
+    x = torch.empty((8, nf * N), device="cuda")
+    for k in range(8):
+        eng.fill_noise(x[k], nf, k * nf)
+    y = torch.empty_like(x)
+    dm = torch.zeros((blocks, nf), device="cuda")
+    junk = torch.empty(64 << 20, device="cuda")
+    s, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for k in range(blocks):
+        if k % 3 == 0:
+            with torch.cuda.stream(s2):
+                junk.mul_(1.0001)                    # 512 MiB of traffic beside the chain kernel
+        eng.process(x[k % 8], out=y[k % 8], mix=dm[k], n_frames=nf, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    # the reference bus: the same engine state sequence with the stand-alone reduction kernels
+    monkeypatch.setenv("DSPFX_MIX_TAIL", "0")
+    ref = dspfx.Engine(N, nf, link_flags=3, tile_channels=256)
+    ref.set_chain(chain5(dspfx, 256))
+    dm0 = torch.zeros((blocks, nf), device="cuda")
+    y0 = torch.empty((nf * N,), device="cuda")
+    for k in range(blocks):
+        ref.process(x[k % 8], out=y0, mix=dm0[k], n_frames=nf)
+    torch.cuda.synchronize()
+    bad = (dm.view(torch.int32) != dm0.view(torch.int32)).nonzero()
+    assert bad.numel() == 0, bad[:8]

@@ -114,3 +114,109 @@ def test_mix_bus_world1_finishes_immediately():
     assert calls == [(128, 64)]
     bus.drain()
     assert calls == [(128, 64)]
+
+
+# ---- PipelinedMixBus (what bench.py --gpus N runs) with two ranks holding DIFFERENT data --------------------------------
+
+class _FakeEngine:
+    """Stands in for dsp_stuff_amd.Engine in a host-only run: the 'chain' is the oracle's partial bus of this rank's
+    channel shard (precomputed per block), delivered the way the engine delivers it -- in the same call (process_bus)
+    or two calls late (process_mixpipe + mixpipe_flush), un-normalised; mix_finish is the Output hop."""
+
+    def __init__(self, partial, B, divisor):
+        self.partial, self.B, self.div = partial, B, divisor
+        self.k = 0
+        self.calls = []
+
+    def _bus(self, k):
+        return torch.from_numpy(self.partial[k * self.B:(k + 1) * self.B].astype(np.float32))
+
+    def process_bus(self, x, out, mix, n_frames, n_connected=0, side=None, stream=0):
+        assert n_frames == self.B and n_connected == 0 and mix is not None
+        mix.copy_(self._bus(self.k))
+        self.k += 1
+
+    def process_mixpipe(self, x, out, mix, n_frames, n_connected=0, side=None, stream=0):
+        assert n_frames == self.B and n_connected == 0
+        if self.k >= 2:
+            assert mix is not None
+            mix.copy_(self._bus(self.k - 2))
+        else:
+            assert mix is None
+        self.k += 1
+
+    def mixpipe_flush(self, mix_older, mix_newer, n_connected=0, stream=0):
+        if self.k >= 2:
+            mix_older.copy_(self._bus(self.k - 2))
+        mix_newer.copy_(self._bus(self.k - 1))
+
+    def mix_finish(self, mix, n_frames, n_connected, stream=0):
+        self.calls.append(n_frames)
+        mix /= float(self.div)
+
+
+def _pipelined_worker(rank, world, port, total, blocks, batch, same_block, out_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle as O
+    from __graft_entry__ import load_package
+    import chains
+    pkg = load_package()
+    from dsp_stuff_amd import parallel as P   # noqa: E402
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    sh = P.shard_channels(total, world, rank)
+    descs = [n.oracle_desc() for n in chains.chain5(pkg, delay=128)]
+    B = 128
+    _, part = O.run_noise_channels(descs, 0x5EED0001, sh.offset, sh.channels, 0, blocks, link_flags=3,
+                                   want_out=False, want_mix=True)
+    eng = _FakeEngine(part, B, O.link_divisor(total))
+    pb = P.PipelinedMixBus(eng, total, B, None, None, world, batch=batch, device="cpu", same_block=same_block,
+                           order=P.HostOrder())
+    lag = 0 if same_block else 2
+    got = {}
+    for k in range(blocks):
+        pb.step(None, None)
+        # a finished batch is complete one submit later (MixBus pipelines the collective); read it before its ring is reused
+        j_done = k - lag + 1 - batch            # blocks below this index belong to batches whose successor was submitted
+        if j_done > 0 and j_done % batch == 0:
+            for j in range(j_done - batch, j_done):
+                got[j] = pb._row(j).clone().numpy()
+    pb.drain()
+    for j, r in pb.results().items():
+        if j not in got:
+            got[j] = r.clone().numpy()
+    assert sorted(got) == list(range(blocks)), sorted(got)
+    assert all(nf == batch * B for nf in eng.calls)           # one Output hop per batch, over the whole ring
+    if rank == 0:
+        out_q.put(np.concatenate([got[j] for j in range(blocks)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_block", [False, True])
+@pytest.mark.parametrize("blocks,batch", [(1, 4), (2, 4), (7, 4), (8, 4), (13, 4), (26, 8), (33, 2)])
+def test_pipelined_mix_bus_world2_every_block_matches_the_oracle(blocks, batch, same_block):
+    """Two ranks, different channel shards, the batched collective path of bench.py --gpus N: rings, batches, the
+    partly filled last batch and the drain, with the engine's delivery (same block / two calls late) faked on the host.
+    Every block's bus equals the single-process oracle's sum over ALL channels divided by f32(0.0001 + N)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    from __graft_entry__ import load_package
+    import chains
+    pkg = load_package()
+    total, world = 301, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, world, port, total, blocks, batch, same_block, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, full = O.run_noise_channels([n.oracle_desc() for n in chains.chain5(pkg, delay=128)], 0x5EED0001, 0, total, 0, blocks,
+                                   link_flags=3, want_out=False, want_mix=True)
+    expect = (full.astype(np.float32) / O.link_divisor(total)).astype(np.float32)
+    assert np.allclose(got, expect, rtol=1e-5, atol=1e-7)
