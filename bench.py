@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--paced-seconds", type=float, default=5.0,
                     help="length of the paced real-time run of the headline config (0 = skip; --paced runs nothing else)")
     ap.add_argument("--paced", action="store_true", help="only the paced real-time run (plus the short settle before it)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: run the launch / rendezvous / communicator / bus-batching control flow on the host (gloo) and print "
+                         "a line marked dry_run -- what tests/test_bench_dryrun_cpu.py executes under torch.distributed.run")
     ap.add_argument("--tile", type=int, default=256,
                     help="channel-tiled HBM layout [N/W][B][W] (engine-native, default 256); 0 = frame-major [B][N]")
     return ap.parse_args()
@@ -121,6 +124,28 @@ def cpu_topology():
         pass
     logical = os.cpu_count() or 1
     return (len(cores) or logical), logical, (len(sockets) or 1)
+
+
+def cpu_quota():
+    """CPUs this process may use: (affinity mask size, cgroup CPU quota in cores or None)."""
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        aff = os.cpu_count() or 1
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    return aff, quota
 
 
 def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
@@ -173,19 +198,37 @@ def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
         tw = run(ch, t)
         scaling.append({"threads": t, "value": ch * nb * block / tw, "channels": ch, "seconds": round(tw, 2)})
     one = scaling[0]["value"]
+    # the same thread counts on a register-only loop: what parallelism does this process really get (CPU quota, SMT)?
+    spin = {}
+    try:
+        w = C.c_double()
+        L.orc_bench_spin(1, 20_000_000, C.byref(w))
+        iters = int(max(1e6, 0.25 * 20_000_000 / max(w.value, 1e-6)))
+        L.orc_bench_spin(1, iters, C.byref(w))
+        t1 = w.value
+        for t in legs:
+            L.orc_bench_spin(t, iters, C.byref(w))
+            spin[t] = round(t * t1 / max(w.value, 1e-9), 2)
+    except Exception:
+        spin = {}
     for e in scaling:
         e["speedup"] = round(e["value"] / one, 2)
+        if e["threads"] in spin:
+            e["register_loop_speedup"] = spin[e["threads"]]
+    affinity, quota = cpu_quota()
     best = max(scaling, key=lambda e: e["value"])
     res = {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "physical_cores": physical,
-           "threads": logical, "sockets": sockets, "cpu_model": cpu_model(), "kind": "port",
+           "threads": logical, "sockets": sockets, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+           "cpu_model": cpu_model(), "kind": "port",
            "sample": f"{best['channels']} channels x {nb} blocks of 128 frames on {best['threads']} threads, same chain/params, "
                      f"hashed-noise input table made before the timed region, {best['seconds']} s; "
                      f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
                      f"pthreads over channels (orc_bench_chain); excludes the reference's tokio/ring/pool overhead",
            "scaling": scaling,
-           "scaling_note": "speedup over one thread; the one-thread leg runs at the single-core boost clock with the whole "
-                           "L2/L3 to itself, the all-core legs at the all-core clock with two SMT threads sharing a core's "
-                           "execution units: cores x single-thread is not reachable"}
+           "scaling_note": "speedup = chain samples/s over the one-thread leg; register_loop_speedup = the same thread count on a loop "
+                           "that touches no memory: where the two agree the chain scales as far as this process is given CPUs "
+                           "(affinity mask / cgroup quota above; the one-thread leg also runs at the single-core boost clock), where "
+                           "the chain falls behind the register loop it is bound by the memory system"}
     if with_single:
         res["single_thread"] = {"value": one, "unit": "samples/s", "cores": 1,
                                 "sample": f"{scaling[0]['channels']} channels x {nb} blocks, one thread, {scaling[0]['seconds']} s"}
@@ -233,7 +276,8 @@ def make_comm(ctx):
         print("bench.py rank %d: C-ABI communicator unavailable (%s); using torch.distributed all_reduce" % (ctx.rank, ctx.comm_fallback),
               file=sys.stderr)
     dist.barrier()
-    torch.cuda.synchronize()
+    if not getattr(ctx, "dry", False):
+        torch.cuda.synchronize()
 
 
 class Ctx:
@@ -316,14 +360,15 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
 
     mixes = [torch.zeros(B, dtype=torch.float32, device=dev) for _ in range(4)] if use_mix else [None] * 4
     total_channels = shard.total_channels
-    # Mix bus.  One GPU: pipelined INSIDE the chain kernel (dspfx_process_mixpipe: block k's launch also finishes
-    # the bus of blocks k-1 / k-2 and applies the Output hop), so the compute stream holds nothing but chain
-    # kernels -- no second stream, no events (measured: the event marker between kernels cost 13 us per step,
-    # profiles/r01_mixpipe.txt).  Several GPUs: the same pipeline, the per-rank sums of BATCH blocks all-reduced in
-    # one RCCL call on the second stream (parallel.PipelinedMixBus).
-    # DSPFX_BENCH_MIX = pipe | deferred | inline selects the path for A/B runs.
+    # Mix bus.  Default ("inline"): the Output node's bus of the SAME block, finished inside the chain launch
+    # (dspfx_process_bus: the launch's last workgroups complete the sum and apply the Output hop) -- one launch per block,
+    # nothing else on the compute stream, and the bus is ready when the block's samples are (round 3; round 2 reported the
+    # "pipe" form, dspfx_process_mixpipe, which delivers the bus two calls late and is 1.6 % faster: timed after the
+    # headline region as `bus_two_calls_late`).  Several GPUs: the per-rank sums of BATCH blocks all-reduced in one RCCL
+    # call on the second stream (parallel.PipelinedMixBus over either form).
+    # DSPFX_BENCH_MIX = inline | pipe | deferred selects the path for A/B runs.
     dist_run = ctx.use_dist or world > 1
-    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "pipe")
+    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "inline")
     mix_stream = ctx.mix_stream
     ms = mix_stream.cuda_stream
     BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
@@ -387,8 +432,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     if os.environ.get("DSPFX_BENCH_COMM_EARLY", "0") != "1":
         make_comm(ctx)              # after the engine's large allocations and the tuning (A/B: DSPFX_BENCH_COMM_EARLY=1)
     pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
-                              comm=ctx.comm)
-            if (use_mix and dist_run and mix_mode == "pipe") else None)
+                              comm=ctx.comm, same_block=(mix_mode == "inline"))
+            if (use_mix and dist_run and mix_mode in ("pipe", "inline")) else None)
 
     def step(k):
         if not use_mix:
@@ -543,6 +588,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     # (the socket's power management answers an idle of >= 10 ms with ~50 slower launches: profiles/r02_idle_transient.txt)
     cold = None
     paced = None
+    alt_bus = None
     if extras and not dist_run:
         idle_s = float(os.environ.get("DSPFX_BENCH_COLD_IDLE", "0.15"))
         ec0, ec1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -556,10 +602,24 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
         fence()
         cold = {"idle_ms": idle_s * 1e3, "steps": 20, "ms_per_step": ec0.elapsed_time(ec1) / 20,
                 "note": "first 20 launches after the idle gap, one event pair; the settled figure is ms_per_step"}
+        if use_mix and mix_mode == "inline" and not is_fir:
+            # the round-2 form on the same engine and buffers: in-kernel pipeline, bus two calls late
+            ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for k in range(60):
+                eng.process_mixpipe(xs[k % n_in], y, mixes[k & 3], B, n_connected=total_channels, stream=stream)
+            ea0.record()
+            for k in range(max(steps, 20)):
+                eng.process_mixpipe(xs[k % n_in], y, mixes[k & 3], B, n_connected=total_channels, stream=stream)
+            ea1.record()
+            eng.mixpipe_flush(mixes[2], mixes[3], n_connected=total_channels, stream=stream)
+            fence()
+            alt_ms = ea0.elapsed_time(ea1) / max(steps, 20)
+            alt_bus = {"what": "dspfx_process_mixpipe: the bus of block k-2 rides in block k's launch", "ms_per_step": alt_ms,
+                       "frac": bps * N * B / (alt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if use_mix and args.paced_seconds > 0:
             paced = paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, args.paced_seconds)
     res = {
-        "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced,
+        "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced, "alt_bus": alt_bus,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags, **({"zero_input": True} if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1" else {}),
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
@@ -578,13 +638,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     return res
 
 
-def main():
-    args = parse()
-    import torch
-    import torch.distributed as dist
-    from __graft_entry__ import load_package
-
-    ctx = Ctx()
+def launch_env(args, ctx):
+    """One process per GPU, launched by torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     world = ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = ctx.rank = int(os.environ.get("RANK", "0"))
     ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -592,14 +647,116 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    return world, rank
+
+
+class _DryEngine:
+    """--dry-run: stands in for the engine on a host without a GPU.  The 'bus' of block k on rank r is a known vector, delivered
+    like the engine delivers it (process_bus: same call; process_mixpipe: two calls late, un-normalised)."""
+
+    def __init__(self, torch, rank, B, divisor):
+        self.torch, self.rank, self.B, self.div, self.k = torch, rank, B, divisor, 0
+
+    def bus(self, k, rank=None):
+        r = self.rank if rank is None else rank
+        return self.torch.arange(self.B, dtype=self.torch.float32) * 0.5 + (k * 7 + r * 1000)
+
+    def process_bus(self, x, out, mix, n_frames, n_connected=0, side=None, stream=0):
+        mix.copy_(self.bus(self.k))
+        self.k += 1
+
+    def process_mixpipe(self, x, out, mix, n_frames, n_connected=0, side=None, stream=0):
+        if self.k >= 2:
+            mix.copy_(self.bus(self.k - 2))
+        self.k += 1
+
+    def mixpipe_flush(self, mix_older, mix_newer, n_connected=0, stream=0):
+        if self.k >= 2:
+            mix_older.copy_(self.bus(self.k - 2))
+        mix_newer.copy_(self.bus(self.k - 1))
+
+    def mix_finish(self, mix, n_frames, n_connected, stream=0):
+        mix /= self.div
+
+
+def dry_run(args):
+    """The host-side control flow of a --gpus N run without touching a GPU: environment, rendezvous (gloo), the
+    communicator's id broadcast and its all-ranks fallback, channel sharding, the batched bus of parallel.PipelinedMixBus over
+    a real collective, the MAX-over-ranks timing and rank 0's line."""
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+    ctx = Ctx()
+    ctx.dry = True
+    world, rank = launch_env(args, ctx)
+    ctx.use_dist = world > 1
+    ctx.dev = torch.device("cpu")
+    if ctx.use_dist:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx.pkg = load_package()
+    from dsp_stuff_amd import parallel as P
+    ctx.comm = None
+    make_comm(ctx)                        # no device: every rank must land in the torch.distributed fallback together
+    cfg = CONFIGS[args.config]
+    N, B = args.channels or cfg["channels"], args.frames or cfg["frames"]
+    shard = P.weak_shard(N, world, rank)
+    mix_mode = os.environ.get("DSPFX_BENCH_MIX", "inline")
+    batch = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
+    div = float(ctx.pkg.link_divisor(shard.total_channels))
+    eng = _DryEngine(torch, rank, B, div)
+    pbus = P.PipelinedMixBus(eng, shard.total_channels, B, None, None, world, batch=batch, device="cpu",
+                             same_block=(mix_mode == "inline"), order=P.HostOrder())
+    if ctx.use_dist:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for k in range(args.warmup + args.steps):
+        pbus.step(None, None)
+    pbus.drain()
+    if ctx.use_dist:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    n = args.warmup + args.steps
+    ok = True
+    for j, row in pbus.results().items():
+        want = sum(eng.bus(j, r) for r in range(world)) / div
+        ok = ok and bool(torch.allclose(row, want, rtol=1e-6))
+    t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64)
+    if ctx.use_dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({
+            "dry_run": True, "metric": "mono-channel-samples/sec through 5-node chain @128-frame blocks", "value": None,
+            "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": float(t[0]) * 1e3 / n,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": cfg["desc"], "channels_per_gpu": N, "total_channels": shard.total_channels, "channel_offset_of_last_rank": P.weak_shard(N, world, world - 1).offset,
+                       "frames_per_block": B, "mix_bus": mix_mode, "parallelism": f"channel-shard x{world}",
+                       "collective": ("torch.distributed all_reduce (fallback: %s)" % ctx.comm_fallback) if getattr(ctx, "comm_fallback", None) else
+                                     ("dspfx_mix_allreduce" if ctx.comm is not None else None)},
+            "bus_checked_blocks": len(pbus.results()), "bus_ok": bool(t[1] == 0.0)}))
+    if ctx.use_dist:
+        dist.destroy_process_group()
+    if t[1] != 0.0:
+        raise SystemExit("dry run: a bus row differs from the sum over ranks")
+
+
+def main():
+    args = parse()
+    if args.dry_run:
+        return dry_run(args)
+    import torch
+    import torch.distributed as dist
+    from __graft_entry__ import load_package
+
+    ctx = Ctx()
+    world, rank = launch_env(args, ctx)
     torch.cuda.set_device(ctx.local_rank)
     dev = ctx.dev = torch.device("cuda", ctx.local_rank)
     # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
     # exercised on a 1-GPU box (the driver launches the real N>1 runs with torch.distributed.run)
     ctx.use_dist = world > 1 or os.environ.get("DSPFX_BENCH_FORCE_DIST") == "1"
     if ctx.use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx.pkg = load_package()
@@ -683,6 +840,8 @@ def main():
         line["cold"] = r["cold"]
     if r.get("paced") is not None:
         line["paced"] = r["paced"]
+    if r.get("alt_bus") is not None:
+        line["bus_two_calls_late"] = r["alt_bus"]
     if others is not None:
         line["other_configs"] = others
     if world == 1 and not args.no_cpu_baseline:

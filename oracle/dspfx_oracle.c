@@ -808,3 +808,50 @@ int orc_bench_chain(orc_node **proto, int n_nodes, int link_flags, uint32_t seed
     return sink == 12345.678 ? 1 : 0; /* keeps the outputs observable */
 }
 
+/* How many CPUs does this process really get?  n_threads threads each run the same register-only loop (the noise hash, no
+ * memory traffic); aggregate rate / one thread's rate = the effective parallelism (a container's CPU quota or SMT sharing
+ * shows here, memory bandwidth does not).  bench.py prints it next to the chain's scaling table. */
+typedef struct {
+    uint64_t iters;
+    pthread_barrier_t *bar;
+    uint32_t sink;
+} spin_job;
+static void *spin_worker(void *arg) {
+    spin_job *j = (spin_job *)arg;
+    uint32_t h = 12345u;
+    pthread_barrier_wait(j->bar);
+    for (uint64_t i = 0; i < j->iters; i++) {
+        h ^= h >> 16;
+        h *= 0x85EBCA6Bu;
+        h ^= h >> 13;
+        h *= 0xC2B2AE35u;
+        h += (uint32_t)i;
+    }
+    j->sink = h;
+    return NULL;
+}
+int orc_bench_spin(int n_threads, uint64_t iters_per_thread, double *wall_seconds) {
+    if (n_threads < 1) n_threads = 1;
+    spin_job *jobs = (spin_job *)calloc((size_t)n_threads, sizeof(spin_job));
+    pthread_t *th = (pthread_t *)calloc((size_t)n_threads, sizeof(pthread_t));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)n_threads + 1u);
+    for (int t = 0; t < n_threads; t++) {
+        jobs[t].iters = iters_per_thread;
+        jobs[t].bar = &bar;
+        pthread_create(&th[t], NULL, spin_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&bar);
+    const double t0 = now_seconds();
+    uint32_t sink = 0;
+    for (int t = 0; t < n_threads; t++) {
+        pthread_join(th[t], NULL);
+        sink ^= jobs[t].sink;
+    }
+    if (wall_seconds) *wall_seconds = now_seconds() - t0;
+    pthread_barrier_destroy(&bar);
+    free(jobs);
+    free(th);
+    return sink == 0x12345678u ? 1 : 0;
+}
+

@@ -187,6 +187,8 @@ float orc_noise(uint32_t seed, uint32_t channel, uint32_t n_abs);
  * threads; node clones and the input noise table are set up before the timed region (dspfx_oracle.c). */
 int orc_bench_chain(orc_node **proto, int n_nodes, int link_flags, uint32_t seed, uint32_t n_channels,
                     uint32_t n_blocks, uint32_t block, int n_threads, double *wall_seconds);
+/* Effective CPU parallelism of this process: a register-only loop on n_threads threads (dspfx_oracle.c). */
+int orc_bench_spin(int n_threads, uint64_t iters_per_thread, double *wall_seconds);
 int orc_run_noise_channels(orc_node **proto, int n_nodes, int link_scale, uint32_t seed,
                            uint32_t c0, uint32_t n_channels, uint32_t n_abs0,
                            uint32_t n_blocks, uint32_t block, float *out, double *mix,

@@ -75,6 +75,9 @@ def _bind(L):
     L.orc_chain_run_ctl.argtypes = [C.POINTER(vp), C.c_int, C.c_int, f32p, f32p, C.POINTER(f32p), f32p, C.c_size_t, C.c_size_t]
     L.orc_noise.restype = C.c_float
     L.orc_noise.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    if hasattr(L, "orc_bench_spin"):
+        L.orc_bench_spin.restype = C.c_int
+        L.orc_bench_spin.argtypes = [C.c_int, C.c_uint64, C.POINTER(C.c_double)]
     if hasattr(L, "orc_bench_chain"):
         L.orc_bench_chain.restype = C.c_int
         L.orc_bench_chain.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
