@@ -48,6 +48,13 @@ struct SlotArgs {
     float p[6];
     float *state;
     float *const *groups;   // REVERB: device table of ring group base pointers
+    // ... and, for launches of at most 128 frames, the three groups the block's rows can lie in, straight from the host (which
+    // keeps the table): the group of row `pos`, the one after it, group 0 (rows past the wrap at D).  The time-sliced kernel
+    // (few channels: nothing hides a wave's latency) forms its tap addresses from these and saves the dependent scalar loads of
+    // the table before its first tap load; the other kernels read the table.  g_ia = index of g_a; g_valid = 0: not filled.
+    float *g_a, *g_b, *g_0;
+    unsigned g_ia;
+    int g_valid;
     unsigned D;
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
@@ -111,6 +118,12 @@ struct ChainArgs {
 // stage: the slices are summed in fixed order.  Fixed association => run-to-run deterministic, and identical in every form
 // (stand-alone kernels, pipelined in later launches, in the tail of the same launch).
 constexpr unsigned MIX_SLICES = 64;
+// Rows per slice: at least 32 (one batch of the in-launch tail's loads), so a launch of few workgroups gets few slices and its
+// final stage is one batch too; 64 slices from 2048 rows on.  Every form of the bus cuts its rows the same way.
+__host__ __device__ __forceinline__ unsigned mix_rows_per_slice(unsigned rows) {
+    const unsigned per = (rows + MIX_SLICES - 1) / MIX_SLICES;
+    return per < 32u ? 32u : per;
+}
 __device__ __forceinline__ float mix_rows_sum(const float *src, unsigned n, unsigned nframes, unsigned f) {
     float a0 = 0.0f, a1 = 0.0f;
     unsigned r = 0;
@@ -124,7 +137,7 @@ __device__ __forceinline__ float mix_rows_sum(const float *src, unsigned n, unsi
 }
 __device__ __forceinline__ void mix_slice_reduce(const float *part, float *part2, unsigned waves, unsigned nframes,
                                                  unsigned b, unsigned tid, unsigned nthreads) {
-    const unsigned per = (waves + MIX_SLICES - 1) / MIX_SLICES;
+    const unsigned per = mix_rows_per_slice(waves);
     const unsigned w0 = min(waves, b * per), w1 = min(waves, w0 + per);
     for (unsigned f = tid; f < nframes; f += nthreads) part2[(size_t)b * nframes + f] = mix_rows_sum(part + (size_t)w0 * nframes, w1 - w0, nframes, f);
 }
@@ -246,7 +259,7 @@ __device__ __forceinline__ void mix_tail(unsigned row, int lane) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the row has left this wave and is in memory
     const ColdArgs a = cold_args();
     const unsigned rows = a.mix_stride, nf = a.nframes;
-    const unsigned per = (rows + MIX_SLICES - 1) / MIX_SLICES;
+    const unsigned per = mix_rows_per_slice(rows);
     const unsigned b = row / per, w0 = b * per, w1 = min(rows, w0 + per);
     if (ticket_take(a.mt_tickets + b, lane) + 1 != w1 - w0) return;
     // last row of slice b: the same sums in the same order as mix_slice_reduce
@@ -256,7 +269,7 @@ __device__ __forceinline__ void mix_tail(unsigned row, int lane) {
     const unsigned live = (rows + per - 1) / per;                     // slices that hold rows; the others count as the +0 their stage would have written
     if (ticket_take(a.mt_tickets + MIX_SLICES, lane) + 1 != live) return;
     // last slice: the same sums in the same order as mix_final_reduce
-    tail_reduce_rows(a.mt_part2, MIX_SLICES, live, nf, a.mt_mix, a.mt_div, false, lane);
+    tail_reduce_rows(a.mt_part2, MIX_SLICES, live, nf, a.mt_mix, a.mt_div, false, lane);      // (batches past `live` load nothing: bounds check)
     if (lane == 0) __hip_atomic_store((dspfx_gu32 *)(a.mt_tickets + MIX_SLICES), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -654,6 +667,8 @@ struct RingGroups {
     float *ga, *gb, *g0;
     unsigned gia;
 };
+// (the time-sliced kernel, whose blocks are exactly 128 frames, takes the three pointers from its arguments instead: ring_groups_host)
+__device__ __forceinline__ RingGroups ring_groups_host(const SlotArgs &s) { return RingGroups{s.g_a, s.g_b, s.g_0, s.g_ia}; }
 __device__ __forceinline__ RingGroups ring_groups(const SlotArgs &s, const Ctx &cx) {
     unsigned r = s.pos + cx.f0;               // < 2*D: host keeps pos < D, nframes <= D
     r = r >= s.D ? r - s.D : r;
@@ -1393,11 +1408,15 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
 #undef DSPFX_TAPS_DECL
 #define DSPFX_TAPS(I)                                                                                            \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
-        rg##I = ring_groups(a.slot[I], cx);                                                                      \
+        rg##I = ring_groups_host(a.slot[I]);   /* blocks of exactly 128 frames: the host named the groups (no table read) */ \
         _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
             load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], true); \
     }
     auto load_taps = [&]() __attribute__((always_inline)) { DSPFX_FOR_SLOTS(DSPFX_TAPS) };
+    // Slice 0's own copy of the body (LATE) also requests the state of the first stateful node right here, behind its samples:
+    // loaded inside its turn it was one more memory round trip on the chain of turns that every other slice waits for.
+    float st_pre[4][CPL];
+    if constexpr (LATE && FS < MAX_SLOTS) load_state<SL::v[FS < MAX_SLOTS ? FS : 0], CPL, false>(a.slot[FS < MAX_SLOTS ? FS : 0], st_pre, c, a.N, true);
     if constexpr (!late) load_taps();
     DSPFX_TS_STAMP(1)
 #define DSPFX_RUN(I)                                                                                             \
@@ -1417,8 +1436,12 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
         _Pragma("unroll 1") for (int turn = 0; turn < 4; ++turn) {                                               \
             if (q == turn) {                                                                                     \
                 float st[4][CPL];                                                                                \
-                if (turn == 0) load_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                    \
-                else {                                                                                           \
+                if (turn == 0) {                                                                                 \
+                    if constexpr (LATE && I == FS) {                                                             \
+                        _Pragma("unroll") for (int k = 0; k < 4; ++k)                                            \
+                            _Pragma("unroll") for (int j = 0; j < CPL; ++j) st[k][j] = st_pre[k][j];             \
+                    } else load_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                        \
+                } else {                                                                                           \
                     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                \
                         _Pragma("unroll") for (int j = 0; j < CPL; ++j) st[k][j] = k < NS ? lds_st[k][j][lane] : 0.0f; \
                 }                                                                                                \

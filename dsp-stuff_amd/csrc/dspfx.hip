@@ -43,6 +43,7 @@ struct Node {
     // REVERB: the ring as separately allocated 128-row groups + the device copy of the pointer table
     std::vector<float *> groups;
     float **d_groups = nullptr;
+    float *probe_group = nullptr;   // placement probes: the node stands in as a one-group ring made of this group
     size_t group_floats = 0;
     int ring_replaced = 0;    // groups re-allocated by the placement probe
     size_t state_bytes = 0;
@@ -998,7 +999,7 @@ int validate_node(dspfx_engine *e, const dspfx_node_desc &d) {
     return DSPFX_OK;
 }
 
-void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
+void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s, uint32_t nframes) {
     const Node &n = e->nodes[idx];
     memset(&s, 0, sizeof s);
     s.kind = n.d.kind;
@@ -1007,6 +1008,22 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s) {
     s.groups = n.d_groups;
     s.D = n.D;
     s.pos = n.pos;
+    if (n.d.kind == DSPFX_REVERB && nframes <= RING_GROUP_ROWS && n.D) {
+        // the block's rows lie in at most three groups: the one row `pos` is in, the next, and group 0 past the wrap -- named
+        // here so that no wave has to read the group table before it can form its first tap address
+        if (n.probe_group) {
+            s.g_a = s.g_b = s.g_0 = n.probe_group;
+            s.g_ia = 0;
+            s.g_valid = 1;
+        } else if (!n.groups.empty()) {
+            const uint32_t gi = n.pos >> 7, glast = (n.D - 1) >> 7;
+            s.g_a = n.groups[gi];
+            s.g_b = n.groups[gi < glast ? gi + 1 : glast];
+            s.g_0 = n.groups[0];
+            s.g_ia = gi;
+            s.g_valid = 1;
+        }
+    }
     s.hop = node_hop(e, idx);
     s.rc = n.d.kind == DSPFX_DISTORT ? 1.0 / (double)n.d.params[0] : 0.0;
     for (int k = 0; k < 3; ++k) {
@@ -1120,7 +1137,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             if (e->desc.link_flags & DSPFX_LINK_INTERNAL) a.side_hop = (e->desc.link_flags & DSPFX_LINK_SIDE_RAW) ? 2 : 3;
             int rows = 0;
             for (int k = 0; k < st.count; ++k) {
-                fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS]);
+                fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS], nframes);
                 rows += state_rows(e->nodes[st.first + k]);
             }
             const Variant *v = st.var, *tail = e->tail;
@@ -1909,6 +1926,7 @@ struct TuneGuard {   // whatever happens inside the probe loop, every node gets 
         if (!n) return;
         n->D = D0;
         n->d_groups = table0;
+        n->probe_group = nullptr;
         e->min_delay = min0;
         n = nullptr;
     }
@@ -2010,6 +2028,7 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
             const bool live = g < G;                    // holds ring rows that must survive
             if (live && hipMemcpyAsync(tg.park, cand[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
             if (rc == DSPFX_OK && hipMemcpyAsync(tg.d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
+            n.probe_group = cand[g];
             float best = 1e30f;
             for (int rep = 0; rep < 3 && rc == DSPFX_OK; ++rep) {
                 tg.rewind();

@@ -11,4 +11,4 @@ for cfg in cfg5 cfg3 cfg2; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/${cfg}_$c -o p -- python3 /root/repo/tools/r03_pmc_workload.py $cfg 40 > $OUT/${cfg}_$c.log 2>$OUT/${cfg}_$c.err || echo "pass $cfg $c failed"
   done
 done
-python3 tools/r03_pmc_report.py $OUT $OUT/profiles
+python3 /root/repo/tools/r03_pmc_report.py $OUT $OUT/profiles
