@@ -19,6 +19,7 @@
 #include <cstring>
 #include <deque>
 #include <atomic>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -852,8 +853,7 @@ int tune_ring(dspfx_engine *e, Node &n) {
     HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
     const size_t scratch_bytes = 2 * gbytes;                     // in + out blocks of 128 frames
     const size_t reserve = (size_t)8 << 30;                      // leave room for the caller's buffers
-    size_t extra = 0;
-    if (free_b > scratch_bytes + reserve) extra = std::min(G, (free_b - scratch_bytes - reserve) / gbytes);
+    (void)total_b;
     float *scratch = nullptr, **d_one = nullptr;
     hipEvent_t a = nullptr, b = nullptr;
     if (hipMalloc((void **)&scratch, scratch_bytes) != hipSuccess) return DSPFX_OK;   // no room: skip tuning
@@ -861,12 +861,6 @@ int tune_ring(dspfx_engine *e, Node &n) {
     HIPCHK(e, hipMalloc((void **)&d_one, sizeof(float *)));
     HIPCHK(e, hipEventCreate(&a));
     HIPCHK(e, hipEventCreate(&b));
-    std::vector<float *> cand = n.groups;
-    for (size_t k = 0; k < extra; ++k) {
-        float *g = nullptr;
-        if (big_alloc((void **)&g, gbytes) != hipSuccess) break;
-        cand.push_back(g);
-    }
     ChainArgs ca;
     memset(&ca, 0, sizeof ca);
     ca.in = scratch;
@@ -897,10 +891,9 @@ int tune_ring(dspfx_engine *e, Node &n) {
     const uint32_t n_main = N - N % 64u;
     ca.n_launch = n_main;
     const unsigned grid = (n_main + WG - 1) / WG;
-    std::vector<float> t(cand.size(), 0.0f);
-    for (size_t g = 0; g < cand.size(); ++g) {
-        HIPCHK(e, hipMemcpy(d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice));
-        float best = 1e30f;
+    auto probe = [&](float *gptr, float &best) -> int {
+        HIPCHK(e, hipMemcpy(d_one, &gptr, sizeof(float *), hipMemcpyHostToDevice));
+        best = 1e30f;
         for (int rep = 0; rep < 3; ++rep) {   // rep 0 warms TLB/clocks
             (void)hipEventRecord(a, nullptr);
             (void)launch_variant(e->dyn, ca, grid, WG, 0, nullptr);
@@ -910,35 +903,70 @@ int tune_ring(dspfx_engine *e, Node &n) {
             (void)hipEventElapsedTime(&ms, a, b);
             if (rep) best = std::min(best, ms);
         }
-        t[g] = best;
+        return DSPFX_OK;
+    };
+    // The ring's own groups first; candidates are allocated only for groups in the slow placement mode (SLOW above the
+    // fastest), about 1.8 per slow group and round -- a fresh device, where every group is fast, allocates eight scouts.
+    const float SLOW = 1.06f;
+    std::vector<float> t(G, 0.0f);
+    int rc = DSPFX_OK;
+    for (size_t g = 0; g < G && rc == DSPFX_OK; ++g) rc = probe(n.groups[g], t[g]);
+    std::vector<std::pair<float, float *>> pool;
+    auto more_candidates = [&](size_t want) {
+        size_t fb = 0, tb = 0;
+        if (hipMemGetInfo(&fb, &tb) != hipSuccess) return;
+        const size_t can = fb > reserve ? (fb - reserve) / gbytes : 0;
+        for (size_t k = 0; k < std::min(want, can) && rc == DSPFX_OK; ++k) {
+            float *g = nullptr;
+            if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+            float ms = 0.0f;
+            rc = probe(g, ms);
+            pool.emplace_back(ms, g);
+        }
+    };
+    if (rc == DSPFX_OK) more_candidates(std::min<size_t>(8, G));
+    int replaced = 0;
+    size_t n_alloc = pool.size();
+    if (rc == DSPFX_OK) {
+        float t_ref = *std::min_element(t.begin(), t.end());
+        for (auto &pr : pool) t_ref = std::min(t_ref, pr.first);
+        for (int round = 0; round < 4 && rc == DSPFX_OK; ++round) {
+            std::vector<size_t> slow;
+            for (size_t g = 0; g < G; ++g)
+                if (t[g] > SLOW * t_ref) slow.push_back(g);
+            std::sort(slow.begin(), slow.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
+            std::sort(pool.begin(), pool.end());
+            size_t used = 0;
+            for (size_t g : slow) {
+                if (used >= pool.size() || pool[used].first > SLOW * t_ref) break;
+                std::swap(n.groups[g], pool[used].second);
+                t[g] = pool[used].first;
+                pool[used].first = 1e30f;
+                ++used;
+                ++replaced;
+            }
+            size_t still = 0;
+            for (size_t g = 0; g < G; ++g) still += t[g] > SLOW * t_ref ? 1 : 0;
+            if (!still) break;
+            const size_t before = pool.size();
+            more_candidates(still + (still * 4 + 4) / 5);
+            n_alloc += pool.size() - before;
+            if (pool.size() == before) break;
+            for (size_t i = before; i < pool.size(); ++i) t_ref = std::min(t_ref, pool[i].first);
+        }
     }
     if (getenv("DSPFX_RING_TUNE_DEBUG")) {
-        fprintf(stderr, "ring probe ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
+        fprintf(stderr, "ring probe: %zu groups, %zu candidates allocated, %d re-placed; ms now:", G, n_alloc, replaced);
         for (float v : t) fprintf(stderr, " %.3f", v);
         fprintf(stderr, "\n");
     }
-    // keep the G fastest candidates (stable: original groups win ties)
-    std::vector<size_t> order(cand.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
-    std::vector<char> keep(cand.size(), 0);
-    for (size_t i = 0; i < G; ++i) keep[order[i]] = 1;
-    std::vector<float *> chosen;
-    int replaced = 0;
-    for (size_t i = 0; i < cand.size(); ++i) {
-        if (keep[i]) {
-            chosen.push_back(cand[i]);
-            if (i >= G) ++replaced;
-        } else {
-            (void)hipFree(cand[i]);
-        }
-    }
-    n.groups = chosen;
+    for (auto &pr : pool) (void)hipFree(pr.second);
     n.ring_replaced = replaced;
     (void)hipFree(scratch);
     (void)hipFree(d_one);
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
+    if (rc) return rc;
     for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, gbytes));   // probing wrote into the groups
     HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
     return DSPFX_OK;
@@ -1997,88 +2025,138 @@ extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const floa
     }
     int rc = DSPFX_OK;
     const size_t tile_frames = e->desc.max_frames;   // the buffers are laid out like a full block of the engine
+    const auto tick = [] { return std::chrono::steady_clock::now(); };
+    const auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
+    const bool debug = getenv("DSPFX_RING_TUNE_DEBUG") != nullptr;
     for (Node &n : e->nodes) {
         if (n.d.kind != DSPFX_REVERB) continue;
         const size_t gbytes = n.group_floats * sizeof(float);
         if (gbytes < ((size_t)64 << 20)) continue;
         const size_t G = n.groups.size();
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipMemGetInfo failed");
-        const size_t reserve = ((size_t)8 << 30) + gbytes;             // room for the caller + the parking group
-        size_t extra = free_b > reserve ? std::min(G, (free_b - reserve) / gbytes) : 0;
         if (!tg.park && big_alloc((void **)&tg.park, gbytes) != hipSuccess) {
             (void)hipGetLastError();
             return fail(e, DSPFX_ERR_OOM, "no room to park a ring group (%zu MiB)", gbytes >> 20);
-        }
-        std::vector<float *> cand = n.groups;
-        for (size_t k = 0; k < extra; ++k) {
-            float *g = nullptr;
-            if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); (void)hipGetLastError(); break; }
-            cand.push_back(g);
-            tg.extras.push_back(g);
         }
         if (!tg.d_one && hipMalloc((void **)&tg.d_one, sizeof(float *)) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "hipMalloc failed");
         // the node as a one-group ring (the guard puts the real geometry back on every exit path)
         tg.arm(n);
         n.D = RING_GROUP_ROWS;
         n.d_groups = tg.d_one;
-        std::vector<float> t(cand.size(), 0.0f);
-        for (size_t g = 0; g < cand.size() && rc == DSPFX_OK; ++g) {
-            const bool live = g < G;                    // holds ring rows that must survive
-            if (live && hipMemcpyAsync(tg.park, cand[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
-            if (rc == DSPFX_OK && hipMemcpyAsync(tg.d_one, &cand[g], sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
-            n.probe_group = cand[g];
-            float best = 1e30f;
-            for (int rep = 0; rep < 3 && rc == DSPFX_OK; ++rep) {
+        // one candidate: the real chain, `reps` launches, the best of all but the first (which warms TLB / clocks)
+        auto probe = [&](float *gptr, bool live, float &best) -> int {
+            if (live && hipMemcpyAsync(tg.park, gptr, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
+            if (hipMemcpyAsync(tg.d_one, &gptr, sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
+            if (hipStreamSynchronize(s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipStreamSynchronize failed");   // (&gptr is a stack slot)
+            n.probe_group = gptr;
+            best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
                 tg.rewind();
                 (void)hipEventRecord(tg.ea, s);
-                rc = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
+                const int r = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
                 (void)hipEventRecord(tg.eb, s);
-                if (rc) break;
-                if (hipEventSynchronize(tg.eb) != hipSuccess) { rc = fail(e, DSPFX_ERR_HIP, "hipEventSynchronize failed"); break; }
+                if (r) return r;
+                if (hipEventSynchronize(tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventSynchronize failed");
                 float ms = 0.0f;
                 (void)hipEventElapsedTime(&ms, tg.ea, tg.eb);
                 if (rep) best = std::min(best, ms);
             }
-            t[g] = best;
-            if (live && rc == DSPFX_OK && hipMemcpyAsync(cand[g], tg.park, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess)
-                rc = fail(e, DSPFX_ERR_HIP, "restoring a ring group failed");
+            if (live && hipMemcpyAsync(gptr, tg.park, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "restoring a ring group failed");
+            return DSPFX_OK;
+        };
+        // 1. the ring's own groups.  Placement comes in two modes ~18 % apart (placement): when every group is
+        //    within SLOW of the fastest one there is nothing to gain and nothing is allocated (a fresh box: 0.25 s).
+        const float SLOW = 1.06f;
+        const auto t_own = tick();
+        std::vector<float> t(G, 0.0f);
+        for (size_t g = 0; g < G && rc == DSPFX_OK; ++g) rc = probe(n.groups[g], true, t[g]);
+        const double ms_own = ms_since(t_own);
+        if (const char *fk = getenv("DSPFX_TUNE_FAKE_SLOW"))            // tests: pretend the first k groups landed in the slow mode
+            for (size_t g = 0; g < std::min<size_t>(G, (size_t)atoi(fk)); ++g) t[g] *= 1.25f;
+        // 2. a few scouts: is the fastest own group really a fast one (or are ALL of them in the slow mode)?
+        auto alloc_candidates = [&](size_t want, std::vector<float *> &got) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+            const size_t reserve = ((size_t)8 << 30);            // room for the caller
+            const size_t can = free_b > reserve ? (free_b - reserve) / gbytes : 0;
+            for (size_t k = 0; k < std::min(want, can); ++k) {
+                float *g = nullptr;
+                if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
+                if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); (void)hipGetLastError(); break; }
+                got.push_back(g);
+                tg.extras.push_back(g);
+            }
+        };
+        std::vector<std::pair<float, float *>> pool;            // probed candidates that are not part of the ring: (ms, group)
+        const auto t_rest = tick();
+        size_t n_alloc = 0;
+        if (rc == DSPFX_OK) {
+            std::vector<float *> scouts;
+            alloc_candidates(std::min<size_t>(8, G), scouts);
+            n_alloc += scouts.size();
+            for (float *g : scouts) {
+                float ms = 0.0f;
+                rc = probe(g, false, ms);
+                if (rc) break;
+                pool.emplace_back(ms, g);
+            }
+        }
+        int replaced = 0;
+        if (rc == DSPFX_OK) {
+            float t_ref = *std::min_element(t.begin(), t.end());
+            for (auto &pr : pool) t_ref = std::min(t_ref, pr.first);
+            // 3. replace slow groups, slowest first, by fast candidates; allocate more candidates (about 1.8 per group still
+            //    slow: roughly 6 in 10 land in the fast mode) until none is slow, memory runs out, or four rounds have passed
+            for (int round = 0; round < 4 && rc == DSPFX_OK; ++round) {
+                std::vector<size_t> slow;
+                for (size_t g = 0; g < G; ++g)
+                    if (t[g] > SLOW * t_ref) slow.push_back(g);
+                std::sort(slow.begin(), slow.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
+                std::sort(pool.begin(), pool.end());
+                size_t used = 0;
+                for (size_t g : slow) {
+                    if (used >= pool.size() || pool[used].first > SLOW * t_ref) break;
+                    float *fresh = pool[used].second;
+                    if (hipMemcpyAsync(fresh, n.groups[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = fail(e, DSPFX_ERR_HIP, "moving a ring group failed"); break; }
+                    std::swap(n.groups[g], pool[used].second);     // the pool now holds the dropped allocation
+                    for (float *&x : tg.extras)                     // ... and so does the guard's list of what to free on an error path
+                        if (x == fresh) x = pool[used].second;
+                    t[g] = pool[used].first;
+                    pool[used].first = 1e30f;                      // never picked again
+                    ++used;
+                    ++replaced;
+                }
+                if (rc) break;
+                size_t still = 0;
+                for (size_t g = 0; g < G; ++g) still += t[g] > SLOW * t_ref ? 1 : 0;
+                if (!still) break;
+                std::vector<float *> more;
+                alloc_candidates(still + (still * 4 + 4) / 5, more);
+                if (more.empty()) break;
+                n_alloc += more.size();
+                for (float *g : more) {
+                    float ms = 0.0f;
+                    rc = probe(g, false, ms);
+                    if (rc) break;
+                    pool.emplace_back(ms, g);
+                    t_ref = std::min(t_ref, ms);
+                }
+            }
         }
         tg.disarm();
         tg.rewind();
         if (rc) return rc;
-        if (getenv("DSPFX_RING_TUNE_DEBUG")) {
-            fprintf(stderr, "placement tuning ms (%zu ring groups + %zu extra candidates):", G, cand.size() - G);
-            for (float v : t) fprintf(stderr, " %.3f", v);
-            fprintf(stderr, "\n");
-        }
-        std::vector<size_t> order(cand.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
-        std::vector<char> keep(cand.size(), 0);
-        for (size_t i = 0; i < G; ++i) keep[order[i]] = 1;
-        // ring position p keeps its rows: a dropped group's rows move into the kept extra that takes its place
-        std::vector<size_t> spare;
-        for (size_t i = G; i < cand.size(); ++i)
-            if (keep[i]) spare.push_back(i);
-        int replaced = 0;
-        size_t next_spare = 0;
-        for (size_t p = 0; p < G; ++p) {
-            if (keep[p]) continue;
-            const size_t x = spare[next_spare++];
-            if (hipMemcpyAsync(cand[x], cand[p], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "moving a ring group failed");
-            std::swap(cand[p], cand[x]);              // cand[p] is the ring's group now, cand[x] the dropped allocation
-            ++replaced;
-        }
         HIPCHK(e, hipStreamSynchronize(s));
-        for (size_t i = G; i < cand.size(); ++i) (void)hipFree(cand[i]);      // dropped originals and unused extras
+        for (auto &pr : pool) (void)hipFree(pr.second);              // dropped originals and unused candidates
         tg.extras.clear();
-        cand.resize(G);
-        n.groups = cand;
         n.ring_replaced = replaced;
         HIPCHK(e, hipMemcpyAsync(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice, s));
         HIPCHK(e, hipStreamSynchronize(s));
+        if (debug) {
+            fprintf(stderr, "placement tuning: %zu ring groups probed in %.0f ms; %zu candidates allocated, %d groups re-placed, %.0f ms; ring groups now (ms):", G, ms_own,
+                    n_alloc, replaced, ms_since(t_rest));
+            for (float v : t) fprintf(stderr, " %.3f", v);
+            fprintf(stderr, "\n");
+        }
     }
     // put back what the probes' blocks overwrote
     tg.rewind();

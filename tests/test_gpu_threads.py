@@ -223,11 +223,14 @@ def test_mode_store_is_queued_like_a_slider_store(dspfx, torch_cuda):
         eng.set_param(7, 0, 1.0)
 
 
-def test_tune_placement_keeps_the_state_of_every_delay_line_and_fir_history(dspfx, torch_cuda):
+@pytest.mark.parametrize("fake_slow", [0, 2])
+def test_tune_placement_keeps_the_state_of_every_delay_line_and_fir_history(dspfx, torch_cuda, monkeypatch, fake_slow):
     """Two large delay rings, a small one and a FIR node in one chain: the probes run whole blocks through ALL of them
     while one ring is being timed.  Outputs before, between and after tuning calls equal those of an engine that was
     never tuned, bit for bit."""
     torch = torch_cuda
+    if fake_slow:                                   # the tuner only replaces groups it finds in the slow placement mode: pretend
+        monkeypatch.setenv("DSPFX_TUNE_FAKE_SLOW", str(fake_slow))
     N, blocks = 131072, 6                           # 64 MiB ring groups: the tuner engages
     chain = [dspfx.Reverb(delay_samples=300, decay=0.5), dspfx.BiQuad(), dspfx.Reverb(delay_samples=128, decay=0.3),
              dspfx.Fir(fir_taps(40)), dspfx.Reverb(delay_samples=257, decay=0.4), dspfx.LowPass(0.3)]
@@ -246,6 +249,8 @@ def test_tune_placement_keeps_the_state_of_every_delay_line_and_fir_history(dspf
             eng.tune_placement(dx[((k + 3) % blocks) * B:((k + 3) % blocks + 1) * B], scratch, B)
     for i in (0, 2, 3, 4):
         assert np.array_equal(eng.state_export(i), ref.state_export(i)), i
+    if fake_slow:
+        assert "%d re-placed" % fake_slow in eng.describe() or "1 re-placed" in eng.describe(), eng.describe()
 
 
 def test_fir_state_round_trip_after_tap_reloads(dspfx, torch_cuda, monkeypatch):
