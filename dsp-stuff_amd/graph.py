@@ -445,6 +445,8 @@ def region_plan(g: Graph, max_nodes: int = GRAPH_MAX_NODES, max_io: int = GRAPH_
         nid = order[i]
         n = g.nodes[nid]
         if _unfusable(n.spec):
+            if any(len(srcs) != 1 for srcs in n.ctl.values()):
+                return None        # a slider port averaging several links (the importer rejects those): never take just the first
             steps.append(("node", n.spec, [ref(v) for v in n.main], {k: ref(srcs[0]) for k, srcs in n.ctl.items()}))
             loc[nid] = (len(steps) - 1, 0)
             i += 1
@@ -721,6 +723,8 @@ class GraphEngine:
             ctl = {}
             for k, m in enumerate(r.nodes):
                 for slider, srcs in m.ctl.items():
+                    if len(srcs) != 1:   # node.rs:162-194 would average them; dspfx_process_ctl takes one signal per port
+                        raise DspConfigError(f"slider port {slider} of node {m.id} averages several links")
                     ctl[(k, slider)] = self._source(srcs[0], x)
             r.engine.process(src, out=r.out, side=side, n_frames=nf, stream=stream, ctl=ctl or None)
         out_node = self.g.nodes[self.g.outputs[0]]

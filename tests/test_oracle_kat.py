@@ -341,3 +341,87 @@ def test_kat11_envelope():
     assert np.abs(step - (1 - np.exp(-k / 10.0))).max() < 1e-5
     node.reset()
     assert np.array_equal(node.process(np.zeros(4, F)), np.zeros(4, F))
+
+
+def test_kat11_envelope_closed_forms_in_both_restatements():
+    """dasp_envelope 0.11.0 Detector::next as written out in oracle/dspfx_oracle.h: a unit step from rest gives
+    env[n] = 1 - g_a^(n+1), the release after it env[n] = env0 * g_r^(n+1) -- the C restatement and the numpy one, each
+    against the closed form (evaluated in f64 from the f32 gain both of them use)."""
+    for attack, release in ((10.0, 100.0), (1.0, 3.0), (250.0, 1000.0)):
+        ga = np.float64(M.Envelope.calc_gain(attack))
+        gr = np.float64(M.Envelope.calc_gain(release))
+        assert abs(ga - math.exp(-1.0 / attack)) < 1e-7 and abs(gr - math.exp(-1.0 / release)) < 1e-7
+        x = np.concatenate([np.ones(96, F), np.zeros(96, F)])
+        n = np.arange(96)
+        rise = 1.0 - ga ** (n + 1)
+        fall = rise[-1] * gr ** (n + 1)
+        want = np.concatenate([rise, fall])
+        for name, got in (("c", np.concatenate([O.Node(O.ENVELOPE, [attack, release]).process(x[:128]), np.zeros(0, F)])),
+                          ("numpy", M.Envelope(attack, release).process(x[:128]))):
+            assert np.abs(got.astype(np.float64) - want[:128]).max() < 128 * 2.0 ** -23, (name, attack, release)
+        # two blocks: the state carries over (envelope.rs keeps the Detector in the node)
+        node, model = O.Node(O.ENVELOPE, [attack, release]), M.Envelope(attack, release)
+        a = np.concatenate([node.process(x[:128]), node.process(x[128:])])
+        b = np.concatenate([model.process(x[:128]), model.process(x[128:])])
+        assert np.abs(a.astype(np.float64) - want).max() < 192 * 2.0 ** -23
+        assert np.abs(b.astype(np.float64) - want).max() < 192 * 2.0 ** -23
+
+
+def _sinc_formula(x, ratio, n_out, depth=8):
+    """Direct evaluation of dasp's Sinc::interpolate as written out in oracle/dspfx_oracle.h, with no ring and no index
+    bookkeeping: output m sits at source time t = m * ratio - depth = j0 + phi; left taps w(phi + n) x[j0 - n], right
+    taps w(1 - phi + n) x[j0 + 1 + n], n = 0..7, w(a) = sinc(a) (0.5 + 0.5 cos(pi a / depth)) -- except that the
+    outermost right tap (n = 7) would be the frame one past the newest in the 16-frame ring, and the ring indexes modulo
+    its length: it reads the OLDEST frame, x[j0 - 8] (weight <= 4e-4).  Frames outside the signal are zeros."""
+    def w(a):
+        return np.sinc(a) * (0.5 + 0.5 * math.cos(math.pi * a / depth))
+
+    def at(j):
+        return x[j] if 0 <= j < len(x) else 0.0
+    out = np.zeros(n_out)
+    for m in range(n_out):
+        t = m * ratio - depth
+        j0 = int(math.floor(t))
+        phi = t - j0
+        acc = 0.0
+        for n in range(depth):
+            acc += w(phi + n) * at(j0 - n)
+            acc += w(1.0 - phi + n) * at(j0 + 1 + n if n < depth - 1 else j0 - depth)
+        out[m] = acc
+    return out
+
+
+def test_kat12_sinc_converter_closed_forms():
+    """dasp 0.11.0 Converter + Sinc (fir.rs:153-165) as restated in dsp-stuff_amd/ir.py (include/dspfx_ir.hpp is held
+    bit-identical to it by tests/test_cpp_ir.py).  (i) At integer rate ratios every output lands on a source frame:
+    EXACT, delayed by the ring's depth of 8 frames.  (ii) 44.1 -> 48 kHz: a band-limited sinusoid is interpolated to
+    within 2.5e-3 of sin(2 pi f t) (the 16-tap Hann window's ripple; measured 1.2e-3).  (iii) The output equals the direct
+    evaluation of the published formula, once the ring has filled."""
+    from __graft_entry__ import load_package
+    load_package()
+    from dsp_stuff_amd import ir
+    n = 1500
+    k = np.arange(n)
+    for f in (100.0, 1000.0, 5000.0, 10000.0):
+        # (i) 1:1 and 2:1
+        for fs in (48000.0, 96000.0):
+            x = np.sin(2 * np.pi * f * k / fs)
+            y = ir.resample_dasp_sinc(x, fs, 48000.0)
+            t = np.arange(len(y)) * (fs / 48000.0) - 8
+            ok = (t > 16) & (t < n - 16)
+            assert np.abs(y[ok] - np.sin(2 * np.pi * f * t[ok] / fs)).max() < 1e-12, (f, fs)
+        # (ii) 44.1 kHz -> 48 kHz
+        x = np.sin(2 * np.pi * f * k / 44100.0)
+        y = ir.resample_dasp_sinc(x, 44100.0, 48000.0)
+        t = np.arange(len(y)) * (44100.0 / 48000.0) - 8
+        ok = (t > 16) & (t < n - 16)
+        assert np.abs(y[ok] - np.sin(2 * np.pi * f * t[ok] / 44100.0)).max() < 2.5e-3, f
+    # (iii) against the formula itself, on noise (any signal), both rate directions
+    rng = np.random.default_rng(12)
+    x = rng.uniform(-1, 1, 400)
+    for src_hz in (44100.0, 32000.0, 88200.0, 96000.0):
+        y = ir.resample_dasp_sinc(x, src_hz, 48000.0)
+        want = _sinc_formula(x, src_hz / 48000.0, len(y))
+        lo = int(math.ceil(24 * 48000.0 / src_hz))          # the ring is full and the index has reached its depth
+        hi = len(y) - lo
+        assert np.abs(y[lo:hi] - want[lo:hi]).max() < 1e-12, src_hz
