@@ -39,15 +39,17 @@ CONFIGS = {
     # name: (channels per GPU, frames per block, chain, delay, description)
     "cfg5": dict(channels=1 << 20, frames=128, chain="chain5", delay=24000,
                  desc="BASELINE config 5 shard: 1048576 ch/GPU, biquad>softclip>delay(24000)>biquad>gain, B=128, mix bus"),
-    "cfg3": dict(channels=1 << 20, frames=256, chain="chain5", delay=24000,
+    # the mix bus is part of config 5 only (BASELINE.json: "... with RCCL xGMI mix-bus all-reduce"); configs 2 - 4 are timed as
+    # BASELINE words them, without one (--bus-everywhere / DSPFX_BENCH_BUS_ALL=1 times them with the same-block bus too)
+    "cfg3": dict(channels=1 << 20, frames=256, chain="chain5", delay=24000, mix=False,
                  desc="BASELINE config 3: 1048576 ch, 5-node chain, B=256"),
-    "cfg2": dict(channels=1 << 16, frames=128, chain="chain3", delay=24000,
+    "cfg2": dict(channels=1 << 16, frames=128, chain="chain3", delay=24000, mix=False,
                  desc="BASELINE config 2: 65536 ch, gain>biquad>delay(24000), B=128"),
     # diagnostics (memory-pattern ceilings of the chain kernel), not BASELINE configs
     "copy": dict(channels=1 << 20, frames=128, chain="copy", delay=0, desc="diagnostic: empty chain (8 B/sample)"),
     "delay": dict(channels=1 << 20, frames=128, chain="delay", delay=24000,
                   desc="diagnostic: delay line only (16 B/sample)"),
-    "cfg4": dict(channels=1 << 18, frames=128, chain="fir", delay=0, taps=4096,
+    "cfg4": dict(channels=1 << 18, frames=128, chain="fir", delay=0, taps=4096, mix=False,
                  desc="BASELINE config 4: 262144 ch, 4096-tap FIR, B=128"),
 }
 
@@ -337,7 +339,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     cfg = dict(CONFIGS[cfg_name])
     cfg.update(overrides or {})
     N, B = cfg["channels"], cfg["frames"]
-    use_mix = not args.no_mix
+    use_mix = not args.no_mix and (cfg.get("mix", True) or os.environ.get("DSPFX_BENCH_BUS_ALL") == "1")
     chain = build_chain(pkg, cfg)
     is_fir = cfg["chain"] == "fir"
 

@@ -118,6 +118,7 @@ struct dspfx_engine {
     bool has_fuzz = false;
     uint32_t min_delay = 0xffffffffu;
     bool has_siggen = false;   // a SIGNAL_GEN wraps its clock per 128-frame block: sub-launches start on block boundaries
+    mutable bool jit_unavailable = false;   // a run-time specialised kernel was wanted and could not be had (headers / hiprtc missing)
     uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
     float div_v = 0.0f;
     // profiling: event pairs per stage
@@ -464,6 +465,7 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
     if (N < 64u * (unsigned)cpl) return nullptr;
     const int f = (N <= 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt)
     const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
+    if (!k) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
     return k ? &k->var : nullptr;
 }
 
@@ -757,6 +759,7 @@ bool long_stage_wanted(const dspfx_engine *e) {
 int plan(dspfx_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
     e->stages.clear();
+    e->jit_unavailable = false;
     e->has_fuzz = false;
     e->has_siggen = false;
     e->min_delay = 0xffffffffu;
@@ -2989,6 +2992,9 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                     s += buf;
                 }
         }
+    if (e->jit_unavailable)
+        s += "note: a run-time specialised kernel was wanted but could not be compiled (chain_kernels.hip.h not found next to the "
+             "library -- DSPFX_KERNEL_HEADERS names its directory -- or hiprtc unavailable): the interpreting kernels serve, 7-25 % slower\n";
     snprintf(dst, cap, "%s", s.c_str());
     return DSPFX_OK;
 }
