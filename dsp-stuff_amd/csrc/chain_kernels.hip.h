@@ -13,7 +13,7 @@
 // relative to /root/reference/): f32, left-to-right, NO fused multiply-add
 // (the translation unit is compiled with -ffp-contract=off), IEEE division.
 #pragma once
-#ifndef __HIPCC_RTC__            // hiprtc (run-time specialisation, see dspfx.hip) brings its own runtime declarations
+#ifndef __HIPCC_RTC__            // hiprtc (run-time specialisation, see jit.hip) brings its own runtime declarations
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #endif

@@ -4,178 +4,14 @@
 // chain into stages (fused chain kernel | Fuzz | FIR) and launches them on the
 // caller's stream.  No CPU fallback exists: without a HIP device every entry
 // point that needs one returns DSPFX_ERR_NO_DEVICE.
-#include "../../include/dspfx.h"
-
-#include <hip/hip_runtime.h>
-#include <hip/hiprtc.h>
-#include <dlfcn.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <deque>
-#include <atomic>
-#include <chrono>
-#include <map>
-#include <mutex>
-#include <string>
-#include <vector>
-
-#include "aux_kernels.h"
-#include "fir_kernels.h"
-#include "variants.h"
-#include "graph_kernel.hip.h"   // GraphArgs
+// This file: lifecycle, parameter stores (queued, thread-safe), the process calls, DSP state, utilities.  The run-time
+// compiler lives in jit.hip, placement tuning in placement.hip, the RCCL collective in comm.hip; engine.h is what they share.
+#include "engine.h"
 
 using namespace dspfx;
+using namespace dspfx_host;
 
-namespace {
-
-enum StageType { ST_FUSED = 0, ST_FUZZ = 1, ST_FIR = 2 };
-
-struct Node {
-    dspfx_node_desc d{};
-    // BIQUAD: normalised coefficients (biquad.rs:62-76)
-    float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
-    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N]
-    // REVERB: the ring as separately allocated 128-row groups + the device copy of the pointer table
-    std::vector<float *> groups;
-    float **d_groups = nullptr;
-    float *probe_group = nullptr;   // placement probes: the node stands in as a one-group ring made of this group
-    size_t group_floats = 0;
-    int ring_replaced = 0;    // groups re-allocated by the placement probe
-    size_t state_bytes = 0;
-    uint32_t D = 0, pos = 0;  // REVERB
-    // FIR
-    std::vector<double> taps;      // reversed, as given
-    FirState fir;
-    // control ports: per-channel latched slider values (derive lib.rs:148)
-    float *latch[3] = {nullptr, nullptr, nullptr};
-    int latch_valid = 0;
-    const float *ctl_now[3] = {nullptr, nullptr, nullptr};   // signals of the call being launched
-};
-
-struct Stage {
-    StageType type;
-    int first, count;
-    const Variant *var = nullptr;   // ST_FUSED
-    const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
-    mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
-    mutable bool var_mod_tried = false;
-    bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
-};
-
-}  // namespace
-
-struct dspfx_engine {
-    dspfx_engine_desc desc{};
-    int device = 0;
-    std::vector<Node> nodes;
-    std::vector<Stage> stages;
-    bool graph_mode = false;                  // dspfx_graph_set: the nodes form a DAG evaluated by one generated kernel
-    bool no_long = false;                     // chain mode: do not fuse more than MAX_SLOTS nodes into one (graph) kernel
-    std::vector<dspfx_graph_link> wiring;     // its links, in the caller's order
-    std::string err;
-    float hop_div = 1.0f;
-    float *mixpart = nullptr;
-    float *mixpart_b = nullptr;   // second-stage scratch [128][max_frames] (one per stream of use: inline / deferred)
-    float *mixpart_b2 = nullptr;
-    unsigned *mt_tickets = nullptr;   // same-block bus inside the chain launch: [MIX_SLICES + 1] arrival counters, zero between launches
-    size_t mixpart_cols = 0;
-    // pipelined mix bus (dspfx_process_partials / dspfx_mix_collect): double-buffered partials
-    float *mixpart2[2] = {nullptr, nullptr};
-    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
-    bool red_pending[2] = {false, false}, collect_due = false;
-    int flip = 0;
-    uint32_t part_stride[2] = {0, 0}, part_frames[2] = {0, 0};
-    float *partials_override = nullptr;   // set while a deferred-mix block is being launched
-    // in-kernel pipelined mix bus (dspfx_process_mixpipe): block k's launch also runs stage 2 of block k-1 and
-    // stage 3 of block k-2.  mp_count = blocks submitted since the last flush.
-    uint64_t mp_count = 0;
-    uint32_t mp_frames = 0, mp_rows[2] = {0, 0};
-    float *mp_mix_now = nullptr;          // where the launch being built delivers block k-2's bus
-    float mp_div_now = 0.0f;
-    bool mp_building = false;
-    float bus_div_now = 0.0f;             // dspfx_process_bus: the Output hop's divisor for the block being launched (0: none)
-    // channel window of the current run_subblock call (pipelined host path): channels [win_c0, win_c0 + win_n), 0 = all;
-    // win_last marks the call that finishes the block (ring positions advance once)
-    uint32_t win_c0 = 0, win_n = 0;
-    bool win_last = true;
-    hipStream_t hs_in = nullptr, hs_out = nullptr, hs_run = nullptr;
-    std::vector<hipEvent_t> hev;
-    uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
-    // dspfx_process_io: input blocks 2.. and output blocks 1.. of the call being launched (graph engines), and the float
-    // offset of the sub-block being launched
-    const float *io_in[GRAPH_IO] = {};
-    float *io_out[GRAPH_IO] = {};
-    size_t io_off = 0;
-    // staging for dspfx_process_host
-    float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
-    const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr, *dyn_mod2 = nullptr;
-    bool has_fuzz = false;
-    uint32_t min_delay = 0xffffffffu;
-    bool has_siggen = false;   // a SIGNAL_GEN wraps its clock per 128-frame block: sub-launches start on block boundaries
-    mutable bool jit_unavailable = false;   // a run-time specialised kernel was wanted and could not be had (headers / hiprtc missing)
-    uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
-    float div_v = 0.0f;
-    // profiling: event pairs per stage
-    bool profiling = false;
-    std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;   // [stage][launch]
-    std::vector<hipEvent_t> ev_pool;
-    // ---- threads and streams (include/dspfx.h, "Threads and streams") ----------------------------------------------
-    // api_mu serialises every entry point that touches the engine; a slider store from another thread never waits
-    // for it: it is queued under pend_mu and applied by whoever holds api_mu next, at a block boundary.
-    mutable std::recursive_mutex api_mu;
-    int api_depth = 0;                        // nesting of entry points (dspfx_process_ctl -> dspfx_process): only the outermost drains
-    mutable std::mutex pend_mu;               // pending, pub_kinds, log, next_seq
-    struct Store { uint64_t seq; int node, param; float value; };   // param -1: a mode store (value = the mode)
-    std::deque<Store> pending;
-    std::vector<int> pub_kinds;               // node kinds as of the last chain / graph set: validation without api_mu
-    std::deque<dspfx_param_event> log;        // the stores already applied, oldest first (bounded)
-    uint64_t next_seq = 1;
-    uint64_t frames_submitted = 0;            // frames handed to the process calls so far
-    // the stream the DSP state was last touched on: every state write (biquad reset, dspfx_reset, ...) is queued on
-    // it, and a call on a different stream first waits for an event recorded there
-    hipStream_t cur_stream = nullptr;
-    bool cur_stream_set = true;               // the null stream to begin with: setup-time writes go there
-    hipEvent_t ev_order = nullptr;
-    mutable std::mutex err_mu;                        // err (also kept per calling thread: dspfx_last_error)
-};
-
-namespace {
-
-hipEvent_t take_event(dspfx_engine *e) {
-    if (!e->ev_pool.empty()) {
-        hipEvent_t ev = e->ev_pool.back();
-        e->ev_pool.pop_back();
-        return ev;
-    }
-    hipEvent_t ev = nullptr;
-    (void)hipEventCreate(&ev);
-    return ev;
-}
-
-struct ProfScope {   // brackets one kernel launch with events on its own stream
-    dspfx_engine *e;
-    hipStream_t s;
-    hipEvent_t a = nullptr, b = nullptr;
-    size_t stage;
-    ProfScope(dspfx_engine *e_, size_t stage_, hipStream_t s_) : e(e_), s(s_), stage(stage_) {
-        if (!e->profiling) return;
-        a = take_event(e);
-        b = take_event(e);
-        (void)hipEventRecord(a, s);
-    }
-    ~ProfScope() {
-        if (!a) return;
-        (void)hipEventRecord(b, s);
-        if (e->prof.size() <= stage) e->prof.resize(stage + 1);
-        e->prof[stage].emplace_back(a, b);
-    }
-};
+namespace dspfx_host {
 
 // The last error text is kept per engine AND per calling thread: a GUI thread whose slider store failed reads its own
 // message, not the one the audio thread produced a microsecond later.
@@ -197,13 +33,6 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
     return code;
 }
 
-#define HIPCHK(e, call)                                                                         \
-    do {                                                                                        \
-        hipError_t err__ = (call);                                                              \
-        if (err__ != hipSuccess)                                                                \
-            return fail(e, err__ == hipErrorOutOfMemory ? DSPFX_ERR_OOM : DSPFX_ERR_HIP,        \
-                        "%s failed: %s", #call, hipGetErrorString(err__));                      \
-    } while (0)
 
 // Is (float)((double)x * RN_f64(1/c)) == x / c for every f32 x?  (div_c in chain_kernels.hip.h has the argument.)
 //   * c not an even integer, or a power of two: yes, by the theorem there -- decided here, no device involved, so a
@@ -213,7 +42,7 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
 //     COMPLETED checks are cached: a HIP failure answers "not fast" for this call and is asked again next time;
 //     have_device = false only consults the cache.
 // DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; read per call so a test can flip it between engines).
-bool divisor_is_fast(float c, bool have_device = true) {
+bool divisor_is_fast(float c, bool have_device) {
     static std::mutex mu;
     static std::map<uint32_t, bool> cache;
     if (const char *fd = getenv("DSPFX_FAST_DIV"))
@@ -248,7 +77,7 @@ bool divisor_is_fast(float c, bool have_device = true) {
     return ok;
 }
 
-bool node_divisors_fast(const Node &n, bool have_device = true) {
+bool node_divisors_fast(const Node &n, bool have_device) {
     if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
         if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
         if (!divisor_is_fast(n.d.params[0], have_device)) return false;
@@ -308,10 +137,6 @@ void collect_variants(std::vector<const Variant *> &out) {
     for (int i = 0; i < n; ++i) out.push_back(v + i);
 }
 
-// DSPFX_VARIANT="f=8,cpl=2,static=1" narrows the choice (tuning / A-B runs).
-struct Pref {
-    int f = -1, cpl = -1, stat = -1;
-};
 Pref read_pref() {
     Pref p;
     const char *s = getenv("DSPFX_VARIANT");
@@ -323,7 +148,7 @@ Pref read_pref() {
     return p;
 }
 
-bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device = true) {
+bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device) {
     if (!divisor_is_fast(e->hop_div, have_device)) return false;
     for (int i = 0; i < st.count; ++i)
         if (!node_divisors_fast(e->nodes[st.first + i], have_device)) return false;
@@ -334,315 +159,6 @@ bool node_needs_libm(const Node &n) {
     if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV || n.d.kind == DSPFX_SIGNAL_GEN) return true;
     return n.d.kind == DSPFX_DISTORT &&
            (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
-}
-
-// ---- run-time specialisation ------------------------------------------------------------------------------------
-// The statically specialised kernel `chain_kernel<F, CPL, SigList<...>>` is a template over the chain's shape; the
-// library ships it for the BASELINE chains only.  For any other fusable chain of a LARGE engine the same template is
-// instantiated at run time with hiprtc (about a second per distinct shape, cached per process), so an arbitrary chain
-// runs the specialised kernel instead of the interpreter (0.383 -> 0.357 ms on the 5-node chain).  The source is the
-// very header this library was built from (found next to libdspfx.so); if it or hiprtc is unavailable the interpreter
-// stays.  DSPFX_JIT=0 switches it off, DSPFX_JIT=1 forces it for engines of any size.
-struct JitKernel {
-    Variant var;            // launch == nullptr: launched through `fn`
-    hipModule_t module = nullptr;
-    hipFunction_t fn = nullptr;
-    std::string name;
-    int vgprs = 0;          // registers per lane the compiler allocated (occupancy: 512 / vgprs waves per SIMD)
-};
-std::mutex g_jit_mu;
-std::map<std::string, JitKernel *> g_jit;     // key -> kernel
-
-// Where chain_kernels.hip.h / graph_kernel.hip.h are: next to the library, or DSPFX_KERNEL_HEADERS when they are installed
-// elsewhere (read per compile).
-std::string csrc_dir() {
-    if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
-    Dl_info info;
-    if (!dladdr((const void *)&dspfx_abi_version, &info) || !info.dli_fname) return "";
-    std::string p(info.dli_fname);
-    const size_t k = p.find_last_of('/');
-    return k == std::string::npos ? "." : p.substr(0, k);
-}
-
-// Compile `src` (which includes headers from this library's directory), load it on the current device and look up the
-// kernel named by `expr`.  Cached per `key` for the life of the process.
-const JitKernel *jit_compile(const std::string &key, const std::string &src, const std::string &expr, const int (&sigs)[MAX_SLOTS],
-                             int n_slots, int f, int cpl, bool mod) {
-    std::lock_guard<std::mutex> lk(g_jit_mu);
-    auto it = g_jit.find(key);
-    if (it != g_jit.end()) return it->second;
-    JitKernel *res = nullptr;
-    const std::string dir = csrc_dir();
-    hiprtcProgram prog = nullptr;
-    if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
-        const std::string inc = "-I" + dir;
-        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", inc.c_str()};
-        if (hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS &&
-            hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS) {
-            const char *lowered = nullptr;
-            size_t cs = 0;
-            if (hiprtcGetLoweredName(prog, expr.c_str(), &lowered) == HIPRTC_SUCCESS && lowered &&
-                hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs) {
-                std::vector<char> code(cs);
-                JitKernel *k = new JitKernel();
-                if (hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS &&
-                    hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
-                    hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
-                    k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
-                    if (hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn) != hipSuccess) {
-                        (void)hipGetLastError();
-                        k->vgprs = 0;
-                    }
-                    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
-                    for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
-                    k->var.name = k->name.c_str();
-                    res = k;
-                } else {
-                    (void)hipGetLastError();
-                    delete k;
-                }
-            }
-        } else if (getenv("DSPFX_JIT_DEBUG")) {
-            size_t ls = 0;
-            (void)hiprtcGetProgramLogSize(prog, &ls);
-            std::vector<char> log(ls + 1, 0);
-            if (ls) (void)hiprtcGetProgramLog(prog, log.data());
-            fprintf(stderr, "dspfx jit: %s failed:\n%s\n", expr.c_str(), log.data());
-        }
-        (void)hiprtcDestroyProgram(&prog);
-    }
-    if (res) g_jit[key] = res;   // failures are not remembered: a missing header directory can be put right while the process lives
-    return res;
-}
-
-// ts: the time-sliced kernel chain_ts_kernel<f, cpl, ...> (f = frames per slice) instead of chain_kernel<f, cpl, ...>
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false) {
-    char key[256];
-    int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
-    for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
-    std::string expr = std::string(ts ? "dspfx::chain_ts_kernel<" : "dspfx::chain_kernel<") + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
-    for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
-    expr += (mod && !ts) ? ">, true>" : "> >";
-    const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
-    if (k && ts) const_cast<JitKernel *>(k)->var.ts = f;
-    return k;
-}
-
-// A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.
-int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
-    if (v->launch) {
-        v->launch(a, grid, block, lds_bytes, s);
-        return 0;
-    }
-    const JitKernel *k = reinterpret_cast<const JitKernel *>(v);   // `var` is the first member
-    // a graph kernel takes GraphArgs: run_subblock's ChainArgs is the first member of one, so the same address serves
-    static_assert(offsetof(GraphArgs, c) == 0, "GraphArgs must begin with its ChainArgs");
-    void *params[] = {const_cast<ChainArgs *>(&a)};
-    return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
-}
-
-// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
-// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
-// 128-frame block goes through the time-sliced kernel (measured on the 3-node chain, rocprofv3 kernel averages:
-// 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt).
-constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 81920;
-
-// Run-time specialised kernel for a fused stage (nullptr: not wanted / not possible).  mod = with control ports.
-const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
-    const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS);
-    if (!want_jit || st.count < 1 || !st.fast_div) return nullptr;
-    int sigs[MAX_SLOTS];
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
-    if (N < 64u * (unsigned)cpl) return nullptr;
-    const int f = (N <= 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt)
-    const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
-    if (!k) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
-    return k ? &k->var : nullptr;
-}
-
-// ---- a whole graph as one kernel (include/dspfx.h: dspfx_graph_set, csrc/graph_kernel.hip.h) --------------------------
-// Sliders with an `as_input` port, per kind: count and the range a connected signal is mapped to.
-int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]) {
-    switch (d.kind) {
-    case DSPFX_GAIN: lo[0] = 0.0f; hi[0] = 10.0f; return 1;                                    // gain.rs:14
-    case DSPFX_DISTORT: lo[0] = 0.0f; hi[0] = 30.0f; return 1;                                 // distort.rs:37 (every mode, Fuzz included: 176-180)
-    case DSPFX_OVERDRIVE: lo[0] = 0.0f; hi[0] = 30.0f; lo[1] = 0.0f; hi[1] = 1.0f; lo[2] = 0.0f; hi[2] = 1.0f; return 3;
-    case DSPFX_MIX: lo[0] = 0.0f; hi[0] = 1.0f; return 1;                                       // mix.rs:15
-    case DSPFX_SIGNAL_GEN: lo[0] = -1.0f; hi[0] = 1.0f; lo[1] = 0.1f; hi[1] = 20000.0f; return 2;   // signal_gen.rs:31-37
-    default: return 0;
-    }
-}
-std::string hexf(float v) {
-    char b[64];
-    snprintf(b, sizeof b, "%af", (double)v);
-    return b;
-}
-std::string hexd(double v) {
-    char b[64];
-    snprintf(b, sizeof b, "%a", v);
-    return b;
-}
-
-// Input block a link source stands for (DSPFX_GRAPH_INPUT.. -> 0..GRAPH_IO-1), or -1 for a node / the zero pipe.
-int graph_input_block(int src) {
-    if (src == DSPFX_GRAPH_INPUT) return 0;
-    if (src == DSPFX_GRAPH_INPUT2) return 1;
-    return (src <= -4 && src > -2 - DSPFX_GRAPH_MAX_IO) ? -src - 2 : -1;
-}
-
-// One link of the program being generated; node indices are local to the stage.  raw: the only link into its port and
-// taken as it is -- a hop of a chain engine whose DSPFX_LINK_* flag is off.
-struct GLink {
-    int src, dst, port;
-    bool raw;
-};
-
-// The generated translation unit: `struct Prog` with the wiring of nodes [first, first + n) spelled out on register arrays.
-std::string graph_source(const dspfx_engine *e, int first, int n, const std::vector<GLink> &links, bool fast, int (&sigs)[GRAPH_SLOTS],
-                         bool have_device = true) {
-    auto port_links = [&](int dst, int port) {
-        std::vector<GLink> v;
-        for (const GLink &l : links)
-            if (l.dst == dst && l.port == port) v.push_back(l);
-        return v;
-    };
-    std::string body;
-    auto gather = [&](const std::string &dst, const std::vector<GLink> &srcs, bool declare) {
-        auto name = [](int sidx) {
-            const int blk = graph_input_block(sidx);
-            return blk >= 0 ? "xs[" + std::to_string(blk) + "]" : "v" + std::to_string(sidx);
-        };
-        body += "        ";
-        if (declare) body += "float " + dst + "[F][CPL]; ";
-        if (srcs.size() == 1 && srcs[0].raw) {
-            body += "g_copy<F, CPL>(" + dst + ", " + name(srcs[0].src) + ");\n";
-            return;
-        }
-        if (srcs.empty() && declare) {                  // an unconnected input port of a node
-            body += "g_unplugged<F, CPL>(" + dst + ");\n";
-            return;
-        }
-        body += "g_zero<F, CPL>(" + dst + ");";
-        for (const GLink &l : srcs) {
-            if (l.src == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";
-            else body += " g_acc<F, CPL>(" + dst + ", " + name(l.src) + ");";
-        }
-        if (!srcs.empty()) {
-            const float div = dspfx_link_divisor(srcs.size());
-            body += std::string(" g_div<") + (divisor_is_fast(div, have_device) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
-                    hexd(1.0 / (double)div) + ");";
-        }
-        body += "\n";
-    };
-    const std::string FAST = fast ? "true" : "false";
-    for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
-    unsigned in_mask = 0;
-    int n_out = 1;
-    for (const GLink &l : links) {
-        if (graph_input_block(l.src) >= 0) in_mask |= 1u << graph_input_block(l.src);
-        if (l.dst >= n) n_out = std::max(n_out, l.dst - n + 1);
-    }
-    for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
-        if (e->nodes[(size_t)(first + i)].d.kind == DSPFX_REVERB)
-            body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(gslot<" + std::to_string(i) +
-                    ">(g), cx, pre" + std::to_string(i) + ");\n";
-    for (int i = 0; i < n; ++i) {
-        const dspfx_node_desc &d = e->nodes[(size_t)(first + i)].d;
-        const bool has_mode = d.kind == DSPFX_DISTORT || d.kind == DSPFX_SIGNAL_GEN;
-        const int mode = has_mode ? d.mode : 0;
-        sigs[i] = sig(d.kind, mode, 0);
-        const std::string I = std::to_string(i), v = "v" + I, slot = "gslot<" + I + ">(g)", KM = std::to_string(d.kind) + ", " + std::to_string(mode);
-        body += "        // node " + I + "\n";
-        gather(v, port_links(i, DSPFX_PORT_MAIN), true);
-        float lo[3], hi[3];
-        const int ns = kind_sliders(d, lo, hi);
-        bool any_ctl = false;
-        std::string pn[3];
-        for (int k = 0; k < ns; ++k) any_ctl = any_ctl || !port_links(i, DSPFX_PORT_SLIDER + k).empty();
-        if (any_ctl)
-            for (int k = 0; k < ns; ++k) {
-                pn[k] = "p" + I + "_" + std::to_string(k);
-                const std::vector<GLink> src = port_links(i, DSPFX_PORT_SLIDER + k);
-                if (src.empty()) {
-                    body += "        float " + pn[k] + "[F][CPL]; g_fill<F, CPL>(" + pn[k] + ", " + slot + ".p[" + std::to_string(k) + "]);\n";
-                } else {
-                    gather(pn[k], src, true);
-                    body += "        g_slider<F, CPL>(" + pn[k] + ", " + hexf(lo[k]) + ", " + hexf(hi[k]) + ");\n";
-                }
-            }
-        if (d.kind == DSPFX_ADD || d.kind == DSPFX_MIX) gather("b" + I, port_links(i, DSPFX_PORT_SIDE), true);
-        body += "        ";
-        if (d.kind == DSPFX_REVERB) body += "ring_apply<F, CPL, false>(" + slot + ", " + v + ", pre" + I + ", cx);";
-        else if (d.kind == DSPFX_ADD) body += "g_add<F, CPL>(" + v + ", b" + I + ");";
-        else if (d.kind == DSPFX_MIX && any_ctl) body += "g_mix_mod<F, CPL>(" + v + ", b" + I + ", " + pn[0] + ");";
-        else if (d.kind == DSPFX_MIX) body += "g_mix<F, CPL>(" + v + ", b" + I + ", " + slot + ".p[0]);";
-        else if (d.kind == DSPFX_GAIN && any_ctl) body += "gain_mod_core<F, CPL>(" + v + ", " + pn[0] + ");";
-        else if (d.kind == DSPFX_DISTORT && any_ctl) body += "distort_mod_core<" + std::to_string(mode) + ", F, CPL>(" + v + ", " + pn[0] + ");";
-        else if (d.kind == DSPFX_OVERDRIVE && any_ctl) body += "overdrive_mod_core<F, CPL>(" + v + ", " + pn[0] + ", " + pn[1] + ", " + pn[2] + ");";
-        else if (d.kind == DSPFX_SIGNAL_GEN && any_ctl)
-            body += "siggen_mod_core<" + std::to_string(mode) + ", F, CPL>(" + slot + ", " + v + ", st[" + I + "], " + pn[0] + ", " + pn[1] + ", cx);";
-        else body += "apply_node<" + KM + ", F, CPL, false, " + FAST + ">(" + slot + ", " + v + ", st[" + I + "], cx);";
-        body += "\n";
-    }
-    for (int m = 0; m < n_out; ++m) {
-        body += m == 0 ? "        // Output node\n" : "        // output block " + std::to_string(m) + "\n";
-        gather("ys[" + std::to_string(m) + "]", port_links(n + m, DSPFX_PORT_MAIN), false);
-    }
-    std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[GRAPH_SLOTS] = {";
-    for (int i = 0; i < GRAPH_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < GRAPH_SLOTS ? ", " : "");
-    src += "};\n    static constexpr unsigned in_mask = " + std::to_string(in_mask) + ";\n";
-    src += "    static constexpr int n_out = " + std::to_string(n_out) + ";\n";
-    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&xs)[GRAPH_IO][F][CPL], float (&ys)[GRAPH_IO][F][CPL],\n"
-           "                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
-    src += body;
-    src += "    }\n};\n}  // namespace dspfx\n";
-    return src;
-}
-
-const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
-    const uint32_t N = e->desc.channels;
-    const int f = 8;
-    int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
-    std::vector<GLink> links;
-    if (e->graph_mode) {
-        for (const dspfx_graph_link &l : e->wiring) links.push_back(GLink{l.src, l.dst, l.port & ~DSPFX_PORT_RAW, (l.port & DSPFX_PORT_RAW) != 0});
-    } else {   // a long stage of a chain engine: node after node, hops as the engine's link flags say, no Output hop
-        for (int i = 0; i < st.count; ++i)
-            links.push_back(GLink{i == 0 ? DSPFX_GRAPH_INPUT : i - 1, i, DSPFX_PORT_MAIN, node_hop(e, st.first + i) == 0});
-        links.push_back(GLink{st.count - 1, st.count, DSPFX_PORT_MAIN, true});
-    }
-    const std::string src = graph_source(e, st.first, st.count, links, st.fast_div, gsigs);
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
-    if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
-    auto build = [&](int cpl) {
-        const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
-        const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
-                                std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
-        return jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
-    };
-    // Two channels per lane as the chain kernels do (large tiled engines), as long as the graph's live values fit:
-    // every node output still needed is F x CPL registers, and past 128 VGPRs the lost occupancy costs more than
-    // the wider accesses gain (profiles/r01_graph_one_kernel.txt).  DSPFX_VARIANT="cpl=1|2" forces either (A/B runs).
-    const Pref pref = read_pref();
-    const bool can2 = N % 128u == 0;
-    if (pref.cpl == 2 && can2) { const JitKernel *k = build(2); return k ? &k->var : nullptr; }
-    if (pref.cpl == 1) { const JitKernel *k = build(1); return k ? &k->var : nullptr; }
-    const JitKernel *k = nullptr;
-    if (e->desc.tile_channels && N > 131072u && can2) {
-        k = build(2);
-        if (k && k->vgprs <= 128) return &k->var;
-    }
-    k = build(1);
-    return k ? &k->var : nullptr;
 }
 
 const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
@@ -822,156 +338,6 @@ int plan(dspfx_engine *e) {
         if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
         if (nd.d.kind == DSPFX_SIGNAL_GEN) e->has_siggen = true;
     }
-    return DSPFX_OK;
-}
-
-// Placement tuning of a delay ring (see chain_kernels.hip.h, ring layout).  Some physical HBM regions
-// stream ~18 % slower under the chain kernel's access pattern (every resident workgroup walking its own
-// 128 KiB tile); the effect is stable over time and independent of the in/out buffers, but a plain
-// streaming sweep does not show it (profiles/r01_placement.txt), so the probe IS the delay node's kernel:
-// each candidate group is timed as a one-node REVERB launch over engine-owned scratch in/out.  As many
-// extra candidates as memory allows (at most as many as the ring has groups) are allocated, all are
-// timed, the fastest are kept.  Setup-time only; DSPFX_RING_TUNE=0/1 forces it off/on (default: rings
-// whose groups are >= 64 MiB).
-// Large streamed buffers (delay-ring groups, engine-owned sample buffers).  DSPFX_CONTIG=1 asks the driver for
-// physically contiguous VRAM, which lets the page tables use their largest fragment size (TLB reach).
-hipError_t big_alloc(void **p, size_t bytes) {
-    static const int contig = [] { const char *c = getenv("DSPFX_CONTIG"); return c ? atoi(c) : 0; }();
-    if (contig && bytes >= ((size_t)2 << 20)) {
-        if (hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous) == hipSuccess) return hipSuccess;
-        (void)hipGetLastError();
-    }
-    return hipMalloc(p, bytes);
-}
-
-int tune_ring(dspfx_engine *e, Node &n) {
-    const char *tv = getenv("DSPFX_RING_TUNE");
-    const int mode = tv ? atoi(tv) : -1;
-    const size_t gbytes = n.group_floats * sizeof(float);
-    if (mode == 0 || (mode < 0 && gbytes < ((size_t)64 << 20))) return DSPFX_OK;
-    const uint32_t N = e->desc.channels;
-    if (N < 64 || !e->dyn) return DSPFX_OK;
-    const size_t G = n.groups.size();
-    size_t free_b = 0, total_b = 0;
-    HIPCHK(e, hipMemGetInfo(&free_b, &total_b));
-    const size_t scratch_bytes = 2 * gbytes;                     // in + out blocks of 128 frames
-    const size_t reserve = (size_t)8 << 30;                      // leave room for the caller's buffers
-    (void)total_b;
-    float *scratch = nullptr, **d_one = nullptr;
-    hipEvent_t a = nullptr, b = nullptr;
-    if (hipMalloc((void **)&scratch, scratch_bytes) != hipSuccess) return DSPFX_OK;   // no room: skip tuning
-    HIPCHK(e, hipMemset(scratch, 0, scratch_bytes));
-    HIPCHK(e, hipMalloc((void **)&d_one, sizeof(float *)));
-    HIPCHK(e, hipEventCreate(&a));
-    HIPCHK(e, hipEventCreate(&b));
-    ChainArgs ca;
-    memset(&ca, 0, sizeof ca);
-    ca.in = scratch;
-    ca.out = scratch + n.group_floats;
-    ca.N = N;
-    ca.nframes = RING_GROUP_ROWS;
-    if (e->desc.tile_channels) {
-        const uint32_t W = e->desc.tile_channels;
-        ca.w_shift = (unsigned)__builtin_ctz(W);
-        ca.w_mask = W - 1;
-        ca.ld = W;
-        ca.io_tile_stride = (size_t)RING_GROUP_ROWS * W;
-    } else {
-        ca.w_shift = 31;
-        ca.w_mask = 0x7fffffffu;
-        ca.ld = N;
-    }
-    ca.hop_div = e->hop_div;
-    ca.hop_rc = 1.0 / (double)e->hop_div;
-    ca.third_rc = 1.0 / 3.0;
-    ca.fast_div = 1;
-    ca.xcd_remap = 1;
-    ca.n_slots = 1;
-    ca.slot[0].kind = DSPFX_REVERB;
-    ca.slot[0].p[0] = 0.5f;
-    ca.slot[0].groups = d_one;
-    ca.slot[0].D = RING_GROUP_ROWS;
-    const uint32_t n_main = N - N % 64u;
-    ca.n_launch = n_main;
-    const unsigned grid = (n_main + WG - 1) / WG;
-    auto probe = [&](float *gptr, float &best) -> int {
-        HIPCHK(e, hipMemcpy(d_one, &gptr, sizeof(float *), hipMemcpyHostToDevice));
-        best = 1e30f;
-        for (int rep = 0; rep < 3; ++rep) {   // rep 0 warms TLB/clocks
-            (void)hipEventRecord(a, nullptr);
-            (void)launch_variant(e->dyn, ca, grid, WG, 0, nullptr);
-            (void)hipEventRecord(b, nullptr);
-            HIPCHK(e, hipEventSynchronize(b));
-            float ms = 0.0f;
-            (void)hipEventElapsedTime(&ms, a, b);
-            if (rep) best = std::min(best, ms);
-        }
-        return DSPFX_OK;
-    };
-    // The ring's own groups first; candidates are allocated only for groups in the slow placement mode (SLOW above the
-    // fastest), about 1.8 per slow group and round -- a fresh device, where every group is fast, allocates eight scouts.
-    const float SLOW = 1.06f;
-    std::vector<float> t(G, 0.0f);
-    int rc = DSPFX_OK;
-    for (size_t g = 0; g < G && rc == DSPFX_OK; ++g) rc = probe(n.groups[g], t[g]);
-    std::vector<std::pair<float, float *>> pool;
-    auto more_candidates = [&](size_t want) {
-        size_t fb = 0, tb = 0;
-        if (hipMemGetInfo(&fb, &tb) != hipSuccess) return;
-        const size_t can = fb > reserve ? (fb - reserve) / gbytes : 0;
-        for (size_t k = 0; k < std::min(want, can) && rc == DSPFX_OK; ++k) {
-            float *g = nullptr;
-            if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-            float ms = 0.0f;
-            rc = probe(g, ms);
-            pool.emplace_back(ms, g);
-        }
-    };
-    if (rc == DSPFX_OK) more_candidates(std::min<size_t>(8, G));
-    int replaced = 0;
-    size_t n_alloc = pool.size();
-    if (rc == DSPFX_OK) {
-        float t_ref = *std::min_element(t.begin(), t.end());
-        for (auto &pr : pool) t_ref = std::min(t_ref, pr.first);
-        for (int round = 0; round < 4 && rc == DSPFX_OK; ++round) {
-            std::vector<size_t> slow;
-            for (size_t g = 0; g < G; ++g)
-                if (t[g] > SLOW * t_ref) slow.push_back(g);
-            std::sort(slow.begin(), slow.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
-            std::sort(pool.begin(), pool.end());
-            size_t used = 0;
-            for (size_t g : slow) {
-                if (used >= pool.size() || pool[used].first > SLOW * t_ref) break;
-                std::swap(n.groups[g], pool[used].second);
-                t[g] = pool[used].first;
-                pool[used].first = 1e30f;
-                ++used;
-                ++replaced;
-            }
-            size_t still = 0;
-            for (size_t g = 0; g < G; ++g) still += t[g] > SLOW * t_ref ? 1 : 0;
-            if (!still) break;
-            const size_t before = pool.size();
-            more_candidates(still + (still * 4 + 4) / 5);
-            n_alloc += pool.size() - before;
-            if (pool.size() == before) break;
-            for (size_t i = before; i < pool.size(); ++i) t_ref = std::min(t_ref, pool[i].first);
-        }
-    }
-    if (getenv("DSPFX_RING_TUNE_DEBUG")) {
-        fprintf(stderr, "ring probe: %zu groups, %zu candidates allocated, %d re-placed; ms now:", G, n_alloc, replaced);
-        for (float v : t) fprintf(stderr, " %.3f", v);
-        fprintf(stderr, "\n");
-    }
-    for (auto &pr : pool) (void)hipFree(pr.second);
-    n.ring_replaced = replaced;
-    (void)hipFree(scratch);
-    (void)hipFree(d_one);
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
-    if (rc) return rc;
-    for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, gbytes));   // probing wrote into the groups
-    HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
     return DSPFX_OK;
 }
 
@@ -1444,26 +810,8 @@ int drain_pending(dspfx_engine *e, hipStream_t s) {
     return rc;
 }
 
-// Every entry point that touches an engine: take api_mu; the outermost one applies the queued stores first.  With a
-// stream (the process calls, tuning) the state is bound to it before anything is queued.
-struct ApiScope {
-    dspfx_engine *e;
-    int rc = DSPFX_OK;
-    bool outer = false;
-    ApiScope(dspfx_engine *e_, bool has_stream = false, hipStream_t s = nullptr) : e(e_) {
-        e->api_mu.lock();
-        outer = e->api_depth++ == 0;
-        if (hipSetDevice(e->device) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
-        if (has_stream && rc == DSPFX_OK) rc = bind_stream(e, s);
-        if (outer && rc == DSPFX_OK) rc = drain_pending(e, e->cur_stream_set ? e->cur_stream : nullptr);
-    }
-    ~ApiScope() {
-        --e->api_depth;
-        e->api_mu.unlock();
-    }
-};
+}  // namespace dspfx_host
 
-}  // namespace
 
 // ------------------------------------------------------------------ library
 
@@ -1614,7 +962,7 @@ extern "C" const char *dspfx_last_error(const dspfx_engine *e) {
     return tl_err.c_str();              // valid until this thread's next failing call
 }
 
-namespace {
+namespace dspfx_host {
 int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
 }
 extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
@@ -1625,7 +973,7 @@ extern "C" int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     e->no_long = false;
     return set_nodes(e, nodes, n_nodes);
 }
-namespace {
+namespace dspfx_host {
 int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     if (n_nodes < 0 || n_nodes > DSPFX_MAX_NODES || (n_nodes > 0 && !nodes))
         return fail(e, DSPFX_ERR_INVALID, "chain length %d out of range", n_nodes);
@@ -1664,52 +1012,8 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     const int rs = settle_null_stream(e);
     return rc ? rc : rs;
 }
-}  // namespace
+}  // namespace dspfx_host
 
-namespace {
-// Shape checks shared by dspfx_graph_set and dspfx_graph_source (e may be null).
-int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links) {
-    if (n_nodes < 0 || (n_nodes > 0 && !nodes) || n_links < 0 || (n_links > 0 && !links))
-        return fail(e, DSPFX_ERR_INVALID, "graph: bad node / link arrays");
-    if (n_nodes > DSPFX_GRAPH_MAX_NODES)
-        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
-    for (int i = 0; i < n_nodes; ++i) {
-        const int rc = validate_node(e, nodes[i]);
-        if (rc) return rc;
-    }
-    std::map<std::pair<int, int>, int> fan_in;
-    for (int i = 0; i < n_links; ++i) {
-        const dspfx_graph_link &l = links[i];
-        if (l.dst < 0 || l.dst >= n_nodes + DSPFX_GRAPH_MAX_IO || l.src <= -2 - DSPFX_GRAPH_MAX_IO || (l.src >= l.dst && l.dst < n_nodes) || l.src >= n_nodes)
-            return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
-        const int port = l.port & ~DSPFX_PORT_RAW;
-        bool ok = port == DSPFX_PORT_MAIN;
-        if (l.dst < n_nodes && !ok) {
-            const dspfx_node_desc &d = nodes[l.dst];
-            float lo[3], hi[3];
-            if (port == DSPFX_PORT_SIDE) ok = d.kind == DSPFX_ADD || d.kind == DSPFX_MIX;
-            else ok = port >= DSPFX_PORT_SLIDER && port - DSPFX_PORT_SLIDER < kind_sliders(d, lo, hi);
-        }
-        if (!ok) return fail(e, DSPFX_ERR_INVALID, "graph link %d: node %d has no port %d", i, l.dst, l.port);
-        if (++fan_in[{l.dst, port}] > DSPFX_MAX_LINKS)
-            return fail(e, DSPFX_ERR_INVALID, "graph link %d: more than %d links into one port", i, DSPFX_MAX_LINKS);
-    }
-    {   // output blocks are stored by the generated kernel for every m < n_out: each of them needs a signal (and a buffer)
-        int n_out = 1;
-        for (int i = 0; i < n_links; ++i) n_out = std::max(n_out, links[i].dst - n_nodes + 1);
-        for (int m = 1; m < n_out; ++m)
-            if (!fan_in.count({n_nodes + m, DSPFX_PORT_MAIN}))
-                return fail(e, DSPFX_ERR_INVALID, "graph: output block %d has no link although block %d has (output blocks must be contiguous)", m, n_out - 1);
-    }
-    for (int i = 0; i < n_links; ++i)   // a RAW link is its port's only link, and it carries a signal
-        if ((links[i].port & DSPFX_PORT_RAW) && (fan_in[{links[i].dst, links[i].port & ~DSPFX_PORT_RAW}] != 1 || links[i].src == DSPFX_GRAPH_ZERO))
-            return fail(e, DSPFX_ERR_INVALID, "graph link %d: a RAW link must be the only link into its port", i);
-    for (int i = 0; i < n_nodes; ++i)
-        if (nodes[i].kind == DSPFX_FIR || (nodes[i].kind == DSPFX_DISTORT && nodes[i].mode == DSPFX_DIST_FUZZ))
-            return fail(e, DSPFX_ERR_UNSUPPORTED, "graph node %d (FIR / Fuzz) has its own kernel and cannot be fused", i);
-    return DSPFX_OK;
-}
-}  // namespace
 
 extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links,
                                int n_links) {
@@ -1730,34 +1034,6 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     return rc;
 }
 
-extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links,
-                                  char *dst, size_t cap) {
-    if (!dst || cap == 0) return DSPFX_ERR_INVALID;
-    const int vrc = validate_graph(nullptr, nodes, n_nodes, links, n_links);
-    if (vrc) return vrc;
-    dspfx_engine tmp;                       // never touches a device: only the node descriptors are read
-    tmp.nodes.resize((size_t)n_nodes);
-    for (int i = 0; i < n_nodes; ++i) {
-        tmp.nodes[(size_t)i].d = nodes[i];
-        tmp.nodes[(size_t)i].d.taps = nullptr;
-    }
-    std::vector<GLink> gl;
-    for (int i = 0; i < n_links; ++i)
-        gl.push_back(GLink{links[i].src, links[i].dst, links[i].port & ~DSPFX_PORT_RAW, (links[i].port & DSPFX_PORT_RAW) != 0});
-    Stage st{};
-    st.type = ST_FUSED;
-    st.first = 0;
-    st.count = n_nodes;
-    int sigs[GRAPH_SLOTS];
-    tmp.hop_div = dspfx_link_divisor(1);
-    // no device is touched: divisions already proven in this process are written in their exact-product form, all others
-    // in the IEEE form (nothing is verified, nothing is cached)
-    const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st, false), sigs, false);
-    if (src.size() + 1 > cap) return DSPFX_ERR_INVALID;
-    memcpy(dst, src.c_str(), src.size() + 1);
-    return DSPFX_OK;
-}
-
 extern "C" int dspfx_chain_len(const dspfx_engine *e) {
     if (!e) return DSPFX_ERR_INVALID;
     std::lock_guard<std::recursive_mutex> lk(e->api_mu);
@@ -1769,7 +1045,7 @@ extern "C" int dspfx_chain_len(const dspfx_engine *e) {
 // store lands between two blocks.  Here: the store is queued (never waiting for a process call in progress) and applied
 // by the next entry point that holds the engine -- at once when the engine is idle, else at the next block boundary --
 // with its state write (the biquad reset) queued in stream order behind the blocks already in flight.
-namespace {
+namespace dspfx_host {
 int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *seq_out) {
     {
         std::lock_guard<std::mutex> lk(e->pend_mu);
@@ -1802,7 +1078,7 @@ int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *s
     }
     return DSPFX_OK;                                    // applied at the next block boundary
 }
-}  // namespace
+}  // namespace dspfx_host
 
 extern "C" int dspfx_set_param(dspfx_engine *e, int node, int param, float value) {
     if (!e) return DSPFX_ERR_INVALID;
@@ -1895,7 +1171,7 @@ extern "C" int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision)
     return DSPFX_OK;
 }
 
-namespace {
+namespace dspfx_host {
 // Zero every node's DSP state, queued on `s`: ordered behind the blocks in flight there, ahead of the next one.
 int reset_on(dspfx_engine *e, hipStream_t s) {
     for (Node &n : e->nodes) {
@@ -1908,7 +1184,7 @@ int reset_on(dspfx_engine *e, hipStream_t s) {
     e->mp_count = 0;   // blocks still in the mix pipeline are dropped
     return DSPFX_OK;
 }
-}  // namespace
+}  // namespace dspfx_host
 
 extern "C" int dspfx_reset(dspfx_engine *e) {
     if (!e) return DSPFX_ERR_INVALID;
@@ -1918,269 +1194,6 @@ extern "C" int dspfx_reset(dspfx_engine *e) {
 }
 
 // ------------------------------------------------------------- the hot path
-
-// Placement tuning against the caller's own buffers (see include/dspfx.h).  Every candidate 128-row group of every
-// large delay ring is timed with the REAL chain (all stages, the engine's chosen kernels) reading `in` and writing
-// `out`: the node temporarily becomes a 128-row ring made of that one group.  The fastest groups are kept.
-// The engine's DSP state survives.  The probes run whole blocks through EVERY node, so everything a block writes is
-// parked first and put back afterwards:
-//   * filter / generator / envelope rows: snapshotted, restored at the end;
-//   * every delay ring (the probed one, the small ones, the ones probed earlier or later): its position is put back
-//     before every probe run, so all probes overwrite the same n_frames rows -- parked once, restored at the end;
-//   * the ring being probed: each of its groups is parked in a scratch group while it stands in as the one-group ring,
-//     and put back (or moved into the candidate that replaces it, at the same ring position);
-//   * FIR nodes: the rows the probes' samples land in, the non-finite flags, the fill-phase sums and the host-side
-//     deque model (fir_park / fir_rewind / fir_unpark).
-namespace {
-struct TuneGuard {   // whatever happens inside the probe loop, every node gets its real geometry / position back and nothing leaks
-    dspfx_engine *e;
-    Node *n = nullptr;
-    uint32_t D0 = 0, min0 = 0;
-    float **table0 = nullptr, **d_one = nullptr;
-    float *park = nullptr;
-    hipEvent_t ea = nullptr, eb = nullptr;
-    std::vector<float *> extras;            // candidates allocated here and not (yet) adopted by the ring
-    std::vector<std::pair<float *, size_t>> snaps;   // device copies of node state: (copy, node index)
-    std::vector<uint32_t> pos0;             // ring position of every node on entry
-    std::vector<float *> rows;              // per node: the parked rows [n_frames][N] of its delay ring (or null)
-    std::vector<FirPark> firs;              // per node
-    explicit TuneGuard(dspfx_engine *e_) : e(e_), pos0(e_->nodes.size(), 0), rows(e_->nodes.size(), nullptr), firs(e_->nodes.size()) {
-        for (size_t i = 0; i < e->nodes.size(); ++i) pos0[i] = e->nodes[i].pos;
-    }
-    void arm(Node &node) {
-        n = &node;
-        D0 = node.D;
-        min0 = e->min_delay;
-        table0 = node.d_groups;
-    }
-    void disarm() {
-        if (!n) return;
-        n->D = D0;
-        n->d_groups = table0;
-        n->probe_group = nullptr;
-        e->min_delay = min0;
-        n = nullptr;
-    }
-    // host-side positions as on entry (the node being probed: a one-group ring at position 0)
-    void rewind() {
-        for (size_t i = 0; i < e->nodes.size(); ++i) {
-            Node &m = e->nodes[i];
-            if (m.d.kind == DSPFX_REVERB) m.pos = &m == n ? 0 : pos0[i];
-            if (m.d.kind == DSPFX_FIR && firs[i].rows) fir_rewind(m.fir, firs[i]);
-        }
-    }
-    ~TuneGuard() {
-        disarm();
-        rewind();
-        for (float *g : extras)
-            if (g) (void)hipFree(g);
-        for (auto &sn : snaps)
-            if (sn.first) (void)hipFree(sn.first);
-        for (float *r : rows)
-            if (r) (void)hipFree(r);
-        for (FirPark &f : firs) fir_park_free(f);
-        if (d_one) (void)hipFree(d_one);
-        if (park) (void)hipFree(park);
-        if (ea) (void)hipEventDestroy(ea);
-        if (eb) (void)hipEventDestroy(eb);
-        (void)hipGetLastError();
-    }
-};
-}  // namespace
-
-extern "C" int dspfx_tune_placement(dspfx_engine *e, const float *in, const float *side, float *out, uint32_t n_frames,
-                                    void *stream) {
-    if (!e) return DSPFX_ERR_INVALID;
-    hipStream_t s = (hipStream_t)stream;
-    ApiScope api(e, true, s);
-    if (api.rc) return api.rc;
-    if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
-    if (n_frames == 0 || n_frames > e->desc.max_frames || n_frames > RING_GROUP_ROWS)
-        return fail(e, DSPFX_ERR_INVALID, "n_frames must be 1..%u here", std::min<uint32_t>(e->desc.max_frames, RING_GROUP_ROWS));
-    if (e->collect_due || e->mp_count) return fail(e, DSPFX_ERR_STATE, "flush the mix pipeline before tuning");
-    bool any = false;
-    for (const Node &n : e->nodes) any = any || (n.d.kind == DSPFX_REVERB && n.group_floats * sizeof(float) >= ((size_t)64 << 20));
-    if (!any) return DSPFX_OK;               // nothing large enough to be placement-sensitive: state untouched
-    if (e->graph_mode)                       // a region kernel with extra blocks: its buffers are not all known here
-        for (const dspfx_graph_link &l : e->wiring)
-            if (graph_input_block(l.src) >= 2 || l.dst > (int)e->nodes.size()) return DSPFX_OK;
-    const uint32_t N = e->desc.channels;
-    const uint32_t W = e->desc.tile_channels ? e->desc.tile_channels : N;
-    TuneGuard tg(e);
-    if (hipEventCreate(&tg.ea) != hipSuccess || hipEventCreate(&tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventCreate failed");
-    HIPCHK(e, hipStreamSynchronize(s));
-    // park what a block writes: small per-channel state rows, the block's rows of every delay ring, FIR histories
-    for (size_t i = 0; i < e->nodes.size(); ++i) {
-        Node &n = e->nodes[i];
-        if (n.d.kind == DSPFX_REVERB) {
-            if (hipMalloc((void **)&tg.rows[i], (size_t)n_frames * N * sizeof(float)) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "no room to park ring rows");
-            launch_ring_copy(n.d_groups, tg.rows[i], N, W, n.D, n.pos, n_frames, true, s);
-            HIPCHK(e, hipGetLastError());
-        } else if (n.d.kind == DSPFX_FIR) {
-            const int rc = fir_park(n.fir, n_frames, s, tg.firs[i]);
-            if (rc) return fail(e, rc, "FIR: %s", fir_last_error());
-        } else if (n.state && n.state_bytes) {
-            float *copy = nullptr;
-            if (hipMalloc((void **)&copy, n.state_bytes) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "no room for a state snapshot");
-            tg.snaps.emplace_back(copy, i);
-            if (hipMemcpyAsync(copy, n.state, n.state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "state snapshot failed");
-        }
-    }
-    int rc = DSPFX_OK;
-    const size_t tile_frames = e->desc.max_frames;   // the buffers are laid out like a full block of the engine
-    const auto tick = [] { return std::chrono::steady_clock::now(); };
-    const auto ms_since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); };
-    const bool debug = getenv("DSPFX_RING_TUNE_DEBUG") != nullptr;
-    for (Node &n : e->nodes) {
-        if (n.d.kind != DSPFX_REVERB) continue;
-        const size_t gbytes = n.group_floats * sizeof(float);
-        if (gbytes < ((size_t)64 << 20)) continue;
-        const size_t G = n.groups.size();
-        if (!tg.park && big_alloc((void **)&tg.park, gbytes) != hipSuccess) {
-            (void)hipGetLastError();
-            return fail(e, DSPFX_ERR_OOM, "no room to park a ring group (%zu MiB)", gbytes >> 20);
-        }
-        if (!tg.d_one && hipMalloc((void **)&tg.d_one, sizeof(float *)) != hipSuccess) return fail(e, DSPFX_ERR_OOM, "hipMalloc failed");
-        // the node as a one-group ring (the guard puts the real geometry back on every exit path)
-        tg.arm(n);
-        n.D = RING_GROUP_ROWS;
-        n.d_groups = tg.d_one;
-        // one candidate: the real chain, `reps` launches, the best of all but the first (which warms TLB / clocks)
-        auto probe = [&](float *gptr, bool live, float &best) -> int {
-            if (live && hipMemcpyAsync(tg.park, gptr, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "parking a ring group failed");
-            if (hipMemcpyAsync(tg.d_one, &gptr, sizeof(float *), hipMemcpyHostToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipMemcpyAsync failed");
-            if (hipStreamSynchronize(s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipStreamSynchronize failed");   // (&gptr is a stack slot)
-            n.probe_group = gptr;
-            best = 1e30f;
-            for (int rep = 0; rep < 3; ++rep) {
-                tg.rewind();
-                (void)hipEventRecord(tg.ea, s);
-                const int r = run_subblock(e, in, side, out, nullptr, n_frames, (uint32_t)tile_frames, s);
-                (void)hipEventRecord(tg.eb, s);
-                if (r) return r;
-                if (hipEventSynchronize(tg.eb) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipEventSynchronize failed");
-                float ms = 0.0f;
-                (void)hipEventElapsedTime(&ms, tg.ea, tg.eb);
-                if (rep) best = std::min(best, ms);
-            }
-            if (live && hipMemcpyAsync(gptr, tg.park, gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "restoring a ring group failed");
-            return DSPFX_OK;
-        };
-        // 1. the ring's own groups.  Placement comes in two modes ~18 % apart (placement): when every group is
-        //    within SLOW of the fastest one there is nothing to gain and nothing is allocated (a fresh box: 0.25 s).
-        const float SLOW = 1.06f;
-        const auto t_own = tick();
-        std::vector<float> t(G, 0.0f);
-        for (size_t g = 0; g < G && rc == DSPFX_OK; ++g) rc = probe(n.groups[g], true, t[g]);
-        const double ms_own = ms_since(t_own);
-        if (const char *fk = getenv("DSPFX_TUNE_FAKE_SLOW"))            // tests: pretend the first k groups landed in the slow mode
-            for (size_t g = 0; g < std::min<size_t>(G, (size_t)atoi(fk)); ++g) t[g] *= 1.25f;
-        // 2. a few scouts: is the fastest own group really a fast one (or are ALL of them in the slow mode)?
-        auto alloc_candidates = [&](size_t want, std::vector<float *> &got) {
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-            const size_t reserve = ((size_t)8 << 30);            // room for the caller
-            const size_t can = free_b > reserve ? (free_b - reserve) / gbytes : 0;
-            for (size_t k = 0; k < std::min(want, can); ++k) {
-                float *g = nullptr;
-                if (big_alloc((void **)&g, gbytes) != hipSuccess) { (void)hipGetLastError(); break; }
-                if (hipMemsetAsync(g, 0, gbytes, s) != hipSuccess) { (void)hipFree(g); (void)hipGetLastError(); break; }
-                got.push_back(g);
-                tg.extras.push_back(g);
-            }
-        };
-        std::vector<std::pair<float, float *>> pool;            // probed candidates that are not part of the ring: (ms, group)
-        const auto t_rest = tick();
-        size_t n_alloc = 0;
-        if (rc == DSPFX_OK) {
-            std::vector<float *> scouts;
-            alloc_candidates(std::min<size_t>(8, G), scouts);
-            n_alloc += scouts.size();
-            for (float *g : scouts) {
-                float ms = 0.0f;
-                rc = probe(g, false, ms);
-                if (rc) break;
-                pool.emplace_back(ms, g);
-            }
-        }
-        int replaced = 0;
-        if (rc == DSPFX_OK) {
-            float t_ref = *std::min_element(t.begin(), t.end());
-            for (auto &pr : pool) t_ref = std::min(t_ref, pr.first);
-            // 3. replace slow groups, slowest first, by fast candidates; allocate more candidates (about 1.8 per group still
-            //    slow: roughly 6 in 10 land in the fast mode) until none is slow, memory runs out, or four rounds have passed
-            for (int round = 0; round < 4 && rc == DSPFX_OK; ++round) {
-                std::vector<size_t> slow;
-                for (size_t g = 0; g < G; ++g)
-                    if (t[g] > SLOW * t_ref) slow.push_back(g);
-                std::sort(slow.begin(), slow.end(), [&](size_t x, size_t y) { return t[x] > t[y]; });
-                std::sort(pool.begin(), pool.end());
-                size_t used = 0;
-                for (size_t g : slow) {
-                    if (used >= pool.size() || pool[used].first > SLOW * t_ref) break;
-                    float *fresh = pool[used].second;
-                    if (hipMemcpyAsync(fresh, n.groups[g], gbytes, hipMemcpyDeviceToDevice, s) != hipSuccess) { rc = fail(e, DSPFX_ERR_HIP, "moving a ring group failed"); break; }
-                    std::swap(n.groups[g], pool[used].second);     // the pool now holds the dropped allocation
-                    for (float *&x : tg.extras)                     // ... and so does the guard's list of what to free on an error path
-                        if (x == fresh) x = pool[used].second;
-                    t[g] = pool[used].first;
-                    pool[used].first = 1e30f;                      // never picked again
-                    ++used;
-                    ++replaced;
-                }
-                if (rc) break;
-                size_t still = 0;
-                for (size_t g = 0; g < G; ++g) still += t[g] > SLOW * t_ref ? 1 : 0;
-                if (!still) break;
-                std::vector<float *> more;
-                alloc_candidates(still + (still * 4 + 4) / 5, more);
-                if (more.empty()) break;
-                n_alloc += more.size();
-                for (float *g : more) {
-                    float ms = 0.0f;
-                    rc = probe(g, false, ms);
-                    if (rc) break;
-                    pool.emplace_back(ms, g);
-                    t_ref = std::min(t_ref, ms);
-                }
-            }
-        }
-        tg.disarm();
-        tg.rewind();
-        if (rc) return rc;
-        HIPCHK(e, hipStreamSynchronize(s));
-        for (auto &pr : pool) (void)hipFree(pr.second);              // dropped originals and unused candidates
-        tg.extras.clear();
-        n.ring_replaced = replaced;
-        HIPCHK(e, hipMemcpyAsync(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice, s));
-        HIPCHK(e, hipStreamSynchronize(s));
-        if (debug) {
-            fprintf(stderr, "placement tuning: %zu ring groups probed in %.0f ms; %zu candidates allocated, %d groups re-placed, %.0f ms; ring groups now (ms):", G, ms_own,
-                    n_alloc, replaced, ms_since(t_rest));
-            for (float v : t) fprintf(stderr, " %.3f", v);
-            fprintf(stderr, "\n");
-        }
-    }
-    // put back what the probes' blocks overwrote
-    tg.rewind();
-    for (size_t i = 0; i < e->nodes.size(); ++i) {
-        Node &n = e->nodes[i];
-        if (n.d.kind == DSPFX_REVERB && tg.rows[i]) {
-            launch_ring_copy(n.d_groups, tg.rows[i], N, W, n.D, n.pos, n_frames, false, s);
-            HIPCHK(e, hipGetLastError());
-        } else if (n.d.kind == DSPFX_FIR) {
-            const int r = fir_unpark(n.fir, tg.firs[i], s);
-            if (r) return fail(e, r, "FIR: %s", fir_last_error());
-        }
-    }
-    for (auto &sn : tg.snaps) {
-        Node &n = e->nodes[sn.second];
-        if (hipMemcpyAsync(n.state, sn.first, n.state_bytes, hipMemcpyDeviceToDevice, s) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "restoring node state failed");
-    }
-    // control-port latches are only written while a port is connected: the probes connect none
-    HIPCHK(e, hipStreamSynchronize(s));
-    return DSPFX_OK;
-}
 
 extern "C" int dspfx_process(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                              uint32_t n_frames, void *stream) {
@@ -2329,7 +1342,7 @@ extern "C" int dspfx_host_free(void *p) {
     return hipHostFree(p) == hipSuccess ? DSPFX_OK : DSPFX_ERR_HIP;
 }
 
-namespace {
+namespace dspfx_host {
 bool is_pinned_host(const void *p) {
     hipPointerAttribute_t at;
     memset(&at, 0, sizeof at);
@@ -2339,7 +1352,7 @@ bool is_pinned_host(const void *p) {
     }
     return at.type == hipMemoryTypeHost;
 }
-}  // namespace
+}  // namespace dspfx_host
 
 extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
                                   uint32_t n_frames) {
@@ -2553,150 +1566,6 @@ extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, 
     }
     launch_mix_finish(mix, n_frames, e->div_v, (hipStream_t)stream);
     HIPCHK(e, hipGetLastError());
-    return DSPFX_OK;
-}
-
-// ------------------------------------------------------- the mix bus across GPUs
-// RCCL through dlopen: the library must load (and every single-GPU entry point work) where RCCL is absent, and in a
-// process that already maps a copy of RCCL (PyTorch ships its own) the collective must use THAT copy and the HIP
-// runtime it is bound to -- two RCCLs over one runtime is asking for trouble.
-namespace {
-struct IdBlob {               // ncclUniqueId: 128 opaque bytes, passed BY VALUE to ncclCommInitRank
-    char bytes[DSPFX_COMM_ID_BYTES];
-};
-struct Rccl {
-    void *lib = nullptr;
-    int (*GetUniqueId)(void *) = nullptr;
-    int (*CommInitRank)(void **, int, IdBlob, int) = nullptr;
-    int (*CommDestroy)(void *) = nullptr;
-    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    const char *(*GetErrorString)(int) = nullptr;
-    std::string err;          // why RCCL is unavailable, or the last failure that left no communicator behind
-    std::mutex err_mu;
-};
-Rccl *rccl() {
-    static Rccl r;
-    static std::once_flag once;
-    std::call_once(once, [] {
-        const char *names[] = {"librccl.so", "librccl.so.1"};
-        for (const char *n : names)                         // a copy already in the process wins
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (const char *p = getenv("DSPFX_RCCL_LIB"))
-            if (!r.lib) r.lib = dlopen(p, RTLD_NOW);
-        for (const char *n : names)
-            if (!r.lib) r.lib = dlopen(n, RTLD_NOW);
-        if (!r.lib) {
-            r.err = "RCCL not found (librccl.so / librccl.so.1; DSPFX_RCCL_LIB overrides)";
-            return;
-        }
-        r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.lib, "ncclGetUniqueId");
-        r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
-        r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-        r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
-        r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.lib, "ncclGetErrorString");
-        if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.AllReduce) {
-            r.err = "RCCL library lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
-            r.lib = nullptr;
-        }
-    });
-    return &r;
-}
-constexpr int kNcclFloat32 = 7, kNcclSum = 0;   // rccl.h: ncclFloat32 / ncclSum
-}  // namespace
-
-struct dspfx_comm {
-    void *comm = nullptr;     // ncclComm_t; null for a single rank
-    int n_ranks = 1, rank = 0, device = 0;
-    std::string err;
-};
-
-extern "C" int dspfx_comm_unique_id(void *id_out) {
-    if (!id_out) return DSPFX_ERR_INVALID;
-    Rccl *r = rccl();
-    if (!r->lib) return DSPFX_ERR_UNSUPPORTED;
-    static_assert(sizeof(IdBlob) == DSPFX_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
-    const int rc = r->GetUniqueId(id_out);
-    if (rc != 0) {
-        std::lock_guard<std::mutex> lk(r->err_mu);
-        r->err = std::string("ncclGetUniqueId: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed");
-        return DSPFX_ERR_HIP;
-    }
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_comm_create(int device, int n_ranks, int rank, const void *id, dspfx_comm **out) {
-    if (!out) return DSPFX_ERR_INVALID;
-    *out = nullptr;
-    if (n_ranks < 1 || rank < 0 || rank >= n_ranks || (n_ranks > 1 && !id)) return DSPFX_ERR_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
-    if (device < 0 || device >= ndev) return DSPFX_ERR_INVALID;
-    dspfx_comm *c = new dspfx_comm();
-    c->n_ranks = n_ranks;
-    c->rank = rank;
-    c->device = device;
-    if (n_ranks > 1 || id) {                 // with an id even one rank gets a real communicator (exercises the RCCL path)
-        Rccl *r = rccl();
-        if (!r->lib) {
-            delete c;
-            return DSPFX_ERR_UNSUPPORTED;
-        }
-        if (hipSetDevice(device) != hipSuccess) {
-            delete c;
-            return DSPFX_ERR_HIP;
-        }
-        IdBlob blob;
-        memcpy(blob.bytes, id, sizeof blob.bytes);
-        const int rc = r->CommInitRank(&c->comm, n_ranks, blob, rank);
-        if (rc != 0) {
-            {   // dspfx_comm_last_error(NULL) reports it: there is no communicator to ask
-                std::lock_guard<std::mutex> lk(r->err_mu);
-                r->err = std::string("ncclCommInitRank: ") + (r->GetErrorString ? r->GetErrorString(rc) : "failed");
-            }
-            delete c;
-            return DSPFX_ERR_HIP;
-        }
-    }
-    *out = c;
-    return DSPFX_OK;
-}
-
-extern "C" void dspfx_comm_destroy(dspfx_comm *c) {
-    if (!c) return;
-    if (c->comm) {
-        (void)hipSetDevice(c->device);
-        (void)rccl()->CommDestroy(c->comm);
-    }
-    delete c;
-}
-
-extern "C" int dspfx_comm_size(const dspfx_comm *c) { return c ? c->n_ranks : DSPFX_ERR_INVALID; }
-extern "C" int dspfx_comm_rank(const dspfx_comm *c) { return c ? c->rank : DSPFX_ERR_INVALID; }
-extern "C" const char *dspfx_comm_last_error(const dspfx_comm *c) {
-    if (c) return c->err.c_str();
-    static thread_local std::string copy;
-    Rccl *r = rccl();
-    std::lock_guard<std::mutex> lk(r->err_mu);
-    copy = r->err;
-    return copy.c_str();
-}
-
-extern "C" int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, uint32_t n_frames, uint64_t n_connected,
-                                   void *stream) {
-    if (!e || !c || !mix) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    if (n_frames == 0) return DSPFX_OK;
-    if (c->device != e->device) return fail(e, DSPFX_ERR_INVALID, "communicator lives on device %d, engine on %d", c->device, e->device);
-    HIPCHK(e, hipSetDevice(e->device));
-    if (c->comm) {   // nodes/output.rs:215-249 + node.rs:181-183 across the shards: ONE all-reduce of n_frames floats
-        const int rc = rccl()->AllReduce(mix, mix, n_frames, kNcclFloat32, kNcclSum, c->comm, (hipStream_t)stream);
-        if (rc != 0) {
-            c->err = rccl()->GetErrorString ? rccl()->GetErrorString(rc) : "ncclAllReduce failed";
-            return fail(e, DSPFX_ERR_HIP, "ncclAllReduce: %s", c->err.c_str());
-        }
-    }
-    if (n_connected) return dspfx_mix_finish(e, mix, n_frames, n_connected, stream);   // node.rs:189-191 with the GLOBAL count
     return DSPFX_OK;
 }
 

@@ -1,0 +1,266 @@
+// engine.h -- what the translation units of libdspfx.so share: the engine object behind the C ABI (include/dspfx.h) and the
+// host-side functions that more than one of them calls.
+//   dspfx.hip      lifecycle, parameter stores, the process calls (stage planning, launches), DSP state, utilities
+//   jit.hip        run-time specialisation (hiprtc) of the chain kernels and the generator of whole-graph kernels
+//   placement.hip  delay-ring placement tuning (setup-time probe, dspfx_tune_placement)
+//   comm.hip       the mix bus across GPUs: RCCL through dlopen, dspfx_comm_*, dspfx_mix_allreduce
+// Not installed: the public interface is include/dspfx.h alone.
+#pragma once
+#include "../../include/dspfx.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hiprtc.h>
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "aux_kernels.h"
+#include "fir_kernels.h"
+#include "variants.h"
+#include "graph_kernel.hip.h"   // GraphArgs
+
+using namespace dspfx;
+
+namespace dspfx_host {
+
+
+enum StageType { ST_FUSED = 0, ST_FUZZ = 1, ST_FIR = 2 };
+
+struct Node {
+    dspfx_node_desc d{};
+    // BIQUAD: normalised coefficients (biquad.rs:62-76)
+    float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
+    float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N]
+    // REVERB: the ring as separately allocated 128-row groups + the device copy of the pointer table
+    std::vector<float *> groups;
+    float **d_groups = nullptr;
+    float *probe_group = nullptr;   // placement probes: the node stands in as a one-group ring made of this group
+    size_t group_floats = 0;
+    int ring_replaced = 0;    // groups re-allocated by the placement probe
+    size_t state_bytes = 0;
+    uint32_t D = 0, pos = 0;  // REVERB
+    // FIR
+    std::vector<double> taps;      // reversed, as given
+    FirState fir;
+    // control ports: per-channel latched slider values (derive lib.rs:148)
+    float *latch[3] = {nullptr, nullptr, nullptr};
+    int latch_valid = 0;
+    const float *ctl_now[3] = {nullptr, nullptr, nullptr};   // signals of the call being launched
+};
+
+struct Stage {
+    StageType type;
+    int first, count;
+    const Variant *var = nullptr;   // ST_FUSED
+    const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
+    mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
+    mutable bool var_mod_tried = false;
+    bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
+};
+
+}  // namespace dspfx_host
+using namespace dspfx_host;
+
+struct dspfx_engine {
+    dspfx_engine_desc desc{};
+    int device = 0;
+    std::vector<Node> nodes;
+    std::vector<Stage> stages;
+    bool graph_mode = false;                  // dspfx_graph_set: the nodes form a DAG evaluated by one generated kernel
+    bool no_long = false;                     // chain mode: do not fuse more than MAX_SLOTS nodes into one (graph) kernel
+    std::vector<dspfx_graph_link> wiring;     // its links, in the caller's order
+    std::string err;
+    float hop_div = 1.0f;
+    float *mixpart = nullptr;
+    float *mixpart_b = nullptr;   // second-stage scratch [128][max_frames] (one per stream of use: inline / deferred)
+    float *mixpart_b2 = nullptr;
+    unsigned *mt_tickets = nullptr;   // same-block bus inside the chain launch: [MIX_SLICES + 1] arrival counters, zero between launches
+    size_t mixpart_cols = 0;
+    // pipelined mix bus (dspfx_process_partials / dspfx_mix_collect): double-buffered partials
+    float *mixpart2[2] = {nullptr, nullptr};
+    hipEvent_t ev_chain[2] = {nullptr, nullptr}, ev_red[2] = {nullptr, nullptr};
+    bool red_pending[2] = {false, false}, collect_due = false;
+    int flip = 0;
+    uint32_t part_stride[2] = {0, 0}, part_frames[2] = {0, 0};
+    float *partials_override = nullptr;   // set while a deferred-mix block is being launched
+    // in-kernel pipelined mix bus (dspfx_process_mixpipe): block k's launch also runs stage 2 of block k-1 and
+    // stage 3 of block k-2.  mp_count = blocks submitted since the last flush.
+    uint64_t mp_count = 0;
+    uint32_t mp_frames = 0, mp_rows[2] = {0, 0};
+    float *mp_mix_now = nullptr;          // where the launch being built delivers block k-2's bus
+    float mp_div_now = 0.0f;
+    bool mp_building = false;
+    float bus_div_now = 0.0f;             // dspfx_process_bus: the Output hop's divisor for the block being launched (0: none)
+    // channel window of the current run_subblock call (pipelined host path): channels [win_c0, win_c0 + win_n), 0 = all;
+    // win_last marks the call that finishes the block (ring positions advance once)
+    uint32_t win_c0 = 0, win_n = 0;
+    bool win_last = true;
+    hipStream_t hs_in = nullptr, hs_out = nullptr, hs_run = nullptr;
+    std::vector<hipEvent_t> hev;
+    uint32_t ctl_tile_frames = 0;         // dspfx_process_ctl: frames of the caller's whole block (tile stride)
+    // dspfx_process_io: input blocks 2.. and output blocks 1.. of the call being launched (graph engines), and the float
+    // offset of the sub-block being launched
+    const float *io_in[GRAPH_IO] = {};
+    float *io_out[GRAPH_IO] = {};
+    size_t io_off = 0;
+    // staging for dspfx_process_host
+    float *h_in = nullptr, *h_side = nullptr, *h_out = nullptr, *h_mix = nullptr;
+    const Variant *tail = nullptr, *dyn = nullptr, *tail_mod = nullptr, *dyn_mod = nullptr, *dyn_mod2 = nullptr;
+    bool has_fuzz = false;
+    uint32_t min_delay = 0xffffffffu;
+    bool has_siggen = false;   // a SIGNAL_GEN wraps its clock per 128-frame block: sub-launches start on block boundaries
+    mutable bool jit_unavailable = false;   // a run-time specialised kernel was wanted and could not be had (headers / hiprtc missing)
+    uint64_t div_n = 0;   // cached Output-hop divisor (dspfx_mix_finish)
+    float div_v = 0.0f;
+    // profiling: event pairs per stage
+    bool profiling = false;
+    std::vector<std::vector<std::pair<hipEvent_t, hipEvent_t>>> prof;   // [stage][launch]
+    std::vector<hipEvent_t> ev_pool;
+    // ---- threads and streams (include/dspfx.h, "Threads and streams") ----------------------------------------------
+    // api_mu serialises every entry point that touches the engine; a slider store from another thread never waits
+    // for it: it is queued under pend_mu and applied by whoever holds api_mu next, at a block boundary.
+    mutable std::recursive_mutex api_mu;
+    int api_depth = 0;                        // nesting of entry points (dspfx_process_ctl -> dspfx_process): only the outermost drains
+    mutable std::mutex pend_mu;               // pending, pub_kinds, log, next_seq
+    struct Store { uint64_t seq; int node, param; float value; };   // param -1: a mode store (value = the mode)
+    std::deque<Store> pending;
+    std::vector<int> pub_kinds;               // node kinds as of the last chain / graph set: validation without api_mu
+    std::deque<dspfx_param_event> log;        // the stores already applied, oldest first (bounded)
+    uint64_t next_seq = 1;
+    uint64_t frames_submitted = 0;            // frames handed to the process calls so far
+    // the stream the DSP state was last touched on: every state write (biquad reset, dspfx_reset, ...) is queued on
+    // it, and a call on a different stream first waits for an event recorded there
+    hipStream_t cur_stream = nullptr;
+    bool cur_stream_set = true;               // the null stream to begin with: setup-time writes go there
+    hipEvent_t ev_order = nullptr;
+    mutable std::mutex err_mu;                        // err (also kept per calling thread: dspfx_last_error)
+};
+
+namespace dspfx_host {
+
+// DSPFX_VARIANT="f=8,cpl=2,static=1" narrows the choice (tuning / A-B runs).
+struct Pref {
+    int f = -1, cpl = -1, stat = -1;
+};
+
+struct JitKernel {
+    Variant var;            // launch == nullptr: launched through `fn`
+    hipModule_t module = nullptr;
+    hipFunction_t fn = nullptr;
+    std::string name;
+    int vgprs = 0;          // registers per lane the compiler allocated (occupancy: 512 / vgprs waves per SIMD)
+};
+
+// One link of the program being generated; node indices are local to the stage.  raw: the only link into its port and
+// taken as it is -- a hop of a chain engine whose DSPFX_LINK_* flag is off.
+struct GLink {
+    int src, dst, port;
+    bool raw;
+};
+
+// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
+// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
+// 128-frame block goes through the time-sliced kernel (profiles/r02_small_n.txt).
+constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 81920;
+
+// ---- errors
+int fail(dspfx_engine *e, int code, const char *fmt, ...);
+#define HIPCHK(e, call)                                                                         \
+    do {                                                                                        \
+        hipError_t err__ = (call);                                                              \
+        if (err__ != hipSuccess)                                                                \
+            return fail(e, err__ == hipErrorOutOfMemory ? DSPFX_ERR_OOM : DSPFX_ERR_HIP,        \
+                        "%s failed: %s", #call, hipGetErrorString(err__));                      \
+    } while (0)
+
+// ---- dspfx.hip
+inline hipEvent_t take_event(dspfx_engine *e) {
+    if (!e->ev_pool.empty()) {
+        hipEvent_t ev = e->ev_pool.back();
+        e->ev_pool.pop_back();
+        return ev;
+    }
+    hipEvent_t ev = nullptr;
+    (void)hipEventCreate(&ev);
+    return ev;
+}
+
+struct ProfScope {   // brackets one kernel launch with events on its own stream
+    dspfx_engine *e;
+    hipStream_t s;
+    hipEvent_t a = nullptr, b = nullptr;
+    size_t stage;
+    ProfScope(dspfx_engine *e_, size_t stage_, hipStream_t s_) : e(e_), s(s_), stage(stage_) {
+        if (!e->profiling) return;
+        a = take_event(e);
+        b = take_event(e);
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!a) return;
+        (void)hipEventRecord(b, s);
+        if (e->prof.size() <= stage) e->prof.resize(stage + 1);
+        e->prof[stage].emplace_back(a, b);
+    }
+};
+
+bool divisor_is_fast(float c, bool have_device = true);
+bool node_divisors_fast(const Node &n, bool have_device = true);
+bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device = true);
+bool fusable(const Node &n);
+int node_hop(const dspfx_engine *e, int idx);
+Pref read_pref();
+int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
+int plan(dspfx_engine *e);
+int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
+                 hipStream_t stream);
+int bind_stream(dspfx_engine *e, hipStream_t s);
+int quiesce(dspfx_engine *e);
+int settle_null_stream(dspfx_engine *e);
+int drain_pending(dspfx_engine *e, hipStream_t s);
+// Every entry point that touches an engine: take api_mu; the outermost one applies the queued stores first.  With a
+// stream (the process calls, tuning) the state is bound to it before anything is queued.
+struct ApiScope {
+    dspfx_engine *e;
+    int rc = DSPFX_OK;
+    bool outer = false;
+    ApiScope(dspfx_engine *e_, bool has_stream = false, hipStream_t s = nullptr) : e(e_) {
+        e->api_mu.lock();
+        outer = e->api_depth++ == 0;
+        if (hipSetDevice(e->device) != hipSuccess) rc = fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+        if (has_stream && rc == DSPFX_OK) rc = bind_stream(e, s);
+        if (outer && rc == DSPFX_OK) rc = drain_pending(e, e->cur_stream_set ? e->cur_stream : nullptr);
+    }
+    ~ApiScope() {
+        --e->api_depth;
+        e->api_mu.unlock();
+    }
+};
+
+// ---- jit.hip
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false);
+int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s);
+const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod);
+const Variant *graph_variant(const dspfx_engine *e, const Stage &st);
+int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]);
+int graph_input_block(int src);
+int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links);
+
+// ---- placement.hip
+hipError_t big_alloc(void **p, size_t bytes);
+int tune_ring(dspfx_engine *e, Node &n);
+
+}  // namespace dspfx_host

@@ -1,0 +1,375 @@
+// jit.hip -- run-time specialisation of the chain kernels (hiprtc) and the generator of whole-graph kernels
+// (include/dspfx.h: dspfx_graph_set / dspfx_graph_source; csrc/graph_kernel.hip.h).  See engine.h for the split.
+#include "engine.h"
+
+using namespace dspfx;
+using namespace dspfx_host;
+
+namespace dspfx_host {
+
+// ---- run-time specialisation ------------------------------------------------------------------------------------
+// The statically specialised kernel `chain_kernel<F, CPL, SigList<...>>` is a template over the chain's shape; the
+// library ships it for the BASELINE chains only.  For any other fusable chain of a LARGE engine the same template is
+// instantiated at run time with hiprtc (about a second per distinct shape, cached per process), so an arbitrary chain
+// runs the specialised kernel instead of the interpreter (0.383 -> 0.357 ms on the 5-node chain).  The source is the
+// very header this library was built from (found next to libdspfx.so); if it or hiprtc is unavailable the interpreter
+// stays.  DSPFX_JIT=0 switches it off, DSPFX_JIT=1 forces it for engines of any size.
+std::mutex g_jit_mu;
+std::map<std::string, JitKernel *> g_jit;     // key -> kernel
+
+// Where chain_kernels.hip.h / graph_kernel.hip.h are: next to the library, or DSPFX_KERNEL_HEADERS when they are installed
+// elsewhere (read per compile).
+std::string csrc_dir() {
+    if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
+    Dl_info info;
+    if (!dladdr((const void *)&dspfx_abi_version, &info) || !info.dli_fname) return "";
+    std::string p(info.dli_fname);
+    const size_t k = p.find_last_of('/');
+    return k == std::string::npos ? "." : p.substr(0, k);
+}
+
+// Compile `src` (which includes headers from this library's directory), load it on the current device and look up the
+// kernel named by `expr`.  Cached per `key` for the life of the process.
+const JitKernel *jit_compile(const std::string &key, const std::string &src, const std::string &expr, const int (&sigs)[MAX_SLOTS],
+                             int n_slots, int f, int cpl, bool mod) {
+    std::lock_guard<std::mutex> lk(g_jit_mu);
+    auto it = g_jit.find(key);
+    if (it != g_jit.end()) return it->second;
+    JitKernel *res = nullptr;
+    const std::string dir = csrc_dir();
+    hiprtcProgram prog = nullptr;
+    if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
+        const std::string inc = "-I" + dir;
+        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", inc.c_str()};
+        if (hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS &&
+            hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS) {
+            const char *lowered = nullptr;
+            size_t cs = 0;
+            if (hiprtcGetLoweredName(prog, expr.c_str(), &lowered) == HIPRTC_SUCCESS && lowered &&
+                hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs) {
+                std::vector<char> code(cs);
+                JitKernel *k = new JitKernel();
+                if (hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS &&
+                    hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
+                    hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
+                    k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
+                    if (hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn) != hipSuccess) {
+                        (void)hipGetLastError();
+                        k->vgprs = 0;
+                    }
+                    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
+                    for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
+                    k->var.name = k->name.c_str();
+                    res = k;
+                } else {
+                    (void)hipGetLastError();
+                    delete k;
+                }
+            }
+        } else if (getenv("DSPFX_JIT_DEBUG")) {
+            size_t ls = 0;
+            (void)hiprtcGetProgramLogSize(prog, &ls);
+            std::vector<char> log(ls + 1, 0);
+            if (ls) (void)hiprtcGetProgramLog(prog, log.data());
+            fprintf(stderr, "dspfx jit: %s failed:\n%s\n", expr.c_str(), log.data());
+        }
+        (void)hiprtcDestroyProgram(&prog);
+    }
+    if (res) g_jit[key] = res;   // failures are not remembered: a missing header directory can be put right while the process lives
+    return res;
+}
+
+// ts: the time-sliced kernel chain_ts_kernel<f, cpl, ...> (f = frames per slice) instead of chain_kernel<f, cpl, ...>
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts) {
+    char key[256];
+    int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
+    for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
+    std::string expr = std::string(ts ? "dspfx::chain_ts_kernel<" : "dspfx::chain_kernel<") + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
+    for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
+    expr += (mod && !ts) ? ">, true>" : "> >";
+    const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
+    if (k && ts) const_cast<JitKernel *>(k)->var.ts = f;
+    return k;
+}
+
+// A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.
+int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
+    if (v->launch) {
+        v->launch(a, grid, block, lds_bytes, s);
+        return 0;
+    }
+    const JitKernel *k = reinterpret_cast<const JitKernel *>(v);   // `var` is the first member
+    // a graph kernel takes GraphArgs: run_subblock's ChainArgs is the first member of one, so the same address serves
+    static_assert(offsetof(GraphArgs, c) == 0, "GraphArgs must begin with its ChainArgs");
+    void *params[] = {const_cast<ChainArgs *>(&a)};
+    return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
+}
+
+// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
+// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
+// 128-frame block goes through the time-sliced kernel (measured on the 3-node chain, rocprofv3 kernel averages:
+// 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt).
+
+// Run-time specialised kernel for a fused stage (nullptr: not wanted / not possible).  mod = with control ports.
+const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS);
+    if (!want_jit || st.count < 1 || !st.fast_div) return nullptr;
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
+    if (N < 64u * (unsigned)cpl) return nullptr;
+    const int f = (N <= 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt)
+    const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
+    if (!k) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
+    return k ? &k->var : nullptr;
+}
+
+// ---- a whole graph as one kernel (include/dspfx.h: dspfx_graph_set, csrc/graph_kernel.hip.h) --------------------------
+// Sliders with an `as_input` port, per kind: count and the range a connected signal is mapped to.
+int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]) {
+    switch (d.kind) {
+    case DSPFX_GAIN: lo[0] = 0.0f; hi[0] = 10.0f; return 1;                                    // gain.rs:14
+    case DSPFX_DISTORT: lo[0] = 0.0f; hi[0] = 30.0f; return 1;                                 // distort.rs:37 (every mode, Fuzz included: 176-180)
+    case DSPFX_OVERDRIVE: lo[0] = 0.0f; hi[0] = 30.0f; lo[1] = 0.0f; hi[1] = 1.0f; lo[2] = 0.0f; hi[2] = 1.0f; return 3;
+    case DSPFX_MIX: lo[0] = 0.0f; hi[0] = 1.0f; return 1;                                       // mix.rs:15
+    case DSPFX_SIGNAL_GEN: lo[0] = -1.0f; hi[0] = 1.0f; lo[1] = 0.1f; hi[1] = 20000.0f; return 2;   // signal_gen.rs:31-37
+    default: return 0;
+    }
+}
+std::string hexf(float v) {
+    char b[64];
+    snprintf(b, sizeof b, "%af", (double)v);
+    return b;
+}
+std::string hexd(double v) {
+    char b[64];
+    snprintf(b, sizeof b, "%a", v);
+    return b;
+}
+
+// Input block a link source stands for (DSPFX_GRAPH_INPUT.. -> 0..GRAPH_IO-1), or -1 for a node / the zero pipe.
+int graph_input_block(int src) {
+    if (src == DSPFX_GRAPH_INPUT) return 0;
+    if (src == DSPFX_GRAPH_INPUT2) return 1;
+    return (src <= -4 && src > -2 - DSPFX_GRAPH_MAX_IO) ? -src - 2 : -1;
+}
+
+
+// The generated translation unit: `struct Prog` with the wiring of nodes [first, first + n) spelled out on register arrays.
+std::string graph_source(const dspfx_engine *e, int first, int n, const std::vector<GLink> &links, bool fast, int (&sigs)[GRAPH_SLOTS],
+                         bool have_device = true) {
+    auto port_links = [&](int dst, int port) {
+        std::vector<GLink> v;
+        for (const GLink &l : links)
+            if (l.dst == dst && l.port == port) v.push_back(l);
+        return v;
+    };
+    std::string body;
+    auto gather = [&](const std::string &dst, const std::vector<GLink> &srcs, bool declare) {
+        auto name = [](int sidx) {
+            const int blk = graph_input_block(sidx);
+            return blk >= 0 ? "xs[" + std::to_string(blk) + "]" : "v" + std::to_string(sidx);
+        };
+        body += "        ";
+        if (declare) body += "float " + dst + "[F][CPL]; ";
+        if (srcs.size() == 1 && srcs[0].raw) {
+            body += "g_copy<F, CPL>(" + dst + ", " + name(srcs[0].src) + ");\n";
+            return;
+        }
+        if (srcs.empty() && declare) {                  // an unconnected input port of a node
+            body += "g_unplugged<F, CPL>(" + dst + ");\n";
+            return;
+        }
+        body += "g_zero<F, CPL>(" + dst + ");";
+        for (const GLink &l : srcs) {
+            if (l.src == DSPFX_GRAPH_ZERO) body += " g_acc_zero<F, CPL>(" + dst + ");";
+            else body += " g_acc<F, CPL>(" + dst + ", " + name(l.src) + ");";
+        }
+        if (!srcs.empty()) {
+            const float div = dspfx_link_divisor(srcs.size());
+            body += std::string(" g_div<") + (divisor_is_fast(div, have_device) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
+                    hexd(1.0 / (double)div) + ");";
+        }
+        body += "\n";
+    };
+    const std::string FAST = fast ? "true" : "false";
+    for (int i = 0; i < GRAPH_SLOTS; ++i) sigs[i] = SIG_NONE;
+    unsigned in_mask = 0;
+    int n_out = 1;
+    for (const GLink &l : links) {
+        if (graph_input_block(l.src) >= 0) in_mask |= 1u << graph_input_block(l.src);
+        if (l.dst >= n) n_out = std::max(n_out, l.dst - n + 1);
+    }
+    for (int i = 0; i < n; ++i)   // delay taps first: their latency hides under the nodes before them (see RingPre)
+        if (e->nodes[(size_t)(first + i)].d.kind == DSPFX_REVERB)
+            body += "        RingPre<F, CPL> pre" + std::to_string(i) + "; ring_prefetch<F, CPL, false>(gslot<" + std::to_string(i) +
+                    ">(g), cx, pre" + std::to_string(i) + ");\n";
+    for (int i = 0; i < n; ++i) {
+        const dspfx_node_desc &d = e->nodes[(size_t)(first + i)].d;
+        const bool has_mode = d.kind == DSPFX_DISTORT || d.kind == DSPFX_SIGNAL_GEN;
+        const int mode = has_mode ? d.mode : 0;
+        sigs[i] = sig(d.kind, mode, 0);
+        const std::string I = std::to_string(i), v = "v" + I, slot = "gslot<" + I + ">(g)", KM = std::to_string(d.kind) + ", " + std::to_string(mode);
+        body += "        // node " + I + "\n";
+        gather(v, port_links(i, DSPFX_PORT_MAIN), true);
+        float lo[3], hi[3];
+        const int ns = kind_sliders(d, lo, hi);
+        bool any_ctl = false;
+        std::string pn[3];
+        for (int k = 0; k < ns; ++k) any_ctl = any_ctl || !port_links(i, DSPFX_PORT_SLIDER + k).empty();
+        if (any_ctl)
+            for (int k = 0; k < ns; ++k) {
+                pn[k] = "p" + I + "_" + std::to_string(k);
+                const std::vector<GLink> src = port_links(i, DSPFX_PORT_SLIDER + k);
+                if (src.empty()) {
+                    body += "        float " + pn[k] + "[F][CPL]; g_fill<F, CPL>(" + pn[k] + ", " + slot + ".p[" + std::to_string(k) + "]);\n";
+                } else {
+                    gather(pn[k], src, true);
+                    body += "        g_slider<F, CPL>(" + pn[k] + ", " + hexf(lo[k]) + ", " + hexf(hi[k]) + ");\n";
+                }
+            }
+        if (d.kind == DSPFX_ADD || d.kind == DSPFX_MIX) gather("b" + I, port_links(i, DSPFX_PORT_SIDE), true);
+        body += "        ";
+        if (d.kind == DSPFX_REVERB) body += "ring_apply<F, CPL, false>(" + slot + ", " + v + ", pre" + I + ", cx);";
+        else if (d.kind == DSPFX_ADD) body += "g_add<F, CPL>(" + v + ", b" + I + ");";
+        else if (d.kind == DSPFX_MIX && any_ctl) body += "g_mix_mod<F, CPL>(" + v + ", b" + I + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_MIX) body += "g_mix<F, CPL>(" + v + ", b" + I + ", " + slot + ".p[0]);";
+        else if (d.kind == DSPFX_GAIN && any_ctl) body += "gain_mod_core<F, CPL>(" + v + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_DISTORT && any_ctl) body += "distort_mod_core<" + std::to_string(mode) + ", F, CPL>(" + v + ", " + pn[0] + ");";
+        else if (d.kind == DSPFX_OVERDRIVE && any_ctl) body += "overdrive_mod_core<F, CPL>(" + v + ", " + pn[0] + ", " + pn[1] + ", " + pn[2] + ");";
+        else if (d.kind == DSPFX_SIGNAL_GEN && any_ctl)
+            body += "siggen_mod_core<" + std::to_string(mode) + ", F, CPL>(" + slot + ", " + v + ", st[" + I + "], " + pn[0] + ", " + pn[1] + ", cx);";
+        else body += "apply_node<" + KM + ", F, CPL, false, " + FAST + ">(" + slot + ", " + v + ", st[" + I + "], cx);";
+        body += "\n";
+    }
+    for (int m = 0; m < n_out; ++m) {
+        body += m == 0 ? "        // Output node\n" : "        // output block " + std::to_string(m) + "\n";
+        gather("ys[" + std::to_string(m) + "]", port_links(n + m, DSPFX_PORT_MAIN), false);
+    }
+    std::string src = "#include \"graph_kernel.hip.h\"\nnamespace dspfx {\nstruct Prog {\n    static constexpr int sigs[GRAPH_SLOTS] = {";
+    for (int i = 0; i < GRAPH_SLOTS; ++i) src += std::to_string(sigs[i]) + (i + 1 < GRAPH_SLOTS ? ", " : "");
+    src += "};\n    static constexpr unsigned in_mask = " + std::to_string(in_mask) + ";\n";
+    src += "    static constexpr int n_out = " + std::to_string(n_out) + ";\n";
+    src += "    template <int F, int CPL>\n    static __device__ __forceinline__ void run(const GraphArgs &g, const float (&xs)[GRAPH_IO][F][CPL], float (&ys)[GRAPH_IO][F][CPL],\n"
+           "                                               float (&st)[GRAPH_SLOTS][4][CPL], const Ctx &cx) {\n";
+    src += body;
+    src += "    }\n};\n}  // namespace dspfx\n";
+    return src;
+}
+
+const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const int f = 8;
+    int gsigs[GRAPH_SLOTS], sigs[MAX_SLOTS];
+    std::vector<GLink> links;
+    if (e->graph_mode) {
+        for (const dspfx_graph_link &l : e->wiring) links.push_back(GLink{l.src, l.dst, l.port & ~DSPFX_PORT_RAW, (l.port & DSPFX_PORT_RAW) != 0});
+    } else {   // a long stage of a chain engine: node after node, hops as the engine's link flags say, no Output hop
+        for (int i = 0; i < st.count; ++i)
+            links.push_back(GLink{i == 0 ? DSPFX_GRAPH_INPUT : i - 1, i, DSPFX_PORT_MAIN, node_hop(e, st.first + i) == 0});
+        links.push_back(GLink{st.count - 1, st.count, DSPFX_PORT_MAIN, true});
+    }
+    const std::string src = graph_source(e, st.first, st.count, links, st.fast_div, gsigs);
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
+    if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
+    auto build = [&](int cpl) {
+        const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
+        const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
+                                std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
+        return jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
+    };
+    // Two channels per lane as the chain kernels do (large tiled engines), as long as the graph's live values fit:
+    // every node output still needed is F x CPL registers, and past 128 VGPRs the lost occupancy costs more than
+    // the wider accesses gain (profiles/r01_graph_one_kernel.txt).  DSPFX_VARIANT="cpl=1|2" forces either (A/B runs).
+    const Pref pref = read_pref();
+    const bool can2 = N % 128u == 0;
+    if (pref.cpl == 2 && can2) { const JitKernel *k = build(2); return k ? &k->var : nullptr; }
+    if (pref.cpl == 1) { const JitKernel *k = build(1); return k ? &k->var : nullptr; }
+    const JitKernel *k = nullptr;
+    if (e->desc.tile_channels && N > 131072u && can2) {
+        k = build(2);
+        if (k && k->vgprs <= 128) return &k->var;
+    }
+    k = build(1);
+    return k ? &k->var : nullptr;
+}
+
+// Shape checks shared by dspfx_graph_set and dspfx_graph_source (e may be null).
+int validate_graph(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links) {
+    if (n_nodes < 0 || (n_nodes > 0 && !nodes) || n_links < 0 || (n_links > 0 && !links))
+        return fail(e, DSPFX_ERR_INVALID, "graph: bad node / link arrays");
+    if (n_nodes > DSPFX_GRAPH_MAX_NODES)
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph of %d nodes: one kernel holds at most %d", n_nodes, DSPFX_GRAPH_MAX_NODES);
+    for (int i = 0; i < n_nodes; ++i) {
+        const int rc = validate_node(e, nodes[i]);
+        if (rc) return rc;
+    }
+    std::map<std::pair<int, int>, int> fan_in;
+    for (int i = 0; i < n_links; ++i) {
+        const dspfx_graph_link &l = links[i];
+        if (l.dst < 0 || l.dst >= n_nodes + DSPFX_GRAPH_MAX_IO || l.src <= -2 - DSPFX_GRAPH_MAX_IO || (l.src >= l.dst && l.dst < n_nodes) || l.src >= n_nodes)
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: %d -> %d does not go forward", i, l.src, l.dst);
+        const int port = l.port & ~DSPFX_PORT_RAW;
+        bool ok = port == DSPFX_PORT_MAIN;
+        if (l.dst < n_nodes && !ok) {
+            const dspfx_node_desc &d = nodes[l.dst];
+            float lo[3], hi[3];
+            if (port == DSPFX_PORT_SIDE) ok = d.kind == DSPFX_ADD || d.kind == DSPFX_MIX;
+            else ok = port >= DSPFX_PORT_SLIDER && port - DSPFX_PORT_SLIDER < kind_sliders(d, lo, hi);
+        }
+        if (!ok) return fail(e, DSPFX_ERR_INVALID, "graph link %d: node %d has no port %d", i, l.dst, l.port);
+        if (++fan_in[{l.dst, port}] > DSPFX_MAX_LINKS)
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: more than %d links into one port", i, DSPFX_MAX_LINKS);
+    }
+    {   // output blocks are stored by the generated kernel for every m < n_out: each of them needs a signal (and a buffer)
+        int n_out = 1;
+        for (int i = 0; i < n_links; ++i) n_out = std::max(n_out, links[i].dst - n_nodes + 1);
+        for (int m = 1; m < n_out; ++m)
+            if (!fan_in.count({n_nodes + m, DSPFX_PORT_MAIN}))
+                return fail(e, DSPFX_ERR_INVALID, "graph: output block %d has no link although block %d has (output blocks must be contiguous)", m, n_out - 1);
+    }
+    for (int i = 0; i < n_links; ++i)   // a RAW link is its port's only link, and it carries a signal
+        if ((links[i].port & DSPFX_PORT_RAW) && (fan_in[{links[i].dst, links[i].port & ~DSPFX_PORT_RAW}] != 1 || links[i].src == DSPFX_GRAPH_ZERO))
+            return fail(e, DSPFX_ERR_INVALID, "graph link %d: a RAW link must be the only link into its port", i);
+    for (int i = 0; i < n_nodes; ++i)
+        if (nodes[i].kind == DSPFX_FIR || (nodes[i].kind == DSPFX_DISTORT && nodes[i].mode == DSPFX_DIST_FUZZ))
+            return fail(e, DSPFX_ERR_UNSUPPORTED, "graph node %d (FIR / Fuzz) has its own kernel and cannot be fused", i);
+    return DSPFX_OK;
+}
+}  // namespace dspfx_host
+
+extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, const dspfx_graph_link *links, int n_links,
+                                  char *dst, size_t cap) {
+    if (!dst || cap == 0) return DSPFX_ERR_INVALID;
+    const int vrc = validate_graph(nullptr, nodes, n_nodes, links, n_links);
+    if (vrc) return vrc;
+    dspfx_engine tmp;                       // never touches a device: only the node descriptors are read
+    tmp.nodes.resize((size_t)n_nodes);
+    for (int i = 0; i < n_nodes; ++i) {
+        tmp.nodes[(size_t)i].d = nodes[i];
+        tmp.nodes[(size_t)i].d.taps = nullptr;
+    }
+    std::vector<GLink> gl;
+    for (int i = 0; i < n_links; ++i)
+        gl.push_back(GLink{links[i].src, links[i].dst, links[i].port & ~DSPFX_PORT_RAW, (links[i].port & DSPFX_PORT_RAW) != 0});
+    Stage st{};
+    st.type = ST_FUSED;
+    st.first = 0;
+    st.count = n_nodes;
+    int sigs[GRAPH_SLOTS];
+    tmp.hop_div = dspfx_link_divisor(1);
+    // no device is touched: divisions already proven in this process are written in their exact-product form, all others
+    // in the IEEE form (nothing is verified, nothing is cached)
+    const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st, false), sigs, false);
+    if (src.size() + 1 > cap) return DSPFX_ERR_INVALID;
+    memcpy(dst, src.c_str(), src.size() + 1);
+    return DSPFX_OK;
+}
