@@ -3,7 +3,10 @@
 // tests/test_cpp_host.py (g++ only: links libdspfx.so and liboracle.so).
 #include <cmath>
 #include <cstdio>
+#include <atomic>
+#include <chrono>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include "../../include/dspfx.hpp"
@@ -110,6 +113,46 @@ int main(int argc, char **argv) {
                 if (ulp(pm[f], mix[f] / div) != 0) { std::printf("FAIL: solo mix_allreduce at %u\n", f); return 1; }
             dspfx_host_free(pinned);
             std::printf("mix_allreduce over a 1-rank RCCL communicator ok\n");
+        }
+        // Two host threads, as in the reference: the audio task drives process (here the synchronous host form, block after
+        // block) while the GUI thread stores a slider (dsp-stuff-derive/src/lib.rs:487-492).  No lock on the caller's side: the
+        // store is queued by the library and lands on a block boundary -- every block of the output was made with ONE level,
+        // the levels appear in the order they were stored, and the log says from which frame on each one held.
+        {
+            const uint32_t NT = 64, nblk = 60;
+            Engine te(NT, BUF_SIZE, 0);
+            te.set_chain({Gain(1.0f)});
+            std::vector<float> tx(BUF_SIZE * NT), ty(BUF_SIZE * NT * nblk);
+            for (size_t i = 0; i < tx.size(); ++i) tx[i] = 1.0f + orc_noise(3, (uint32_t)(i % NT), (uint32_t)(i / NT));
+            std::atomic<bool> go{false}, done{false};
+            std::vector<std::uint64_t> seqs;
+            std::thread gui([&] {
+                while (!go.load()) std::this_thread::yield();
+                for (int k = 1; k <= 25 && !done.load(); ++k) {
+                    seqs.push_back(te.set_param_seq(0, 0, 0.25f * (float)k));
+                    std::this_thread::sleep_for(std::chrono::microseconds(300));
+                }
+            });
+            for (uint32_t b = 0; b < nblk; ++b) {
+                if (b == 3) go.store(true);
+                te.process_host(tx.data(), ty.data() + (size_t)b * BUF_SIZE * NT, BUF_SIZE);
+            }
+            done.store(true);
+            gui.join();
+            te.process_host(tx.data(), ty.data(), 0);                    // an entry point: whatever is still queued is applied
+            const std::vector<dspfx_param_event> log = te.param_log();
+            if (log.size() != seqs.size()) { std::printf("FAIL: %zu stores made, %zu logged\n", seqs.size(), log.size()); return 1; }
+            float level = 1.0f;
+            size_t li = 0;
+            for (uint32_t b = 0; b < nblk; ++b) {
+                while (li < log.size() && log[li].frame <= (std::uint64_t)b * BUF_SIZE) {
+                    if (log[li].seq != seqs[li] || log[li].frame % BUF_SIZE) { std::printf("FAIL: log entry %zu\n", li); return 1; }
+                    level = log[li++].value;
+                }
+                for (size_t i = 0; i < (size_t)BUF_SIZE * NT; ++i)
+                    if (ty[(size_t)b * BUF_SIZE * NT + i] != tx[i] * level) { std::printf("FAIL: block %u is not level %g throughout\n", b, level); return 1; }
+            }
+            std::printf("slider stores from a second thread: %zu applied on block boundaries, in order\n", log.size());
         }
         // error behaviour: exceptions, not aborts
         bool threw = false;

@@ -16,7 +16,7 @@ def _build():
     orc = os.path.join(ROOT, "oracle")
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-o", EXE, os.path.join(ROOT, "tests", "cpp", "test_host.cpp"),
            f"-L{cs}", "-ldspfx", f"-L{orc}", "-loracle", f"-Wl,-rpath,{cs}", f"-Wl,-rpath,{orc}", "-L/opt/rocm/lib",
-           "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined"]
+           "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-pthread"]
     subprocess.check_call(cmd)
 
 
@@ -37,3 +37,4 @@ def test_cpp_host_parity_on_gpu():
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max ulp" in r.stdout
     assert "mix_allreduce over a 1-rank RCCL communicator ok" in r.stdout
+    assert "slider stores from a second thread" in r.stdout
