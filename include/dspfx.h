@@ -223,12 +223,12 @@ int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
 int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode);
 /* How the FIR node's steady-state sweep multiplies (the reference accumulates in f64, fir.rs:201-216; every form below meets
  * the stated 1e-6 relative RMS bar and is bit-exact on data whose products and sums are exact in f32):
- *   DSPFX_FIR_PRECISION_DEFAULT  f32 products on the f32 matrix pipe (unless DSPFX_FIR_SPLIT=1 is set in the environment);
- *   DSPFX_FIR_PRECISION_F32      always that;
  *   DSPFX_FIR_PRECISION_SPLIT    every f32 operand split exactly into three bf16 parts, six bf16 products per term on the
- *                                bf16 matrix pipe, f32 accumulation: as accurate (measured 2.9e-7 against 3.3e-7 at 4096
- *                                taps) and 1.5 x faster; used for whole 128-frame slices while the tap tables fit the LDS
- *                                (<= ~5000 taps), the f32 sweep otherwise.
+ *                                bf16 matrix pipe, f32 accumulation: as accurate as the f32 products (measured 2.9e-7 against
+ *                                3.3e-7 relative RMS at 4096 taps) and 1.5 x faster; used for whole 128-frame slices while
+ *                                the tap tables fit the LDS (<= ~5000 taps), the f32 sweep otherwise;
+ *   DSPFX_FIR_PRECISION_F32      f32 products on the f32 matrix pipe (v_mfma_f32_32x32x2_f32), always;
+ *   DSPFX_FIR_PRECISION_DEFAULT  the split form (round 3; DSPFX_FIR_SPLIT=0 in the environment makes it the f32 form).
  * Takes effect from the next block; history and taps are untouched. */
 typedef enum dspfx_fir_precision {
     DSPFX_FIR_PRECISION_DEFAULT = 0,

@@ -11,6 +11,16 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "fir_default: leave the FIR sweep at the engine's default (split precision) for this test")
+
+
+@pytest.fixture(autouse=True)
+def _f32_fir_sweep_unless_asked(monkeypatch, request):
+    """The engine's default steady-state FIR sweep is the split-precision one (round 3).  The parity tests name the sweep they
+    mean -- f32 (`kernel = 1 / rect`) or split (`kernel = split`, dspfx_set_fir_precision) -- so DSPFX_FIR_SPLIT=0 is the
+    baseline of every test; tests marked `fir_default` see the default as a host would."""
+    if "fir_default" not in request.keywords:
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
 
 
 @pytest.fixture(scope="session")

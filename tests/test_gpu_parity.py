@@ -759,6 +759,35 @@ def test_fir_config4_taps_small_n(dspfx, torch_cuda):
     assert fir_rel_rms(y[:2048], ref[:2048]) < FIR_RMS_TOL      # warm-up alone
 
 
+@pytest.mark.fir_default
+def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_cuda):
+    """A host that asks for nothing gets the split-precision sweep in steady state (whole 128-frame blocks, tables fit the
+    LDS), the f32 sweep where it does not apply (short slices), the stated tolerance either way, integer data bit for bit;
+    DSPFX_FIR_PRECISION_F32 is the opt-out."""
+    T, N, blocks = 1024, 64, 20
+    x = noise_block(N, 128 * blocks)
+    ch = [dspfx.Fir(fir_taps(T))]
+    eng = dspfx.Engine(N, 128, link_flags=3)
+    eng.set_chain(ch)
+    y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
+    assert "fir_split_kernel" in eng.describe(), eng.describe()
+    ref = run_oracle(ch, x, 3)
+    assert fir_rel_rms(y[T:], ref[T:]) < FIR_RMS_TOL
+    _run_fir_blocks(dspfx, torch_cuda, eng, x[:64], block=64)            # a 64-frame slice: the f32 sweep serves
+    assert "fir_skew_kernel" in eng.describe(), eng.describe()
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_F32)
+    _run_fir_blocks(dspfx, torch_cuda, eng, x[:128])
+    assert "fir_skew_kernel" in eng.describe(), eng.describe()
+    rng = np.random.default_rng(3)
+    h = rng.integers(-4, 5, 300).astype(np.float64)
+    xi = rng.integers(-8, 9, (128 * 6, 96)).astype(F)
+    ei = dspfx.Engine(96, 128, link_flags=0)
+    ei.set_chain([dspfx.Fir(h)])
+    yi = _run_fir_blocks(dspfx, torch_cuda, ei, xi)
+    assert "fir_split_kernel" in ei.describe()
+    assert np.array_equal(yi, run_oracle([dspfx.Fir(h)], xi, 0))
+
+
 def test_fir_split_precision_sweep_config4_accuracy(dspfx, torch_cuda, monkeypatch):
     """The opt-in split-precision sweep (DSPFX_FIR_SPLIT=1) on config 4's filter: within the same stated tolerance as the
     f32 sweep (measured 2.9e-7 against 3.3e-7), it really is the kernel that ran, huge finite samples (whose bf16 part
@@ -886,6 +915,7 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
     if kernel == "rect":        # the rectangular MFMA sweep in steady state too
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
+    monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")      # the f32 sweeps unless asked otherwise (the engine's default is the split one)
     if kernel == "split":       # the split-precision sweep in steady state
         monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
         kernel = "1"
@@ -931,6 +961,7 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
     if kernel == "rect":        # the rectangular MFMA sweep in steady state too
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
+    monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")      # the f32 sweeps unless asked otherwise (the engine's default is the split one)
     if kernel == "split":       # the split-precision sweep in steady state
         monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
         kernel = "1"

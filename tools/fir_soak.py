@@ -20,10 +20,9 @@ for T, N, B in ((333, 40, 128), (64, 70, 256), (1500, 33, 128)):
         for mode in ("skew", "rect", "split"):
             for k in ("DSPFX_FIR_SKEW", "DSPFX_FIR_SPLIT"):
                 os.environ.pop(k, None)
+            os.environ["DSPFX_FIR_SPLIT"] = "1" if mode == "split" else "0"     # (the engine's default is the split sweep)
             if mode == "rect":
                 os.environ["DSPFX_FIR_SKEW"] = "0"
-            if mode == "split":
-                os.environ["DSPFX_FIR_SPLIT"] = "1"
             eng = fx.Engine(N, B, link_flags=0)
             eng.set_chain([fx.Fir(h)])
             dx = torch.from_numpy(x).cuda()

@@ -26,8 +26,7 @@ for case in range(n_cases):
     os.environ["DSPFX_FIR_KERNEL"] = "0" if mode == "exact" else "1"
     if mode == "rect":
         os.environ["DSPFX_FIR_SKEW"] = "0"
-    if mode == "split":
-        os.environ["DSPFX_FIR_SPLIT"] = "1"
+    os.environ["DSPFX_FIR_SPLIT"] = "1" if mode == "split" else "0"     # (the engine's default is the split sweep)
     tile = int(rng.choice([0, 0, 64, 256]))
     N = int(rng.integers(1, 6)) * tile if tile else int(rng.integers(1, 400))
     B = int(rng.choice([16, 48, 64, 100, 128, 128, 128, 256]))

@@ -40,6 +40,6 @@ bash tools/r03_bus_ab.sh > /dev/null 2>&1
 bash tools/r03_cfg2_ab.sh > /dev/null 2>&1
 tail -3 $OUT/timed_regions.txt; cat $OUT/paced_kernel.txt; tail -4 $OUT/pmc.txt; cat gpurun_out/r03_bus_ab.txt gpurun_out/r03_cfg2_ab.txt
 # FIR counter passes of this build (tools/fir_pmc.sh writes under gpurun_out/firpmc_<round>/)
-bash tools/fir_pmc.sh r03 > $OUT/firpmc.txt 2>&1
+DSPFX_FIR_SPLIT=0 bash tools/fir_pmc.sh r03 > $OUT/firpmc.txt 2>&1
 DSPFX_FIR_SPLIT=1 bash tools/fir_pmc.sh r03split > $OUT/firpmc_split.txt 2>&1
 find gpurun_out/firpmc_r03 gpurun_out/firpmc_r03split -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
