@@ -314,7 +314,7 @@ int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, 
                            uint32_t n_frames, void *stream);
 int dspfx_mix_collect(dspfx_engine *e, float *mix, uint32_t n_frames, void *stream);
 /* Mix bus pipelined INSIDE the chain kernel: no second stream, no events, no extra launches.  The launch of
- * block k also runs, in its first 129 workgroups, the slice reduction of block k-1's partials and the final
+ * block k also runs, in its first 65 workgroups, the slice reduction of block k-1's partials and the final
  * reduction (+ the Output hop when n_connected != 0) of block k-2, so `mix` receives the bus of the block
  * submitted TWO calls earlier (it is not written by the first two calls after a flush / reset; it may be NULL
  * there).  Same reduction tree as dspfx_process(mix) and dspfx_mix_collect: bit-identical sums.  n_frames must
