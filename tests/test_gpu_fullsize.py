@@ -182,3 +182,72 @@ def test_whole_graph_kernel_million_channels(dspfx, tc, name):
     assert ulp_diff(got, ref).max() <= 1
     one.close()
     runs.close()
+
+
+def test_config5_as_specified_eight_shards_against_the_monolith(dspfx, tc):
+    """BASELINE config 5 as specified -- 8 388 608 channels sharded 8 x 1 048 576, 5-node chain, B = 128, the mix bus
+    all-reduced -- on ONE GPU: the eight per-GPU engines (channel_offset = rank * 1 048 576) run one after the other, their
+    un-normalised buses are summed in rank order (what the all-reduce computes) and divided by f32(0.0001 + 8 388 608)
+    (dspfx_mix_allreduce's Output hop, through a one-rank communicator); next to them ONE engine holds all 8 388 608
+    channels.  Every shard's output block equals the monolith's channel slice bit for bit (channels are independent and the
+    noise is keyed by the global channel index), the sharded bus equals the monolith's bus within the bus' bar (the
+    summation is associated differently), and sampled channels -- first / last of every shard among them -- equal the
+    oracle to <= 1 ulp.  The delay is 256 samples here (at 24 000 the monolith's ring alone would be 805 GB); the 24 000-sample
+    ring of one shard is what test_config3_and_5_million_channels_chain5 runs."""
+    ranks, Nr, B, blocks, tile = 8, 1 << 20, 128, 4, 256
+    N = ranks * Nr
+    chain = chain5(dspfx, 256)
+    mono = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
+    mono.set_chain(chain)
+    xm = tc.empty(B * N, dtype=tc.float32, device="cuda")
+    ym = tc.empty_like(xm)
+    bus_m = tc.empty((blocks, B), dtype=tc.float32, device="cuda")
+    ys_m = []
+    chans = sorted({0, 1, Nr - 1, Nr, 3 * Nr + 12345, 5 * Nr - 1, 5 * Nr, N - Nr, N - 2, N - 1})
+    got = np.empty((blocks * B, len(chans)), F)
+    for k in range(blocks):
+        mono.fill_noise(xm, B, k * B, SEED)
+        mono.process_bus(xm, ym, bus_m[k], B, n_connected=N)
+        got[k * B:(k + 1) * B] = gather(dspfx, ym, chans, B, N, tile)
+        ys_m.append(ym.view(N // tile, B, tile).clone())
+    tc.cuda.synchronize()
+    mono.close()
+    del xm, ym
+    comm = dspfx.Comm(0, 1, 0, dspfx.comm_unique_id())           # RCCL really runs (one rank: the sum over ranks is the identity)
+    acc = tc.zeros((blocks, B), dtype=tc.float64, device="cuda")
+    acc32 = tc.zeros((blocks, B), dtype=tc.float32, device="cuda")
+    x = tc.empty(B * Nr, dtype=tc.float32, device="cuda")
+    y = tc.empty_like(x)
+    part = tc.empty(B, dtype=tc.float32, device="cuda")
+    last = None
+    for r in range(ranks):
+        eng = dspfx.Engine(Nr, B, link_flags=3, tile_channels=tile, channel_offset=r * Nr)
+        eng.set_chain(chain)
+        for k in range(blocks):
+            eng.fill_noise(x, B, k * B, SEED)
+            eng.process_bus(x, y, part, B, n_connected=0)        # the rank-local, un-normalised bus
+            tc.cuda.synchronize()
+            shard = ys_m[k][r * (Nr // tile):(r + 1) * (Nr // tile)]
+            assert tc.equal(y.view(Nr // tile, B, tile), shard), (r, k)
+            acc32[k] += part                                      # f32 sums in rank order, as a ring all-reduce over 8 ranks adds them
+            acc[k] += part.double()
+        if last is not None:
+            last.close()
+        last = eng
+    for k in range(blocks):
+        last.mix_allreduce(comm, acc32[k], B, n_connected=N)      # the Output hop with the GLOBAL channel count
+    tc.cuda.synchronize()
+    div = float(dspfx.link_divisor(N))
+    assert div == 8388608.0                                       # f32(0.0001 + 2^23) == 2^23: the increment is below half an ulp
+    want = (acc / div).float()
+    assert tc.allclose(acc32, want, rtol=1e-6, atol=1e-9)
+    scale = float(bus_m.abs().max())
+    assert float((acc32 - bus_m).abs().max()) <= 1e-5 * scale, (float((acc32 - bus_m).abs().max()), scale)
+    last.close()
+    comm.close()
+    ref = np.empty_like(got)
+    descs = [n.oracle_desc() for n in chain]
+    for i, c in enumerate(chans):
+        yc, _ = O.run_noise_channels(descs, SEED, c, 1, 0, blocks, link_flags=3)
+        ref[:, i] = yc[:, 0]
+    assert ulp_diff(got, ref).max() <= 1
