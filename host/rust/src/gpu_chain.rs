@@ -90,6 +90,13 @@ impl Drop for PinnedBlock {
 }
 
 impl Bank {
+    /// The handle the GUI thread keeps for this bank's sliders: `Send + Sync`, stores are queued by libdspfx and applied at
+    /// the next block boundary, so the widget code never contends with `process` for the bank (lib.rs:487-492's Relaxed
+    /// atomic store, across the FFI).
+    pub fn params(&self) -> super::engine::ParamHandle {
+        self.engine.params()
+    }
+
     pub fn new(channels: u32, chain: &[NodeDesc], link_flags: u32) -> Result<Self, super::engine::Error> {
         let mut engine = Engine::new(channels, BUF_SIZE as u32, link_flags, 0)?;
         engine.set_chain(chain)?;
