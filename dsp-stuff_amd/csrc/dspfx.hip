@@ -924,6 +924,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
 extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();            // blocks still in flight read the state that is about to be freed
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);

@@ -175,8 +175,8 @@ float dspfx_link_divisor(uint64_t n_connected);
 
 /* ---- engine lifecycle -------------------------------------------------- */
 int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine **out);
-/* Waits for nothing and takes no lock: call it when no other thread is inside an entry point of this engine (or holds a
- * ParamHandle-style reference to it) and the streams the engine was driven on have been synchronised. */
+/* Waits for the device (blocks in flight still read the engine's state), then frees everything.  Takes no lock: call it
+ * when no other thread is inside an entry point of this engine or still holds a reference to it. */
 void dspfx_engine_destroy(dspfx_engine *e);
 const char *dspfx_last_error(const dspfx_engine *e);
 
