@@ -536,6 +536,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     if region_timing:
         kern_ms_total, kern_launches = region_ms, steps
         kern_name = stage_lines[-1].split("kernel ")[1].split(" ")[0]
+        if "time-sliced " in stage_lines[-1] and B == 128:       # whole 128-frame blocks of a few-channel engine run the time-sliced kernel
+            kern_name = stage_lines[-1].split("time-sliced ")[1].split(")")[0]
         kern_method = "one HIP-event pair around the timed region on the compute stream / launches"
     else:
         eng.profile_enable(0)
