@@ -133,12 +133,24 @@ int main(int argc, char **argv) {
                     std::this_thread::sleep_for(std::chrono::microseconds(300));
                 }
             });
+            std::atomic<int> reads{0};
+            std::thread monitor([&] {                            // a third thread only looks: plan text, counters, state sizes
+                char text[4096];
+                while (!done.load()) {
+                    if (dspfx_describe(te.raw(), text, sizeof text) != DSPFX_OK || dspfx_chain_len(te.raw()) != 1 ||
+                        dspfx_state_size(te.raw(), 0) != 0) { reads.store(-1000000); return; }
+                    (void)te.frames_submitted();
+                    reads.fetch_add(1);
+                }
+            });
             for (uint32_t b = 0; b < nblk; ++b) {
                 if (b == 3) go.store(true);
                 te.process_host(tx.data(), ty.data() + (size_t)b * BUF_SIZE * NT, BUF_SIZE);
             }
             done.store(true);
             gui.join();
+            monitor.join();
+            if (reads.load() <= 0) { std::printf("FAIL: the monitoring thread saw an inconsistent engine\n"); return 1; }
             te.process_host(tx.data(), ty.data(), 0);                    // an entry point: whatever is still queued is applied
             const std::vector<dspfx_param_event> log = te.param_log();
             if (log.size() != seqs.size()) { std::printf("FAIL: %zu stores made, %zu logged\n", seqs.size(), log.size()); return 1; }
