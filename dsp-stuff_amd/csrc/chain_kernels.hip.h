@@ -117,7 +117,10 @@ struct ChainArgs {
 // stage: slice b sums a fixed range of rows for every frame (lane = frame: coalesced row reads) into part2[b][frame]; final
 // stage: the slices are summed in fixed order.  Fixed association => run-to-run deterministic, and identical in every form
 // (stand-alone kernels, pipelined in later launches, in the tail of the same launch).
-constexpr unsigned MIX_SLICES = 64;
+#ifndef DSPFX_MIX_SLICES
+#define DSPFX_MIX_SLICES 64
+#endif
+constexpr unsigned MIX_SLICES = DSPFX_MIX_SLICES;   // <= 128 (the engine's slice buffers)
 // Rows per slice: at least 32 (one batch of the in-launch tail's loads), so a launch of few workgroups gets few slices and its
 // final stage is one batch too; 64 slices from 2048 rows on.  Every form of the bus cuts its rows the same way.
 __host__ __device__ __forceinline__ unsigned mix_rows_per_slice(unsigned rows) {
@@ -209,7 +212,7 @@ __device__ __forceinline__ unsigned ticket_take(unsigned *t, int lane) {
 // association of mix_slice_reduce / mix_final_reduce.  ONE wave; the rows are read with sc1 loads, TAIL_BATCH of them in
 // flight per lane (a dependent chain of single loads would cost a memory round trip per row: the whole tail is latency).
 #ifndef DSPFX_TAIL_BATCH
-#define DSPFX_TAIL_BATCH 32
+#define DSPFX_TAIL_BATCH 16    // 16 and 32 rows in flight measure the same (profiles/r03_bus_ab.txt); 16 leaves the small kernels their occupancy
 #endif
 constexpr int TAIL_BATCH = DSPFX_TAIL_BATCH;   // even
 typedef unsigned dspfx_u32x2 __attribute__((ext_vector_type(2)));
