@@ -301,6 +301,9 @@ def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
     lag = np.empty(n)
     n_in = len(xs)
     torch.cuda.synchronize()
+    import gc
+    gc_was = gc.isenabled()
+    gc.disable()                                      # a collection in the middle of a block is the host's jitter, not the engine's
     t_next = time.perf_counter() + 0.005
     t_begin = t_next
     for k in range(n):
@@ -320,6 +323,8 @@ def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
         lag[k] = t_sub - t_next
         t_next += period
     wall = time.perf_counter() - t_begin
+    if gc_was:
+        gc.enable()
     gpu = np.array([a.elapsed_time(b) for a, b in ev])
     q = lambda v, p: float(np.percentile(v, p))
     return {"what": "one block per block period from a host timer; bus of the same block (dspfx_process_bus); latency = submit call -> host sees out and mix complete",
