@@ -522,10 +522,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.hop_rc = 1.0 / (double)e->hop_div;
             a.third_rc = 1.0 / 3.0;
             a.fast_div = st.fast_div ? 1 : 0;
-            {   // DSPFX_XCD_REMAP=0 switches the XCD-contiguous block mapping off (A/B runs); read per launch
-                const char *xr = getenv("DSPFX_XCD_REMAP");
-                a.xcd_remap = xr ? atoi(xr) : 1;
-            }
+            // DSPFX_XCD_REMAP=0 / 1 switches the XCD-contiguous block mapping off / on (A/B runs); read per launch
+            const char *xcd_env = getenv("DSPFX_XCD_REMAP");
+            a.xcd_remap = xcd_env ? atoi(xcd_env) : 1;
             a.n_slots = st.count;
             a.skip_store = (st.count == 0 && src == out) ? 1 : 0;   // an empty stage in place exists only for the mix bus
             // hop flag of the side input and of control links (both are ordinary links between nodes);
@@ -553,7 +552,13 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 }
             }
             // few channels, a whole 128-frame block, no control ports in play: four time slices per channel group
-            if (st.var_ts && v == st.var && nframes == 4u * (uint32_t)st.var_ts->ts) v = st.var_ts;
+            if (st.var_ts && v == st.var && nframes == 4u * (uint32_t)st.var_ts->ts) {
+                v = st.var_ts;
+                // Its workgroups all issue their whole slices together; neighbouring channel groups on DIFFERENT XCDs (the
+                // dispatcher's round robin) serve the HBM better than an eighth of the channels per XCD: config 2 25.6 -> 23.3 us
+                // tiled, 24.2 -> 23.7 frame-major (profiles/r03_small_n.txt).  The large kernels keep the contiguous mapping.
+                if (!xcd_env) a.xcd_remap = 0;
+            }
             const uint32_t per_wave = 64u * v->cpl;
             const uint32_t n_main = N - N % per_wave;
             const uint32_t waves_main = n_main / per_wave;

@@ -20,3 +20,15 @@ static const Variant k_s5[] = {
 };
 const Variant *variants_static5(int *n) { *n = (int)(sizeof(k_s5) / sizeof(k_s5[0])); return k_s5; }
 }  // namespace dspfx
+#ifdef DSPFX_TS_TRACE
+// debug build only (tools/ts_timeline.py chain5): the stamps of the last time-sliced launch of THIS file's kernels
+extern "C" int dspfx_debug_ts_trace5(unsigned long long *host, size_t count, int clear) {
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dspfx::dspfx_ts_trace)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(dspfx::dspfx_ts_trace)) == hipSuccess ? 0 : -1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dspfx::dspfx_ts_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif

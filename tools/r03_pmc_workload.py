@@ -20,7 +20,8 @@ N, B = cfg["channels"], cfg["frames"]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.Stream(device=dev, priority=-1)
 torch.cuda.set_stream(stream)
-eng = pkg.Engine(N, B, link_flags=3, tile_channels=256)
+tile = cfg.get("tile", 256)
+eng = pkg.Engine(N, B, link_flags=3, tile_channels=tile)
 eng.set_chain(bench.build_chain(pkg, cfg))
 desc = eng.describe()
 kern = [l for l in desc.splitlines() if l.startswith("stage")][-1]
@@ -29,7 +30,7 @@ name = kern.split("time-sliced ")[1].split(")")[0] if ts else kern.split("kernel
 cpl = int(name.rsplit("_c", 1)[1])
 # the calibration kernel: the empty chain at the same channels per lane (same load / store widths)
 os.environ["DSPFX_VARIANT"] = "cpl=%d" % cpl
-cal = pkg.Engine(N, B, link_flags=3, tile_channels=256)
+cal = pkg.Engine(N, B, link_flags=3, tile_channels=tile)
 cal.set_chain([])
 del os.environ["DSPFX_VARIANT"]
 xs = [torch.empty(B * N, dtype=torch.float32, device=dev) for _ in range(2)]
@@ -40,7 +41,10 @@ for j, x in enumerate(xs):
 for k in range(launches):
     cal.process(xs[k & 1], out=y, n_frames=B, stream=stream.cuda_stream)
 for k in range(launches):
-    eng.process_bus(xs[k & 1], y, m, B, n_connected=N, stream=stream.cuda_stream)
+    if cfg.get("mix", True):
+        eng.process_bus(xs[k & 1], y, m, B, n_connected=N, stream=stream.cuda_stream)
+    else:
+        eng.process(xs[k & 1], out=y, n_frames=B, stream=stream.cuda_stream)
 torch.cuda.synchronize()
 print("PMCINFO", cfg_name, N, B, name, "copy_f8_c%d" % cpl, eng.algorithmic_bytes_per_sample(B), flush=True)
 print(desc, flush=True)

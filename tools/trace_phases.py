@@ -35,7 +35,8 @@ def main():
             regions.append((start, i))
             start = None
     out = {"trace": sys.argv[1], "regions": []}
-    names = ["cfg5", "cfg3", "cfg2", "cfg4"]
+    names = (bench or {}).get("timed_order") or ["cfg5", "cfg3", "cfg2", "cfg4"]
+    headline = "cfg5"
     k = -1
     for (a, b) in regions:
         inner = rows[a + 1:b]
@@ -60,7 +61,7 @@ def main():
                "durations_us": [round(d, 1) for d in dur],
                "preceding_64_launches_us": [round(d, 1) for d in pre_dur]}
         if bench is not None:
-            b = bench if k == 0 else (bench.get("other_configs") or {}).get(reg["config"])
+            b = bench if reg["config"] == headline else (bench.get("other_configs") or {}).get(reg["config"])
             if b and "roofline" in b:
                 reg["bench_reported"] = {"kernel_ms_avg": b["roofline"]["kernel_ms_avg"], "ms_per_step": b["ms_per_step"],
                                          "frac": b["roofline"]["frac"]}

@@ -13,10 +13,12 @@ fx = load_package()
 import bench
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
+which = sys.argv[2] if len(sys.argv) > 2 else "chain3"        # chain3 (config 2's) | chain5 (the headline chain)
 B = 128
 lib = ctypes.CDLL(os.environ["DSPFX_LIB"])
-lib.dspfx_debug_ts_trace.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-cfg = dict(bench.CONFIGS["cfg2"]); cfg["channels"] = N
+trace_fn = lib.dspfx_debug_ts_trace if which == "chain3" else lib.dspfx_debug_ts_trace5
+trace_fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+cfg = dict(bench.CONFIGS["cfg2" if which == "chain3" else "cfg5"]); cfg["channels"] = N
 chain = bench.build_chain(fx, cfg)
 eng = fx.Engine(N, B, link_flags=3, tile_channels=256)
 eng.set_chain(chain)
@@ -25,17 +27,22 @@ eng.fill_noise(x, B, 0)
 for _ in range(300):
     eng.process(x, out=y, n_frames=B)
 torch.cuda.synchronize()
-lib.dspfx_debug_ts_trace(None, 0, 1)
+trace_fn(None, 0, 1)
 eng.process(x, out=y, n_frames=B)
 torch.cuda.synchronize()
 G = min(4096, N // 64)
 buf = np.zeros(G * 4 * 16, np.uint64)
-assert lib.dspfx_debug_ts_trace(buf.ctypes.data, buf.size, 0) == 0
+assert trace_fn(buf.ctypes.data, buf.size, 0) == 0
 t = buf.reshape(G, 4, 16).astype(np.float64)
 valid = t[:, :, 0] > 0
 t0 = t[:, :, 0][valid].min()
 us = (t - t0) / 100.0
-names = {0: "entry", 1: "loads issued", 2: "node0 (gain) begins", 3: "node1 (biquad) begins", 4: "node2 (delay) begins", 12: "nodes done", 13: "out stores issued", 14: "exit"}
+if which == "chain3":
+    names = {0: "entry", 1: "loads issued", 2: "node0 (gain) begins", 3: "node1 (biquad) begins", 4: "node2 (delay) begins", 12: "nodes done", 13: "out stores issued", 14: "exit"}
+    spans = ((0, 1, "issue loads"), (1, 2, "(address math)"), (2, 3, "gain incl. wait for the block's samples"), (3, 4, "biquad incl. turns"), (4, 12, "delay incl. wait for taps + ring stores"), (12, 13, "issue out stores"), (13, 14, "exit"))
+else:
+    names = {0: "entry", 1: "loads issued", 2: "node0 (biquad) begins", 3: "node1 (softclip) begins", 4: "node2 (delay) begins", 5: "node3 (biquad) begins", 6: "node4 (gain) begins", 12: "nodes done", 13: "out stores issued", 14: "exit"}
+    spans = ((0, 1, "issue loads"), (1, 2, "(address math)"), (2, 3, "biquad incl. wait for the samples + turns"), (3, 4, "softclip"), (4, 5, "delay incl. wait for taps + ring stores"), (5, 6, "second biquad incl. turns"), (6, 12, "gain"), (12, 13, "issue out stores"), (13, 14, "exit"))
 print("N = %d, %d workgroups of 4 waves; microseconds after the first wave's entry: min / p10 / median / p90 / max" % (N, G))
 for q in range(4):
     print(" slice q = %d" % q)
@@ -44,6 +51,6 @@ for q in range(4):
         print("   %-24s %6.2f %6.2f %6.2f %6.2f %6.2f" % (nm, v.min(), np.percentile(v, 10), np.median(v), np.percentile(v, 90), v.max()))
 d = us[:, :, 14] - us[:, :, 0]
 print(" wave lifetime: median %.2f  p90 %.2f  max %.2f" % (np.median(d[valid]), np.percentile(d[valid], 90), d[valid].max()))
-for a, b, nm in ((0, 1, "issue loads"), (1, 2, "(address math)"), (2, 3, "gain incl. wait for the block's samples"), (3, 4, "biquad incl. turns"), (4, 12, "delay incl. wait for taps + ring stores"), (12, 13, "issue out stores"), (13, 14, "exit")):
+for a, b, nm in spans:
     dd = (us[:, :, b] - us[:, :, a])[valid]
     print("   %-44s median %6.2f  p90 %6.2f" % (nm, np.median(dd), np.percentile(dd, 90)))
