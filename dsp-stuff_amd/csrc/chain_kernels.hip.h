@@ -1398,9 +1398,9 @@ template <class SL> constexpr int ts_first_reverb() {
 // slice waits for -- before the whole workgroup's reads were served.  The other slices request their taps first: they
 // have to wait for their turn anyway.  (Two copies of the body rather than one with conditional loads: at a join of
 // paths with different loads in flight the compiler's counter pass waits for all of them.)
-template <int S, int CPL, class SL, bool LATE>
+template <int S, int CPL, class SL, bool LATE, bool GUARD>
 __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CPL][64], const Ctx &cx, const WaveAddr &w, float (&v)[S][CPL],
-                                       int q, int lane, size_t c, unsigned group, MixStage &ms, unsigned f_begin) {
+                                       int q, int lane, size_t c, unsigned group, MixStage &ms, unsigned f_begin, bool active) {
     constexpr int FS = ts_first_stateful<SL>(), FR = ts_first_reverb<SL>();
     constexpr bool late = LATE && FS < FR && FR < MAX_SLOTS;
     // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
@@ -1413,13 +1413,13 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         rg##I = ring_groups_host(a.slot[I]);   /* blocks of exactly 128 frames: the host named the groups (no table read) */ \
         _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
-            load_vec<CPL, false, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], true); \
+            load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], active); \
     }
     auto load_taps = [&]() __attribute__((always_inline)) { DSPFX_FOR_SLOTS(DSPFX_TAPS) };
     // Slice 0's own copy of the body (LATE) also requests the state of the first stateful node right here, behind its samples:
     // loaded inside its turn it was one more memory round trip on the chain of turns that every other slice waits for.
     float st_pre[4][CPL];
-    if constexpr (LATE && FS < MAX_SLOTS) load_state<SL::v[FS < MAX_SLOTS ? FS : 0], CPL, false>(a.slot[FS < MAX_SLOTS ? FS : 0], st_pre, c, a.N, true);
+    if constexpr (LATE && FS < MAX_SLOTS) load_state<SL::v[FS < MAX_SLOTS ? FS : 0], CPL, GUARD>(a.slot[FS < MAX_SLOTS ? FS : 0], st_pre, c, a.N, active);
     if constexpr (!late) load_taps();
     DSPFX_TS_STAMP(1)
 #define DSPFX_RUN(I)                                                                                             \
@@ -1429,11 +1429,11 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
         const float decay = a.slot[I].p[0];                                                                      \
         _Pragma("unroll") for (int f = 0; f < S; ++f) {                                                          \
             _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
-            store_vec<CPL, false, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), v[f], true); \
+            store_vec<CPL, GUARD, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), v[f], active); \
         }                                                                                                        \
     } else if constexpr (SL::v[I] != SIG_NONE && kind_nstate(sig_kind(SL::v[I])) == 0) {                         \
         float none[4][CPL];                                                                                      \
-        run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, none, cx);                                  \
+        run_slot<SL::v[I], S, CPL, GUARD, true, false>(a.slot[I], v, none, cx);                                  \
     } else if constexpr (SL::v[I] != SIG_NONE) {                                                                 \
         constexpr int NS = kind_nstate(sig_kind(SL::v[I]));                                                      \
         _Pragma("unroll 1") for (int turn = 0; turn < 4; ++turn) {                                               \
@@ -1443,15 +1443,15 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
                     if constexpr (LATE && I == FS) {                                                             \
                         _Pragma("unroll") for (int k = 0; k < 4; ++k)                                            \
                             _Pragma("unroll") for (int j = 0; j < CPL; ++j) st[k][j] = st_pre[k][j];             \
-                    } else load_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                        \
+                    } else load_state<SL::v[I], CPL, GUARD>(a.slot[I], st, c, a.N, active);                        \
                 } else {                                                                                           \
                     _Pragma("unroll") for (int k = 0; k < 4; ++k)                                                \
                         _Pragma("unroll") for (int j = 0; j < CPL; ++j) st[k][j] = k < NS ? lds_st[k][j][lane] : 0.0f; \
                 }                                                                                                \
-                run_slot<SL::v[I], S, CPL, false, true, false>(a.slot[I], v, st, cx);                            \
+                run_slot<SL::v[I], S, CPL, GUARD, true, false>(a.slot[I], v, st, cx);                            \
                 if (turn == 3) {                                                                                 \
                     if constexpr (sig_is<K_SIGNAL_GEN>(SL::v[I])) signal_gen_close_block<CPL>(a.slot[I], st, a.nframes); \
-                    store_state<SL::v[I], CPL, false>(a.slot[I], st, c, a.N, true);                              \
+                    store_state<SL::v[I], CPL, GUARD>(a.slot[I], st, c, a.N, active);                              \
                 } else {                                                                                         \
                     _Pragma("unroll") for (int k = 0; k < NS; ++k)                                               \
                         _Pragma("unroll") for (int j = 0; j < CPL; ++j) lds_st[k][j][lane] = st[k][j];           \
@@ -1467,13 +1467,16 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     DSPFX_TS_STAMP(12)
 #pragma unroll
     for (int f = 0; f < S; ++f)
-        if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+        if (!a.skip_store) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], active);
     DSPFX_TS_STAMP(13)
-    if (a.mixpart) mixbus_partial<S, CPL>(ms, v, true, f_begin, lane, 0);      // the four slices of ONE row
+    if (a.mixpart) mixbus_partial<S, CPL>(ms, v, active, f_begin, lane, 0);      // the four slices of ONE row
     DSPFX_TS_STAMP(14)
 }
 
-template <int S, int CPL, class SL>
+// GUARD: the launch for the N % (64 * CPL) channels the whole-wave launch leaves over (one workgroup per 64 channels, CPL = 1):
+// out-of-range lanes stay alive, read zeros and store nothing -- four slices in parallel instead of the interpreter's one wave
+// walking the block chunk by chunk (43 -> ~9 us behind the main launch).
+template <int S, int CPL, class SL, bool GUARD = false>
 __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     // (Passing the state from slice to slice with an LDS flag instead of a workgroup barrier per turn -- so that the early
     // slices store while the later ones still take their turns -- was tried: config 2 27.3 -> 30.2 us, the 5-node chain at
@@ -1488,24 +1491,26 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     const unsigned group = work_block(a.xcd_remap);                        // channel group of 64*CPL channels
     const unsigned wave_global = a.wave_base + group;
     const size_t rel = ((size_t)group * 64 + lane) * CPL;
-    if (rel >= a.n_launch) return;                 // uniform over the whole workgroup: no barrier is left waiting
+    bool active = true;
+    if constexpr (GUARD) active = rel < a.n_launch;
+    else if (rel >= a.n_launch) return;            // uniform over the whole workgroup: no barrier is left waiting
     DSPFX_TS_STAMP(0)
-    const size_t c = a.c_base + rel;
+    const size_t c = a.c_base + (active ? rel : 0);
     const WaveAddr w = wave_addr(a, c);
     const unsigned f_begin = (unsigned)q * S;
-    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
+    const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     float v[S][CPL];
 #pragma unroll
-    for (int f = 0; f < S; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], true);
+    for (int f = 0; f < S; ++f) load_vec<CPL, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], active);
     // slice 0's late taps cost registers (the second copy of the body): 3-node chain 119 -> 153 (one channel per lane, still
     // three workgroups per CU where that form is used), 218 -> 243 (two); the 5-node chain would drop from four workgroups
     // per CU to three (108 -> 155) and ran 36 -> 42 us at 65536 channels: short chains only.  (Late taps for EVERY slice --
     // one copy of the body -- expose the taps' latency in the later slices: config 2 33.4 us.)
     if constexpr (ts_slot_count<SL>() <= 3) {
-        if (q == 0) ts_run<S, CPL, SL, true>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
-        else ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
+        if (q == 0) ts_run<S, CPL, SL, true, GUARD>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin, active);
+        else ts_run<S, CPL, SL, false, GUARD>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin, active);
     } else {
-        ts_run<S, CPL, SL, false>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin);
+        ts_run<S, CPL, SL, false, GUARD>(a, lds_st, cx, w, v, q, lane, c, group, ms, f_begin, active);
     }
     if (a.mixpart) {                               // 4 S frames == one segment; the workgroup's row is the four slices side by side
         mixbus_flush(a, ms, 0, 4 * S, wave_global, 1, q, lane);

@@ -230,7 +230,7 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
     collect_variants(all);
     const Variant *best = nullptr;
     for (const Variant *v : all) {
-        if (!v->ts || v->n_slots != st.count || N < 64u * (unsigned)v->cpl || N % (unsigned)v->cpl) continue;
+        if (!v->ts || v->guard || v->n_slots != st.count || N < 64u * (unsigned)v->cpl || N % (unsigned)v->cpl) continue;
         bool ok = true;
         for (int i = 0; i < st.count && ok; ++i) {
             const Node &n = e->nodes[st.first + i];
@@ -259,6 +259,77 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
     return k ? &k->var : nullptr;
 }
 
+// The channels a whole-wave launch leaves over (N % (64 cpl) of them) used to go through ONE wave per 64 channels of the
+// guarded interpreter, walking the block chunk by chunk on an otherwise idle chip: 43 us behind every block, at any N.
+// For blocks of exactly 128 frames the guarded time-sliced kernel of the same chain shape takes them instead -- four slices in
+// parallel, every load issued at once -- when the library has one or the run-time compiler is in use for this engine.
+// DSPFX_TS_TAIL=0 keeps the interpreter (A/B runs, tests: bit-identical).
+const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const char *off = getenv("DSPFX_TS_TAIL");
+    if ((off && atoi(off) == 0) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    unsigned cpl = st.var ? (unsigned)st.var->cpl : 1u;
+    if (st.var_ts) cpl = std::max(cpl, (unsigned)st.var_ts->cpl);
+    if (N % (64u * cpl) == 0) return nullptr;          // no launch of this engine leaves channels over
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    for (const Variant *v : all) {
+        if (!v->ts || !v->guard || v->n_slots != st.count) continue;
+        bool ok = true;
+        for (int i = 0; i < MAX_SLOTS && ok; ++i) ok = v->sigs[i] == sigs[i];
+        if (ok) return v;
+    }
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const Pref pref = read_pref();
+    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0) return nullptr;
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true);
+    return k ? &k->var : nullptr;
+}
+
+// A small engine on the interpreter: have its chain shape specialised in the background (jit.hip) and adopt the kernels
+// when they are ready.  Engines from JIT_MIN_CHANNELS on got theirs synchronously in pick_variant.
+void request_async_jit(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
+    if ((jit_env && atoi(jit_env) != -1) || (async_env && atoi(async_env) == 0)) return;     // forced on (synchronous) or off
+    if (e->graph_mode || !st.var || st.var->sigs[0] != SIG_DYN || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return;
+    if (N >= JIT_MIN_CHANNELS || read_pref().stat == 0 || getenv("DSPFX_VARIANT")) return;
+    auto job = std::make_shared<AsyncJit>();
+    job->device = e->device;
+    job->n_slots = st.count;
+    for (int i = 0; i < MAX_SLOTS; ++i) job->sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        job->sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    job->want_ts = N >= 64u;
+    job->want_tail = N % 64u != 0;
+    st.async = job;
+    async_jit_submit(job);
+}
+
+// run_subblock, at a block boundary: the background compiler is done with this stage's shape
+static void adopt_async_jit(dspfx_engine *e, const Stage &st) {
+    const std::shared_ptr<AsyncJit> job = st.async;
+    st.async.reset();
+    if (job->ready.load(std::memory_order_acquire) < 0 || !job->k_std) {
+        e->jit_unavailable = true;
+        return;
+    }
+    st.var = &job->k_std->var;
+    if (job->k_ts) st.var_ts = &job->k_ts->var;
+    if (job->k_tail) st.var_ts_tail = &job->k_tail->var;
+}
+
 // Chain engines: may a fusable run of more than MAX_SLOTS nodes become one generated kernel?  The conditions of the
 // run-time specialised chain kernels (jit_variant), whole waves only, and not after control ports were used (those are
 // evaluated by the chain kernels).
@@ -274,6 +345,8 @@ bool long_stage_wanted(const dspfx_engine *e) {
 
 int plan(dspfx_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
+    for (const Stage &st : e->stages)
+        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
     e->stages.clear();
     e->jit_unavailable = false;
     e->has_fuzz = false;
@@ -332,6 +405,8 @@ int plan(dspfx_engine *e) {
                 return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
                                                                     : "no kernel variant for stage");
             st.var_ts = e->graph_mode ? nullptr : pick_ts_variant(e, st);
+            st.var_ts_tail = e->graph_mode ? nullptr : pick_ts_tail_variant(e, st);
+            request_async_jit(e, st);
         }
     for (const Node &nd : e->nodes) {
         if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
@@ -536,6 +611,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS], nframes);
                 rows += state_rows(e->nodes[st.first + k]);
             }
+            if (st.async && st.async->ready.load(std::memory_order_acquire) != 0) adopt_async_jit(e, st);
             const Variant *v = st.var, *tail = e->tail;
             for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the MOD interpreter evaluates them
                 const Node &nd = e->nodes[st.first + k];
@@ -560,7 +636,14 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 if (!xcd_env) a.xcd_remap = 0;
             }
             const uint32_t per_wave = 64u * v->cpl;
-            const uint32_t n_main = N - N % per_wave;
+            // A few-channel engine (the time-sliced kernel is its main launch) whose N is not whole waves: two launches in a
+            // row would both be latency-bound (11 + 11 us), so the guarded time-sliced kernel takes ALL channels in one
+            // (N = 4099, 3-node chain: 61 us with the interpreter's one-wave launch behind the main one, 28 with the guarded
+            // time-sliced launch behind it, ~12 alone).  Engines in channel windows keep the two launches.
+            // Up to 32768 channels: one resident round of one-channel-per-lane workgroups, the same rows of bus partials.
+            const bool whole_guard = v->ts && v->cpl == 1 && N < 32768u && st.var_ts_tail && tail == e->tail && N % per_wave && !e->win_n &&
+                                     nframes == 4u * (uint32_t)st.var_ts_tail->ts;
+            const uint32_t n_main = whole_guard ? 0u : N - N % per_wave;
             const uint32_t waves_main = n_main / per_wave;
             const bool deferred = last && e->partials_override != nullptr;
             a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
@@ -623,12 +706,17 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     return fail(e, DSPFX_ERR_HIP, "kernel launch failed");
             }
             a.mp_stage = 0;   // the guarded tail launch never hosts the prologue
-            if (N % per_wave && (!e->win_n || e->win_c0 + e->win_n >= N)) {   // ragged tail: guarded one-wave blocks, lane per channel
+            if ((N % per_wave || whole_guard) && (!e->win_n || e->win_c0 + e->win_n >= N)) {   // ragged tail: guarded one-wave blocks, lane per channel
                 const uint32_t n_tail = N - n_main;
                 a.c_base = n_main;
                 a.n_launch = n_tail;
                 a.wave_base = grid_main;
-                (void)launch_variant(tail, a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
+                if (st.var_ts_tail && tail == e->tail && nframes == 4u * (uint32_t)st.var_ts_tail->ts) {
+                    a.xcd_remap = 0;            // whole 128-frame blocks: four slices per 64 channels (pick_ts_tail_variant)
+                    (void)launch_variant(st.var_ts_tail, a, (n_tail + 63) / 64, WG, 0, stream);
+                } else {
+                    (void)launch_variant(tail, a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
+                }
             }
             HIPCHK(e, hipGetLastError());
             if (deferred) {
@@ -930,6 +1018,8 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();            // blocks still in flight read the state that is about to be freed
+    for (const Stage &st : e->stages)
+        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);
@@ -1837,6 +1927,10 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
             }
             if (st.var_ts) {
                 snprintf(buf, sizeof buf, "; %d-frame blocks: time-sliced %s", 4 * st.var_ts->ts, st.var_ts->name);
+                s += buf;
+            }
+            if (st.var_ts_tail) {
+                snprintf(buf, sizeof buf, "; channels left over, %d-frame blocks: %s", 4 * st.var_ts_tail->ts, st.var_ts_tail->name);
                 s += buf;
             }
             s += "):";

@@ -24,6 +24,11 @@
 #include <chrono>
 #include <map>
 #include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <atomic>
+#include <thread>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -61,11 +66,26 @@ struct Node {
     const float *ctl_now[3] = {nullptr, nullptr, nullptr};   // signals of the call being launched
 };
 
+// A small engine's chain shape being specialised in the background (jit.hip: async_jit_submit).  The engine runs the
+// interpreter until `ready`, then adopts the kernels at its next block boundary.  Shared between the engine (which may drop
+// it: abandoned) and the compiler thread (which owns nothing of the engine).
+struct JitKernel;
+struct AsyncJit {
+    std::atomic<int> ready{0};           // 1: compiled (whatever could be), -1: no run-time compiler / headers
+    std::atomic<bool> abandoned{false};  // the engine re-planned or is gone: skip if not started yet
+    int device = 0, n_slots = 0;
+    int sigs[dspfx::MAX_SLOTS];
+    bool want_ts = false, want_tail = false;
+    const JitKernel *k_std = nullptr, *k_ts = nullptr, *k_tail = nullptr;
+};
+
 struct Stage {
     StageType type;
     int first, count;
-    const Variant *var = nullptr;   // ST_FUSED
-    const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
+    mutable const Variant *var = nullptr;   // ST_FUSED
+    mutable const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
+    mutable const Variant *var_ts_tail = nullptr;   // ST_FUSED, N % (64 cpl) != 0: the guarded time-sliced kernel for the channels left over (same blocks)
+    mutable std::shared_ptr<AsyncJit> async;    // ST_FUSED on the interpreter, few channels: its specialisation is on the way
     mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
     mutable bool var_mod_tried = false;
     bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
@@ -223,6 +243,7 @@ bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device = t
 bool fusable(const Node &n);
 int node_hop(const dspfx_engine *e, int idx);
 Pref read_pref();
+void async_jit_submit(const std::shared_ptr<AsyncJit> &job);   // jit.hip: background specialisation for small engines
 int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
 int plan(dspfx_engine *e);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
@@ -251,7 +272,7 @@ struct ApiScope {
 };
 
 // ---- jit.hip
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false);
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false, bool guard = false);
 int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s);
 const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod);
 const Variant *graph_variant(const dspfx_engine *e, const Stage &st);

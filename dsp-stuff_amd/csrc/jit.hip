@@ -80,16 +80,87 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
 }
 
 // ts: the time-sliced kernel chain_ts_kernel<f, cpl, ...> (f = frames per slice) instead of chain_kernel<f, cpl, ...>
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts) {
+// guard (ts only): chain_ts_kernel<f, 1, ..., true>, the launch for the channels a whole-wave launch leaves over
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts, bool guard) {
     char key[256];
-    int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "");   // modules belong to the device they were loaded on
+    int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "", (guard && ts) ? "_tail" : "");   // modules belong to the device they were loaded on
     for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
     std::string expr = std::string(ts ? "dspfx::chain_ts_kernel<" : "dspfx::chain_kernel<") + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
     for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
-    expr += (mod && !ts) ? ">, true>" : "> >";
+    expr += ((mod && !ts) || (guard && ts)) ? ">, true>" : "> >";
     const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
-    if (k && ts) const_cast<JitKernel *>(k)->var.ts = f;
+    if (k && ts) {
+        const_cast<JitKernel *>(k)->var.ts = f;
+        const_cast<JitKernel *>(k)->var.guard = guard;
+    }
     return k;
+}
+
+// ---- background specialisation for small engines ---------------------------------------------------------------------
+// Below JIT_MIN_CHANNELS an engine does not wait for the compiler (a host that edits its graph would stall a second per
+// edit): it starts on the interpreter and its chain shape goes to ONE worker thread, which compiles the standard, the
+// time-sliced and the left-over-channels kernel of the shape into the process-wide cache; the engine adopts them at the next
+// block boundary after they are ready (run_subblock).  64-4096 channels, five nodes no kernel was compiled in for: 72-78 us
+// per 128-frame block on the interpreter, 11-16 us afterwards (profiles/r03_small_n.txt).  Results do not change: both are
+// the same per-node device functions under the same compiler flags.  DSPFX_JIT_ASYNC=0 (or DSPFX_JIT=0) switches it off.
+namespace {
+struct AsyncCompiler {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::shared_ptr<AsyncJit>> q;
+    std::thread worker;
+    bool started = false, stop = false;
+    void run() {
+        for (;;) {
+            std::shared_ptr<AsyncJit> job;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (stop) return;
+                job = q.front();
+                q.pop_front();
+            }
+            if (job->abandoned.load(std::memory_order_acquire)) continue;
+            if (hipSetDevice(job->device) != hipSuccess) {
+                (void)hipGetLastError();
+                job->ready.store(-1, std::memory_order_release);
+                continue;
+            }
+            job->k_std = jit_get(job->device, job->sigs, job->n_slots, 16, 1, false);
+            if (job->k_std && job->want_ts && !job->abandoned.load(std::memory_order_acquire))
+                job->k_ts = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true);
+            if (job->k_std && job->want_tail && !job->abandoned.load(std::memory_order_acquire))
+                job->k_tail = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true, true);
+            job->ready.store(job->k_std ? 1 : -1, std::memory_order_release);
+        }
+    }
+    void shutdown() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+            q.clear();
+        }
+        cv.notify_all();
+        if (worker.joinable()) worker.join();      // at most the compile in flight
+    }
+};
+AsyncCompiler *g_async = nullptr;      // never destroyed: the worker may outlive every static of this library but not the process
+std::once_flag g_async_once;
+}  // namespace
+
+void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
+    std::call_once(g_async_once, [] {
+        g_async = new AsyncCompiler();
+        std::atexit([] { if (g_async) g_async->shutdown(); });   // registered after the HIP runtime's own handlers: runs before them
+    });
+    std::lock_guard<std::mutex> lk(g_async->mu);
+    if (g_async->stop) return;
+    if (!g_async->started) {
+        g_async->started = true;
+        g_async->worker = std::thread([] { g_async->run(); });
+    }
+    g_async->q.push_back(job);
+    g_async->cv.notify_one();
 }
 
 // A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.

@@ -28,10 +28,10 @@ void launch_static(const ChainArgs &a, unsigned grid, unsigned block, unsigned l
     (void)lds_bytes;
     hipLaunchKernelGGL((chain_kernel<F, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
 }
-template <int S, int CPL, class SL>
+template <int S, int CPL, class SL, bool GUARD = false>
 void launch_ts(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
     (void)lds_bytes;
-    hipLaunchKernelGGL((chain_ts_kernel<S, CPL, SL>), dim3(grid), dim3(block), 0, s, a);
+    hipLaunchKernelGGL((chain_ts_kernel<S, CPL, SL, GUARD>), dim3(grid), dim3(block), 0, s, a);
 }
 template <int F, int CPL, bool GUARD, bool MOD, bool LIBM>
 void launch_dyn(const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s) {
@@ -47,6 +47,9 @@ const Variant *variants_static5(int *n);
     Variant { NAME, {__VA_ARGS__}, NSLOTS, F, CPL, false, false, true, &launch_static<F, CPL, SigList<__VA_ARGS__>> }
 #define DSPFX_TS_VARIANT(NAME, NSLOTS, S, CPL, ...) \
     Variant { NAME, {__VA_ARGS__}, NSLOTS, S, CPL, false, false, true, &launch_ts<S, CPL, SigList<__VA_ARGS__>>, S }
+// the guarded form for the channels a whole-wave launch leaves over (guard = true AND ts != 0; one workgroup per 64 channels)
+#define DSPFX_TS_TAIL_VARIANT(NAME, NSLOTS, S, ...) \
+    Variant { NAME, {__VA_ARGS__}, NSLOTS, S, 1, true, false, true, &launch_ts<S, 1, SigList<__VA_ARGS__>, true>, S }
 #define DSPFX_DYN_VARIANT(NAME, F, GUARD, MOD, LIBM) \
     Variant { NAME, {SIG_DYN}, 0, F, 1, GUARD, MOD, LIBM, &launch_dyn<F, 1, GUARD, MOD, LIBM> }
 #define DSPFX_DYN_VARIANT_C(NAME, F, CPL, LIBM) \

@@ -14,6 +14,7 @@ static const Variant k_s3[] = {
     DSPFX_STATIC_VARIANT("s3h_f32_c1", 3, 32, 1, S3H),   // few channels: one wave per SIMD, memory-level parallelism from F
     DSPFX_TS_VARIANT("s3h_ts32_c1", 3, 32, 1, S3H),      // few channels: four time slices per channel group (chain_ts_kernel)
     DSPFX_TS_VARIANT("s3h_ts32_c2", 3, 32, 2, S3H),
+    DSPFX_TS_TAIL_VARIANT("s3h_ts32_tail", 3, 32, S3H),    // the channels a whole-wave launch leaves over, guarded
     DSPFX_STATIC_VARIANT("s3n_f8_c1", 3, 8, 1, S3N),
     DSPFX_STATIC_VARIANT("s3n_f8_c2", 3, 8, 2, S3N),
     DSPFX_STATIC_VARIANT("s3n_f8_c4", 3, 8, 4, S3N),

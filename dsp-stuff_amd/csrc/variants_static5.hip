@@ -14,6 +14,7 @@ static const Variant k_s5[] = {
     DSPFX_STATIC_VARIANT("s5h_f32_c1", 5, 32, 1, S5H),   // few channels: one wave per SIMD, memory-level parallelism from F
     DSPFX_TS_VARIANT("s5h_ts32_c1", 5, 32, 1, S5H),      // few channels: four time slices per channel group (chain_ts_kernel)
     DSPFX_TS_VARIANT("s5h_ts32_c2", 5, 32, 2, S5H),
+    DSPFX_TS_TAIL_VARIANT("s5h_ts32_tail", 5, 32, S5H),    // the channels a whole-wave launch leaves over, guarded
     DSPFX_STATIC_VARIANT("s5n_f8_c1", 5, 8, 1, S5N),
     DSPFX_STATIC_VARIANT("s5n_f8_c2", 5, 8, 2, S5N),
     DSPFX_STATIC_VARIANT("s5n_f8_c4", 5, 8, 4, S5N),

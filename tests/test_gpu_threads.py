@@ -438,3 +438,105 @@ def test_many_stores_under_contention_replayed_from_the_log(dspfx, torch_cuda):
     ref = _oracle_blocks(chain, x[:, sample], stores)
     assert ulp_diff(got, ref).max() <= 1, ulp_diff(got, ref).max()
     assert len(stores) > 1                           # the stores really were spread over several block boundaries
+
+
+@pytest.mark.parametrize("N,which", [
+    (1, "chain3"),            # config 1's single channel: the whole engine is the launch for the channels left over
+    (63, "chain5"),
+    (100, "chain3"),          # one time-sliced workgroup and 36 channels left over
+    (129, "chain5"),
+    (4099, "chain3"),
+    (70000, "chain3"),        # two channels per lane in the main launch: up to 127 channels left over, two workgroups
+    (131072 + 77, "chain5"),  # behind the standard kernel
+    (200, "jit"),             # any other chain shape when the run-time compiler serves the engine
+])
+def test_channels_left_over_go_through_the_guarded_time_sliced_kernel(dspfx, torch_cuda, monkeypatch, N, which):
+    """N % (64 * channels per lane) channels cannot go through whole waves.  For blocks of exactly 128 frames they take the
+    guarded time-sliced kernel of the chain's shape (four slices in parallel) instead of one wave of the guarded
+    interpreter: same samples, same bus, same state, block after block, as with DSPFX_TS_TAIL=0 -- and as the oracle."""
+    from chains import chain3
+    if which == "chain3":
+        mk = lambda: chain3(dspfx, 256)
+    elif which == "chain5":
+        mk = lambda: chain5(dspfx, 384)
+    else:
+        monkeypatch.setenv("DSPFX_JIT", "1")
+        mk = lambda: [dspfx.Gain(0.8), dspfx.LowPass(0.3), dspfx.Reverb(delay_samples=200, decay=0.4), dspfx.HighPass(0.6)]
+    blocks, nf = 6, 128
+    monkeypatch.setenv("DSPFX_TS_TAIL", "1")
+    y1, m1, desc = _bus_blocks(dspfx, torch_cuda, N, mk(), nf, blocks)
+    assert "channels left over" in desc, desc
+    monkeypatch.setenv("DSPFX_TS_TAIL", "0")
+    y0, m0, desc0 = _bus_blocks(dspfx, torch_cuda, N, mk(), nf, blocks)
+    assert "channels left over" not in desc0
+    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+    assert np.array_equal(m1.view(np.uint32), m0.view(np.uint32))
+    if N <= 4099:
+        from chains import ulp_diff
+        x = O.noise(3, np.arange(N), np.arange(nf * blocks))
+        ref = O.run_channels([n.oracle_desc() for n in mk()], x, 3)
+        assert int(ulp_diff(y1.reshape(blocks * nf, N), ref).max()) <= 1
+
+
+def test_channels_left_over_other_block_lengths_keep_the_interpreter(dspfx, torch_cuda, monkeypatch):
+    """The guarded time-sliced kernel serves blocks of exactly 128 frames; any other length goes through the guarded
+    interpreter as before, on the same engine, with the state carried across."""
+    from chains import chain3
+    N = 100
+    outs = []
+    for tail in ("1", "0"):
+        monkeypatch.setenv("DSPFX_TS_TAIL", tail)
+        eng = dspfx.Engine(N, 256, link_flags=3)
+        eng.set_chain(chain3(dspfx, 300))
+        x = O.noise(5, np.arange(N), np.arange(128 + 64 + 128 + 256))
+        got, f0 = [], 0
+        for nf in (128, 64, 128, 256):
+            dx = torch_cuda.from_numpy(x[f0:f0 + nf].copy()).cuda()
+            dy = torch_cuda.empty_like(dx)
+            eng.process(dx, out=dy, n_frames=nf)
+            got.append(dy.cpu().numpy().reshape(nf, N))
+            f0 += nf
+        outs.append(np.concatenate(got))
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+
+
+@pytest.mark.jit_async
+@pytest.mark.parametrize("N", [256, 100])
+def test_a_small_engine_adopts_its_specialised_kernels_in_mid_stream(dspfx, torch_cuda, monkeypatch, N):
+    """Below 16384 channels an engine does not wait for the run-time compiler: it starts on the interpreter, its chain shape
+    is specialised by a background thread, and the kernels are adopted at a block boundary.  The samples before, across
+    and after the switch are those of an engine that stays on the interpreter (DSPFX_JIT_ASYNC=0), bit for bit."""
+    import time
+    mk = lambda: [dspfx.Gain(0.7), dspfx.HighPass(0.4), dspfx.Distort(1.5, dspfx.HARD_CLIP), dspfx.Reverb(delay_samples=300, decay=0.45),
+                  dspfx.LowPass(0.2)]
+    nf = 128
+    monkeypatch.delenv("DSPFX_JIT", raising=False)
+    monkeypatch.setenv("DSPFX_JIT_ASYNC", "0")
+    ref = dspfx.Engine(N, nf, link_flags=3)
+    ref.set_chain(mk())
+    monkeypatch.setenv("DSPFX_JIT_ASYNC", "1")
+    eng = dspfx.Engine(N, nf, link_flags=3)
+    eng.set_chain(mk())
+    assert "dyn" in eng.describe()
+    k, switched_at, t0 = 0, None, time.time()
+    after = 0
+    while after < 40:
+        x = torch_cuda.from_numpy(O.noise(9, np.arange(N), np.arange(k * nf, (k + 1) * nf))).cuda()
+        y, y0 = torch_cuda.empty_like(x), torch_cuda.empty_like(x)
+        eng.process(x, out=y, n_frames=nf)
+        ref.process(x, out=y0, n_frames=nf)
+        assert torch_cuda.equal(y.view(torch_cuda.int32), y0.view(torch_cuda.int32)), (k, switched_at)
+        k += 1
+        if switched_at is None:
+            d = eng.describe()
+            if "jit_" in d:
+                switched_at = k
+            elif "could not be compiled" in d or time.time() - t0 > 120:
+                pytest.skip("no run-time compiler on this box: the interpreter stays (dspfx_describe says so)")
+            else:
+                time.sleep(0.02)
+        else:
+            after += 1
+    d = eng.describe()
+    assert "time-sliced jit_" in d and ("channels left over" in d) == (N % 64 != 0), d
+    assert "jit_" not in ref.describe()
