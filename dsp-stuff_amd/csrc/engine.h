@@ -77,6 +77,7 @@ struct AsyncJit {
     int sigs[dspfx::MAX_SLOTS];
     bool want_ts = false, want_tail = false;
     const JitKernel *k_std = nullptr, *k_ts = nullptr, *k_tail = nullptr;
+    std::string headers_dir;             // where the kernel headers are, as the submitting thread saw it
 };
 
 struct Stage {

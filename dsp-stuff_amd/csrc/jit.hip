@@ -19,7 +19,11 @@ std::map<std::string, JitKernel *> g_jit;     // key -> kernel
 
 // Where chain_kernels.hip.h / graph_kernel.hip.h are: next to the library, or DSPFX_KERNEL_HEADERS when they are installed
 // elsewhere (read per compile).
+// (the background compiler's thread never calls getenv -- a host may be changing its environment at that moment: it is given
+// the directory the submitting thread saw)
+static thread_local const std::string *t_dir_override = nullptr;
 std::string csrc_dir() {
+    if (t_dir_override) return *t_dir_override;
     if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
     Dl_info info;
     if (!dladdr((const void *)&dspfx_abi_version, &info) || !info.dli_fname) return "";
@@ -66,7 +70,7 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
                     delete k;
                 }
             }
-        } else if (getenv("DSPFX_JIT_DEBUG")) {
+        } else if (!t_dir_override && getenv("DSPFX_JIT_DEBUG")) {
             size_t ls = 0;
             (void)hiprtcGetProgramLogSize(prog, &ls);
             std::vector<char> log(ls + 1, 0);
@@ -126,11 +130,13 @@ struct AsyncCompiler {
                 job->ready.store(-1, std::memory_order_release);
                 continue;
             }
+            t_dir_override = &job->headers_dir;
             job->k_std = jit_get(job->device, job->sigs, job->n_slots, 16, 1, false);
             if (job->k_std && job->want_ts && !job->abandoned.load(std::memory_order_acquire))
                 job->k_ts = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true);
             if (job->k_std && job->want_tail && !job->abandoned.load(std::memory_order_acquire))
                 job->k_tail = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true, true);
+            t_dir_override = nullptr;
             job->ready.store(job->k_std ? 1 : -1, std::memory_order_release);
         }
     }
@@ -149,6 +155,7 @@ std::once_flag g_async_once;
 }  // namespace
 
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
+    job->headers_dir = csrc_dir();
     std::call_once(g_async_once, [] {
         g_async = new AsyncCompiler();
         std::atexit([] { if (g_async) g_async->shutdown(); });   // registered after the HIP runtime's own handlers: runs before them
