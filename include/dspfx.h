@@ -38,6 +38,11 @@
  *     dspfx_set_taps, dspfx_state_import / _export) wait for the device first.
  *   - there is NO CPU fallback: without a HIP device every entry point that
  *     needs one fails with DSPFX_ERR_NO_DEVICE.
+ *   - kernels: which kernel serves a chain is the engine's business and never changes a sample
+ *     (dspfx_describe names it).  Engines from 16384 channels on get kernels specialised for
+ *     their chain's shape when the chain is set (about a second per new shape); smaller ones
+ *     start on an interpreting kernel at once and adopt specialised ones at a block boundary
+ *     when the library's background thread has compiled them.  N need not be a multiple of 64.
  */
 #ifndef DSPFX_H
 #define DSPFX_H
