@@ -312,7 +312,8 @@ void request_async_jit(const dspfx_engine *e, const Stage &st) {
         job->sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
     }
     job->want_ts = N >= 64u;
-    job->want_tail = N % 64u != 0;
+    const char *tail_env = getenv("DSPFX_TS_TAIL");
+    job->want_tail = N % 64u != 0 && !(tail_env && atoi(tail_env) == 0);
     st.async = job;
     async_jit_submit(job);
 }
@@ -1024,7 +1025,10 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();            // blocks still in flight read the state that is about to be freed
     for (const Stage &st : e->stages)
-        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
+        if (st.async) {
+            st.async->abandoned.store(true, std::memory_order_release);
+            async_jit_wait(st.async);        // not queued any more and not finished: at most the rest of one compile
+        }
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);

@@ -73,6 +73,7 @@ struct JitKernel;
 struct AsyncJit {
     std::atomic<int> ready{0};           // 1: compiled (whatever could be), -1: no run-time compiler / headers
     std::atomic<bool> abandoned{false};  // the engine re-planned or is gone: skip if not started yet
+    std::atomic<int> state{0};           // 0 queued, 1 being compiled, 2 finished or skipped
     int device = 0, n_slots = 0;
     int sigs[dspfx::MAX_SLOTS];
     bool want_ts = false, want_tail = false;
@@ -245,6 +246,7 @@ bool fusable(const Node &n);
 int node_hop(const dspfx_engine *e, int idx);
 Pref read_pref();
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job);   // jit.hip: background specialisation for small engines
+void async_jit_wait(const std::shared_ptr<AsyncJit> &job);     // ... until the compiler is not working on `job` (bounded)
 int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
 int plan(dspfx_engine *e);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,

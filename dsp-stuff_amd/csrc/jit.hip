@@ -1,6 +1,7 @@
 // jit.hip -- run-time specialisation of the chain kernels (hiprtc) and the generator of whole-graph kernels
 // (include/dspfx.h: dspfx_graph_set / dspfx_graph_source; csrc/graph_kernel.hip.h).  See engine.h for the split.
 #include "engine.h"
+#include <chrono>
 
 using namespace dspfx;
 using namespace dspfx_host;
@@ -107,6 +108,7 @@ const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, 
 // block boundary after they are ready (run_subblock).  64-4096 channels, five nodes no kernel was compiled in for: 72-78 us
 // per 128-frame block on the interpreter, 11-16 us afterwards (profiles/r03_small_n.txt).  Results do not change: both are
 // the same per-node device functions under the same compiler flags.  DSPFX_JIT_ASYNC=0 (or DSPFX_JIT=0) switches it off.
+static void async_exit_handler();
 namespace {
 struct AsyncCompiler {
     std::mutex mu;
@@ -124,10 +126,15 @@ struct AsyncCompiler {
                 job = q.front();
                 q.pop_front();
             }
-            if (job->abandoned.load(std::memory_order_acquire)) continue;
+            job->state.store(1, std::memory_order_release);
+            if (job->abandoned.load(std::memory_order_acquire)) {
+                job->state.store(2, std::memory_order_release);
+                continue;
+            }
             if (hipSetDevice(job->device) != hipSuccess) {
                 (void)hipGetLastError();
                 job->ready.store(-1, std::memory_order_release);
+                job->state.store(2, std::memory_order_release);
                 continue;
             }
             t_dir_override = &job->headers_dir;
@@ -138,6 +145,12 @@ struct AsyncCompiler {
                 job->k_tail = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true, true);
             t_dir_override = nullptr;
             job->ready.store(job->k_std ? 1 : -1, std::memory_order_release);
+            job->state.store(2, std::memory_order_release);
+            // Exit handlers run newest first, and the compiler's libraries (loaded lazily, inside the first compile) register
+            // theirs when they are loaded: registered again here, ours -- which waits for a compile in flight -- stays ahead of
+            // every one of them that exists by now.  (Found by tests/cpp/test_host: a process that left main() while its last
+            // engine's shape was being compiled crashed inside comgr, whose globals the exiting thread had destroyed.)
+            std::atexit(async_exit_handler);
         }
     }
     void shutdown() {
@@ -153,12 +166,15 @@ struct AsyncCompiler {
 AsyncCompiler *g_async = nullptr;      // never destroyed: the worker may outlive every static of this library but not the process
 std::once_flag g_async_once;
 }  // namespace
+static void async_exit_handler() {
+    if (g_async) g_async->shutdown();
+}
 
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     job->headers_dir = csrc_dir();
     std::call_once(g_async_once, [] {
         g_async = new AsyncCompiler();
-        std::atexit([] { if (g_async) g_async->shutdown(); });   // registered after the HIP runtime's own handlers: runs before them
+        std::atexit(async_exit_handler);       // registered after the HIP runtime's own handlers: runs before them
     });
     std::lock_guard<std::mutex> lk(g_async->mu);
     if (g_async->stop) return;
@@ -168,6 +184,12 @@ void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     }
     g_async->q.push_back(job);
     g_async->cv.notify_one();
+}
+
+// dspfx_engine_destroy: a host that destroys its engines before it exits never exits with ITS shapes in the compiler
+void async_jit_wait(const std::shared_ptr<AsyncJit> &job) {
+    for (int ms = 0; ms < 20000 && job->state.load(std::memory_order_acquire) == 1; ++ms)
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
 }
 
 // A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.

@@ -25,7 +25,7 @@ def _f32_fir_sweep_unless_asked(monkeypatch, request):
     # Small engines have their chain shape specialised in the background and switch kernels when it is ready (jit.hip): same
     # samples, but WHEN the switch happens is a matter of timing, and the tests compare engines block for block (the bus'
     # summation order follows the kernel).  Off by default here; tests marked `jit_async` exercise it.
-    if "jit_async" not in request.keywords:
+    if "jit_async" not in request.keywords and os.environ.get("DSPFX_TEST_JIT_ASYNC") != "1":   # (=1: the whole suite with it on)
         monkeypatch.setenv("DSPFX_JIT_ASYNC", "0")
 
 

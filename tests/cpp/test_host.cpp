@@ -8,6 +8,9 @@
 #include <cstring>
 #include <thread>
 #include <vector>
+#include <csignal>
+#include <execinfo.h>
+#include <unistd.h>
 
 #include "../../include/dspfx.hpp"
 #include "../../oracle/dspfx_oracle.h"
@@ -22,7 +25,22 @@ static int ulp(float a, float b) {
     return std::abs(ia - ib);
 }
 
+// a crash anywhere (this program, the library, its background compiler thread) leaves its call stack on stderr for the test's report
+static void on_crash(int sig) {
+    void *frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "FAIL: fatal signal; call stack:\n";
+    (void)!write(2, msg, sizeof msg - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int main(int argc, char **argv) {
+    signal(SIGSEGV, on_crash);
+    signal(SIGBUS, on_crash);
+    signal(SIGABRT, on_crash);
+    setvbuf(stdout, nullptr, _IOLBF, 0);        // what was printed before a crash is in the report
     const bool expect_no_device = argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0;
     try {
         using namespace dspfx;

@@ -16,7 +16,7 @@ def _build():
     orc = os.path.join(ROOT, "oracle")
     cmd = ["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-o", EXE, os.path.join(ROOT, "tests", "cpp", "test_host.cpp"),
            f"-L{cs}", "-ldspfx", f"-L{orc}", "-loracle", f"-Wl,-rpath,{cs}", f"-Wl,-rpath,{orc}", "-L/opt/rocm/lib",
-           "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-pthread"]
+           "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-pthread", "-rdynamic"]
     subprocess.check_call(cmd)
 
 
