@@ -174,7 +174,13 @@ void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     job->headers_dir = csrc_dir();
     std::call_once(g_async_once, [] {
         g_async = new AsyncCompiler();
-        std::atexit(async_exit_handler);       // registered after the HIP runtime's own handlers: runs before them
+        // hiprtc loads the compiler (comgr, with LLVM inside) lazily, at the first compile -- on the worker thread, i.e. AFTER
+        // the registration below, which would put comgr's exit-time destructors ahead of ours.  Loaded here first, they are
+        // behind it: a process that exits during its very first background compile waits for it instead of pulling the
+        // compiler's globals from under it.
+        for (const char *name : {"libamd_comgr.so.3", "libamd_comgr.so"})
+            if (dlopen(name, RTLD_NOW | RTLD_GLOBAL)) break;
+        std::atexit(async_exit_handler);       // registered after the HIP runtime's and the compiler's own handlers: runs before them
     });
     std::lock_guard<std::mutex> lk(g_async->mu);
     if (g_async->stop) return;

@@ -7,6 +7,7 @@ caller's (non-blocking) stream, so "between two blocks" has to hold against bloc
 the store is queued, applied at the next block boundary, and its state reset travels in stream order.  Every test
 below keeps the stream busy behind a long spin kernel so that nothing has executed when the host-side calls are made;
 the oracle takes the same stores at the block the engine's own log reports."""
+import os
 import threading
 
 import numpy as np
@@ -540,3 +541,32 @@ def test_a_small_engine_adopts_its_specialised_kernels_in_mid_stream(dspfx, torc
     d = eng.describe()
     assert "time-sliced jit_" in d and ("channels left over" in d) == (N % 64 != 0), d
     assert "jit_" not in ref.describe()
+
+
+@pytest.mark.jit_async
+def test_a_process_may_exit_while_its_shape_is_being_compiled():
+    """The background compiler must not take the process down when it ends: a script that installs a chain on a small
+    engine and leaves at once -- engine still alive, its shape in the compiler -- exits with status 0 (the library's exit
+    handler waits for the compile in flight; without it the compiler's globals were destroyed under the worker thread)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, time\n"
+        "sys.path.insert(0, ROOT)\n"
+        "import torch\n"
+        "from __graft_entry__ import load_package\n"
+        "fx = load_package()\n"
+        "k = int(sys.argv[1])\n"
+        "eng = fx.Engine(192, 128, link_flags=3)\n"
+        "eng.set_chain([fx.Gain(0.5)] + [fx.HighPass(0.3)] * (1 + k) + [fx.LowPass(0.7)] * (2 - k % 2))\n"
+        "x = torch.zeros(128 * 192, device='cuda'); y = torch.empty_like(x)\n"
+        "eng.process(x, out=y, n_frames=128); torch.cuda.synchronize()\n"
+        "time.sleep(0.07 * k)\n"
+        "print('leaving', flush=True)\n").replace("ROOT", repr(root))
+    env = dict(os.environ)
+    env.pop("DSPFX_JIT_ASYNC", None)
+    env.pop("DSPFX_JIT", None)
+    for k in range(4):
+        r = subprocess.run([sys.executable, "-c", script, str(k)], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "leaving" in r.stdout, (k, r.returncode, r.stdout[-500:], r.stderr[-1500:])
