@@ -762,13 +762,24 @@ def main():
 
     ctx = Ctx()
     world, rank = launch_env(args, ctx)
+    # DSPFX_BENCH_SHARE_GPU=1 (a test rig for one-GPU boxes, tools/r03_two_ranks_one_gpu.sh): every rank uses GPU 0 and the
+    # process group runs over gloo -- RCCL refuses two ranks on one device.  Everything else is the N > 1 path as the driver
+    # launches it: sharding, per-rank engines and tuning, the batched bus with its collective on the second stream, barriers,
+    # MAX over ranks, one line from rank 0.  The numbers of such a run mean nothing (the ranks time-slice one chip).
+    share_gpu = os.environ.get("DSPFX_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        ctx.local_rank = 0
+        os.environ.setdefault("DSPFX_BENCH_COMM", "torch")
     torch.cuda.set_device(ctx.local_rank)
     dev = ctx.dev = torch.device("cuda", ctx.local_rank)
     # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
     # exercised on a 1-GPU box (the driver launches the real N>1 runs with torch.distributed.run)
     ctx.use_dist = world > 1 or os.environ.get("DSPFX_BENCH_FORCE_DIST") == "1"
     if ctx.use_dist:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     ctx.pkg = load_package()
     from dsp_stuff_amd import parallel as P
