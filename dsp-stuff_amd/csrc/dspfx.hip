@@ -4,8 +4,10 @@
 // chain into stages (fused chain kernel | Fuzz | FIR) and launches them on the
 // caller's stream.  No CPU fallback exists: without a HIP device every entry
 // point that needs one returns DSPFX_ERR_NO_DEVICE.
-// This file: lifecycle, parameter stores (queued, thread-safe), the process calls, DSP state, utilities.  The run-time
-// compiler lives in jit.hip, placement tuning in placement.hip, the RCCL collective in comm.hip; engine.h is what they share.
+// This file: lifecycle, parameter stores (queued, thread-safe), run_subblock and the process calls.  Which kernels serve a
+// chain is decided in plan.hip; the run-time compiler lives in jit.hip, placement tuning in placement.hip, the RCCL collective
+// in comm.hip, the host-buffer pipeline in host_pipe.hip, state export / import and the utilities in state_util.hip;
+// engine.h is what they share.
 #include "engine.h"
 
 using namespace dspfx;
@@ -33,69 +35,6 @@ int fail(dspfx_engine *e, int code, const char *fmt, ...) {
     return code;
 }
 
-
-// Is (float)((double)x * RN_f64(1/c)) == x / c for every f32 x?  (div_c in chain_kernels.hip.h has the argument.)
-//   * c not an even integer, or a power of two: yes, by the theorem there -- decided here, no device involved, so a
-//     slider store, a fan-in divisor f32(0.0001 + k) or dspfx_graph_source never launch anything;
-//   * c an even integer that is not a power of two (6, 10, 12, ... -- exact ties exist among its subnormal quotients):
-//     the exhaustive 2^32-input check decides, on the CURRENT device (plan() selects the engine's device first).  Only
-//     COMPLETED checks are cached: a HIP failure answers "not fast" for this call and is asked again next time;
-//     have_device = false only consults the cache.
-// DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; read per call so a test can flip it between engines).
-bool divisor_is_fast(float c, bool have_device) {
-    static std::mutex mu;
-    static std::map<uint32_t, bool> cache;
-    if (const char *fd = getenv("DSPFX_FAST_DIV"))
-        if (atoi(fd) == 0) return false;
-    if (!(c == c) || c == 0.0f || std::isinf(c)) return false;
-    const float ac = fabsf(c), half = ac * 0.5f;
-    int ex = 0;
-    const bool even_integer = ac >= 2.0f && half == floorf(half);
-    const bool pow2 = frexpf(ac, &ex) == 0.5f;
-    if (!even_integer || pow2) return true;
-    uint32_t bits;
-    memcpy(&bits, &c, 4);
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = cache.find(bits);
-    if (it != cache.end()) return it->second;
-    if (!have_device) return false;
-    bool done = false, ok = false;
-    unsigned long long *d = nullptr, h = 1;
-    if (hipMalloc((void **)&d, sizeof h) == hipSuccess) {
-        if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
-            hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-            done = true;
-            ok = h == 0;
-        }
-        (void)hipFree(d);
-    }
-    if (!done) {
-        (void)hipGetLastError();
-        return false;
-    }
-    cache[bits] = ok;
-    return ok;
-}
-
-bool node_divisors_fast(const Node &n, bool have_device) {
-    if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
-        if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
-        if (!divisor_is_fast(n.d.params[0], have_device)) return false;
-        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f, have_device)) return false;
-    }
-    return true;
-}
-
-bool fusable(const Node &n) {
-    if (n.d.kind == DSPFX_FIR) return false;
-    if (n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ) return false;
-    return true;
-}
-
-int node_hop(const dspfx_engine *e, int idx) {
-    return idx == 0 ? ((e->desc.link_flags & DSPFX_LINK_INPUT) ? 1 : 0)
-                    : ((e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0);
-}
 
 void biquad_regenerate(Node &n) {   // biquad.rs:62-76
     const float a0 = n.d.params[0];
@@ -125,296 +64,6 @@ void free_node(Node &n) {
         n.latch[k] = nullptr;
     }
     n.latch_valid = 0;
-}
-
-void collect_variants(std::vector<const Variant *> &out) {
-    int n = 0;
-    const Variant *v = variants_dyn(&n);
-    for (int i = 0; i < n; ++i) out.push_back(v + i);
-    v = variants_static3(&n);
-    for (int i = 0; i < n; ++i) out.push_back(v + i);
-    v = variants_static5(&n);
-    for (int i = 0; i < n; ++i) out.push_back(v + i);
-}
-
-Pref read_pref() {
-    Pref p;
-    const char *s = getenv("DSPFX_VARIANT");
-    if (!s) return p;
-    const char *q;
-    if ((q = strstr(s, "f="))) p.f = atoi(q + 2);
-    if ((q = strstr(s, "cpl="))) p.cpl = atoi(q + 4);
-    if ((q = strstr(s, "static="))) p.stat = atoi(q + 7);
-    return p;
-}
-
-bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device) {
-    if (!divisor_is_fast(e->hop_div, have_device)) return false;
-    for (int i = 0; i < st.count; ++i)
-        if (!node_divisors_fast(e->nodes[st.first + i], have_device)) return false;
-    return true;
-}
-
-bool node_needs_libm(const Node &n) {
-    if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV || n.d.kind == DSPFX_SIGNAL_GEN) return true;
-    return n.d.kind == DSPFX_DISTORT &&
-           (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
-}
-
-const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
-    std::vector<const Variant *> all;
-    collect_variants(all);
-    const Pref pref = read_pref();
-    const uint32_t N = e->desc.channels;
-    const Variant *best = nullptr;
-    int best_score = -1;
-    for (const Variant *v : all) {
-        if (v->guard || v->mod || v->ts) continue;
-        const bool is_dyn = v->sigs[0] == SIG_DYN;
-        if (is_dyn) {
-            bool need = false;
-            for (int i = 0; i < st.count; ++i) need = need || node_needs_libm(e->nodes[st.first + i]);
-            if (v->libm != need) continue;
-        }
-        if (!is_dyn) {
-            if (pref.stat == 0) continue;
-            if (!st.fast_div) continue;          // static kernels are built with the fast division only
-            if (v->n_slots != st.count) continue;
-            bool ok = true;
-            for (int i = 0; i < st.count && ok; ++i) {
-                const Node &n = e->nodes[st.first + i];
-                const int mode = n.d.kind == DSPFX_DISTORT ? n.d.mode : 0;
-                ok = v->sigs[i] == sig(n.d.kind, mode, node_hop(e, st.first + i));
-            }
-            if (!ok) continue;
-        }
-        if (!is_dyn || v->cpl > 1) {     // the one-channel interpreter is the fallback for every N (the tail launch covers N < 64)
-            if (N % (64u * v->cpl) != 0 && N < 64u * v->cpl) continue;
-            if (N % v->cpl != 0) continue;   // vector loads need aligned rows
-        }
-        int score = is_dyn ? 0 : 100;
-        // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
-        // Few channels (<= 2 waves per SIMD at one channel per lane): nothing hides a wave's memory latency, so
-        // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
-        const bool few = N <= 131072u;
-        const int want_f = (few && !is_dyn) ? 16 : 8;
-        // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
-        // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
-        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
-        if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
-        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
-        if (score > best_score) {
-            best_score = score;
-            best = v;
-        }
-    }
-    // no compiled-in specialisation: instantiate one at run time (large engines, or DSPFX_JIT=1)
-    if (best && best->sigs[0] == SIG_DYN && pref.stat != 0)
-        if (const Variant *j = jit_variant(e, st, false)) return j;
-    return best;
-}
-
-// Few channels (at most two waves per SIMD at one channel per lane): the time-sliced kernel of the same chain shape, if the
-// library has one.  DSPFX_VARIANT="ts=0" switches it off, "ts=1" forces it at any size (A/B runs).
-const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
-    const uint32_t N = e->desc.channels;
-    int want = -1;
-    if (const char *sv = getenv("DSPFX_VARIANT"))
-        if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
-    // Measured crossover against the standard kernels (profiles/r02_small_n.txt): 81920 channels for chains of up to three
-    // nodes, 65536 for longer ones (more registers per wave, fewer co-resident workgroups).
-    const uint32_t ts_max = st.count <= 3 ? TS_MAX_CHANNELS : 65536u;
-    if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
-    const Pref pref = read_pref();
-    std::vector<const Variant *> all;
-    collect_variants(all);
-    const Variant *best = nullptr;
-    for (const Variant *v : all) {
-        if (!v->ts || v->guard || v->n_slots != st.count || N < 64u * (unsigned)v->cpl || N % (unsigned)v->cpl) continue;
-        bool ok = true;
-        for (int i = 0; i < st.count && ok; ++i) {
-            const Node &n = e->nodes[st.first + i];
-            const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-            ok = v->sigs[i] == sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-        }
-        if (!ok) continue;
-        // two channels per lane (half the load / store instructions per byte) once there are still two workgroups per CU
-        // at that width and the chain is short enough for the doubled registers: 3-node chain at 65536 channels 29.0 -> 27.6 us
-        const int want_cpl = pref.cpl > 0 ? pref.cpl : (st.count <= 3 && N >= 57344u ? 2 : 1);
-        if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
-    }
-    if (best) return best;
-    // no compiled-in time-sliced kernel for this chain shape: instantiate one at run time, like the standard kernel
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0 || N % 64u) return nullptr;
-    int sigs[MAX_SLOTS];
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true);
-    return k ? &k->var : nullptr;
-}
-
-// The channels a whole-wave launch leaves over (N % (64 cpl) of them) used to go through ONE wave per 64 channels of the
-// guarded interpreter, walking the block chunk by chunk on an otherwise idle chip: 43 us behind every block, at any N.
-// For blocks of exactly 128 frames the guarded time-sliced kernel of the same chain shape takes them instead -- four slices in
-// parallel, every load issued at once -- when the library has one or the run-time compiler is in use for this engine.
-// DSPFX_TS_TAIL=0 keeps the interpreter (A/B runs, tests: bit-identical).
-const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st) {
-    const uint32_t N = e->desc.channels;
-    const char *off = getenv("DSPFX_TS_TAIL");
-    if ((off && atoi(off) == 0) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
-    unsigned cpl = st.var ? (unsigned)st.var->cpl : 1u;
-    if (st.var_ts) cpl = std::max(cpl, (unsigned)st.var_ts->cpl);
-    if (N % (64u * cpl) == 0) return nullptr;          // no launch of this engine leaves channels over
-    int sigs[MAX_SLOTS];
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    std::vector<const Variant *> all;
-    collect_variants(all);
-    for (const Variant *v : all) {
-        if (!v->ts || !v->guard || v->n_slots != st.count) continue;
-        bool ok = true;
-        for (int i = 0; i < MAX_SLOTS && ok; ++i) ok = v->sigs[i] == sigs[i];
-        if (ok) return v;
-    }
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    const Pref pref = read_pref();
-    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0) return nullptr;
-    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true);
-    return k ? &k->var : nullptr;
-}
-
-// A small engine on the interpreter: have its chain shape specialised in the background (jit.hip) and adopt the kernels
-// when they are ready.  Engines from JIT_MIN_CHANNELS on got theirs synchronously in pick_variant.
-void request_async_jit(const dspfx_engine *e, const Stage &st) {
-    const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
-    if ((jit_env && atoi(jit_env) != -1) || (async_env && atoi(async_env) == 0)) return;     // forced on (synchronous) or off
-    if (e->graph_mode || !st.var || st.var->sigs[0] != SIG_DYN || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return;
-    if (N >= JIT_MIN_CHANNELS || read_pref().stat == 0 || getenv("DSPFX_VARIANT")) return;
-    auto job = std::make_shared<AsyncJit>();
-    job->device = e->device;
-    job->n_slots = st.count;
-    for (int i = 0; i < MAX_SLOTS; ++i) job->sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        job->sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    job->want_ts = N >= 64u;
-    const char *tail_env = getenv("DSPFX_TS_TAIL");
-    job->want_tail = N % 64u != 0 && !(tail_env && atoi(tail_env) == 0);
-    st.async = job;
-    async_jit_submit(job);
-}
-
-// run_subblock, at a block boundary: the background compiler is done with this stage's shape
-static void adopt_async_jit(dspfx_engine *e, const Stage &st) {
-    const std::shared_ptr<AsyncJit> job = st.async;
-    st.async.reset();
-    if (job->ready.load(std::memory_order_acquire) < 0 || !job->k_std) {
-        e->jit_unavailable = true;
-        return;
-    }
-    st.var = &job->k_std->var;
-    if (job->k_ts) st.var_ts = &job->k_ts->var;
-    if (job->k_tail) st.var_ts_tail = &job->k_tail->var;
-}
-
-// Chain engines: may a fusable run of more than MAX_SLOTS nodes become one generated kernel?  The conditions of the
-// run-time specialised chain kernels (jit_variant), whole waves only, and not after control ports were used (those are
-// evaluated by the chain kernels).
-bool long_stage_wanted(const dspfx_engine *e) {
-    if (e->no_long) return false;
-    const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    if (!(jit_mode == 1 || (jit_mode != 0 && N > 131072u))) return false;
-    if (read_pref().stat == 0) return false;
-    return N % 64u == 0;
-}
-
-int plan(dspfx_engine *e) {
-    HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
-    for (const Stage &st : e->stages)
-        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
-    e->stages.clear();
-    e->jit_unavailable = false;
-    e->has_fuzz = false;
-    e->has_siggen = false;
-    e->min_delay = 0xffffffffu;
-    const int n = (int)e->nodes.size();
-    int i = 0;
-    while (i < n) {
-        Stage st{};
-        if (fusable(e->nodes[i])) {
-            st.type = ST_FUSED;
-            st.first = i;
-            int limit = e->graph_mode ? GRAPH_SLOTS : MAX_SLOTS;
-            if (!e->graph_mode && long_stage_wanted(e)) {
-                // A fusable run longer than one chain launch holds: up to GRAPH_SLOTS of its nodes become one generated
-                // kernel (the chain as a graph) instead of two chain launches with a round trip through memory in
-                // between (12 nodes: 0.575 -> 0.429 ms).  Add / Mix read the engine's side input from memory, which
-                // that kernel does not do: a run with one of them is cut as before.
-                int j = i;
-                bool mixers = false;
-                while (j < n && fusable(e->nodes[j]) && j - i < GRAPH_SLOTS) {
-                    mixers = mixers || e->nodes[j].d.kind == DSPFX_ADD || e->nodes[j].d.kind == DSPFX_MIX;
-                    ++j;
-                }
-                if (j - i > MAX_SLOTS && !mixers) limit = GRAPH_SLOTS;
-            }
-            while (i < n && fusable(e->nodes[i]) && i - st.first < limit) ++i;
-            st.count = i - st.first;
-        } else {
-            st.type = e->nodes[i].d.kind == DSPFX_FIR ? ST_FIR : ST_FUZZ;
-            st.first = i;
-            st.count = 1;
-            ++i;
-        }
-        e->stages.push_back(st);
-    }
-    // the mix bus is reduced in the epilogue of a fused stage: make sure one is last
-    if (e->stages.empty() || e->stages.back().type != ST_FUSED) {
-        Stage st{};
-        st.type = ST_FUSED;
-        st.first = n;
-        st.count = 0;
-        e->stages.push_back(st);
-    }
-    if (e->graph_mode && (e->stages.size() != 1 || e->stages[0].type != ST_FUSED || e->stages[0].count != n))
-        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph has a node that cannot be fused (FIR, Fuzz) or more than %d nodes", GRAPH_SLOTS);
-    for (Stage &st : e->stages)
-        if (st.type == ST_FUSED) {
-            st.fast_div = stage_fast_div(e, st);
-            st.var = (e->graph_mode || st.count > MAX_SLOTS) ? graph_variant(e, st) : pick_variant(e, st);
-            if (!st.var && !e->graph_mode && st.count > MAX_SLOTS) {   // no run-time compiler: cut the run as usual
-                e->no_long = true;
-                return plan(e);
-            }
-            if (!st.var)
-                return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
-                                                                    : "no kernel variant for stage");
-            st.var_ts = e->graph_mode ? nullptr : pick_ts_variant(e, st);
-            st.var_ts_tail = e->graph_mode ? nullptr : pick_ts_tail_variant(e, st);
-            request_async_jit(e, st);
-        }
-    for (const Node &nd : e->nodes) {
-        if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
-        if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
-        if (nd.d.kind == DSPFX_SIGNAL_GEN) e->has_siggen = true;
-    }
-    return DSPFX_OK;
 }
 
 int alloc_node_state(dspfx_engine *e, Node &n) {
@@ -1429,119 +1078,6 @@ extern "C" int dspfx_process_ctl(dspfx_engine *e, const float *in, const float *
     return rc;
 }
 
-extern "C" int dspfx_host_alloc(size_t bytes, void **out) {
-    if (!out || bytes == 0) return DSPFX_ERR_INVALID;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
-    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
-        (void)hipGetLastError();
-        *out = nullptr;
-        return DSPFX_ERR_OOM;
-    }
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_host_free(void *p) {
-    if (!p) return DSPFX_OK;
-    return hipHostFree(p) == hipSuccess ? DSPFX_OK : DSPFX_ERR_HIP;
-}
-
-namespace dspfx_host {
-bool is_pinned_host(const void *p) {
-    hipPointerAttribute_t at;
-    memset(&at, 0, sizeof at);
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    return at.type == hipMemoryTypeHost;
-}
-}  // namespace dspfx_host
-
-extern "C" int dspfx_process_host(dspfx_engine *e, const float *in, const float *side, float *out, float *mix,
-                                  uint32_t n_frames) {
-    if (!e) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    if (!in || !out) return fail(e, DSPFX_ERR_INVALID, "in/out must not be null");
-    if (n_frames > e->desc.max_frames)
-        return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
-    const size_t cap = (size_t)e->desc.max_frames * e->desc.channels * sizeof(float);
-    const size_t bytes = (size_t)n_frames * e->desc.channels * sizeof(float);
-    if (!e->h_in) HIPCHK(e, hipMalloc((void **)&e->h_in, cap));
-    if (!e->h_out) HIPCHK(e, hipMalloc((void **)&e->h_out, cap));
-    if (side && !e->h_side) HIPCHK(e, hipMalloc((void **)&e->h_side, cap));
-    if (mix && !e->h_mix) HIPCHK(e, hipMalloc((void **)&e->h_mix, e->desc.max_frames * sizeof(float)));
-    // Pipelined form: the block is cut into channel parts; while part p runs, part p+1 is uploaded and part p-1
-    // downloaded (both directions of the bus busy).  Needs a single fused stage per part (no FIR / Fuzz / mix bus),
-    // the frame-major layout and a block that is not split at a short delay line.
-    bool fused_only = !e->desc.tile_channels && n_frames <= e->min_delay && !e->has_siggen && !e->collect_due && !e->mp_count;
-    for (const Stage &st : e->stages) fused_only = fused_only && st.type == ST_FUSED;
-    const uint32_t N = e->desc.channels;
-    static const uint32_t part = getenv("DSPFX_HOST_PART") ? (uint32_t)atoi(getenv("DSPFX_HOST_PART")) : 65536u;   // channels per part (multiple of 1024); 32k 15.5, 64k 13.7, 128k 14.1, 256k 15.1 ms
-    static const bool pipe_off = getenv("DSPFX_HOST_PIPELINE") && atoi(getenv("DSPFX_HOST_PIPELINE")) == 0;
-    // page-locked buffers only (dspfx_host_alloc): copies from pageable memory are staged by the runtime and do not overlap
-    if (fused_only && !pipe_off && N >= 2 * part && is_pinned_host(in) && is_pinned_host(out) && (!side || is_pinned_host(side))) {
-        if (!e->hs_in) {
-            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_in, hipStreamNonBlocking));
-            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_out, hipStreamNonBlocking));
-            HIPCHK(e, hipStreamCreateWithFlags(&e->hs_run, hipStreamNonBlocking));
-        }
-        {   // the parts run on the engine's own stream: order it behind whatever used the state last
-            const int brc = bind_stream(e, e->hs_run);
-            if (brc) return brc;
-        }
-        const uint32_t n_parts = (N + part - 1) / part;
-        while (e->hev.size() < 2 * (size_t)n_parts) {
-            hipEvent_t ev = nullptr;
-            HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-            e->hev.push_back(ev);
-        }
-        const size_t pitch = (size_t)N * sizeof(float);
-        int rc = DSPFX_OK;
-        for (uint32_t p = 0; p < n_parts && rc == DSPFX_OK; ++p) {
-            const uint32_t c0 = p * part, cn = std::min(part, N - c0);
-            const size_t width = (size_t)cn * sizeof(float);
-            HIPCHK(e, hipMemcpy2DAsync(e->h_in + c0, pitch, in + c0, pitch, width, n_frames, hipMemcpyHostToDevice, e->hs_in));
-            if (side) HIPCHK(e, hipMemcpy2DAsync(e->h_side + c0, pitch, side + c0, pitch, width, n_frames, hipMemcpyHostToDevice, e->hs_in));
-            HIPCHK(e, hipEventRecord(e->hev[2 * p], e->hs_in));
-            HIPCHK(e, hipStreamWaitEvent(e->hs_run, e->hev[2 * p], 0));
-            e->win_c0 = c0;
-            e->win_n = cn;
-            e->win_last = p + 1 == n_parts;
-            if (mix) e->partials_override = e->mixpart;   // every part leaves its waves' partial sums; reduced once below
-            rc = run_subblock(e, e->h_in, side ? e->h_side : nullptr, e->h_out, nullptr, n_frames, n_frames, e->hs_run);
-            e->partials_override = nullptr;
-            e->win_c0 = 0;
-            e->win_n = 0;
-            e->win_last = true;
-            if (rc) break;
-            HIPCHK(e, hipEventRecord(e->hev[2 * p + 1], e->hs_run));
-            HIPCHK(e, hipStreamWaitEvent(e->hs_out, e->hev[2 * p + 1], 0));
-            HIPCHK(e, hipMemcpy2DAsync(out + c0, pitch, e->h_out + c0, pitch, width, n_frames, hipMemcpyDeviceToHost, e->hs_out));
-        }
-        if (rc == DSPFX_OK && mix) {
-            launch_mix_reduce(e->mixpart, e->mixpart_b, e->h_mix, n_frames, e->part_stride[e->flip], e->hs_run);
-            HIPCHK(e, hipMemcpyAsync(mix, e->h_mix, n_frames * sizeof(float), hipMemcpyDeviceToHost, e->hs_run));
-        }
-        (void)hipStreamSynchronize(e->hs_in);
-        (void)hipStreamSynchronize(e->hs_run);
-        HIPCHK(e, hipStreamSynchronize(e->hs_out));
-        if (rc == DSPFX_OK) e->frames_submitted += n_frames;
-        return rc;
-    }
-    HIPCHK(e, hipMemcpy(e->h_in, in, bytes, hipMemcpyHostToDevice));
-    if (side) HIPCHK(e, hipMemcpy(e->h_side, side, bytes, hipMemcpyHostToDevice));
-    const int rc = dspfx_process(e, e->h_in, side ? e->h_side : nullptr, e->h_out, mix ? e->h_mix : nullptr,
-                                 n_frames, nullptr);
-    if (rc) return rc;
-    HIPCHK(e, hipStreamSynchronize(nullptr));
-    HIPCHK(e, hipMemcpy(out, e->h_out, bytes, hipMemcpyDeviceToHost));
-    if (mix) HIPCHK(e, hipMemcpy(mix, e->h_mix, n_frames * sizeof(float), hipMemcpyDeviceToHost));
-    return DSPFX_OK;
-}
-
 extern "C" int dspfx_process_partials(dspfx_engine *e, const float *in, const float *side, float *out,
                                       uint32_t n_frames, void *stream) {
     if (!e) return DSPFX_ERR_INVALID;
@@ -1674,305 +1210,3 @@ extern "C" int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, 
     return DSPFX_OK;
 }
 
-// -------------------------------------------------------------------- state
-
-extern "C" int dspfx_link_average(dspfx_engine *e, const float *const *srcs, int n_srcs, float *dst, uint32_t n_frames,
-                                  void *stream) {
-    if (!e) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    if (!dst || n_srcs < 0 || (n_srcs > 0 && !srcs)) return fail(e, DSPFX_ERR_INVALID, "bad link list");
-    if (n_srcs > DSPFX_MAX_LINKS) return fail(e, DSPFX_ERR_UNSUPPORTED, "more than %d links into one port", DSPFX_MAX_LINKS);
-    if (n_frames == 0) return DSPFX_OK;
-    if (n_frames > e->desc.max_frames) return fail(e, DSPFX_ERR_INVALID, "n_frames %u > max_frames %u", n_frames, e->desc.max_frames);
-    for (int k = 0; k < n_srcs; ++k)
-        if (!srcs[k]) return fail(e, DSPFX_ERR_INVALID, "link %d is null", k);
-    HIPCHK(e, hipSetDevice(e->device));
-    LinkAvgArgs a;
-    memset(&a, 0, sizeof a);
-    for (int k = 0; k < n_srcs; ++k) a.src[k] = srcs[k];
-    a.n_srcs = n_srcs;
-    a.dst = dst;
-    a.count = (size_t)n_frames * e->desc.channels;   // element-wise: the same in either layout
-    a.div = dspfx_link_divisor((uint64_t)n_srcs);
-    launch_link_average(a, (hipStream_t)stream);
-    HIPCHK(e, hipGetLastError());
-    return DSPFX_OK;
-}
-
-extern "C" int64_t dspfx_state_size(const dspfx_engine *e, int node) {
-    if (!e) return DSPFX_ERR_INVALID;
-    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
-    if (node < 0 || node >= (int)e->nodes.size()) return DSPFX_ERR_INVALID;
-    const Node &n = e->nodes[(size_t)node];
-    if (n.d.kind == DSPFX_FIR) return (int64_t)fir_state_bytes(n.fir);
-    if (n.d.kind == DSPFX_REVERB) return (int64_t)n.D * e->desc.channels * (int64_t)sizeof(float);   // canonical [D][N]
-    return (int64_t)n.state_bytes;
-}
-
-extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, size_t size) {
-    if (!e || !host_dst) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
-    Node &n = e->nodes[(size_t)node];
-    const int64_t need = dspfx_state_size(e, node);
-    if ((int64_t)size != need) return fail(e, DSPFX_ERR_INVALID, "state size %zu != %lld", size, (long long)need);
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipDeviceSynchronize());
-    if (n.d.kind == DSPFX_FIR) {
-        const int rc = fir_state_export(n.fir, host_dst);
-        return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
-    }
-    if (n.d.kind == DSPFX_REVERB)   // canonical form: [D][N], row 0 = the oldest sample
-        return ring_rows_copy(e, n, n.pos, n.D, (char *)host_dst, true);
-    if (need) HIPCHK(e, hipMemcpy(host_dst, n.state, (size_t)need, hipMemcpyDeviceToHost));
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_src, size_t size) {
-    if (!e || !host_src) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    if (node < 0 || node >= (int)e->nodes.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);
-    Node &n = e->nodes[(size_t)node];
-    // a FIR node's blob carries its own length (the deque's, which need not be this engine's current one)
-    const int64_t need = n.d.kind == DSPFX_FIR ? fir_state_import_bytes(n.fir, host_src, size) : dspfx_state_size(e, node);
-    if ((int64_t)size != need) return fail(e, DSPFX_ERR_INVALID, "state size %zu != %lld", size, (long long)need);
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipDeviceSynchronize());
-    if (n.d.kind == DSPFX_FIR) {
-        const int rc = fir_state_import(n.fir, host_src);
-        return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
-    }
-    if (n.d.kind == DSPFX_REVERB) {
-        const int rc = ring_rows_copy(e, n, 0, n.D, (char *)const_cast<void *>(host_src), false);
-        if (rc) return rc;
-    } else if (need) {
-        HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
-    }
-    n.pos = 0;
-    return settle_null_stream(e);
-}
-
-// ---------------------------------------------------------------- utilities
-
-extern "C" int dspfx_fill_noise(dspfx_engine *e, float *dst, uint32_t n_frames, uint32_t n_abs0, uint32_t seed,
-                                void *stream) {
-    if (!e || !dst) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    Layout lay{};
-    if (e->desc.tile_channels) {
-        const uint32_t W = e->desc.tile_channels;
-        lay = Layout{(unsigned)__builtin_ctz(W), W - 1, W, 0, (size_t)n_frames * W};
-    } else {
-        lay = Layout{31, 0x7fffffffu, e->desc.channels, 0, 0};
-    }
-    launch_noise(dst, e->desc.channels, n_frames, (uint32_t)e->desc.channel_offset, n_abs0, seed, lay,
-                 (hipStream_t)stream);
-    HIPCHK(e, hipGetLastError());
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_sync(dspfx_engine *e, void *stream) {
-    if (!e) return DSPFX_ERR_INVALID;
-    HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipStreamSynchronize((hipStream_t)stream));
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_verify_fast_division(int device, float c, uint64_t *mismatches) {
-    if (!mismatches) return DSPFX_ERR_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
-    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return DSPFX_ERR_INVALID;
-    unsigned long long *d = nullptr, h = 0;
-    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return DSPFX_ERR_OOM;
-    int rc = DSPFX_ERR_HIP;
-    if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
-        hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-        *mismatches = h;
-        rc = DSPFX_OK;
-    }
-    (void)hipFree(d);
-    return rc;
-}
-
-extern "C" int dspfx_verify_libm(int device, int func, uint64_t *mismatches, uint32_t *max_ulp) {
-    if (!mismatches || !max_ulp || func < 0 || func > 64) return DSPFX_ERR_INVALID;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
-    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return DSPFX_ERR_INVALID;
-    unsigned long long *d = nullptr, h[2] = {0, 0};
-    if (hipMalloc((void **)&d, sizeof h) != hipSuccess) return DSPFX_ERR_OOM;
-    int rc = DSPFX_ERR_HIP;
-    if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_libm_on_device(func, d, nullptr) == 0 &&
-        hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
-        *mismatches = h[0];
-        *max_ulp = (uint32_t)std::min<unsigned long long>(h[1], 0xffffffffull);
-        rc = DSPFX_OK;
-    }
-    (void)hipFree(d);
-    return rc;
-}
-
-extern "C" int dspfx_profile_enable(dspfx_engine *e, int enable) {
-    if (!e) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    e->profiling = enable != 0;
-    if (enable > 0) {   // `enable` doubles as a hint: events for that many launches are created now,
-        HIPCHK(e, hipSetDevice(e->device));   // outside the timed region (hipEventCreate is slow)
-        while (e->ev_pool.size() < 2u * (size_t)enable * std::max<size_t>(1, e->stages.size())) {
-            hipEvent_t ev = nullptr;
-            HIPCHK(e, hipEventCreate(&ev));
-            e->ev_pool.push_back(ev);
-        }
-    }
-    return DSPFX_OK;
-}
-
-extern "C" int dspfx_profile_read(dspfx_engine *e, double *total_ms, uint32_t *launches, char *kernel_name,
-                                  size_t cap, int reset) {
-    if (!e) return DSPFX_ERR_INVALID;
-    ApiScope api(e);
-    if (api.rc) return api.rc;
-    double best = -1.0;
-    uint32_t best_n = 0;
-    size_t best_stage = 0;
-    for (size_t si = 0; si < e->prof.size(); ++si) {
-        double tot = 0.0;
-        for (auto &p : e->prof[si]) {
-            HIPCHK(e, hipEventSynchronize(p.second));
-            float ms = 0.0f;
-            HIPCHK(e, hipEventElapsedTime(&ms, p.first, p.second));
-            tot += ms;
-        }
-        if (tot > best) {
-            best = tot;
-            best_n = (uint32_t)e->prof[si].size();
-            best_stage = si;
-        }
-    }
-    if (total_ms) *total_ms = best < 0 ? 0.0 : best;
-    if (launches) *launches = best_n;
-    if (kernel_name && cap) {
-        const char *nm = "";
-        if (best_stage < e->stages.size()) {
-            const Stage &st = e->stages[best_stage];
-            nm = st.type == ST_FUSED ? (st.var ? st.var->name : "fused")
-                 : st.type == ST_FUZZ ? "fuzz_kernel" : fir_kernel_name(e->nodes[(size_t)st.first].fir);
-        }
-        snprintf(kernel_name, cap, "%s", nm);
-    }
-    if (reset) {
-        for (auto &st : e->prof) {
-            for (auto &p : st) {
-                e->ev_pool.push_back(p.first);
-                e->ev_pool.push_back(p.second);
-            }
-            st.clear();
-        }
-    }
-    return DSPFX_OK;
-}
-
-extern "C" double dspfx_algorithmic_bytes_per_sample(const dspfx_engine *e, uint32_t n_frames) {
-    // 4 B in + 4 B out, + 8 B per delay line (tap read + write),
-    // + per-block state traffic / n_frames, + 4 B side input for ADD/MIX,
-    // FIR: + 4 B history write + 4*(T-1)/n_frames history re-read.
-    if (!e || n_frames == 0) return 0.0;
-    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
-    double b = 8.0;
-    bool side = false;
-    for (const Node &n : e->nodes) {
-        switch (n.d.kind) {
-        case DSPFX_BIQUAD: b += 32.0 / n_frames; break;
-        case DSPFX_LOW_PASS:
-        case DSPFX_HIGH_PASS:
-        case DSPFX_SIGNAL_GEN:
-        case DSPFX_ENVELOPE: b += 8.0 / n_frames; break;
-        case DSPFX_REVERB: b += 8.0; break;
-        case DSPFX_FIR: b += 4.0 + 4.0 * ((double)n.taps.size() - 1.0) / n_frames; break;
-        case DSPFX_ADD:
-        case DSPFX_MIX: side = true; break;
-        default: break;
-        }
-    }
-    if (side && !e->graph_mode) b += 4.0;   // a fused graph's "b" ports are fed from registers
-    if (e->graph_mode) {                    // ... and a graph reads / writes exactly the blocks its links name
-        unsigned in_mask = 0;
-        int n_out = 1;
-        for (const dspfx_graph_link &l : e->wiring) {
-            if (graph_input_block(l.src) >= 0) in_mask |= 1u << graph_input_block(l.src);
-            n_out = std::max(n_out, l.dst - (int)e->nodes.size() + 1);
-        }
-        b -= 4.0;                           // `in` was counted above
-        b += 4.0 * __builtin_popcount(in_mask) + 4.0 * (n_out - 1);
-    }
-    return b;
-}
-
-extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
-    if (!e || !dst || cap == 0) return DSPFX_ERR_INVALID;
-    std::lock_guard<std::recursive_mutex> lk(e->api_mu);
-    static const char *kn[] = {"gain", "biquad", "low_pass", "high_pass", "reverb", "distort", "overdrive",
-                               "chebyshev", "fir", "add", "mix", "signal_gen", "envelope"};
-    std::string s;
-    char buf[256];
-    snprintf(buf, sizeof buf, "engine: N=%u max_frames=%u link_flags=%u\n", e->desc.channels, e->desc.max_frames,
-             e->desc.link_flags);
-    s += buf;
-    for (size_t i = 0; i < e->stages.size(); ++i) {
-        const Stage &st = e->stages[i];
-        if (st.type == ST_FUSED) {
-            snprintf(buf, sizeof buf, "stage %zu: fused kernel %s (F=%d, CPL=%d", i, st.var ? st.var->name : "?",
-                     st.var ? st.var->f : 0, st.var ? st.var->cpl : 0);
-            s += buf;
-            if (st.var && !st.var->launch) {   // compiled at run time: say what the compiler allocated
-                snprintf(buf, sizeof buf, ", %d VGPRs", reinterpret_cast<const JitKernel *>(st.var)->vgprs);
-                s += buf;
-            }
-            if (st.var_ts) {
-                snprintf(buf, sizeof buf, "; %d-frame blocks: time-sliced %s", 4 * st.var_ts->ts, st.var_ts->name);
-                s += buf;
-            }
-            if (st.var_ts_tail) {
-                snprintf(buf, sizeof buf, "; channels left over, %d-frame blocks: %s", 4 * st.var_ts_tail->ts, st.var_ts_tail->name);
-                s += buf;
-            }
-            s += "):";
-            for (int k = 0; k < st.count; ++k) {
-                s += " ";
-                s += kn[e->nodes[(size_t)(st.first + k)].d.kind];
-            }
-            if (st.count == 0 && i > 0 && e->stages[i - 1].type == ST_FIR)
-                s += " (mix bus only; not launched for whole blocks: the FIR sweep leaves the bus' partial sums)";
-            s += "\n";
-        } else if (st.type == ST_FUZZ) {
-            snprintf(buf, sizeof buf, "stage %zu: fuzz kernel\n", i);
-            s += buf;
-        } else {
-            snprintf(buf, sizeof buf, "stage %zu: fir kernel %s (T=%zu)\n", i,
-                     fir_kernel_name(e->nodes[(size_t)st.first].fir), e->nodes[(size_t)st.first].taps.size());
-            s += buf;
-        }
-    }
-    for (size_t i = 0; i < e->nodes.size(); ++i)
-        if (!e->nodes[i].groups.empty()) {
-            snprintf(buf, sizeof buf, "node %zu delay ring: %zu groups x %zu MiB, %d re-placed by the placement probe\n", i,
-                     e->nodes[i].groups.size(), (e->nodes[i].group_floats * sizeof(float)) >> 20, e->nodes[i].ring_replaced);
-            s += buf;
-            if (getenv("DSPFX_DESCRIBE_GROUPS"))
-                for (size_t g = 0; g < e->nodes[i].groups.size(); ++g) {
-                    snprintf(buf, sizeof buf, "  group %zu @%p\n", g, (void *)e->nodes[i].groups[g]);
-                    s += buf;
-                }
-        }
-    if (e->jit_unavailable)
-        s += "note: a run-time specialised kernel was wanted but could not be compiled (chain_kernels.hip.h not found next to the "
-             "library -- DSPFX_KERNEL_HEADERS names its directory -- or hiprtc unavailable): the interpreting kernels serve, 7-25 % slower\n";
-    snprintf(dst, cap, "%s", s.c_str());
-    return DSPFX_OK;
-}

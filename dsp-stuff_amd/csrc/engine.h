@@ -1,6 +1,9 @@
 // engine.h -- what the translation units of libdspfx.so share: the engine object behind the C ABI (include/dspfx.h) and the
 // host-side functions that more than one of them calls.
-//   dspfx.hip      lifecycle, parameter stores, the process calls (stage planning, launches), DSP state, utilities
+//   dspfx.hip      lifecycle, parameter stores, run_subblock and the process calls
+//   plan.hip       which kernels serve a chain: exact-division decision, variant selection, background specialisation, plan()
+//   host_pipe.hip  dspfx_process_host (pinned staging, overlapped upload / kernel / download) and its allocator
+//   state_util.hip DSP state export / import, fan-in averaging, utilities (noise, checks, profiling read-out, dspfx_describe)
 //   jit.hip        run-time specialisation (hiprtc) of the chain kernels and the generator of whole-graph kernels
 //   placement.hip  delay-ring placement tuning (setup-time probe, dspfx_tune_placement)
 //   comm.hip       the mix bus across GPUs: RCCL through dlopen, dspfx_comm_*, dspfx_mix_allreduce
@@ -249,6 +252,9 @@ void async_jit_submit(const std::shared_ptr<AsyncJit> &job);   // jit.hip: backg
 void async_jit_wait(const std::shared_ptr<AsyncJit> &job);     // ... until the compiler is not working on `job` (bounded)
 int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
 int plan(dspfx_engine *e);
+void collect_variants(std::vector<const Variant *> &out);
+void adopt_async_jit(dspfx_engine *e, const Stage &st);      // plan.hip: run_subblock calls it at a block boundary
+int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *host, bool to_host);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
                  hipStream_t stream);
 int bind_stream(dspfx_engine *e, hipStream_t s);

@@ -1,0 +1,365 @@
+// plan.hip -- which kernels serve a chain: the exact-division decision, variant selection (compiled in, specialised at run
+// time, time-sliced, the guarded form for channels left over), the background specialisation of small engines, and plan(),
+// which cuts the chain into stages.  See engine.h for the split.
+#include "engine.h"
+
+using namespace dspfx;
+using namespace dspfx_host;
+
+namespace dspfx_host {
+
+
+// Is (float)((double)x * RN_f64(1/c)) == x / c for every f32 x?  (div_c in chain_kernels.hip.h has the argument.)
+//   * c not an even integer, or a power of two: yes, by the theorem there -- decided here, no device involved, so a
+//     slider store, a fan-in divisor f32(0.0001 + k) or dspfx_graph_source never launch anything;
+//   * c an even integer that is not a power of two (6, 10, 12, ... -- exact ties exist among its subnormal quotients):
+//     the exhaustive 2^32-input check decides, on the CURRENT device (plan() selects the engine's device first).  Only
+//     COMPLETED checks are cached: a HIP failure answers "not fast" for this call and is asked again next time;
+//     have_device = false only consults the cache.
+// DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; read per call so a test can flip it between engines).
+bool divisor_is_fast(float c, bool have_device) {
+    static std::mutex mu;
+    static std::map<uint32_t, bool> cache;
+    if (const char *fd = getenv("DSPFX_FAST_DIV"))
+        if (atoi(fd) == 0) return false;
+    if (!(c == c) || c == 0.0f || std::isinf(c)) return false;
+    const float ac = fabsf(c), half = ac * 0.5f;
+    int ex = 0;
+    const bool even_integer = ac >= 2.0f && half == floorf(half);
+    const bool pow2 = frexpf(ac, &ex) == 0.5f;
+    if (!even_integer || pow2) return true;
+    uint32_t bits;
+    memcpy(&bits, &c, 4);
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(bits);
+    if (it != cache.end()) return it->second;
+    if (!have_device) return false;
+    bool done = false, ok = false;
+    unsigned long long *d = nullptr, h = 1;
+    if (hipMalloc((void **)&d, sizeof h) == hipSuccess) {
+        if (hipMemset(d, 0, sizeof h) == hipSuccess && verify_divisor_on_device(c, 1.0 / (double)c, d, nullptr) == 0 &&
+            hipMemcpy(&h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+            done = true;
+            ok = h == 0;
+        }
+        (void)hipFree(d);
+    }
+    if (!done) {
+        (void)hipGetLastError();
+        return false;
+    }
+    cache[bits] = ok;
+    return ok;
+}
+
+bool node_divisors_fast(const Node &n, bool have_device) {
+    if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
+        if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
+        if (!divisor_is_fast(n.d.params[0], have_device)) return false;
+        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f, have_device)) return false;
+    }
+    return true;
+}
+
+bool fusable(const Node &n) {
+    if (n.d.kind == DSPFX_FIR) return false;
+    if (n.d.kind == DSPFX_DISTORT && n.d.mode == DSPFX_DIST_FUZZ) return false;
+    return true;
+}
+
+int node_hop(const dspfx_engine *e, int idx) {
+    return idx == 0 ? ((e->desc.link_flags & DSPFX_LINK_INPUT) ? 1 : 0)
+                    : ((e->desc.link_flags & DSPFX_LINK_INTERNAL) ? 1 : 0);
+}
+
+void collect_variants(std::vector<const Variant *> &out) {
+    int n = 0;
+    const Variant *v = variants_dyn(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+    v = variants_static3(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+    v = variants_static5(&n);
+    for (int i = 0; i < n; ++i) out.push_back(v + i);
+}
+
+Pref read_pref() {
+    Pref p;
+    const char *s = getenv("DSPFX_VARIANT");
+    if (!s) return p;
+    const char *q;
+    if ((q = strstr(s, "f="))) p.f = atoi(q + 2);
+    if ((q = strstr(s, "cpl="))) p.cpl = atoi(q + 4);
+    if ((q = strstr(s, "static="))) p.stat = atoi(q + 7);
+    return p;
+}
+
+bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device) {
+    if (!divisor_is_fast(e->hop_div, have_device)) return false;
+    for (int i = 0; i < st.count; ++i)
+        if (!node_divisors_fast(e->nodes[st.first + i], have_device)) return false;
+    return true;
+}
+
+bool node_needs_libm(const Node &n) {
+    if (n.d.kind == DSPFX_OVERDRIVE || n.d.kind == DSPFX_CHEBYSHEV || n.d.kind == DSPFX_SIGNAL_GEN) return true;
+    return n.d.kind == DSPFX_DISTORT &&
+           (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
+}
+
+const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    const Pref pref = read_pref();
+    const uint32_t N = e->desc.channels;
+    const Variant *best = nullptr;
+    int best_score = -1;
+    for (const Variant *v : all) {
+        if (v->guard || v->mod || v->ts) continue;
+        const bool is_dyn = v->sigs[0] == SIG_DYN;
+        if (is_dyn) {
+            bool need = false;
+            for (int i = 0; i < st.count; ++i) need = need || node_needs_libm(e->nodes[st.first + i]);
+            if (v->libm != need) continue;
+        }
+        if (!is_dyn) {
+            if (pref.stat == 0) continue;
+            if (!st.fast_div) continue;          // static kernels are built with the fast division only
+            if (v->n_slots != st.count) continue;
+            bool ok = true;
+            for (int i = 0; i < st.count && ok; ++i) {
+                const Node &n = e->nodes[st.first + i];
+                const int mode = n.d.kind == DSPFX_DISTORT ? n.d.mode : 0;
+                ok = v->sigs[i] == sig(n.d.kind, mode, node_hop(e, st.first + i));
+            }
+            if (!ok) continue;
+        }
+        if (!is_dyn || v->cpl > 1) {     // the one-channel interpreter is the fallback for every N (the tail launch covers N < 64)
+            if (N % (64u * v->cpl) != 0 && N < 64u * v->cpl) continue;
+            if (N % v->cpl != 0) continue;   // vector loads need aligned rows
+        }
+        int score = is_dyn ? 0 : 100;
+        // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
+        // Few channels (<= 2 waves per SIMD at one channel per lane): nothing hides a wave's memory latency, so
+        // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
+        const bool few = N <= 131072u;
+        const int want_f = (few && !is_dyn) ? 16 : 8;
+        // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
+        // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
+        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
+        if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
+        if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
+        if (score > best_score) {
+            best_score = score;
+            best = v;
+        }
+    }
+    // no compiled-in specialisation: instantiate one at run time (large engines, or DSPFX_JIT=1)
+    if (best && best->sigs[0] == SIG_DYN && pref.stat != 0)
+        if (const Variant *j = jit_variant(e, st, false)) return j;
+    return best;
+}
+
+// Few channels (at most two waves per SIMD at one channel per lane): the time-sliced kernel of the same chain shape, if the
+// library has one.  DSPFX_VARIANT="ts=0" switches it off, "ts=1" forces it at any size (A/B runs).
+const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    int want = -1;
+    if (const char *sv = getenv("DSPFX_VARIANT"))
+        if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
+    // Measured crossover against the standard kernels (profiles/r02_small_n.txt): 81920 channels for chains of up to three
+    // nodes, 65536 for longer ones (more registers per wave, fewer co-resident workgroups).
+    const uint32_t ts_max = st.count <= 3 ? TS_MAX_CHANNELS : 65536u;
+    if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    const Pref pref = read_pref();
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    const Variant *best = nullptr;
+    for (const Variant *v : all) {
+        if (!v->ts || v->guard || v->n_slots != st.count || N < 64u * (unsigned)v->cpl || N % (unsigned)v->cpl) continue;
+        bool ok = true;
+        for (int i = 0; i < st.count && ok; ++i) {
+            const Node &n = e->nodes[st.first + i];
+            const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+            ok = v->sigs[i] == sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+        }
+        if (!ok) continue;
+        // two channels per lane (half the load / store instructions per byte) once there are still two workgroups per CU
+        // at that width and the chain is short enough for the doubled registers: 3-node chain at 65536 channels 29.0 -> 27.6 us
+        const int want_cpl = pref.cpl > 0 ? pref.cpl : (st.count <= 3 && N >= 57344u ? 2 : 1);
+        if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
+    }
+    if (best) return best;
+    // no compiled-in time-sliced kernel for this chain shape: instantiate one at run time, like the standard kernel
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0 || N % 64u) return nullptr;
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true);
+    return k ? &k->var : nullptr;
+}
+
+// The channels a whole-wave launch leaves over (N % (64 cpl) of them) used to go through ONE wave per 64 channels of the
+// guarded interpreter, walking the block chunk by chunk on an otherwise idle chip: 43 us behind every block, at any N.
+// For blocks of exactly 128 frames the guarded time-sliced kernel of the same chain shape takes them instead -- four slices in
+// parallel, every load issued at once -- when the library has one or the run-time compiler is in use for this engine.
+// DSPFX_TS_TAIL=0 keeps the interpreter (A/B runs, tests: bit-identical).
+const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const char *off = getenv("DSPFX_TS_TAIL");
+    if ((off && atoi(off) == 0) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    unsigned cpl = st.var ? (unsigned)st.var->cpl : 1u;
+    if (st.var_ts) cpl = std::max(cpl, (unsigned)st.var_ts->cpl);
+    if (N % (64u * cpl) == 0) return nullptr;          // no launch of this engine leaves channels over
+    int sigs[MAX_SLOTS];
+    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    std::vector<const Variant *> all;
+    collect_variants(all);
+    for (const Variant *v : all) {
+        if (!v->ts || !v->guard || v->n_slots != st.count) continue;
+        bool ok = true;
+        for (int i = 0; i < MAX_SLOTS && ok; ++i) ok = v->sigs[i] == sigs[i];
+        if (ok) return v;
+    }
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const Pref pref = read_pref();
+    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0) return nullptr;
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true);
+    return k ? &k->var : nullptr;
+}
+
+// A small engine on the interpreter: have its chain shape specialised in the background (jit.hip) and adopt the kernels
+// when they are ready.  Engines from JIT_MIN_CHANNELS on got theirs synchronously in pick_variant.
+void request_async_jit(const dspfx_engine *e, const Stage &st) {
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
+    if ((jit_env && atoi(jit_env) != -1) || (async_env && atoi(async_env) == 0)) return;     // forced on (synchronous) or off
+    if (e->graph_mode || !st.var || st.var->sigs[0] != SIG_DYN || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return;
+    if (N >= JIT_MIN_CHANNELS || read_pref().stat == 0 || getenv("DSPFX_VARIANT")) return;
+    auto job = std::make_shared<AsyncJit>();
+    job->device = e->device;
+    job->n_slots = st.count;
+    for (int i = 0; i < MAX_SLOTS; ++i) job->sigs[i] = SIG_NONE;
+    for (int i = 0; i < st.count; ++i) {
+        const Node &n = e->nodes[st.first + i];
+        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
+        job->sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
+    }
+    job->want_ts = N >= 64u;
+    const char *tail_env = getenv("DSPFX_TS_TAIL");
+    job->want_tail = N % 64u != 0 && !(tail_env && atoi(tail_env) == 0);
+    st.async = job;
+    async_jit_submit(job);
+}
+
+// run_subblock, at a block boundary: the background compiler is done with this stage's shape
+void adopt_async_jit(dspfx_engine *e, const Stage &st) {
+    const std::shared_ptr<AsyncJit> job = st.async;
+    st.async.reset();
+    if (job->ready.load(std::memory_order_acquire) < 0 || !job->k_std) {
+        e->jit_unavailable = true;
+        return;
+    }
+    st.var = &job->k_std->var;
+    if (job->k_ts) st.var_ts = &job->k_ts->var;
+    if (job->k_tail) st.var_ts_tail = &job->k_tail->var;
+}
+
+// Chain engines: may a fusable run of more than MAX_SLOTS nodes become one generated kernel?  The conditions of the
+// run-time specialised chain kernels (jit_variant), whole waves only, and not after control ports were used (those are
+// evaluated by the chain kernels).
+bool long_stage_wanted(const dspfx_engine *e) {
+    if (e->no_long) return false;
+    const uint32_t N = e->desc.channels;
+    const char *jit_env = getenv("DSPFX_JIT");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    if (!(jit_mode == 1 || (jit_mode != 0 && N > 131072u))) return false;
+    if (read_pref().stat == 0) return false;
+    return N % 64u == 0;
+}
+
+int plan(dspfx_engine *e) {
+    HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
+    for (const Stage &st : e->stages)
+        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
+    e->stages.clear();
+    e->jit_unavailable = false;
+    e->has_fuzz = false;
+    e->has_siggen = false;
+    e->min_delay = 0xffffffffu;
+    const int n = (int)e->nodes.size();
+    int i = 0;
+    while (i < n) {
+        Stage st{};
+        if (fusable(e->nodes[i])) {
+            st.type = ST_FUSED;
+            st.first = i;
+            int limit = e->graph_mode ? GRAPH_SLOTS : MAX_SLOTS;
+            if (!e->graph_mode && long_stage_wanted(e)) {
+                // A fusable run longer than one chain launch holds: up to GRAPH_SLOTS of its nodes become one generated
+                // kernel (the chain as a graph) instead of two chain launches with a round trip through memory in
+                // between (12 nodes: 0.575 -> 0.429 ms).  Add / Mix read the engine's side input from memory, which
+                // that kernel does not do: a run with one of them is cut as before.
+                int j = i;
+                bool mixers = false;
+                while (j < n && fusable(e->nodes[j]) && j - i < GRAPH_SLOTS) {
+                    mixers = mixers || e->nodes[j].d.kind == DSPFX_ADD || e->nodes[j].d.kind == DSPFX_MIX;
+                    ++j;
+                }
+                if (j - i > MAX_SLOTS && !mixers) limit = GRAPH_SLOTS;
+            }
+            while (i < n && fusable(e->nodes[i]) && i - st.first < limit) ++i;
+            st.count = i - st.first;
+        } else {
+            st.type = e->nodes[i].d.kind == DSPFX_FIR ? ST_FIR : ST_FUZZ;
+            st.first = i;
+            st.count = 1;
+            ++i;
+        }
+        e->stages.push_back(st);
+    }
+    // the mix bus is reduced in the epilogue of a fused stage: make sure one is last
+    if (e->stages.empty() || e->stages.back().type != ST_FUSED) {
+        Stage st{};
+        st.type = ST_FUSED;
+        st.first = n;
+        st.count = 0;
+        e->stages.push_back(st);
+    }
+    if (e->graph_mode && (e->stages.size() != 1 || e->stages[0].type != ST_FUSED || e->stages[0].count != n))
+        return fail(e, DSPFX_ERR_UNSUPPORTED, "graph has a node that cannot be fused (FIR, Fuzz) or more than %d nodes", GRAPH_SLOTS);
+    for (Stage &st : e->stages)
+        if (st.type == ST_FUSED) {
+            st.fast_div = stage_fast_div(e, st);
+            st.var = (e->graph_mode || st.count > MAX_SLOTS) ? graph_variant(e, st) : pick_variant(e, st);
+            if (!st.var && !e->graph_mode && st.count > MAX_SLOTS) {   // no run-time compiler: cut the run as usual
+                e->no_long = true;
+                return plan(e);
+            }
+            if (!st.var)
+                return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
+                                                                    : "no kernel variant for stage");
+            st.var_ts = e->graph_mode ? nullptr : pick_ts_variant(e, st);
+            st.var_ts_tail = e->graph_mode ? nullptr : pick_ts_tail_variant(e, st);
+            request_async_jit(e, st);
+        }
+    for (const Node &nd : e->nodes) {
+        if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;
+        if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
+        if (nd.d.kind == DSPFX_SIGNAL_GEN) e->has_siggen = true;
+    }
+    return DSPFX_OK;
+}
+
+}  // namespace dspfx_host
