@@ -570,3 +570,33 @@ def test_a_process_may_exit_while_its_shape_is_being_compiled():
     for k in range(4):
         r = subprocess.run([sys.executable, "-c", script, str(k)], capture_output=True, text=True, env=env, timeout=300)
         assert r.returncode == 0 and "leaving" in r.stdout, (k, r.returncode, r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("N,which,nf", [(4096, "chain3", 256), (100, "chain3", 384), (16384 + 64, "chain5", 256), (65536, "chain3", 256)])
+def test_longer_blocks_of_a_few_channel_engine_go_block_by_block(dspfx, torch_cuda, N, which, nf):
+    """A 256-frame call IS two reference blocks back to back (node.rs:257).  A few-channel engine sends it through
+    its time-sliced kernels 128 frames at a time instead of one launch of the standard kernel (2 x faster at 4096-32768
+    channels): the samples and the bus of the SAME frames as an engine that is given 128-frame calls, bit for bit."""
+    from chains import chain3
+    mk = (lambda: chain3(dspfx, 256)) if which == "chain3" else (lambda: chain5(dspfx, 384))
+    total = 768
+    x = O.noise(11, np.arange(N), np.arange(total))
+    outs = []
+    for block in (nf, 128):
+        eng = dspfx.Engine(N, nf, link_flags=3)
+        eng.set_chain(mk())
+        assert "time-sliced" in eng.describe()
+        ys, ms = [], []
+        for f0 in range(0, total, block):
+            dx = torch_cuda.from_numpy(np.ascontiguousarray(x[f0:f0 + block])).cuda()
+            dy, dm = torch_cuda.empty_like(dx), torch_cuda.zeros(block, device="cuda")
+            eng.process(dx, out=dy, mix=dm, n_frames=block)
+            ys.append(dy.cpu().numpy().reshape(block, N)); ms.append(dm.cpu().numpy())
+        outs.append((np.concatenate(ys), np.concatenate(ms)))
+    (y1, m1), (y0, m0) = outs
+    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+    assert np.array_equal(m1.view(np.uint32), m0.view(np.uint32))
+    if N <= 4096:
+        from chains import ulp_diff
+        ref = O.run_channels([n.oracle_desc() for n in mk()], x, 3)
+        assert int(ulp_diff(y1, ref).max()) <= 1
