@@ -1,6 +1,7 @@
 // jit.hip -- run-time specialisation of the chain kernels (hiprtc) and the generator of whole-graph kernels
 // (include/dspfx.h: dspfx_graph_set / dspfx_graph_source; csrc/graph_kernel.hip.h).  See engine.h for the split.
 #include "engine.h"
+#include <pthread.h>
 #include <chrono>
 
 using namespace dspfx;
@@ -153,7 +154,9 @@ struct AsyncCompiler {
             std::atexit(async_exit_handler);
         }
     }
+    bool forked = false;          // this process is a fork()ed child: the worker thread does not exist here
     void shutdown() {
+        if (forked) return;
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
@@ -180,8 +183,11 @@ void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
         // compiler's globals from under it.
         for (const char *name : {"libamd_comgr.so.3", "libamd_comgr.so"})
             if (dlopen(name, RTLD_NOW | RTLD_GLOBAL)) break;
+        // a fork()ed child inherits this object but not the thread: it must neither queue work for it nor join it at exit
+        (void)pthread_atfork(nullptr, nullptr, [] { if (g_async) g_async->forked = true; });
         std::atexit(async_exit_handler);       // registered after the HIP runtime's and the compiler's own handlers: runs before them
     });
+    if (g_async->forked) return;
     std::lock_guard<std::mutex> lk(g_async->mu);
     if (g_async->stop) return;
     if (!g_async->started) {
