@@ -198,8 +198,8 @@ struct GLink {
 
 // Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
 // shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
-// 128-frame block goes through the time-sliced kernel (profiles/r02_small_n.txt).
-constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 81920;
+// 128-frame block of a chain of up to three nodes goes through the time-sliced kernel (profiles/r03_small_n.txt).
+constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 98304;
 
 // ---- errors
 int fail(dspfx_engine *e, int code, const char *fmt, ...);

@@ -166,8 +166,9 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
     int want = -1;
     if (const char *sv = getenv("DSPFX_VARIANT"))
         if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
-    // Measured crossover against the standard kernels (profiles/r02_small_n.txt): 81920 channels for chains of up to three
-    // nodes, 65536 for longer ones (more registers per wave, fewer co-resident workgroups).
+    // Measured crossover against the standard kernels (tools/r03_ts_threshold.py, placement tuned, three engines each;
+    // profiles/r03_small_n.txt): 98304 channels for chains of up to three nodes (38.5 against 44.2 us there, a tie at 114688),
+    // 65536 for longer ones (more registers per wave, fewer co-resident workgroups: 32.8 against 33.7 us, a tie at 73728).
     const uint32_t ts_max = st.count <= 3 ? TS_MAX_CHANNELS : 65536u;
     if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     const Pref pref = read_pref();
