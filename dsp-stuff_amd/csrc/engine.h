@@ -200,6 +200,8 @@ struct GLink {
 // shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
 // 128-frame block of a chain of up to three nodes goes through the time-sliced kernel (profiles/r03_small_n.txt).
 constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 98304;
+// from here on the specialised standard kernels take two channels per lane in the tiled layout (below: one; plan.hip has the sweep)
+constexpr uint32_t STATIC_CPL2_MIN_CHANNELS = 229376;
 
 // ---- errors
 int fail(dspfx_engine *e, int code, const char *fmt, ...);

@@ -236,9 +236,9 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
         const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
         sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
     }
-    const int cpl = (e->desc.tile_channels && N > 131072u && N % 2u == 0) ? 2 : 1;
+    const int cpl = (e->desc.tile_channels && N >= STATIC_CPL2_MIN_CHANNELS && N % 2u == 0) ? 2 : 1;    // as pick_variant (plan.hip)
     if (N < 64u * (unsigned)cpl) return nullptr;
-    const int f = (N <= 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt)
+    const int f = (N < 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt, r03_small_n.txt)
     const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
     if (!k) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
     return k ? &k->var : nullptr;

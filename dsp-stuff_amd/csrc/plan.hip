@@ -141,11 +141,15 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         // defaults chosen from measurements on MI355X (profiles/): see DESIGN.md
         // Few channels (<= 2 waves per SIMD at one channel per lane): nothing hides a wave's memory latency, so
         // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
+        // Round 3 sweep of every compiled (F, CPL) at 114688 ... 262144 channels with tuned placement
+        // (tools/r03_midn_variants.py, profiles/r03_small_n.txt): F 16 only BELOW 131072 (5-node chain at 131072: 60.4 us at
+        // F 16, 53.6 at F 8), and one channel per lane up to ~229000 (163840 channels: 74.0 us at CPL 2, 63.3 at CPL 1;
+        // 196608: 79.8 / 75.7; 262144: 92.5 / 95.2 -- from there two channels per lane win).
         const bool few = N <= 131072u;
-        const int want_f = (few && !is_dyn) ? 16 : 8;
+        const int want_f = (N < 131072u && !is_dyn) ? 16 : 8;
         // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
         // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
-        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || few) ? 1 : 2);
+        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || N < STATIC_CPL2_MIN_CHANNELS) ? 1 : 2);
         if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
