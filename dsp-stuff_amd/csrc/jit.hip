@@ -406,7 +406,9 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     if (pref.cpl == 2 && can2) { const JitKernel *k = build(2); return k ? &k->var : nullptr; }
     if (pref.cpl == 1) { const JitKernel *k = build(1); return k ? &k->var : nullptr; }
     const JitKernel *k = nullptr;
-    if (e->desc.tile_channels && N > 131072u && can2) {
+    // (below STATIC_CPL2_MIN_CHANNELS one channel per lane wins as for the chain kernels: a 4-node LFO graph at 163840 /
+    // 196608 channels 0.079 / 0.084 ms at CPL 2, 0.063 / 0.069 at CPL 1; profiles/r03_small_n.txt)
+    if (e->desc.tile_channels && N >= STATIC_CPL2_MIN_CHANNELS && can2) {
         k = build(2);
         if (k && k->vgprs <= 128) return &k->var;
     }
