@@ -24,7 +24,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSPFX_LIB") or os.path.join(_HERE, "csrc", "libdspfx.so")
 
 BUF_SIZE = 128  # dsp-stuff/src/node.rs:257
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # dspfx_kind
 GAIN, BIQUAD, LOW_PASS, HIGH_PASS, REVERB, DISTORT, OVERDRIVE, CHEBYSHEV, FIR, ADD, MIX, SIGNAL_GEN, ENVELOPE = range(13)
@@ -290,11 +290,17 @@ def HighPass(ratio: float = 0.5) -> NodeSpec:
 
 def Reverb(seconds: Optional[float] = None, decay: float = 0.5, delay_samples: Optional[int] = None,
            page_round: bool = False) -> NodeSpec:
-    """nodes/reverb.rs: feedback delay.  `seconds` goes through reverb.rs:58; with neither
-    argument the node keeps make_buffer()'s 128-sample ring (reverb.rs:44-52)."""
+    """nodes/reverb.rs: feedback delay; params = [decay, seconds], mode bit 0 = page_round.
+      Reverb(seconds=s)         a restored node: refresh_seconds has run, the ring is reverb.rs:58's length for s;
+      Reverb()                  a node fresh from the menu: make_buffer()'s 128-sample ring (reverb.rs:44-52) under the default
+                                0.5 s slider -- its first slider change makes it a 24000-sample delay, like the reference's;
+      Reverb(delay_samples=D)   an explicit ring and no seconds slider: a slider change swaps in a zero ring of the same D.
+    Any set_param on the node -- decay included -- swaps in a NEW ZERO ring (reverb.rs:19, 55-71; include/dspfx.h)."""
     if delay_samples is None:
-        delay_samples = 128 if seconds is None else delay_len(seconds, page_round)
-    return NodeSpec(REVERB, [decay], delay_len=int(delay_samples))
+        if seconds is None:
+            return NodeSpec(REVERB, [decay, 0.5], mode=int(page_round), delay_len=128)
+        delay_samples = delay_len(seconds, page_round)
+    return NodeSpec(REVERB, [decay, 0.0 if seconds is None else float(seconds)], mode=int(page_round), delay_len=int(delay_samples))
 
 
 def Distort(level: float = 0.0, mode: int = SOFT_CLIP) -> NodeSpec:

@@ -63,7 +63,10 @@ def _node_from_cfg(typename: str, cfg: dict, page_round: bool) -> NodeSpec:
     except KeyError as e:
         raise DspConfigError(f"{typename} node lacks saved field {e}") from None
     if kind == REVERB:
-        return NodeSpec(REVERB, params, delay_len=delay_len(float(cfg["seconds"]), page_round))
+        # restore() sets the fields, then runs refresh_seconds (lib.rs:319-337): the ring has reverb.rs:58's length; the
+        # seconds slider travels with the node (params[1]) so that a later slider store refreshes to the same length
+        return NodeSpec(REVERB, params + [float(np.float32(cfg["seconds"]))], mode=int(bool(page_round)),
+                        delay_len=delay_len(float(cfg["seconds"]), page_round))
     if kind == DISTORT:
         mode = cfg.get("mode", "SoftClip")
         if mode not in DISTORT_MODES:
@@ -211,7 +214,10 @@ def dump_dspconfig(chain: List[NodeSpec], seconds_for_delay=None, faithful_lowpa
         for f, v in zip(fields, n.params):
             cfg[f] = float(np.float32(v))
         if n.kind == REVERB:
-            cfg["seconds"] = float(seconds_for_delay(n.delay_len) if seconds_for_delay else np.float32(n.delay_len / 48000.0))
+            if len(n.params) > 1 and n.params[1] > 0:          # the node carries its seconds slider: save that
+                cfg["seconds"] = float(np.float32(n.params[1]))
+            else:
+                cfg["seconds"] = float(seconds_for_delay(n.delay_len) if seconds_for_delay else np.float32(n.delay_len / 48000.0))
         if n.kind == DISTORT:
             cfg["mode"] = DISTORT_MODES[n.mode]
         if n.kind == SIGNAL_GEN:

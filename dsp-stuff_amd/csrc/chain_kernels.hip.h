@@ -58,7 +58,12 @@ struct SlotArgs {
     unsigned D;
     unsigned pos;
     int hop;     // apply collect_and_average (one pipe) to this node's input
-    int pad_;
+    // REVERB: the first zero_rows frames of this launch read their taps as +0.0 whatever the ring rows hold.  This is how a
+    // NEW zero-filled ring (Reverb::refresh_seconds, reverb.rs:55-71 -- run by the reference on every slider change of the
+    // node, dsp-stuff-derive/src/lib.rs:560-568 -- and dspfx_reset) costs nothing: the host counts D frames down from the
+    // clear instead of rewriting up to 94 GiB of rows; the launches keep overwriting the rows they read, so after D frames the
+    // ring holds only samples written since.  0 in steady state (one scalar compare per chunk).
+    unsigned zero_rows;
     double rc;   // DISTORT Hard/SoftClip: f64 1/level for the exact fast division (see div_c)
     // control ports (`as_input` sliders, dsp-stuff-derive/src/lib.rs:122-161), slider field order:
     const float *ctl[3];   // connected port: signal in the sample layout, else nullptr
@@ -705,9 +710,25 @@ __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, 
         load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(pre.row[f], cx.ring_off), pre.tap[f], cx.active);
     }
 }
+// A tap of frame cx.f0 + f that was written before the ring's last clear reads as the +0.0 the reference's new ring holds
+// (SlotArgs::zero_rows).  The compare is wave-uniform; the product with `decay` is still formed (0.0 * decay keeps the
+// reference's signs and NaNs).  A branch of its own so that the steady state pays one scalar compare per chunk.
+template <int F, int CPL>
+__device__ __forceinline__ void ring_zero_cleared(const SlotArgs &s, const Ctx &cx, float (&tap)[F][CPL]) {
+    const unsigned zr = s.zero_rows;
+    if (zr > cx.f0) {
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            const bool cleared = cx.f0 + (unsigned)f < zr;
+#pragma unroll
+            for (int j = 0; j < CPL; ++j) tap[f][j] = cleared ? 0.0f : tap[f][j];
+        }
+    }
+}
 template <int F, int CPL, bool GUARD>
-__device__ __forceinline__ void ring_apply(const SlotArgs &s, float (&v)[F][CPL], const RingPre<F, CPL> &pre, const Ctx &cx) {
+__device__ __forceinline__ void ring_apply(const SlotArgs &s, float (&v)[F][CPL], RingPre<F, CPL> &pre, const Ctx &cx) {
     const float decay = s.p[0];
+    ring_zero_cleared<F, CPL>(s, cx, pre.tap);
 #pragma unroll
     for (int f = 0; f < F; ++f) {
 #pragma unroll
@@ -1427,6 +1448,7 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         if constexpr (sig_hop(SL::v[I])) apply_hop<S, CPL, true>(v, cx.hop_div, cx.hop_rc);                      \
         const float decay = a.slot[I].p[0];                                                                      \
+        ring_zero_cleared<sig_is<K_REVERB>(SL::v[I]) ? S : 1, CPL>(a.slot[I], cx, tap##I);   /* taps from before the ring's last clear: +0.0 */ \
         _Pragma("unroll") for (int f = 0; f < S; ++f) {                                                          \
             _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
             store_vec<CPL, GUARD, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), v[f], active); \

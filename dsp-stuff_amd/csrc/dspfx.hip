@@ -85,6 +85,7 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     n.state_bytes = bytes;
     if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
     n.pos = 0;
+    n.zero_left = 0;          // (a ring allocated below is zero-filled for real)
     if (n.d.kind == DSPFX_REVERB) {   // reverb.rs:55-71: a brand-new zero-filled ring
         free_ring(n);
         const size_t ngroups = ((size_t)n.D + RING_GROUP_ROWS - 1) / RING_GROUP_ROWS;
@@ -130,6 +131,7 @@ void fill_slot(const dspfx_engine *e, int idx, SlotArgs &s, uint32_t nframes) {
     s.groups = n.d_groups;
     s.D = n.D;
     s.pos = n.pos;
+    s.zero_rows = n.zero_left;
     if (n.d.kind == DSPFX_REVERB && nframes <= RING_GROUP_ROWS && n.D) {
         // the block's rows lie in at most three groups: the one row `pos` is in, the next, and group 0 past the wrap -- named
         // here so that no wave has to read the group table before it can form its first tap address
@@ -448,7 +450,10 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             if (n.ctl_now[k]) n.latch_valid |= 1 << k;
     // advance the delay rings (FIFO: the block's rows now hold the newest samples)
     for (Node &n : e->nodes)
-        if (n.d.kind == DSPFX_REVERB) n.pos = (uint32_t)(((uint64_t)n.pos + nframes) % n.D);
+        if (n.d.kind == DSPFX_REVERB) {
+            n.pos = (uint32_t)(((uint64_t)n.pos + nframes) % n.D);
+            n.zero_left -= std::min(n.zero_left, nframes);   // rows written since the ring's last clear are real samples
+        }
     return DSPFX_OK;
 }
 
@@ -495,7 +500,7 @@ void publish_kinds(dspfx_engine *e) {
 
 // One slider / mode store takes effect (api_mu held).  State writes go to `s` in stream order.  *replan: the stage split or a
 // stage's division verdict changed.
-int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char> &biquad_reset, bool &replan) {
+int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char> &biquad_reset, std::vector<char> &reverb_refresh, bool &replan) {
     if (st.node < 0 || st.node >= (int)e->nodes.size()) return DSPFX_OK;   // the chain was replaced since
     Node &n = e->nodes[(size_t)st.node];
     if (st.param < 0) {                                  // dspfx_set_mode
@@ -510,6 +515,10 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
         biquad_regenerate(n);
         biquad_reset[(size_t)st.node] = 1;
     }
+    // Reverb's hook is attached to the NODE, not to the `seconds` slider: the generated render() runs it when ANY widget of
+    // the node changed (reverb.rs:19, dsp-stuff-derive/src/lib.rs:487-497, 560-568), so a `decay` store swaps in a new
+    // zero-filled ring too (reverb.rs:55-71).
+    if (n.d.kind == DSPFX_REVERB) reverb_refresh[(size_t)st.node] = 1;
     if (n.d.kind == DSPFX_DISTORT) {
         // A new clip level is a new constant divisor.  Whether its fast form is exact is decided on the host (see
         // divisor_is_fast) for everything but the even integers, so a slider store launches nothing and keeps the
@@ -524,6 +533,33 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
     return DSPFX_OK;
 }
 
+// Reverb::refresh_seconds (reverb.rs:55-71): `num_samples = max((seconds * 48000) as usize, 128)` from the CURRENT seconds
+// slider, a new ring of that length, zero-filled.  The ring length is explicit in this ABI (rivulet's capacity rounding is not
+// in the reference tree): a node that was given its seconds slider (params[1] > 0) derives the new length from it -- mode bit 0
+// picks the page-rounded reading -- so a node fresh from the menu (make_buffer's 128-sample ring under a 0.5 s slider,
+// reverb.rs:44-52) jumps to 24000 samples at its first slider change like the reference's; without one the ring keeps its length.
+uint32_t reverb_refresh_len(const Node &n) {
+    return n.d.params[1] > 0.0f ? dspfx_delay_len(n.d.params[1], n.d.mode & 1) : n.D;
+}
+// A NEW zero ring of D samples for node n.  Same length as the ring it has: O(1) -- the next D frames read their taps as +0.0
+// (Node::zero_left), nothing is written, freed or re-placed, blocks in flight are untouched (they carry their own count).  A
+// different length frees and re-allocates the ring's groups: waits for the device, like dspfx_chain_set.
+int reverb_new_ring(dspfx_engine *e, Node &n, uint32_t D, bool &replan) {
+    if (D < DSPFX_BUF_SIZE) D = DSPFX_BUF_SIZE;
+    if (D == n.D && !n.groups.empty()) {
+        n.zero_left = n.D;
+        return DSPFX_OK;
+    }
+    int rc = quiesce(e);
+    if (rc) return rc;
+    n.D = D;
+    n.d.delay_len = D;
+    rc = alloc_node_state(e, n);
+    replan = true;                       // the shortest delay line bounds the sub-block length
+    const int rs = settle_null_stream(e);
+    return rc ? rc : rs;
+}
+
 // Apply every queued store, in order, at this block boundary (api_mu held); biquad resets are queued on `s` -- the
 // stream of the block about to be launched, or the stream the state was last used on.
 int drain_pending(dspfx_engine *e, hipStream_t s) {
@@ -533,17 +569,22 @@ int drain_pending(dspfx_engine *e, hipStream_t s) {
         if (e->pending.empty()) return DSPFX_OK;
         todo.swap(e->pending);
     }
-    std::vector<char> biquad_reset(e->nodes.size(), 0);
+    std::vector<char> biquad_reset(e->nodes.size(), 0), reverb_refresh(e->nodes.size(), 0);
     bool replan = false;
     int rc = DSPFX_OK;
     for (const auto &st : todo) {
-        const int r = apply_store(e, st, biquad_reset, replan);
+        const int r = apply_store(e, st, biquad_reset, reverb_refresh, replan);
         if (r && !rc) rc = r;
     }
     HIPCHK(e, hipSetDevice(e->device));
     for (size_t i = 0; i < biquad_reset.size(); ++i)
         if (biquad_reset[i] && e->nodes[i].state)
             HIPCHK(e, hipMemsetAsync(e->nodes[i].state, 0, e->nodes[i].state_bytes, s));
+    for (size_t i = 0; i < reverb_refresh.size(); ++i)      // once per node and boundary: every store leaves a zero ring behind
+        if (reverb_refresh[i]) {
+            const int r = reverb_new_ring(e, e->nodes[i], reverb_refresh_len(e->nodes[i]), replan);
+            if (r && !rc) rc = r;
+        }
     if (replan) {
         const int r = plan(e);
         if (r && !rc) rc = r;
@@ -596,7 +637,7 @@ extern "C" int dspfx_node_defaults(int kind, dspfx_node_desc *d) {
         break;
     case DSPFX_LOW_PASS:
     case DSPFX_HIGH_PASS: d->params[0] = 0.5f; break;                  // low_pass.rs:20
-    case DSPFX_REVERB: d->params[0] = 0.5f; d->delay_len = 128; break; // reverb.rs:37, 44-52 (make_buffer)
+    case DSPFX_REVERB: d->params[0] = 0.5f; d->params[1] = 0.5f; d->delay_len = 128; break; // reverb.rs:29-38; 44-52: make_buffer's 128-sample ring under the 0.5 s slider
     case DSPFX_DISTORT: d->mode = DSPFX_DIST_SOFT_CLIP; break;         // distort.rs:46-50
     case DSPFX_MIX: d->params[0] = 0.5f; break;                        // mix.rs:22-28
     case DSPFX_SIGNAL_GEN: d->params[0] = 0.5f; d->params[1] = 100.0f; break;   // signal_gen.rs:41-49 (mode Sine)
@@ -873,18 +914,17 @@ extern "C" int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_REVERB)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a REVERB node", node);
     if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
-    {   // the old ring is freed: nothing may still be reading it
-        const int rc = quiesce(e);
-        if (rc) return rc;
-    }
-    Node &n = e->nodes[(size_t)node];
-    n.D = delay_len;   // reverb.rs:55-71: a brand-new zero-filled ring
-    n.d.delay_len = delay_len;
-    int rc = alloc_node_state(e, n);
+    // reverb.rs:55-71: a brand-new zero-filled ring.  An unchanged length takes the O(1) path (reverb_new_ring): no wait
+    // for the device, nothing re-allocated; a new length frees the old ring first, so nothing may still be reading it.
+    bool replan = false;
+    int rc = reverb_new_ring(e, e->nodes[(size_t)node], delay_len, replan);
     if (rc) return rc;
-    rc = plan(e);
-    const int rs = settle_null_stream(e);
-    return rc ? rc : rs;
+    if (replan) {
+        rc = plan(e);
+        const int rs = settle_null_stream(e);
+        if (!rc) rc = rs;
+    }
+    return rc;
 }
 
 extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode) {
@@ -931,8 +971,7 @@ int reset_on(dspfx_engine *e, hipStream_t s) {
     for (Node &n : e->nodes) {
         if (n.state) HIPCHK(e, hipMemsetAsync(n.state, 0, n.d.kind == DSPFX_BIQUAD ? 4 * (size_t)e->desc.channels * sizeof(float)
                                                                                    : (size_t)e->desc.channels * sizeof(float), s));
-        for (float *g : n.groups) HIPCHK(e, hipMemsetAsync(g, 0, n.group_floats * sizeof(float), s));
-        n.pos = 0;
+        if (!n.groups.empty()) n.zero_left = n.D;   // a zero ring without touching its (up to 94 GiB of) rows: see Node::zero_left
         if (n.d.kind == DSPFX_FIR) fir_reset(n.fir, s);
     }
     e->mp_count = 0;   // blocks still in the mix pipeline are dropped

@@ -60,6 +60,10 @@ struct Node {
     int ring_replaced = 0;    // groups re-allocated by the placement probe
     size_t state_bytes = 0;
     uint32_t D = 0, pos = 0;  // REVERB
+    // REVERB: frames still to come whose taps read +0.0 whatever the rows hold -- a NEW zero ring of the same length
+    // (Reverb::refresh_seconds on a slider change, dspfx_reset, dspfx_set_delay_len with an unchanged D) is this counter set
+    // to D: O(1), no memset of up to 94 GiB, placement kept.  Counted down by every block (SlotArgs::zero_rows).
+    uint32_t zero_left = 0;
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;

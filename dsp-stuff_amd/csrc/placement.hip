@@ -182,10 +182,14 @@ struct TuneGuard {   // whatever happens inside the probe loop, every node gets 
     std::vector<float *> extras;            // candidates allocated here and not (yet) adopted by the ring
     std::vector<std::pair<float *, size_t>> snaps;   // device copies of node state: (copy, node index)
     std::vector<uint32_t> pos0;             // ring position of every node on entry
+    std::vector<uint32_t> zero0;            // ... and its count of frames still reading a cleared ring (Node::zero_left)
     std::vector<float *> rows;              // per node: the parked rows [n_frames][N] of its delay ring (or null)
     std::vector<FirPark> firs;              // per node
-    explicit TuneGuard(dspfx_engine *e_) : e(e_), pos0(e_->nodes.size(), 0), rows(e_->nodes.size(), nullptr), firs(e_->nodes.size()) {
-        for (size_t i = 0; i < e->nodes.size(); ++i) pos0[i] = e->nodes[i].pos;
+    explicit TuneGuard(dspfx_engine *e_) : e(e_), pos0(e_->nodes.size(), 0), zero0(e_->nodes.size(), 0), rows(e_->nodes.size(), nullptr), firs(e_->nodes.size()) {
+        for (size_t i = 0; i < e->nodes.size(); ++i) {
+            pos0[i] = e->nodes[i].pos;
+            zero0[i] = e->nodes[i].zero_left;
+        }
     }
     void arm(Node &node) {
         n = &node;
@@ -205,7 +209,10 @@ struct TuneGuard {   // whatever happens inside the probe loop, every node gets 
     void rewind() {
         for (size_t i = 0; i < e->nodes.size(); ++i) {
             Node &m = e->nodes[i];
-            if (m.d.kind == DSPFX_REVERB) m.pos = &m == n ? 0 : pos0[i];
+            if (m.d.kind == DSPFX_REVERB) {
+                m.pos = &m == n ? 0 : pos0[i];
+                m.zero_left = zero0[i];       // the probes' blocks count it down like any block
+            }
             if (m.d.kind == DSPFX_FIR && firs[i].rows) fir_rewind(m.fir, firs[i]);
         }
     }

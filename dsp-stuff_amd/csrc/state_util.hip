@@ -56,8 +56,12 @@ extern "C" int dspfx_state_export(dspfx_engine *e, int node, void *host_dst, siz
         const int rc = fir_state_export(n.fir, host_dst);
         return rc ? fail(e, rc, "FIR: %s", fir_last_error()) : DSPFX_OK;
     }
-    if (n.d.kind == DSPFX_REVERB)   // canonical form: [D][N], row 0 = the oldest sample
-        return ring_rows_copy(e, n, n.pos, n.D, (char *)host_dst, true);
+    if (n.d.kind == DSPFX_REVERB) {   // canonical form: [D][N], row 0 = the oldest sample
+        const int rc = ring_rows_copy(e, n, n.pos, n.D, (char *)host_dst, true);
+        // rows from before the ring's last clear (Node::zero_left of them, the oldest) ARE zeros as far as any block can tell
+        if (rc == DSPFX_OK && n.zero_left) memset(host_dst, 0, (size_t)std::min(n.zero_left, n.D) * e->desc.channels * sizeof(float));
+        return rc;
+    }
     if (need) HIPCHK(e, hipMemcpy(host_dst, n.state, (size_t)need, hipMemcpyDeviceToHost));
     return DSPFX_OK;
 }
@@ -84,6 +88,7 @@ extern "C" int dspfx_state_import(dspfx_engine *e, int node, const void *host_sr
         HIPCHK(e, hipMemcpy(n.state, host_src, (size_t)need, hipMemcpyHostToDevice));
     }
     n.pos = 0;
+    n.zero_left = 0;
     return settle_null_stream(e);
 }
 

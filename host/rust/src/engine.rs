@@ -44,9 +44,11 @@ impl NodeDesc {
     pub fn biquad(a0: f32, a1: f32, a2: f32, b0: f32, b1: f32, b2: f32) -> Self { Self::with(DSPFX_BIQUAD, &[a0, a1, a2, b0, b1, b2]) }
     pub fn low_pass(ratio: f32) -> Self { Self::with(DSPFX_LOW_PASS, &[ratio]) }
     pub fn high_pass(ratio: f32) -> Self { Self::with(DSPFX_HIGH_PASS, &[ratio]) }
-    /// nodes/reverb.rs: feedback delay; `seconds` goes through reverb.rs:58
+    /// nodes/reverb.rs: feedback delay, a RESTORED node (`refresh_seconds` has run: the ring has reverb.rs:58's length).
+    /// The seconds slider travels with the node (params[1]): any later `set_param` on it -- decay included -- swaps in a
+    /// new zero ring of that length, like the reference's after_settings_change (reverb.rs:19, 55-71).
     pub fn reverb(seconds: f32, decay: f32) -> Self {
-        let mut n = Self::with(DSPFX_REVERB, &[decay]);
+        let mut n = Self::with(DSPFX_REVERB, &[decay, seconds]);
         n.d.delay_len = unsafe { dspfx_delay_len(seconds, 0) };
         n
     }
@@ -143,7 +145,8 @@ impl Engine {
     }
 
     /// A slider store (dsp-stuff-derive/src/lib.rs:487-492) including the reference's
-    /// `after_settings_change` side effects (biquad.rs:62-76: state reset).
+    /// `after_settings_change` side effects: biquad.rs:15, 62-76 (coefficients renormalised, state reset); reverb.rs:19, 55-71
+    /// (ANY slider of a Reverb node, decay included: a new zero-filled ring -- the echo tail is cut).
     pub fn set_param(&mut self, node: usize, param: usize, value: f32) -> Result<(), Error> {
         let rc = unsafe { dspfx_set_param(self.h, node as c_int, param as c_int, value) };
         self.check(rc)

@@ -67,7 +67,7 @@ pub struct dspfx_param_event {
     pub reserved: i32,
 }
 
-pub const DSPFX_ABI_VERSION: u32 = 1;
+pub const DSPFX_ABI_VERSION: u32 = 2;
 pub const DSPFX_BUF_SIZE: u32 = 128; // dsp-stuff/src/node.rs:257
 pub const DSPFX_MAX_NODES: u32 = 32;
 pub const DSPFX_COMM_ID_BYTES: usize = 128;

@@ -54,7 +54,10 @@
 extern "C" {
 #endif
 
-#define DSPFX_ABI_VERSION 1
+/* 2 (round 4): REVERB carries its `seconds` slider (params[1]) and every slider store on a REVERB node swaps in a new zero
+ *    ring like the reference's after_settings_change; the FIR state blob is {32-byte header, held samples} (round 3);
+ *    DSPFX_FIR_PRECISION_DEFAULT means the split bf16 sweep (round 3).  Engines refuse a descriptor of another version. */
+#define DSPFX_ABI_VERSION 2
 /* dsp-stuff/src/node.rs:257 `pub const BUF_SIZE: usize = 128;` */
 #define DSPFX_BUF_SIZE 128
 /* longest chain one engine accepts */
@@ -142,7 +145,9 @@ typedef struct dspfx_engine_desc {
  *   BIQUAD     params[0..5]=a0,a1,a2,b0,b1,b2 (raw sliders -10..=10)  biquad.rs:18-41
  *   LOW_PASS   params[0]=ratio (0..=1, default 0.5)                   low_pass.rs:20-21
  *   HIGH_PASS  params[0]=ratio                                        high_pass.rs:20-21
- *   REVERB     params[0]=decay (0..=1, default .5); delay_len=D       reverb.rs:29-38
+ *   REVERB     params[0]=decay (0..=1, default .5), params[1]=seconds (0..=1, default .5; 0 = not given);
+ *              delay_len=D, the ring the node STARTS with; mode bit 0: the page-rounded reading of seconds -> samples
+ *              (see dspfx_set_param for what a slider store does to the ring)   reverb.rs:29-38, 44-71
  *   DISTORT    params[0]=level (0..=30, default 0); mode              distort.rs:46-50
  *   OVERDRIVE  params[0]=boost, [1]=drive, [2]=level                  overdrive.rs:21-28
  *   CHEBYSHEV  params[0]=level_pos, [1]=level_neg                     chebyshev.rs:21-25
@@ -191,9 +196,18 @@ const char *dspfx_last_error(const dspfx_engine *e);
 int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
 int dspfx_chain_len(const dspfx_engine *e);
 
-/* Slider store + `after_settings_change` (dsp-stuff-derive/src/lib.rs:487-492,
- * 560-568): BIQUAD renormalises by a0 and ZEROES its state (biquad.rs:62-76);
- * other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
+/* Slider store + `after_settings_change` (dsp-stuff-derive/src/lib.rs:487-497, 560-568: the generated render() runs the
+ * node's hook when ANY of its widgets changed):
+ *   BIQUAD renormalises by a0 and ZEROES its state (biquad.rs:15, 62-76);
+ *   REVERB -- ANY slider, `decay` included -- swaps in a NEW ZERO-FILLED ring (reverb.rs:19, 55-71: refresh_seconds): the echo
+ *          tail is cut.  Its length is what the seconds slider says, max((seconds * 48000) as usize, 128) (mode bit 0: rounded up
+ *          to whole 4 KiB pages), when the node was given one (params[1] > 0) -- so a node fresh from the menu (dspfx_node_defaults:
+ *          make_buffer's 128-sample ring under a 0.5 s slider, reverb.rs:44-52) becomes a 24000-sample delay at its first slider
+ *          change, like the reference's -- and the ring's current length otherwise.  An unchanged length costs NOTHING: no
+ *          memset, no re-allocation, placement kept -- the next D frames simply read their taps as +0.0 (a per-node frame
+ *          counter in the kernel arguments), in order with the blocks in flight.  A changed length re-allocates the ring at
+ *          that block boundary (waits for the device, like dspfx_set_delay_len);
+ *   other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
  * exactness of a DISTORT level as a constant divisor is decided on the host; only a level that is an even integer
  * other than a power of two runs the 2 ms device check, once per value and process).
  * Safe from a second thread while another one is inside a process call (the reference's GUI thread does exactly
@@ -220,7 +234,9 @@ typedef struct dspfx_param_event {
 int dspfx_param_log(dspfx_engine *e, dspfx_param_event *dst, int cap, uint64_t after_seq);
 /* Frames handed to the process calls since the engine was created (all sub-blocks counted). */
 uint64_t dspfx_frames_submitted(const dspfx_engine *e);
-/* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring. */
+/* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring.  With the length the ring already has this is
+ * the O(1) clear of dspfx_set_param (no wait for the device); a new length frees and re-allocates the ring (waits for the
+ * device first).  The node's seconds slider (params[1]) is left as it is. */
 int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
 /* Fir tap reload (fir.rs:153-171).  Like the reference it replaces the taps ONLY: the history is kept (`state`,
  * fir.rs:64-65, is never cleared), and because at most one sample is popped per step (fir.rs:193-197) a history longer
@@ -244,7 +260,8 @@ typedef enum dspfx_fir_precision {
 } dspfx_fir_precision;
 int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision);
 /* Zero every node's DSP state (fresh nodes); parameters are kept.  Asynchronous: the clears are queued on the stream
- * the engine was last driven on, behind the blocks in flight there. */
+ * the engine was last driven on, behind the blocks in flight there (delay rings are not rewritten at all: their next D
+ * frames read zeros, see dspfx_set_param). */
 int dspfx_reset(dspfx_engine *e);
 
 /* ---- the hot path ------------------------------------------------------ */

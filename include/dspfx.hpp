@@ -54,16 +54,24 @@ inline Node BiQuad(float a0 = 1.0f, float a1 = -0.24f, float a2 = 0.0f, float b0
 }
 inline Node LowPass(float ratio = 0.5f) { Node n = make(DSPFX_LOW_PASS); n.d.params[0] = ratio; return n; }
 inline Node HighPass(float ratio = 0.5f) { Node n = make(DSPFX_HIGH_PASS); n.d.params[0] = ratio; return n; }
-// nodes/reverb.rs: `seconds` goes through reverb.rs:58
+// nodes/reverb.rs: a RESTORED node -- refresh_seconds has run (dsp-stuff-derive/src/lib.rs:319-337), the ring has
+// reverb.rs:58's length for `seconds`; the seconds slider travels with the node (params[1]) so that a later slider store --
+// which swaps in a new zero ring, decay included (reverb.rs:19, 55-71) -- refreshes to the same length
 inline Node Reverb(float seconds = 0.5f, float decay = 0.5f, bool page_round = false) {
     Node n = make(DSPFX_REVERB);
     n.d.params[0] = decay;
+    n.d.params[1] = seconds;
+    n.d.mode = page_round ? 1 : 0;
     n.d.delay_len = dspfx_delay_len(seconds, page_round ? 1 : 0);
     return n;
 }
+// a node fresh from the menu: make_buffer()'s 128-sample ring under the 0.5 s slider (reverb.rs:44-52) = dspfx_node_defaults
+inline Node ReverbFresh() { return make(DSPFX_REVERB); }
+// an explicit ring and no seconds slider: a slider store swaps in a zero ring of the same length
 inline Node ReverbSamples(std::uint32_t delay_len, float decay = 0.5f) {
     Node n = make(DSPFX_REVERB);
     n.d.params[0] = decay;
+    n.d.params[1] = 0.0f;
     n.d.delay_len = delay_len;
     return n;
 }

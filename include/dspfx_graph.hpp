@@ -600,8 +600,11 @@ class SavedGraph {
             if (!v) throw ConfigError(tn + " node lacks saved field \"" + row.fields[k] + "\"");
             n.d.params[k] = (float)v->num;
         }
-        if (row.kind == DSPFX_REVERB)     // restoring a reverb runs refresh_seconds (lib.rs:319-337): reverb.rs:58
+        if (row.kind == DSPFX_REVERB) {   // restoring a reverb runs refresh_seconds (lib.rs:319-337): reverb.rs:58
+            n.d.params[1] = (float)cfg.at("seconds").num;      // the slider travels with the node (a later store refreshes from it)
+            n.d.mode = page_round ? 1 : 0;
             n.d.delay_len = dspfx_delay_len((float)cfg.at("seconds").num, page_round ? 1 : 0);
+        }
         if (row.kind == DSPFX_DISTORT) {
             const json::Value *m = cfg.find("mode");
             n.d.mode = index_of({"HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"},
@@ -758,7 +761,7 @@ inline std::string dump_dspconfig(const std::vector<Node> &chain, bool faithful_
         const int out_port = next_id++;
         std::string cfg = "\"id\": " + std::to_string(node_id) + ", \"inputs\": {" + ins + "}, \"outputs\": {\"out\": " + std::to_string(out_port) + "}";
         for (std::size_t f = 0; f < fields[(std::size_t)kind].size(); ++f) cfg += ", \"" + fields[(std::size_t)kind][f] + "\": " + num(n.d.params[f], 9);
-        if (kind == DSPFX_REVERB) cfg += ", \"seconds\": " + num((float)(n.d.delay_len / 48000.0), 9);
+        if (kind == DSPFX_REVERB) cfg += ", \"seconds\": " + num(n.d.params[1] > 0.0f ? n.d.params[1] : (float)(n.d.delay_len / 48000.0), 9);
         if (kind == DSPFX_DISTORT) cfg += std::string(", \"mode\": \"") + distort_modes[n.d.mode] + "\"";
         if (kind == DSPFX_SIGNAL_GEN) cfg += std::string(", \"mode\": \"") + signal_modes[n.d.mode] + "\"";
         if (kind == DSPFX_FIR) {

@@ -92,8 +92,10 @@ orc_node *orc_node_new(int kind) {
     case ORC_HIGH_PASS: /* high_pass.rs:20 */
         n->p[0] = 0.5f;
         break;
-    case ORC_REVERB: /* reverb.rs:37 decay 0.5; 44-52 make_buffer(): ring of 128 */
+    case ORC_REVERB: /* reverb.rs:29-38: seconds 0.5, decay 0.5; 44-52 make_buffer(): a ring of 128 -- NOT the half
+                        second the slider shows: refresh_seconds has not run on a node fresh from the menu */
         n->p[0] = 0.5f;
+        n->p[1] = 0.5f;
         orc_reverb_set_len(n, 128);
         break;
     case ORC_DISTORT: /* distort.rs:46-50: level Default (0.0), mode SoftClip */
@@ -152,10 +154,32 @@ orc_node *orc_node_clone(const orc_node *src) {
     return n;
 }
 
-void orc_node_set_param(orc_node *n, int idx, float v) {
+/* `this.field = value` of the generated restore() (dsp-stuff-derive/src/lib.rs:300-312) / a field initialiser of new():
+ * the plain store, NO hook. */
+void orc_node_init_param(orc_node *n, int idx, float v) {
     if (idx < 0 || idx >= 8) return;
     n->p[idx] = v;
-    if (n->kind == ORC_BIQUAD) biquad_regenerate(n); /* after_settings_change, biquad.rs:14 */
+}
+
+/* The node's `after_settings_change` hook, where it has one (grep over nodes/: biquad.rs:15 and reverb.rs:19, no other):
+ *   BiQuad::regenerate_filter (biquad.rs:62-76): coefficients / a0, reset_state, update_coefficients;
+ *   Reverb::refresh_seconds   (reverb.rs:55-71): num_samples = max((seconds * 48000) as usize, 128) from the CURRENT
+ *       seconds slider, a NEW ring of that length, zero-filled, swapped in under the mutex -- the old ring and every echo
+ *       in it are gone.  The ring length is explicit in this restatement (rivulet's capacity rounding is not in the tree):
+ *       with the seconds slider given (p[1] > 0) the new length is orc_delay_len(seconds, mode & 1), else the current one.
+ * Called (a) by the generated render() when ANY widget of the node changed -- `changed |= true` per slider / select, then
+ * `if changed { hook(self) }`, lib.rs:487-497, 521-525, 560-568, 570-578 -- i.e. by orc_node_set_param for EVERY slot of the node,
+ * Reverb's decay included; (b) once by the generated restore() after all fields are set (lib.rs:319-337).  A node fresh
+ * from the menu (NodeStatic::new) has NOT run it: a Reverb keeps make_buffer()'s 128-sample ring until its first change. */
+void orc_node_after_settings_change(orc_node *n) {
+    if (n->kind == ORC_BIQUAD) biquad_regenerate(n);
+    if (n->kind == ORC_REVERB) orc_reverb_set_len(n, n->p[1] > 0.0f ? orc_delay_len(n->p[1], n->mode & 1) : n->ring_len);
+}
+
+void orc_node_set_param(orc_node *n, int idx, float v) {
+    if (idx < 0 || idx >= 8) return;
+    n->p[idx] = v;                       /* lib.rs:487-492: the slider's Relaxed store */
+    orc_node_after_settings_change(n);   /* lib.rs:560-568 */
 }
 
 void orc_node_set_mode(orc_node *n, int mode) { n->mode = mode; }

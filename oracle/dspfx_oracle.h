@@ -99,13 +99,37 @@ enum { ORC_SIG_SINE = 0, ORC_SIG_TRIANGLE = 1, ORC_SIG_SQUARE = 2, ORC_SIG_CONST
 enum { ORC_FIR_BALANCED = 0, ORC_FIR_AVERAGE = 1 };
 
 /*
+ * EVERY path of the cited nodes that touches DSP state outside `process`, and where this file restates it
+ * (the Reverb hook on `decay` had slipped through both restatements):
+ *
+ *   reference path                                         | what it does to state                      | restated by
+ *   -------------------------------------------------------+--------------------------------------------+------------------------------
+ *   render(): any widget of the node changed               | runs after_settings_change (below)         | orc_node_set_param (every slot),
+ *     dsp-stuff-derive/src/lib.rs:487-497,560-568,570-578   |                                            | (select widgets set `changed` too,
+ *                                                          |                                            | lib.rs:521-525, but no node with a
+ *                                                          |                                            | hook has one: orc_node_set_mode
+ *                                                          |                                            | is the plain store)
+ *   BiQuad::regenerate_filter  biquad.rs:15, 62-76         | coeffs / a0; reset_state(): x1,x2,y1,y2 = 0 | biquad_regenerate
+ *   Reverb::refresh_seconds    reverb.rs:19, 55-71         | NEW ring of max(seconds*48000,128) zeros   | orc_node_after_settings_change ->
+ *                                                          |                                            | orc_reverb_set_len
+ *   restore(): after the field setters                     | runs after_settings_change ONCE            | orc_node_after_settings_change
+ *     dsp-stuff-derive/src/lib.rs:319-337                   | (biquad filter rebuilt, reverb ring sized)  | (oracle.py Node(restored=True))
+ *   new() (menu): field defaults only, NO hook             | BiQuad::initial_filter biquad.rs:48-60;    | orc_node_new
+ *     dsp-stuff-derive/src/lib.rs:196-210                   | make_buffer(): 128 zeros reverb.rs:44-52   |
+ *   `<slider>_input` latch  lib.rs:148                      | slider atomic <- first mapped sample of    | orc_slider_input (*atomic = out[0])
+ *                                                          | the block (as_input sliders only)          |
+ *   Fir: custom_render, no hook; load_file fir.rs:153-171  | replaces `taps` ONLY, `state` kept         | orc_fir_set_taps
+ *   no other node on the path has a hook, a Mutex'd state or a custom render (grep after_settings_change|custom_render
+ *   nodes/: biquad, reverb, fir only); low/high-pass `z`, signal_gen `clock`, envelope `detector` change in process() only.
+ *
  * One node instance for ONE mono channel: parameters (the reference's slider
  * atomics) + DSP state.  Parameter slots by kind (same slot numbering as
  * dspfx_node_desc.params in include/dspfx.h):
  *   GAIN       p[0]=level
  *   BIQUAD     p[0..5]=a0,a1,a2,b0,b1,b2 (raw sliders, normalised by a0)
  *   LOW_PASS   p[0]=ratio      HIGH_PASS p[0]=ratio
- *   REVERB     p[0]=decay, ip[0]=D (delay length in samples, explicit)
+ *   REVERB     p[0]=decay, p[1]=seconds (0 = not given), ip[0]=D (delay length in samples, explicit), mode bit 0 = the
+ *              page-rounded reading of seconds -> samples when a refresh derives D from the seconds slider
  *   DISTORT    p[0]=level, mode
  *   OVERDRIVE  p[0]=boost, p[1]=drive, p[2]=level
  *   CHEBYSHEV  p[0]=level_pos, p[1]=level_neg
@@ -143,10 +167,13 @@ typedef struct orc_node {
 /* Create with the reference's defaults for `kind` (derive `default=`). */
 orc_node *orc_node_new(int kind);
 void orc_node_free(orc_node *n);
-/* Set slot `idx`; runs the reference's after_settings_change hook where one
- * exists (biquad.rs:62-76: renormalise + RESET state; reverb is resized via
- * orc_reverb_set_len). */
+/* A slider change made in the GUI: store slot `idx`, then the node's after_settings_change hook (see the table below):
+ * BIQUAD renormalises + RESETS its state; REVERB -- for ANY slot, decay included -- swaps in a new zero ring. */
 void orc_node_set_param(orc_node *n, int idx, float v);
+/* The plain field store of new() / restore(): no hook. */
+void orc_node_init_param(orc_node *n, int idx, float v);
+/* The hook alone (what restore() runs once after setting every field). */
+void orc_node_after_settings_change(orc_node *n);
 void orc_node_set_mode(orc_node *n, int mode);
 /* reverb.rs:55-71 with D explicit: fresh zero-filled ring of D samples. */
 void orc_reverb_set_len(orc_node *n, uint32_t d);

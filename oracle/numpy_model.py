@@ -73,6 +73,15 @@ class OnePole:
         return out
 
 
+def delay_len_from_seconds(seconds, page_round=False):
+    """reverb.rs:58: ((seconds * 48000.0) as usize).max(128), f32 product, truncating cast; page_round: the reading in which
+    rivulet rounds the ring to whole 4 KiB pages (1024 f32)."""
+    s = F(F(seconds) * F(48000.0))
+    d = 0 if not s > 0 else int(min(float(s), 4294967295.0))
+    d = max(d, 128)
+    return (d + 1023) // 1024 * 1024 if page_round else d
+
+
 class Reverb:
     """reverb.rs:76-110 as y[n] = x[n] + decay*y[n-D], zero history."""
 
@@ -392,7 +401,9 @@ class NodeModel:
             self.impl = Biquad(*[float(v) for v in self.p[:6]])
         elif kind in (K_LOW_PASS, K_HIGH_PASS):
             self.impl = OnePole(self.p[0], high=kind == K_HIGH_PASS)
-        elif kind == K_REVERB:
+        elif kind == K_REVERB:                                    # make_buffer(): 128 zeros (reverb.rs:44-52) unless D is named
+            if params is None or len(params) < 2:                 # no seconds slider given: the default one (0.5 s) for a fresh
+                self.p[1] = F(0.0) if delay_len else F(0.5)       # node, none to refresh from beside an explicit ring
             self.impl = Reverb(delay_len or 128, self.p[0])
         elif kind == K_FIR:
             self.impl = Fir(taps_reversed if taps_reversed is not None else [1.0], average=self.mode == 1)
@@ -408,7 +419,12 @@ class NodeModel:
         elif self.kind in (K_LOW_PASS, K_HIGH_PASS):
             self.impl.r = F(v)
         elif self.kind == K_REVERB:
-            self.impl.decay = F(v)
+            # after_settings_change = Reverb::refresh_seconds (reverb.rs:19, 55-71), run by the generated render() whenever
+            # ANY widget of the node changed (dsp-stuff-derive/src/lib.rs:487-497, 560-568): decay AND seconds both swap in
+            # a NEW zero ring of max((seconds * 48000) as usize, 128) samples -- of the current length when the node was
+            # not given its seconds slider (the ring length is explicit in this restatement)
+            d = delay_len_from_seconds(self.p[1], bool(self.mode & 1)) if self.p[1] > 0 else self.impl.d
+            self.impl = Reverb(d, self.p[0])
         elif self.kind == K_ENVELOPE:
             self.impl.attack, self.impl.release = self.p[0], self.p[1]
 

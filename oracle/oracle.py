@@ -59,6 +59,8 @@ def _bind(L):
     L.orc_node_clone.restype = vp
     L.orc_node_clone.argtypes = [vp]
     L.orc_node_set_param.argtypes = [vp, C.c_int, C.c_float]
+    L.orc_node_init_param.argtypes = [vp, C.c_int, C.c_float]
+    L.orc_node_after_settings_change.argtypes = [vp]
     L.orc_node_set_mode.argtypes = [vp, C.c_int]
     L.orc_reverb_set_len.argtypes = [vp, C.c_uint32]
     L.orc_delay_len.restype = C.c_uint32
@@ -95,7 +97,12 @@ def _f32p(a):
 class Node:
     """One reference node instance for one mono channel."""
 
-    def __init__(self, kind: int, params=None, mode=None, delay_len=None, taps_reversed=None, _lib=None):
+    def __init__(self, kind: int, params=None, mode=None, delay_len=None, taps_reversed=None, _lib=None, restored=False):
+        """NodeStatic::new + the field values: the fields are stored WITHOUT the node's after_settings_change hook (the
+        generated new() / the setters of restore(), dsp-stuff-derive/src/lib.rs:196-210, 300-312).  A BiQuad's filter is
+        then built from its sliders (what the engine's dspfx_chain_set does with the six params; restore() does the same
+        through the hook).  A Reverb keeps make_buffer()'s 128-sample ring unless `delay_len` names the ring (the explicit
+        D of this restatement) or `restored` runs the hook as restore() would (lib.rs:319-337: D from the seconds slider)."""
         self.L = _lib or lib()
         self.kind = kind
         self.h = C.c_void_p(self.L.orc_node_new(kind))
@@ -104,7 +111,11 @@ class Node:
         if params:
             for i, v in enumerate(params):
                 if v is not None:
-                    self.L.orc_node_set_param(self.h, i, float(v))
+                    self.L.orc_node_init_param(self.h, i, float(v))
+        if kind == REVERB and delay_len is not None and not (params and len(params) > 1 and params[1] is not None):
+            self.L.orc_node_init_param(self.h, 1, 0.0)     # an explicit ring and no seconds slider given: nothing to refresh from
+        if kind == BIQUAD or restored:
+            self.L.orc_node_after_settings_change(self.h)
         if delay_len is not None:
             self.L.orc_reverb_set_len(self.h, int(delay_len))
         if taps_reversed is not None:
@@ -112,7 +123,13 @@ class Node:
             self.L.orc_fir_set_taps(self.h, t.ctypes.data_as(C.POINTER(C.c_double)), len(t))
 
     def set_param(self, idx, v):
+        """A slider change in the GUI: the store AND the node's after_settings_change hook (biquad: new filter, state
+        reset; reverb -- any slider, decay included -- a new zero ring: dspfx_oracle.h has the table)."""
         self.L.orc_node_set_param(self.h, idx, float(v))
+
+    def set_delay_len(self, d):
+        """reverb.rs:55-71 with D explicit: a new zero ring of d samples."""
+        self.L.orc_reverb_set_len(self.h, int(d))
 
     def set_taps(self, taps_reversed):
         """Impulse-response reload (fir.rs:153-171): new taps, the deque of past samples is KEPT."""

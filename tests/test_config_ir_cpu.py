@@ -45,7 +45,7 @@ def test_import_reference_style_file(mods):
     assert info["order"] == [2, 3, 4, 5, 6]
     assert [n.kind for n in chain] == [dspfx.BIQUAD, dspfx.DISTORT, dspfx.REVERB, dspfx.HIGH_PASS, dspfx.GAIN]
     assert chain[1].mode == dspfx.SOFT_CLIP and chain[1].params == [3.0]
-    assert chain[2].delay_len == 24000 and chain[2].params == [0.5]          # refresh_seconds on restore
+    assert chain[2].delay_len == 24000 and chain[2].params == [0.5, 0.5]     # refresh_seconds on restore; [decay, seconds]
     assert config.load_dspconfig(json.dumps(REFERENCE_STYLE), page_round=True)[0][2].delay_len == 24576
     # the imported chain runs on the oracle exactly like the hand-built one
     import oracle as O

@@ -185,7 +185,7 @@ def test_cpp_exporter_writes_what_the_importers_read(dspfx, tmp_path):
     r = subprocess.run([EXE, "--dump-chain"], capture_output=True, text=True)
     assert r.returncode == 0
     chain, info = config.load_dspconfig(r.stdout)
-    want = [E.BiQuad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025), E.LowPass(0.3), E.Distort(3.0, E.TANH), E.Reverb(delay_samples=24000, decay=0.4),
+    want = [E.BiQuad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025), E.LowPass(0.3), E.Distort(3.0, E.TANH), E.Reverb(seconds=0.5, decay=0.4),
             E.Mix(0.25), E.Overdrive(2.0, 0.5, 0.75), E.Fir([0.5, 0.25, -0.125], E.FIR_AVERAGE), E.Envelope(4.0, 100.0), E.Gain(0.1)]
     assert len(chain) == len(want) and info["side_from_input"]
     for a, b in zip(chain, want):

@@ -1787,3 +1787,138 @@ def test_long_chain_runs_as_one_generated_kernel(dspfx, torch_cuda, monkeypatch,
     eng.set_chain(chain[:6] + [E.Add()] + chain[6:])
     assert eng.describe().count("fused kernel") == 2 and "jit_graph" not in eng.describe(), eng.describe()
     eng.close()
+
+
+# ---------------------------------------------------------------- Reverb: every slider store swaps in a new zero ring
+
+def _run_with_stores(dspfx, torch, eng, x, actions, block, tile=0):
+    """x [frames][N] block by block through `eng`; actions = {block index: callable(eng)} run BEFORE that block."""
+    nf, N = x.shape
+    y = np.empty_like(x)
+    for k, f0 in enumerate(range(0, nf, block)):
+        n = min(block, nf - f0)
+        if k in actions:
+            actions[k](eng)
+        dx = torch.from_numpy(dspfx.to_layout(x[f0:f0 + n], tile)).cuda()
+        dy = torch.empty_like(dx)
+        eng.process(dx, out=dy, n_frames=n)
+        torch.cuda.synchronize()
+        y[f0:f0 + n] = dspfx.from_layout(dy.cpu().numpy(), n, N, tile)
+    return y
+
+
+def _oracle_with_stores(chain, x, actions, block, link_flags=3):
+    """The same through per-channel oracle nodes; actions = {block index: callable(list of nodes of one channel)}."""
+    descs = [n.oracle_desc() for n in chain]
+    out = np.empty_like(x)
+    for c in range(x.shape[1]):
+        nodes = [O.node_from_desc(d) for d in descs]
+        for k, f0 in enumerate(range(0, x.shape[0], block)):
+            if k in actions:
+                actions[k](nodes)
+            out[f0:f0 + block, c] = O.chain_run(nodes, x[f0:f0 + block, c], link_flags, block=min(block, 128))
+    return out
+
+
+@pytest.mark.parametrize("N,tile,variant,block,D", [
+    (192, 0, "static=0,f=8,cpl=1", 128, 203),        # the interpreter; 203 - 128 = 75 cleared rows end inside a chunk
+    (256, 0, "static=0,f=8,cpl=2", 128, 203),        # ... two channels per lane
+    (192, 0, "static=1,f=8,cpl=1", 128, 203),        # the statically specialised chain3 / chain5 kernels
+    (512, 256, "static=1,f=8,cpl=2", 128, 128),      # D == block: every row of the block is cleared, none of the next
+    (256, 0, "static=1,f=16,cpl=1", 100, 1000),      # blocks of 100 frames: the one-frame remainder chunks
+    (512, 256, "static=1,f=8,cpl=4", 256, 300),      # 256-frame blocks over a 300-sample ring
+    (64 * 9, 64, "ts=1", 128, 203),                  # the time-sliced kernel (four slices: 75 ends inside slice 2)
+    (64 * 5 + 17, 0, "ts=1", 128, 300),              # ... and its guarded form for the channels left over
+    (131, 0, None, 128, 203),                        # defaults, ragged: the guarded interpreter tail
+])
+@pytest.mark.parametrize("which", ["chain3", "chain5"])
+def test_reverb_slider_store_swaps_in_a_zero_ring(dspfx, torch_cuda, monkeypatch, which, N, tile, variant, block, D):
+    """reverb.rs:19 + dsp-stuff-derive/src/lib.rs:560-568: ANY slider store on a Reverb node -- `decay` included -- runs
+    refresh_seconds, i.e. a new zero-filled ring (reverb.rs:55-71).  The engine does it without touching the ring: the next D
+    frames read their taps as +0.0 (SlotArgs::zero_rows).  Against the oracle with the same stores at the same blocks, in
+    every kernel family; the second store lands while the first clear is still counting down."""
+    if variant:
+        monkeypatch.setenv("DSPFX_VARIANT", variant)
+    chain = chain3(dspfx, D) if which == "chain3" else chain5(dspfx, D)
+    ridx = 2
+    nblocks = max(8, 3 * D // block + 4)
+    x = noise_block(N, block * nblocks)
+    k1 = D // block + 2                                # the ring is full of echoes by then
+    k2 = k1 + 1 if D > block else k1 + 2               # second store: inside the first clear's countdown when D > block
+    k3 = k2 + D // block + 2
+    eng = dspfx.Engine(N, block, link_flags=3, tile_channels=tile)
+    eng.set_chain(chain)
+    if variant and variant.startswith("ts"):
+        assert "time-sliced" in eng.describe(), eng.describe()
+    gpu_actions = {k1: lambda e: e.set_param(ridx, 0, 0.7), k2: lambda e: e.set_param(ridx, 0, 0.3),
+                   k3: lambda e: e.set_delay_len(ridx, D)}          # an unchanged D: the same O(1) path
+    orc_actions = {k1: lambda ns: ns[ridx].set_param(0, 0.7), k2: lambda ns: ns[ridx].set_param(0, 0.3),
+                   k3: lambda ns: ns[ridx].set_delay_len(D)}
+    y = _run_with_stores(dspfx, torch_cuda, eng, x, gpu_actions, block, tile)
+    ref = _oracle_with_stores(chain, x, orc_actions, block)
+    assert ulp_diff(y, ref).max() <= 1, (ulp_diff(y, ref).max(), np.argwhere(ulp_diff(y, ref) > 1)[:4])
+    # ... and the tail really was cut: ignoring the hook (the round-3 behaviour) gives something else
+    orc_plain = {k1: lambda ns: ns[ridx].L.orc_node_init_param(ns[ridx].h, 0, 0.7), k2: lambda ns: ns[ridx].L.orc_node_init_param(ns[ridx].h, 0, 0.3)}
+    assert ulp_diff(y, _oracle_with_stores(chain, x, orc_plain, block)).max() > 1000
+    # the exported ring: what a block would read -- zeros for the rows from before the last clear, samples for the rest
+    st = eng.state_export(ridx).view(np.float32).reshape(D, N)
+    eng.set_delay_len(ridx, D)
+    assert not eng.state_export(ridx).any()
+    assert st.any()
+    eng.close()
+
+
+def test_reverb_fresh_node_and_seconds_slider_resize_the_ring(dspfx, torch_cuda):
+    """A node fresh from the menu keeps make_buffer()'s 128-sample ring until its first slider change, which sizes the ring
+    from the seconds slider (reverb.rs:44-52, 55-71); a seconds store re-sizes it again; with the page-rounded reading of
+    rivulet's capacity (mode bit 0) 0.01 s is 1024 samples.  A changed length re-allocates the ring at that block boundary."""
+    N, B = 96, 128
+    for page_round in (False, True):
+        chain = [dspfx.Gain(0.9), dspfx.Reverb(page_round=page_round), dspfx.LowPass(0.3)]
+        assert chain[1].delay_len == 128 and list(chain[1].params) == [0.5, 0.5]
+        x = noise_block(N, B * 24)
+        eng = dspfx.Engine(N, B, link_flags=3)
+        eng.set_chain(chain)
+        gpu = {3: lambda e: e.set_param(1, 1, 0.01), 14: lambda e: e.set_param(1, 0, 0.4), 19: lambda e: e.set_param(1, 1, 0.004)}
+        orc = {3: lambda ns: ns[1].set_param(1, 0.01), 14: lambda ns: ns[1].set_param(0, 0.4), 19: lambda ns: ns[1].set_param(1, 0.004)}
+        y = _run_with_stores(dspfx, torch_cuda, eng, x, gpu, B)
+        ref = _oracle_with_stores(chain, x, orc, B)
+        assert ulp_diff(y, ref).max() <= 1
+        assert len(eng.state_export(1)) == 4 * N * (O.delay_len(0.004, page_round))
+        eng.close()
+    # the default half second: 128 -> 24000 samples at the first touch of `decay`
+    eng = dspfx.Engine(64, B, link_flags=0)
+    eng.set_chain([dspfx.Reverb()])
+    assert len(eng.state_export(0)) == 4 * 64 * 128
+    eng.set_param(0, 0, 0.5)
+    assert len(eng.state_export(0)) == 4 * 64 * 24000
+    eng.close()
+
+
+def test_reverb_store_inside_a_generated_graph_kernel(dspfx, torch_cuda):
+    """The whole-graph kernel shares the ring code: a decay store on a Reverb node of a fused DAG cuts its tail too."""
+    N, B, D = 256, 128, 203
+    nodes = [dspfx.Gain(0.8), dspfx.Reverb(delay_samples=D, decay=0.6), dspfx.HighPass(0.2), dspfx.Add()]
+    links = [(dspfx.GRAPH_INPUT, 0, dspfx.PORT_MAIN), (0, 1, dspfx.PORT_MAIN), (0, 2, dspfx.PORT_MAIN), (1, 3, dspfx.PORT_MAIN),
+             (2, 3, dspfx.PORT_SIDE), (3, 4, dspfx.PORT_MAIN)]
+    x = noise_block(N, B * 10)
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_graph(nodes, links)
+    y = _run_with_stores(dspfx, torch_cuda, eng, x, {4: lambda e: e.set_param(1, 0, 0.2), 5: lambda e: e.reset()}, B)
+    eng.close()
+    ref = np.empty_like(x)
+    for c in range(0, N, 37):
+        ns = [O.node_from_desc(n.oracle_desc()) for n in nodes]
+        for k in range(10):
+            if k == 4:
+                ns[1].set_param(0, 0.2)
+            if k == 5:
+                ns = [O.node_from_desc(dict(n.oracle_desc(), params=[0.2, 0.0] if i == 1 else n.oracle_desc()["params"])) for i, n in enumerate(nodes)]
+            seg = x[k * B:(k + 1) * B, c]
+            hop = lambda v: (np.zeros(B, F) + v) / O.link_divisor(1)
+            g = ns[0].process(hop(seg))
+            r = ns[1].process(hop(g))
+            h = ns[2].process(hop(g))
+            a = ns[3].process(hop(r), hop(h))
+            ref[k * B:(k + 1) * B, c] = hop(a)
+        assert ulp_diff(y[:, c], ref[:, c]).max() <= 1, c

@@ -90,7 +90,8 @@ def test_slider_store_from_another_thread_with_blocks_in_flight(dspfx, torch_cud
         submitted.wait()
         result["seq"] = [eng.set_param_seq(0, 1, -1.7),      # biquad 0: a1 (state reset, biquad.rs:74)
                          eng.set_param_seq(4, 0, 0.25),      # gain
-                         eng.set_param_seq(3, 3, 0.9)]       # biquad 3: b0
+                         eng.set_param_seq(3, 3, 0.9),       # biquad 3: b0
+                         eng.set_param_seq(2, 0, 0.3)]       # the delay's decay: a NEW ZERO ring (reverb.rs:19, 55-71) -- O(1), in stream order
         result["busy"] = not s.query()
 
     t = threading.Thread(target=gui_thread)
@@ -105,7 +106,7 @@ def test_slider_store_from_another_thread_with_blocks_in_flight(dspfx, torch_cud
     assert result["busy"], "the stream drained before the store: nothing was in flight"
     s.synchronize()
     log = eng.param_log()
-    assert [ev[0] for ev in log] == result["seq"] == [1, 2, 3]           # applied in the order they were made
+    assert [ev[0] for ev in log] == result["seq"] == [1, 2, 3, 4]        # applied in the order they were made
     stores = {}
     for seq, frame, node, param, value in log:
         assert frame % B == 0 and 64 * B <= frame <= blocks * B, frame   # a block boundary after the 64 queued blocks

@@ -425,3 +425,82 @@ def test_kat12_sinc_converter_closed_forms():
         lo = int(math.ceil(24 * 48000.0 / src_hz))          # the ring is full and the index has reached its depth
         hi = len(y) - lo
         assert np.abs(y[lo:hi] - want[lo:hi]).max() < 1e-12, src_hz
+
+
+def _both(kind, params, mode=0, delay_len=None, restored=False):
+    """The same node in the C restatement and in the numpy one (set_param / process have the same shape in both)."""
+    c = O.Node(kind, list(params), mode, delay_len, restored=restored)
+    m = M.NodeModel(kind, list(params), mode, delay_len)
+    if restored and kind == M.K_REVERB:
+        m.impl = M.Reverb(M.delay_len_from_seconds(m.p[1], bool(mode & 1)), m.p[0])
+    return c, m
+
+
+def test_kat13_reverb_any_slider_store_swaps_in_a_zero_ring():
+    """reverb.rs:19 attaches Reverb::refresh_seconds to the NODE: the generated render() runs it when ANY widget changed
+    (dsp-stuff-derive/src/lib.rs:487-497, 560-568), so a `decay` store replaces the ring by a new zero-filled one
+    (reverb.rs:55-71) -- the echo tail is cut.  Closed form: an impulse into a D-sample delay with decay g gives g^k at n = kD;
+    a store at n = 1.5 D leaves NOTHING at 2 D, and the node behaves like a fresh one from the store on."""
+    D, g = 256, F(0.5)
+    x = np.zeros(4 * D, F)
+    x[0] = 1.0
+    x[2 * D + 5] = 0.25                                              # a second impulse after the store
+    for node in _both(O.REVERB, [g], delay_len=D):
+        y = np.concatenate([node.process(x[k:k + 128]) for k in range(0, 3 * D // 2, 128)])
+        assert y[0] == 1.0 and y[D] == g and np.count_nonzero(y) == 2
+        node.set_param(0, 0.25)                                      # the decay slider moves: refresh_seconds
+        z = np.concatenate([node.process(x[k:k + 128]) for k in range(3 * D // 2, 4 * D, 128)])
+        assert z[D // 2] == 0.0                                      # n = 2 D: the old ring held g^2 here -- gone
+        want = np.zeros_like(z)
+        want[D // 2 + 5] = 0.25                                      # the new impulse and its echo, with the NEW decay
+        want[D // 2 + 5 + D] = F(0.25) * F(0.25)
+        assert np.array_equal(bits(z), bits(want))
+    # without the hook the tail would be there: the restatement's own process() keeps it
+    keep = O.Node(O.REVERB, [g], delay_len=D)
+    t = np.concatenate([keep.process(x[k:k + 128]) for k in range(0, 4 * D, 128)])
+    assert t[2 * D] == g * g
+
+
+def test_kat13_reverb_fresh_node_becomes_a_half_second_delay_at_its_first_slider_change():
+    """NodeStatic::new leaves make_buffer()'s 128-sample ring (reverb.rs:44-52) under a slider that shows 0.5 s: the first
+    widget change runs refresh_seconds with seconds = 0.5 -> max((0.5 * 48000) as usize, 128) = 24000 samples (reverb.rs:58);
+    restore() runs the hook once itself (lib.rs:319-337)."""
+    x = np.zeros(128, F)
+    x[3] = 1.0
+
+    def echo_at(node, blocks):
+        y = np.concatenate([node.process(x if k == 0 else np.zeros(128, F)) for k in range(blocks)])
+        return np.flatnonzero(y)
+
+    for node in _both(O.REVERB, [0.5, 0.5]):                         # fresh from the menu
+        assert list(echo_at(node, 3)) == [3, 131, 259]               # a 128-sample delay
+        node.set_param(0, 0.5)                                       # "changed" even to the same value: a new ring, 24000 long
+        assert list(echo_at(node, 190)) == [3, 24003]
+    for node in _both(O.REVERB, [0.5, 0.01], restored=True):         # restored with seconds = 0.01: 480 samples
+        assert list(echo_at(node, 5)) == [3, 483]
+    for node in _both(O.REVERB, [0.5, 0.01], mode=1, restored=True):  # the page-rounded reading: 1024
+        assert list(echo_at(node, 9)) == [3, 1027]
+    for node in _both(O.REVERB, [0.5, 0.002], delay_len=300):        # explicit ring, seconds slider 0.002 -> 128 at a store
+        assert list(echo_at(node, 4))[:2] == [3, 303]
+        node.set_param(1, 0.002)                                     # the seconds slider itself
+        assert list(echo_at(node, 3)) == [3, 131, 259]
+    assert M.delay_len_from_seconds(0.5) == O.delay_len(0.5) == 24000 and M.delay_len_from_seconds(0.5, True) == O.delay_len(0.5, True) == 24576
+    for s in (0.0, 0.001, 0.0026666, 0.0026667, 0.3333, 1.0):
+        assert M.delay_len_from_seconds(s) == O.delay_len(s), s
+
+
+def test_kat13_biquad_store_resets_state_and_other_nodes_keep_theirs():
+    """The other hook (biquad.rs:15, 62-76) and the absence of one: a one-pole's `z` survives a ratio store (low_pass.rs has
+    no after_settings_change), a biquad's history does not survive a coefficient store."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, 256).astype(F)
+    for node in _both(O.BIQUAD, [1.0, -0.5, 0.2, 0.3, 0.2, 0.1]):
+        node.process(x[:128])
+        node.set_param(3, 0.3)                                       # same value: still "changed" -> reset_state
+        fresh = O.Node(O.BIQUAD, [1.0, -0.5, 0.2, 0.3, 0.2, 0.1])
+        assert np.array_equal(bits(node.process(x[128:])), bits(fresh.process(x[128:])))
+    for node in _both(O.LOW_PASS, [0.9]):
+        node.process(x[:128])
+        node.set_param(0, 0.5)
+        fresh = O.Node(O.LOW_PASS, [0.5])
+        assert not np.array_equal(bits(node.process(x[128:])), bits(fresh.process(x[128:])))
