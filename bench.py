@@ -354,6 +354,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     eng = pkg.Engine(shard.channels, B, link_flags=args.link_flags, device=ctx.local_rank,
                      channel_offset=shard.offset, tile_channels=tile)
     eng.set_chain(chain)
+    eng.kernels_ready(120000)     # setup time: a shape without a compiled-in kernel gets its run-time kernel BEFORE anything is timed
     stream = ctx.compute_stream.cuda_stream
 
     # ---- every host-side allocation happens HERE, before any settling: the chip's power management reacts to

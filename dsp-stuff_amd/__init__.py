@@ -55,7 +55,7 @@ EXPORTS = [
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
     "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
-    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus",
+    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus", "dspfx_kernels_ready",
 ]
 COMM_ID_BYTES = 128
 
@@ -128,6 +128,7 @@ def lib():
     L.dspfx_last_error.argtypes = [vp]
     L.dspfx_chain_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int]
     L.dspfx_chain_len.argtypes = [vp]
+    L.dspfx_kernels_ready.argtypes = [vp, C.c_int]
     L.dspfx_graph_set.argtypes = [vp, C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int]
     L.dspfx_graph_source.argtypes = [C.POINTER(_NodeDesc), C.c_int, C.POINTER(_GraphLink), C.c_int, C.c_char_p, C.c_size_t]
     L.dspfx_set_param.argtypes = [vp, C.c_int, C.c_int, C.c_float]
@@ -427,6 +428,14 @@ class Engine:
         arr, larr = self._graph_arrays(nodes, links)
         self._chk(self.L.dspfx_graph_set(self.h, arr, len(nodes), larr, len(links)))
         self.nodes = list(nodes)
+
+    def kernels_ready(self, wait_ms: int = 60000) -> bool:
+        """Adopt the kernels the background compiler has finished for this engine's chain and wait up to wait_ms for the rest
+        (dspfx_kernels_ready): True when nothing is pending any more.  Results never depend on it."""
+        rc = self.L.dspfx_kernels_ready(self.h, int(wait_ms))
+        if rc < 0:
+            self._chk(rc)
+        return rc == 1
 
     def set_param(self, node: int, param: int, value: float):
         self._chk(self.L.dspfx_set_param(self.h, node, param, float(value)))

@@ -111,6 +111,11 @@ struct ChainArgs {
     // Same-block mix bus (mix_tail): the slice and final stages of THIS block run inside this launch -- the workgroup
     // that completes a slice of rows reduces it, the one that completes the last slice finishes the bus.
     float mt_div;            // Output-node divisor, or 0
+    // 1: every WAVE of a 256-lane workgroup leaves its own row of partial sums (row = wave_base + 4 workgroup + wave) instead
+    // of one row per workgroup.  Engines below 16384 channels run this way, so that their rows are the time-sliced kernels'
+    // rows -- one per 64 channels -- and the bus' summation order does not change when such an engine moves from the
+    // interpreter to the kernels the background compiler made for it (jit.hip), whenever that happens.
+    int mix_per_wave;
     unsigned *mt_tickets;    // [MIX_SLICES + 1] arrival counters, zero between launches; nullptr: no tail
     float *mt_part2;         // [MIX_SLICES][nframes] slice sums
     float *mt_mix;           // [nframes] the bus of this block
@@ -174,6 +179,7 @@ struct ColdArgs {
     unsigned nframes, mix_stride, wave_base, n_launch;
     int xcd_remap;
     float mt_div;
+    int mix_per_wave;
     unsigned *mt_tickets;
     float *mt_part2, *mt_mix;
 };
@@ -189,6 +195,7 @@ __device__ __forceinline__ ColdArgs cold_args() {
     c.n_launch = ka->n_launch;
     c.xcd_remap = ka->xcd_remap;
     c.mt_div = ka->mt_div;
+    c.mix_per_wave = ka->mix_per_wave;
     c.mt_tickets = ka->mt_tickets;
     c.mt_part2 = ka->mt_part2;
     c.mt_mix = ka->mt_mix;
@@ -1280,11 +1287,22 @@ __device__ __forceinline__ void mixbus_partial(MixStage &ms, const float (&v)[F]
     }
 }
 // Frames [seg0, seg0 + len) are parked by every wave of the workgroup (nw of them are alive; they all call this).
+// per_wave (ChainArgs::mix_per_wave): every live wave writes the row it parked itself, `row` being the workgroup's first.
 template <class ARGS>
-__device__ __forceinline__ void mixbus_flush(const ARGS &a, MixStage &ms, unsigned seg0, unsigned len, unsigned row, int nw, int wave, int lane) {
+__device__ __forceinline__ void mixbus_flush(const ARGS &a, MixStage &ms, unsigned seg0, unsigned len, unsigned row, int nw, int wave, int lane, bool per_wave = false) {
     __syncthreads();
-    if (wave != 0) return;
     const int buf = (seg0 / MIX_SEG) & 1;
+    if (per_wave) {
+        if (wave >= nw) return;
+        float *dst = a.mixpart + (size_t)(row + (unsigned)wave) * a.nframes + seg0;
+        for (unsigned f = lane; f < len; f += 64) {
+            const float t = ms.row[buf][wave][f];
+            if (a.mt_tickets) st_sc1(dst + f, t);
+            else dst[f] = t;
+        }
+        return;
+    }
+    if (wave != 0) return;
     float *dst = a.mixpart + (size_t)row * a.nframes + seg0;
     for (unsigned f = lane; f < len; f += 64) {
         float t = ms.row[buf][0][f];
@@ -1315,7 +1333,15 @@ __device__ __forceinline__ void mixbus_after_chunk(const ChainArgs &hot, MixStag
     const unsigned len = end % MIX_SEG ? end % MIX_SEG : MIX_SEG;
     const unsigned wb = blockDim.x == WG ? work_block(a.xcd_remap) : blockIdx.x;   // guarded tail launches use 64-lane blocks
     const int nw = mixbus_live_waves<CPL>(a, (size_t)wb * blockDim.x * CPL, (int)(blockDim.x / 64));
-    mixbus_flush(a, ms, end - len, len, a.wave_base + wb, nw, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63);
+    const bool per_wave = a.mix_per_wave && blockDim.x == WG;
+    mixbus_flush(a, ms, end - len, len, a.wave_base + (per_wave ? wb * (WG / 64) : wb), nw, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), threadIdx.x & 63, per_wave);
+}
+// The same-block bus' tail for the rows this workgroup wrote (called by every wave at the end of a chain / graph kernel).
+__device__ __forceinline__ void mix_tail_rows(unsigned wb, int wave, int lane) {
+    const ColdArgs a = cold_args();
+    if (!a.mt_tickets) return;
+    if (a.mix_per_wave && blockDim.x == WG) mix_tail(a.wave_base + wb * (WG / 64) + (unsigned)wave, lane);   // (waves past n_launch have returned)
+    else if (wave == 0) mix_tail(a.wave_base + wb, lane);
 }
 
 template <int F, int CPL, class SL, bool MOD = false>
@@ -1376,7 +1402,7 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
     store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_ST)
 #undef DSPFX_ST
-    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + work_block(a.xcd_remap), lane);
+    if (a.mt_tickets) mix_tail_rows(work_block(a.xcd_remap), wave, lane);
 }
 
 // ---- the fused chain kernel, time-sliced: few channels ------------------------------------------------
@@ -1660,7 +1686,7 @@ __global__ void __launch_bounds__(WG) chain_dyn_kernel(const ChainArgs a) {
             row += ns;
         }
     }
-    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + wb, lane);
+    if (a.mt_tickets) mix_tail_rows(wb, wave, lane);
 }
 
 }  // namespace dspfx

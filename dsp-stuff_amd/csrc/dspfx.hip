@@ -263,19 +263,18 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS], nframes);
                 rows += state_rows(e->nodes[st.first + k]);
             }
-            if (st.async && st.async->ready.load(std::memory_order_acquire) != 0) adopt_async_jit(e, st);
+            if (st.async || st.async_mod) adopt_async_jit(e, st);      // kernels the background compiler has finished: from this block on
             const Variant *v = st.var, *tail = e->tail;
             for (int k = 0; k < st.count; ++k) {   // modulated or latched sliders: only the MOD interpreter evaluates them
                 const Node &nd = e->nodes[st.first + k];
                 if (nd.latch_valid || nd.ctl_now[0] || nd.ctl_now[1] || nd.ctl_now[2]) {
                     // a run-time specialised kernel with control ports when one can be had (compiled on first use),
                     // else the control-port interpreter: two channels per lane above 131072 channels
-                    if (!st.var_mod_tried) {
-                        st.var_mod_tried = true;
-                        const char *vp = getenv("DSPFX_VARIANT");
-                        if (!(vp && strstr(vp, "static=0"))) st.var_mod = jit_variant(e, st, true);
-                    }
-                    v = st.var_mod ? st.var_mod : ((e->dyn_mod2 && N > 131072u && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod);
+                    // else the control-port interpreter: two channels per lane above 131072 channels -- or, while the
+                    // specialised kernel is on its way, the channels per lane of THAT kernel (the same rows of bus partials)
+                    if (!st.var_mod_tried) request_mod_kernel(e, st);
+                    const bool two = st.async_mod ? jit_std_cpl(e) == 2 : N > 131072u;
+                    v = st.var_mod ? st.var_mod : ((e->dyn_mod2 && two && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod);
                     tail = e->tail_mod;
                 }
             }
@@ -301,8 +300,16 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.mixpart = deferred ? e->partials_override : ((last && mix) ? e->mixpart : nullptr);
             const unsigned grid_main = v->ts ? waves_main : (waves_main * 64 + WG - 1) / WG;   // time-sliced: one workgroup per channel group
             // the bus' first stage leaves one row of partial sums per WORKGROUP (chain_kernels.hip.h, mixbus_flush); the
-            // guarded tail launch runs one-wave workgroups
-            a.mix_stride = grid_main + (N - n_main + 63) / 64;
+            // guarded tail launch runs one-wave workgroups.  Engines up to TS_MAX_CHANNELS -- the ones a time-sliced kernel
+            // may serve -- leave one row per WAVE instead: one row per 64 x cpl channels in the interpreter, the specialised
+            // standard kernel and the time-sliced kernels alike.  An engine starts on the interpreter and adopts the kernels
+            // the background thread compiled at a block boundary nobody can predict (plan.hip): with the same rows before and
+            // after -- and, above this size, the interpreter instantiation of the coming kernel's channels per lane -- the
+            // bus' f32 summation order does not change at that switch (it used to).
+            const bool rows_per_wave = !v->ts && N <= TS_MAX_CHANNELS;
+            a.mix_per_wave = rows_per_wave ? 1 : 0;
+            const unsigned rows_main = (v->ts || rows_per_wave) ? waves_main : grid_main;
+            a.mix_stride = rows_main + (N - n_main + 63) / 64;
             if (a.mixpart && a.mix_stride > e->mixpart_cols) return fail(e, DSPFX_ERR_STATE, "mix partial buffer too small");
             // Same-block bus: the slice and final stages ride in the tail of this very launch (mix_tail) instead of two more
             // kernels behind it.  DSPFX_MIX_TAIL=0: the stand-alone kernels (A/B runs, tests: bit-identical).
@@ -343,7 +350,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 if (w1 > w0) {
                     a.c_base = w0;
                     a.n_launch = w1 - w0;
-                    a.wave_base = v->ts ? w0 / per_wave : w0 / (per_wave * (WG / 64));   // rows of the windows before this one
+                    a.wave_base = (v->ts || rows_per_wave) ? w0 / per_wave : w0 / (per_wave * (WG / 64));   // rows of the windows before this one
                     ProfScope ps(e, si, stream);
                     if (launch_variant(v, a, v->ts ? (w1 - w0) / per_wave : ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream))
                         return fail(e, DSPFX_ERR_HIP, "kernel launch failed");
@@ -362,7 +369,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                 const uint32_t n_tail = N - n_main;
                 a.c_base = n_main;
                 a.n_launch = n_tail;
-                a.wave_base = grid_main;
+                a.wave_base = rows_main;
                 if (st.var_ts_tail && tail == e->tail && nframes == 4u * (uint32_t)st.var_ts_tail->ts) {
                     a.xcd_remap = 0;            // whole 128-frame blocks: four slices per 64 channels (pick_ts_tail_variant)
                     if (whole_guard) {          // the stage's only launch: it is the one dspfx_profile_read reports
@@ -684,6 +691,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return DSPFX_ERR_NO_DEVICE;
     if (desc->device < 0 || desc->device >= ndev) return DSPFX_ERR_INVALID;
     if (hipSetDevice(desc->device) != hipSuccess) return DSPFX_ERR_HIP;
+    jit_arm_exit_guard();
     dspfx_engine *e = new dspfx_engine();
     e->desc = *desc;
     e->device = desc->device;
@@ -714,11 +722,13 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     (void)hipDeviceSynchronize();            // blocks still in flight read the state that is about to be freed
-    for (const Stage &st : e->stages)
-        if (st.async) {
-            st.async->abandoned.store(true, std::memory_order_release);
-            async_jit_wait(st.async);        // not queued any more and not finished: at most the rest of one compile
-        }
+    // shapes of this engine still with the background compiler: skipped if not started; a compile in flight finishes into the
+    // process-wide table and the disk cache (it touches nothing of the engine), and the library's exit handler waits for it --
+    // a host that re-creates its engines on every graph edit (runtime.rs:319-362) is not held up here
+    for (const Stage &st : e->stages) {
+        if (st.async) st.async->abandoned.store(true, std::memory_order_release);
+        if (st.async_mod) st.async_mod->abandoned.store(true, std::memory_order_release);
+    }
     for (Node &n : e->nodes) free_node(n);
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);
@@ -827,6 +837,35 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
         e->err = msg;
     }
     return rc;
+}
+
+// Kernels compiled in the background are adopted at a block boundary; a host (or a benchmark) that wants them BEFORE its
+// first block waits here.
+extern "C" int dspfx_kernels_ready(dspfx_engine *e, int wait_ms) {
+    if (!e) return DSPFX_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        std::vector<std::shared_ptr<AsyncJit>> jobs;
+        {
+            ApiScope api(e);
+            if (api.rc) return api.rc;
+            bool pending = false;
+            for (const Stage &st : e->stages) {
+                if (st.type != ST_FUSED) continue;
+                if (st.async || st.async_mod) adopt_async_jit(e, st);       // whatever is finished takes effect now (the engine is ours)
+                if (st.async) jobs.push_back(st.async);
+                if (st.async_mod) jobs.push_back(st.async_mod);
+                pending = pending || st.async || st.async_mod;
+            }
+            if (!pending) return 1;
+        }
+        // wait WITHOUT the engine's lock: the thread that drives the blocks is not held up by this one
+        const int left = wait_ms - (int)std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (left <= 0) return 0;
+        bool all = true;
+        for (const auto &j : jobs) all = async_jit_wait(j, std::max(1, left)) && all;
+        if (!all) return 0;
+    }
 }
 
 extern "C" int dspfx_chain_len(const dspfx_engine *e) {

@@ -83,9 +83,13 @@ struct AsyncJit {
     std::atomic<int> state{0};           // 0 queued, 1 being compiled, 2 finished or skipped
     int device = 0, n_slots = 0;
     int sigs[dspfx::MAX_SLOTS];
-    bool want_ts = false, want_tail = false;
-    const JitKernel *k_std = nullptr, *k_ts = nullptr, *k_tail = nullptr;
+    // which kernels of the shape: the standard one <f_std, cpl_std>, the one with control ports <f_mod, cpl_std, mod>, the
+    // time-sliced one <32, cpl_ts>, the guarded time-sliced one for the channels a whole-wave launch leaves over
+    bool want_std = false, want_mod = false, want_ts = false, want_tail = false;
+    int f_std = 16, f_mod = 8, cpl_std = 1, cpl_ts = 1;
+    const JitKernel *k_std = nullptr, *k_mod = nullptr, *k_ts = nullptr, *k_tail = nullptr;
     std::string headers_dir;             // where the kernel headers are, as the submitting thread saw it
+    std::string cache_dir;               // ... and the on-disk cache of code objects ("": none)
 };
 
 struct Stage {
@@ -94,9 +98,11 @@ struct Stage {
     mutable const Variant *var = nullptr;   // ST_FUSED
     mutable const Variant *var_ts = nullptr;   // ST_FUSED, few channels: the time-sliced kernel, used for blocks of exactly 4 * ts frames
     mutable const Variant *var_ts_tail = nullptr;   // ST_FUSED, N % (64 cpl) != 0: the guarded time-sliced kernel for the channels left over (same blocks)
-    mutable std::shared_ptr<AsyncJit> async;    // ST_FUSED on the interpreter, few channels: its specialisation is on the way
-    mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, compiled on first use
+    mutable std::shared_ptr<AsyncJit> async;    // ST_FUSED on the interpreter: its specialisation is on the way (adopted at a block boundary)
+    mutable bool jit_failed = false;            // ... and could not be had (no compiler / headers): the best interpreter instantiation serves
+    mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, asked for on first use
     mutable bool var_mod_tried = false;
+    mutable std::shared_ptr<AsyncJit> async_mod;   // ... being compiled in the background
     bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
 };
 
@@ -255,11 +261,12 @@ bool fusable(const Node &n);
 int node_hop(const dspfx_engine *e, int idx);
 Pref read_pref();
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job);   // jit.hip: background specialisation for small engines
-void async_jit_wait(const std::shared_ptr<AsyncJit> &job);     // ... until the compiler is not working on `job` (bounded)
+bool async_jit_wait(const std::shared_ptr<AsyncJit> &job, int wait_ms);   // ... until the compiler is done with `job` (bounded)
 int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
 int plan(dspfx_engine *e);
 void collect_variants(std::vector<const Variant *> &out);
 void adopt_async_jit(dspfx_engine *e, const Stage &st);      // plan.hip: run_subblock calls it at a block boundary
+void request_mod_kernel(dspfx_engine *e, const Stage &st);   // plan.hip: the stage's control-port kernel, on first use
 int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *host, bool to_host);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
                  hipStream_t stream);
@@ -287,9 +294,18 @@ struct ApiScope {
 };
 
 // ---- jit.hip
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts = false, bool guard = false);
+enum JitMode { JIT_MEMORY = 0, JIT_DISK = 1, JIT_COMPILE = 2 };      // how far jit_get goes: this process' table, + the disk cache, + the compiler
+enum JitPolicy { JP_OFF = 0, JP_SYNC = 1, JP_ASYNC = 2 };
+JitPolicy jit_policy(const dspfx_engine *e);
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts, bool guard, int mode);
+void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]);
+int jit_std_cpl(const dspfx_engine *e);
+int jit_std_f(const dspfx_engine *e, bool mod);
+std::string jit_cache_dir();
+void jit_arm_exit_guard();   // the calling thread waits for a background compile in flight when it ends (jit.hip: ExitGuard)
+extern std::atomic<uint64_t> g_jit_compiled, g_jit_from_disk, g_jit_disk_written;
 int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s);
-const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod);
+const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod, int mode);
 const Variant *graph_variant(const dspfx_engine *e, const Stage &st);
 int kind_sliders(const dspfx_node_desc &d, float (&lo)[3], float (&hi)[3]);
 int graph_input_block(int src);

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(WG) graph_kernel(const GraphArgs g) {
     store_state<PROG::sigs[I], CPL, false>(gslot<I>(g), st[I], c, a.N, true);
     DSPFX_FOR_GSLOTS(DSPFX_ST)
 #undef DSPFX_ST
-    if (a.mt_tickets && wave == 0) mix_tail(a.wave_base + wb, lane);
+    if (a.mt_tickets) mix_tail_rows(wb, wave, lane);
 }
 
 }  // namespace dspfx

@@ -3,6 +3,9 @@
 #include "engine.h"
 #include <pthread.h>
 #include <chrono>
+#include <sys/stat.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 using namespace dspfx;
 using namespace dspfx_host;
@@ -34,42 +37,192 @@ std::string csrc_dir() {
     return k == std::string::npos ? "." : p.substr(0, k);
 }
 
-// Compile `src` (which includes headers from this library's directory), load it on the current device and look up the
-// kernel named by `expr`.  Cached per `key` for the life of the process.
+// ---- the on-disk cache of code objects ---------------------------------------------------------------------------------
+// A host that edits its graph re-creates its nodes (runtime.rs:319-362) and a host that is restarted re-creates all of them:
+// the run-time compiler (0.3-1.5 s per kernel) must not run twice for the same kernel.  Every compiled code object is kept in
+//   $DSPFX_CACHE_DIR, else $XDG_CACHE_HOME/dspfx, else $HOME/.cache/dspfx          (DSPFX_DISK_CACHE=0: no disk cache)
+// under a name derived from EVERYTHING the object depends on: the text of chain_kernels.hip.h and graph_kernel.hip.h as found
+// next to the library, the translation unit, the kernel's name expression, the compile options (target arch included) and the
+// hiprtc version.  A second process loads it in a few milliseconds (hipModuleLoadData of ~100 KB).  Files are written to a
+// temporary name and renamed, so concurrent processes never see a partial object; a file that does not parse or load is
+// ignored and overwritten.
+static const char *const k_jit_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+std::atomic<uint64_t> g_jit_compiled{0}, g_jit_from_disk{0}, g_jit_disk_written{0};
+
+static void fnv(uint64_t &h, const void *p, size_t n) {
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) {
+        h ^= b[i];
+        h *= 0x100000001b3ull;
+    }
+}
+static bool read_file(const std::string &path, std::string &out) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    char buf[1 << 16];
+    size_t n;
+    out.clear();
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
+    fclose(f);
+    return true;
+}
+// (the background compiler's thread never calls getenv: it is handed the directory with its job, AsyncJit::cache_dir)
+static thread_local const std::string *t_cache_override = nullptr;
+std::string jit_cache_dir() {
+    if (const char *off = getenv("DSPFX_DISK_CACHE"))
+        if (atoi(off) == 0) return "";
+    if (const char *d = getenv("DSPFX_CACHE_DIR")) return d;
+    if (const char *x = getenv("XDG_CACHE_HOME"))
+        if (*x) return std::string(x) + "/dspfx";
+    if (const char *h = getenv("HOME"))
+        if (*h) return std::string(h) + "/.cache/dspfx";
+    return "";
+}
+static std::string cache_dir_now() { return t_cache_override ? *t_cache_override : jit_cache_dir(); }
+static void mkdirs(const std::string &dir) {
+    std::string cur;
+    for (size_t i = 0; i <= dir.size(); ++i)
+        if (i == dir.size() || dir[i] == '/') {
+            cur = dir.substr(0, i);
+            if (!cur.empty()) (void)mkdir(cur.c_str(), 0777);
+        }
+}
+// name of the cache file for (translation unit, kernel expression) given the headers in `hdr_dir`; "" when there is no cache
+static std::string cache_file(const std::string &hdr_dir, const std::string &src, const std::string &expr) {
+    const std::string dir = cache_dir_now();
+    if (dir.empty() || hdr_dir.empty()) return "";
+    std::string h1, h2;
+    if (!read_file(hdr_dir + "/chain_kernels.hip.h", h1)) return "";
+    (void)read_file(hdr_dir + "/graph_kernel.hip.h", h2);
+    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+    int ver_major = 0, ver_minor = 0;
+    (void)hiprtcVersion(&ver_major, &ver_minor);
+    for (uint64_t *h : {&a, &b}) {
+        fnv(*h, h1.data(), h1.size());
+        fnv(*h, "\x01", 1);
+        fnv(*h, h2.data(), h2.size());
+        fnv(*h, "\x02", 1);
+        fnv(*h, src.data(), src.size());
+        fnv(*h, "\x03", 1);
+        fnv(*h, expr.data(), expr.size());
+        for (const char *o : k_jit_opts) fnv(*h, o, strlen(o) + 1);
+        fnv(*h, &ver_major, sizeof ver_major);
+        fnv(*h, &ver_minor, sizeof ver_minor);
+        fnv(*h, h == &a ? "A" : "B", 1);
+    }
+    char name[64];
+    snprintf(name, sizeof name, "/%016llx%016llx.co", (unsigned long long)a, (unsigned long long)b);
+    return dir + name;
+}
+// file = "DSPFXCO1" u32 name_len, name bytes, u64 code_len, code bytes
+static bool cache_read(const std::string &path, std::string &lowered, std::vector<char> &code) {
+    std::string all;
+    if (path.empty() || !read_file(path, all) || all.size() < 8 + 4 + 8 || memcmp(all.data(), "DSPFXCO1", 8) != 0) return false;
+    uint32_t nl = 0;
+    memcpy(&nl, all.data() + 8, 4);
+    if (all.size() < 12 + (size_t)nl + 8) return false;
+    uint64_t cl = 0;
+    memcpy(&cl, all.data() + 12 + nl, 8);
+    if (all.size() != 12 + (size_t)nl + 8 + cl || cl == 0) return false;
+    lowered.assign(all.data() + 12, nl);
+    code.assign(all.begin() + 12 + nl + 8, all.end());
+    return true;
+}
+static void cache_write(const std::string &path, const char *lowered, const std::vector<char> &code) {
+    if (path.empty()) return;
+    mkdirs(path.substr(0, path.find_last_of('/')));
+    char tmp[64];
+    snprintf(tmp, sizeof tmp, ".tmp.%ld.%p", (long)getpid(), (void *)&code);
+    const std::string tpath = path + tmp;
+    FILE *f = fopen(tpath.c_str(), "wb");
+    if (!f) return;
+    const uint32_t nl = (uint32_t)strlen(lowered);
+    const uint64_t cl = code.size();
+    bool ok = fwrite("DSPFXCO1", 1, 8, f) == 8 && fwrite(&nl, 4, 1, f) == 1 && fwrite(lowered, 1, nl, f) == nl && fwrite(&cl, 8, 1, f) == 1 &&
+              fwrite(code.data(), 1, code.size(), f) == code.size();
+    ok = fclose(f) == 0 && ok;
+    if (ok && rename(tpath.c_str(), path.c_str()) == 0) g_jit_disk_written.fetch_add(1);
+    else (void)remove(tpath.c_str());
+}
+
+// A loaded code object -> a kernel the engine can launch (nullptr: it does not load on this device).
+static JitKernel *jit_load(const std::string &key, const std::vector<char> &code, const char *lowered, const int (&sigs)[MAX_SLOTS], int n_slots, int f,
+                           int cpl, bool mod) {
+    JitKernel *k = new JitKernel();
+    if (hipModuleLoadData(&k->module, code.data()) != hipSuccess || hipModuleGetFunction(&k->fn, k->module, lowered) != hipSuccess) {
+        (void)hipGetLastError();
+        if (k->module) (void)hipModuleUnload(k->module);
+        delete k;
+        return nullptr;
+    }
+    k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
+    if (hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn) != hipSuccess) {
+        (void)hipGetLastError();
+        k->vgprs = 0;
+    }
+    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
+    for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
+    k->var.name = k->name.c_str();
+    return k;
+}
+
+// `src` (which includes headers from this library's directory) as the kernel named by `expr`, on the current device:
+//   JIT_MEMORY   only what this process already holds;
+//   JIT_DISK     ... or a code object from the disk cache (milliseconds);
+//   JIT_COMPILE  ... or compile it now (0.3-1.5 s), and leave it in the disk cache.
+// The process-wide table is only locked for look-ups and inserts: a compile in progress on the background thread does not hold
+// up a look-up from the thread that drives the blocks.  Cached per `key` for the life of the process.
 const JitKernel *jit_compile(const std::string &key, const std::string &src, const std::string &expr, const int (&sigs)[MAX_SLOTS],
-                             int n_slots, int f, int cpl, bool mod) {
-    std::lock_guard<std::mutex> lk(g_jit_mu);
-    auto it = g_jit.find(key);
-    if (it != g_jit.end()) return it->second;
-    JitKernel *res = nullptr;
+                             int n_slots, int f, int cpl, bool mod, int mode) {
+    auto lookup = [&]() -> const JitKernel * {
+        std::lock_guard<std::mutex> lk(g_jit_mu);
+        auto it = g_jit.find(key);
+        return it != g_jit.end() ? it->second : nullptr;
+    };
+    auto insert = [&](JitKernel *k) -> const JitKernel * {
+        std::lock_guard<std::mutex> lk(g_jit_mu);
+        auto it = g_jit.find(key);
+        if (it != g_jit.end()) {                 // another thread was faster: keep its kernel (the engine may already hold it)
+            if (k->module) (void)hipModuleUnload(k->module);
+            delete k;
+            return it->second;
+        }
+        g_jit[key] = k;
+        return k;
+    };
+    if (const JitKernel *k = lookup()) return k;
+    if (mode == JIT_MEMORY) return nullptr;
     const std::string dir = csrc_dir();
+    const std::string cfile = cache_file(dir, src, expr);
+    {
+        std::string lowered;
+        std::vector<char> code;
+        if (cache_read(cfile, lowered, code))
+            if (JitKernel *k = jit_load(key, code, lowered.c_str(), sigs, n_slots, f, cpl, mod)) {
+                g_jit_from_disk.fetch_add(1);
+                return insert(k);
+            }
+    }
+    if (mode == JIT_DISK) return nullptr;
+    JitKernel *res = nullptr;
     hiprtcProgram prog = nullptr;
     if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
         const std::string inc = "-I" + dir;
-        const char *opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math", inc.c_str()};
+        std::vector<const char *> opts(k_jit_opts, k_jit_opts + sizeof k_jit_opts / sizeof k_jit_opts[0]);
+        opts.push_back(inc.c_str());
         if (hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS &&
-            hiprtcCompileProgram(prog, 6, opts) == HIPRTC_SUCCESS) {
+            hiprtcCompileProgram(prog, (int)opts.size(), opts.data()) == HIPRTC_SUCCESS) {
             const char *lowered = nullptr;
             size_t cs = 0;
             if (hiprtcGetLoweredName(prog, expr.c_str(), &lowered) == HIPRTC_SUCCESS && lowered &&
                 hiprtcGetCodeSize(prog, &cs) == HIPRTC_SUCCESS && cs) {
                 std::vector<char> code(cs);
-                JitKernel *k = new JitKernel();
-                if (hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS &&
-                    hipModuleLoadData(&k->module, code.data()) == hipSuccess &&
-                    hipModuleGetFunction(&k->fn, k->module, lowered) == hipSuccess) {
-                    k->name = std::string("jit_") + key.substr(0, key.find('\n'));   // graph keys carry their source after a newline
-                    if (hipFuncGetAttribute(&k->vgprs, HIP_FUNC_ATTRIBUTE_NUM_REGS, k->fn) != hipSuccess) {
-                        (void)hipGetLastError();
-                        k->vgprs = 0;
+                if (hiprtcGetCode(prog, code.data()) == HIPRTC_SUCCESS) {
+                    res = jit_load(key, code, lowered, sigs, n_slots, f, cpl, mod);
+                    if (res) {
+                        g_jit_compiled.fetch_add(1);
+                        cache_write(cfile, lowered, code);
                     }
-                    k->var = Variant{nullptr, {}, n_slots, f, cpl, false, mod, true, nullptr};
-                    for (int i = 0; i < MAX_SLOTS; ++i) k->var.sigs[i] = sigs[i];
-                    k->var.name = k->name.c_str();
-                    res = k;
-                } else {
-                    (void)hipGetLastError();
-                    delete k;
                 }
             }
         } else if (!t_dir_override && getenv("DSPFX_JIT_DEBUG")) {
@@ -81,20 +234,19 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
         }
         (void)hiprtcDestroyProgram(&prog);
     }
-    if (res) g_jit[key] = res;   // failures are not remembered: a missing header directory can be put right while the process lives
-    return res;
+    return res ? insert(res) : nullptr;   // failures are not remembered: a missing header directory can be put right while the process lives
 }
 
 // ts: the time-sliced kernel chain_ts_kernel<f, cpl, ...> (f = frames per slice) instead of chain_kernel<f, cpl, ...>
 // guard (ts only): chain_ts_kernel<f, 1, ..., true>, the launch for the channels a whole-wave launch leaves over
-const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts, bool guard) {
+const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts, bool guard, int mode) {
     char key[256];
     int off = snprintf(key, sizeof key, "d%d_%s%d_c%d%s%s", device, ts ? "ts" : "f", f, cpl, mod ? "_mod" : "", (guard && ts) ? "_tail" : "");   // modules belong to the device they were loaded on
     for (int i = 0; i < MAX_SLOTS; ++i) off += snprintf(key + off, sizeof key - (size_t)off, "_%d", sigs[i]);
     std::string expr = std::string(ts ? "dspfx::chain_ts_kernel<" : "dspfx::chain_kernel<") + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::SigList<";
     for (int i = 0; i < MAX_SLOTS; ++i) expr += std::to_string(sigs[i]) + (i + 1 < MAX_SLOTS ? ", " : "");
     expr += ((mod && !ts) || (guard && ts)) ? ">, true>" : "> >";
-    const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod);
+    const JitKernel *k = jit_compile(key, "#include \"chain_kernels.hip.h\"\n", expr, sigs, n_slots, f, cpl, mod, mode);
     if (k && ts) {
         const_cast<JitKernel *>(k)->var.ts = f;
         const_cast<JitKernel *>(k)->var.guard = guard;
@@ -116,7 +268,7 @@ struct AsyncCompiler {
     std::condition_variable cv;
     std::deque<std::shared_ptr<AsyncJit>> q;
     std::thread worker;
-    bool started = false, stop = false;
+    bool started = false, stop = false, reregistered = false;
     void run() {
         for (;;) {
             std::shared_ptr<AsyncJit> job;
@@ -139,19 +291,28 @@ struct AsyncCompiler {
                 continue;
             }
             t_dir_override = &job->headers_dir;
-            job->k_std = jit_get(job->device, job->sigs, job->n_slots, 16, 1, false);
-            if (job->k_std && job->want_ts && !job->abandoned.load(std::memory_order_acquire))
-                job->k_ts = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true);
-            if (job->k_std && job->want_tail && !job->abandoned.load(std::memory_order_acquire))
-                job->k_tail = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true, true);
+            t_cache_override = &job->cache_dir;
+            const JitKernel *first = nullptr;
+            if (job->want_std) first = job->k_std = jit_get(job->device, job->sigs, job->n_slots, job->f_std, job->cpl_std, false, false, false, JIT_COMPILE);
+            if (job->want_mod) first = job->k_mod = jit_get(job->device, job->sigs, job->n_slots, job->f_mod, job->cpl_std, true, false, false, JIT_COMPILE);
+            const bool go_on = first || !(job->want_std || job->want_mod);     // no compiler: do not try the other kernels either
+            if (go_on && job->want_ts && !job->abandoned.load(std::memory_order_acquire))
+                job->k_ts = jit_get(job->device, job->sigs, job->n_slots, 32, job->cpl_ts, false, true, false, JIT_COMPILE);
+            if (go_on && job->want_tail && !job->abandoned.load(std::memory_order_acquire))
+                job->k_tail = jit_get(job->device, job->sigs, job->n_slots, 32, 1, false, true, true, JIT_COMPILE);
             t_dir_override = nullptr;
-            job->ready.store(job->k_std ? 1 : -1, std::memory_order_release);
+            t_cache_override = nullptr;
+            job->ready.store((job->k_std || job->k_mod || job->k_ts || job->k_tail) ? 1 : -1, std::memory_order_release);
             job->state.store(2, std::memory_order_release);
             // Exit handlers run newest first, and the compiler's libraries (loaded lazily, inside the first compile) register
-            // theirs when they are loaded: registered again here, ours -- which waits for a compile in flight -- stays ahead of
-            // every one of them that exists by now.  (Found by tests/cpp/test_host: a process that left main() while its last
-            // engine's shape was being compiled crashed inside comgr, whose globals the exiting thread had destroyed.)
-            std::atexit(async_exit_handler);
+            // theirs when they are loaded: registered once more after the FIRST compile, ours -- which waits for a compile in
+            // flight -- is ahead of every one of them.  (Found by tests/cpp/test_host: a process that left main() while its last
+            // engine's shape was being compiled crashed inside comgr, whose globals the exiting thread had destroyed.  Round 3
+            // registered it after every compile: an unbounded list in a host that edits its graph all day)
+            if (!reregistered) {
+                reregistered = true;
+                std::atexit(async_exit_handler);
+            }
         }
     }
     bool forked = false;          // this process is a fork()ed child: the worker thread does not exist here
@@ -172,9 +333,29 @@ std::once_flag g_async_once;
 static void async_exit_handler() {
     if (g_async) g_async->shutdown();
 }
+// Exit handlers are the second line of defence: the compiler constructs function-local statics WHILE it compiles, whose
+// destructors are registered at that moment -- after ours, so they run before ours -- and an exiting process would pull
+// them from under a compile in flight (seen as a segfault at exit in tests/test_gpu_threads.py).  What runs before EVERY exit
+// handler is the exiting thread's thread_local destructors (glibc: exit() -> __call_tls_dtors() first).  So every thread that
+// hands a shape to the background compiler carries this guard: when the MAIN thread ends -- the process is exiting -- it
+// stops the worker and waits for the compile in flight, before anything is torn down; any other thread just waits for it.
+namespace {
+struct ExitGuard {
+    bool armed = false;
+    ~ExitGuard() {
+        if (!armed || !g_async || g_async->forked) return;
+        if ((long)getpid() == (long)syscall(SYS_gettid)) g_async->shutdown();
+    }
+};
+thread_local ExitGuard t_exit_guard;
+}  // namespace
+
+void jit_arm_exit_guard() { t_exit_guard.armed = true; }   // (touching it constructs it on this thread: its destructor runs when the thread ends)
 
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
+    t_exit_guard.armed = true;
     job->headers_dir = csrc_dir();
+    job->cache_dir = jit_cache_dir();
     std::call_once(g_async_once, [] {
         g_async = new AsyncCompiler();
         // hiprtc loads the compiler (comgr, with LLVM inside) lazily, at the first compile -- on the worker thread, i.e. AFTER
@@ -198,10 +379,14 @@ void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     g_async->cv.notify_one();
 }
 
-// dspfx_engine_destroy: a host that destroys its engines before it exits never exits with ITS shapes in the compiler
-void async_jit_wait(const std::shared_ptr<AsyncJit> &job) {
-    for (int ms = 0; ms < 20000 && job->state.load(std::memory_order_acquire) == 1; ++ms)
+// dspfx_kernels_ready: until the background compiler is done with `job` (or was never going to be: no worker in a forked
+// child), at most wait_ms milliseconds.  true: finished (whatever the outcome).
+bool async_jit_wait(const std::shared_ptr<AsyncJit> &job, int wait_ms) {
+    for (int ms = 0; job->state.load(std::memory_order_acquire) != 2; ++ms) {
+        if (ms >= wait_ms || !g_async || g_async->forked) return false;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return true;
 }
 
 // A kernel variant is launched through its compiled-in launcher or, for a run-time specialised one, through the module API.
@@ -222,25 +407,49 @@ int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned
 // 128-frame block goes through the time-sliced kernel (measured on the 3-node chain, rocprofv3 kernel averages:
 // 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt).
 
-// Run-time specialised kernel for a fused stage (nullptr: not wanted / not possible).  mod = with control ports.
-const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod) {
-    const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    const bool want_jit = jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS);
-    if (!want_jit || st.count < 1 || !st.fast_div) return nullptr;
-    int sigs[MAX_SLOTS];
+// The shape of a fused chain stage as template arguments of the chain kernels.
+void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]) {
     for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
+    for (int i = 0; i < st.count && i < MAX_SLOTS; ++i) {
         const Node &n = e->nodes[st.first + i];
         const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
         sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
     }
-    const int cpl = (e->desc.tile_channels && N >= STATIC_CPL2_MIN_CHANNELS && N % 2u == 0) ? 2 : 1;    // as pick_variant (plan.hip)
+}
+// channels per lane / frames per chunk of the run-time specialised standard kernel of an engine of N channels (plan.hip has the sweeps)
+int jit_std_cpl(const dspfx_engine *e) {
+    const uint32_t N = e->desc.channels;
+    return (e->desc.tile_channels && N >= STATIC_CPL2_MIN_CHANNELS && N % 2u == 0) ? 2 : 1;
+}
+int jit_std_f(const dspfx_engine *e, bool mod) { return (e->desc.channels < 131072u && !mod) ? 16 : 8; }   // few channels: more loads in flight per wave
+
+// How run-time specialised kernels are obtained (DSPFX_JIT / DSPFX_JIT_ASYNC / DSPFX_VARIANT, read per call):
+//   JP_OFF     never: the interpreter serves (DSPFX_JIT=0; below JIT_MIN_CHANNELS also with DSPFX_JIT_ASYNC=0 or DSPFX_VARIANT set:
+//              a small engine whose kernels must not change under a test);
+//   JP_SYNC    compiled where they are asked for, about a second per new shape inside dspfx_chain_set (DSPFX_JIT=1; from
+//              JIT_MIN_CHANNELS on with DSPFX_JIT_ASYNC=0 or DSPFX_VARIANT set -- the behaviour of rounds 1-3, A/B tooling);
+//   JP_ASYNC   the default, at every size: this process' table and the disk cache at once (milliseconds), else the engine starts
+//              on the interpreter, the background thread compiles, and the kernels are adopted at a block boundary.
+JitPolicy jit_policy(const dspfx_engine *e) {
+    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
+    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    if (jit_mode == 0) return JP_OFF;
+    if (jit_mode == 1) return JP_SYNC;
+    if ((async_env && atoi(async_env) == 0) || getenv("DSPFX_VARIANT")) return e->desc.channels >= JIT_MIN_CHANNELS ? JP_SYNC : JP_OFF;
+    return JP_ASYNC;
+}
+
+// Run-time specialised standard kernel for a fused stage, as far as `mode` goes (nullptr: not wanted / not there).
+// mod = with control ports.
+const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod, int mode) {
+    const uint32_t N = e->desc.channels;
+    if (st.count < 1 || st.count > MAX_SLOTS || !st.fast_div) return nullptr;
+    int sigs[MAX_SLOTS];
+    stage_sigs(e, st, sigs);
+    const int cpl = jit_std_cpl(e);
     if (N < 64u * (unsigned)cpl) return nullptr;
-    const int f = (N < 131072u && !mod) ? 16 : 8;   // few channels: more loads in flight per wave (profiles/r01_small_n.txt, r03_small_n.txt)
-    const JitKernel *k = jit_get(e->device, sigs, st.count, f, cpl, mod);
-    if (!k) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
+    const JitKernel *k = jit_get(e->device, sigs, st.count, jit_std_f(e, mod), cpl, mod, false, false, mode);
+    if (!k && mode == JIT_COMPILE) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
     return k ? &k->var : nullptr;
 }
 
@@ -396,7 +605,7 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
         const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
         const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
                                 std::to_string(std::hash<std::string>{}(src)) + "\n" + src;   // the text itself disambiguates
-        return jit_compile(key, src, expr, sigs, st.count, f, cpl, false);
+        return jit_compile(key, src, expr, sigs, st.count, f, cpl, false, JIT_COMPILE);
     };
     // Two channels per lane as the chain kernels do (large tiled engines), as long as the graph's live values fit:
     // every node output still needed is F x CPL registers, and past 128 VGPRs the lost occupancy costs more than

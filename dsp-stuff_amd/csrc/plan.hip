@@ -106,13 +106,44 @@ bool node_needs_libm(const Node &n) {
            (n.d.mode == DSPFX_DIST_TANH || n.d.mode == DSPFX_DIST_SIN || n.d.mode == DSPFX_DIST_ATAN);
 }
 
-const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
+// Does the library hold a compiled-in specialisation of this stage's shape?
+static bool has_static_variant(const dspfx_engine *e, const Stage &st, const std::vector<const Variant *> &all) {
+    int sigs[MAX_SLOTS];
+    stage_sigs(e, st, sigs);
+    for (const Variant *v : all) {
+        if (v->guard || v->mod || v->ts || v->sigs[0] == SIG_DYN || v->n_slots != st.count) continue;
+        bool ok = true;
+        for (int i = 0; i < st.count && ok; ++i) {
+            const Node &n = e->nodes[st.first + i];
+            ok = v->sigs[i] == sig(n.d.kind, n.d.kind == DSPFX_DISTORT ? n.d.mode : 0, node_hop(e, st.first + i));
+        }
+        if (ok) return true;
+    }
+    return false;
+}
+
+// *pending: no specialised kernel yet, the background compiler is to make one (request_async_jit): the interpreter
+// instantiation returned then has the channels per lane OF THAT KERNEL, so that the bus' rows of partial sums -- one per
+// workgroup of 256 x cpl channels, or per wave below TS_MAX_CHANNELS -- are the same before and after the switch.
+const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     std::vector<const Variant *> all;
     collect_variants(all);
     const Pref pref = read_pref();
     const uint32_t N = e->desc.channels;
     const Variant *best = nullptr;
     int best_score = -1;
+    bool pend = false;
+    if (pending) *pending = false;
+    // no compiled-in specialisation: one made at run time -- already in this process or in the disk cache, compiled now
+    // (JP_SYNC), or on its way (JP_ASYNC)
+    const JitPolicy policy = jit_policy(e);
+    const bool jit_ok = policy != JP_OFF && pref.stat != 0 && st.fast_div && st.count >= 1 && st.count <= MAX_SLOTS && !e->graph_mode &&
+                        !(st.fast_div && pref.stat != 0 && has_static_variant(e, st, all));
+    if (jit_ok) {
+        if (const Variant *j = jit_variant(e, st, false, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK)) return j;
+        pend = policy == JP_ASYNC && !st.jit_failed && N >= 64u * (unsigned)jit_std_cpl(e);
+    }
+    if (pending) *pending = pend;
     for (const Variant *v : all) {
         if (v->guard || v->mod || v->ts) continue;
         const bool is_dyn = v->sigs[0] == SIG_DYN;
@@ -149,7 +180,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
         const int want_f = (N < 131072u && !is_dyn) ? 16 : 8;
         // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
         // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
-        const int want_cpl = is_dyn ? (few ? 1 : 2) : ((!e->desc.tile_channels || N < STATIC_CPL2_MIN_CHANNELS) ? 1 : 2);
+        const int want_cpl = is_dyn ? (pend ? jit_std_cpl(e) : (few ? 1 : 2)) : ((!e->desc.tile_channels || N < STATIC_CPL2_MIN_CHANNELS) ? 1 : 2);
         if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
@@ -157,16 +188,14 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st) {
             best = v;
         }
     }
-    // no compiled-in specialisation: instantiate one at run time (large engines, or DSPFX_JIT=1)
-    if (best && best->sigs[0] == SIG_DYN && pref.stat != 0)
-        if (const Variant *j = jit_variant(e, st, false)) return j;
     return best;
 }
 
 // Few channels (at most two waves per SIMD at one channel per lane): the time-sliced kernel of the same chain shape, if the
 // library has one.  DSPFX_VARIANT="ts=0" switches it off, "ts=1" forces it at any size (A/B runs).
-const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
+const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     const uint32_t N = e->desc.channels;
+    if (pending) *pending = false;
     int want = -1;
     if (const char *sv = getenv("DSPFX_VARIANT"))
         if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
@@ -196,18 +225,13 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
         if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
     }
     if (best) return best;
-    // no compiled-in time-sliced kernel for this chain shape: instantiate one at run time, like the standard kernel
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
-    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0 || N % 64u) return nullptr;
+    // no compiled-in time-sliced kernel for this chain shape: one made at run time, like the standard kernel (one channel per lane)
+    const JitPolicy policy = jit_policy(e);
+    if (policy == JP_OFF || pref.stat == 0 || N < 64u || e->graph_mode) return nullptr;
     int sigs[MAX_SLOTS];
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true);
+    stage_sigs(e, st, sigs);
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, false, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
+    if (!k && pending) *pending = policy == JP_ASYNC && !st.jit_failed;
     return k ? &k->var : nullptr;
 }
 
@@ -216,20 +240,16 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st) {
 // For blocks of exactly 128 frames the guarded time-sliced kernel of the same chain shape takes them instead -- four slices in
 // parallel, every load issued at once -- when the library has one or the run-time compiler is in use for this engine.
 // DSPFX_TS_TAIL=0 keeps the interpreter (A/B runs, tests: bit-identical).
-const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st) {
+const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     const uint32_t N = e->desc.channels;
+    if (pending) *pending = false;
     const char *off = getenv("DSPFX_TS_TAIL");
     if ((off && atoi(off) == 0) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     unsigned cpl = st.var ? (unsigned)st.var->cpl : 1u;
     if (st.var_ts) cpl = std::max(cpl, (unsigned)st.var_ts->cpl);
     if (N % (64u * cpl) == 0) return nullptr;          // no launch of this engine leaves channels over
     int sigs[MAX_SLOTS];
-    for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
+    stage_sigs(e, st, sigs);
     std::vector<const Variant *> all;
     collect_variants(all);
     for (const Variant *v : all) {
@@ -238,47 +258,72 @@ const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st) {
         for (int i = 0; i < MAX_SLOTS && ok; ++i) ok = v->sigs[i] == sigs[i];
         if (ok) return v;
     }
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const JitPolicy policy = jit_policy(e);
     const Pref pref = read_pref();
-    if (!(jit_mode == 1 || (jit_mode != 0 && N >= JIT_MIN_CHANNELS)) || pref.stat == 0) return nullptr;
-    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true);
+    if (policy == JP_OFF || pref.stat == 0 || e->graph_mode) return nullptr;
+    const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
+    if (!k && pending) *pending = policy == JP_ASYNC && !st.jit_failed;
     return k ? &k->var : nullptr;
 }
 
-// A small engine on the interpreter: have its chain shape specialised in the background (jit.hip) and adopt the kernels
-// when they are ready.  Engines from JIT_MIN_CHANNELS on got theirs synchronously in pick_variant.
-void request_async_jit(const dspfx_engine *e, const Stage &st) {
-    const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
-    if ((jit_env && atoi(jit_env) != -1) || (async_env && atoi(async_env) == 0)) return;     // forced on (synchronous) or off
-    if (e->graph_mode || !st.var || st.var->sigs[0] != SIG_DYN || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return;
-    if (N >= JIT_MIN_CHANNELS || read_pref().stat == 0 || getenv("DSPFX_VARIANT")) return;
+// Kernels of this stage's shape that neither this process nor the disk cache holds: have the background thread compile them
+// (jit.hip) and adopt them when they are ready.  The engine serves its blocks meanwhile -- on the interpreter, or on whichever
+// of the kernels it already has.
+void request_async_jit(const dspfx_engine *e, const Stage &st, bool want_std, bool want_ts, bool want_tail) {
+    if (!(want_std || want_ts || want_tail) || jit_policy(e) != JP_ASYNC) return;
     auto job = std::make_shared<AsyncJit>();
     job->device = e->device;
     job->n_slots = st.count;
-    for (int i = 0; i < MAX_SLOTS; ++i) job->sigs[i] = SIG_NONE;
-    for (int i = 0; i < st.count; ++i) {
-        const Node &n = e->nodes[st.first + i];
-        const bool has_mode = n.d.kind == DSPFX_DISTORT || n.d.kind == DSPFX_SIGNAL_GEN;
-        job->sigs[i] = sig(n.d.kind, has_mode ? n.d.mode : 0, node_hop(e, st.first + i));
-    }
-    job->want_ts = N >= 64u;
-    const char *tail_env = getenv("DSPFX_TS_TAIL");
-    job->want_tail = N % 64u != 0 && !(tail_env && atoi(tail_env) == 0);
+    stage_sigs(e, st, job->sigs);
+    job->want_std = want_std;
+    job->f_std = jit_std_f(e, false);
+    job->cpl_std = jit_std_cpl(e);
+    job->want_ts = want_ts;
+    job->want_tail = want_tail;
     st.async = job;
     async_jit_submit(job);
 }
 
+// The stage's kernel with control ports, the first time a port is connected (run_subblock): from the caches, compiled now
+// (JP_SYNC), or by the background thread -- the control-port interpreter serves meanwhile.
+void request_mod_kernel(dspfx_engine *e, const Stage &st) {
+    st.var_mod_tried = true;
+    const char *vp = getenv("DSPFX_VARIANT");
+    const JitPolicy policy = jit_policy(e);
+    if ((vp && strstr(vp, "static=0")) || policy == JP_OFF || e->graph_mode) return;
+    st.var_mod = jit_variant(e, st, true, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
+    if (st.var_mod || policy != JP_ASYNC || st.count < 1 || st.count > MAX_SLOTS || !st.fast_div || e->desc.channels < 64u * (unsigned)jit_std_cpl(e)) return;
+    auto job = std::make_shared<AsyncJit>();
+    job->device = e->device;
+    job->n_slots = st.count;
+    stage_sigs(e, st, job->sigs);
+    job->want_mod = true;
+    job->f_mod = jit_std_f(e, true);
+    job->cpl_std = jit_std_cpl(e);
+    st.async_mod = job;
+    async_jit_submit(job);
+}
+
+const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pending);
 // run_subblock, at a block boundary: the background compiler is done with this stage's shape
 void adopt_async_jit(dspfx_engine *e, const Stage &st) {
+    if (st.async_mod && st.async_mod->ready.load(std::memory_order_acquire) != 0) {
+        const std::shared_ptr<AsyncJit> job = st.async_mod;
+        st.async_mod.reset();
+        if (job->k_mod) st.var_mod = &job->k_mod->var;
+        else e->jit_unavailable = true;
+    }
+    if (!st.async || st.async->ready.load(std::memory_order_acquire) == 0) return;
     const std::shared_ptr<AsyncJit> job = st.async;
     st.async.reset();
-    if (job->ready.load(std::memory_order_acquire) < 0 || !job->k_std) {
+    if (job->ready.load(std::memory_order_acquire) < 0 || (job->want_std && !job->k_std)) {
+        // no run-time compiler here: the interpreter stays -- from now on its best instantiation for this size, not the one that
+        // mimics the kernel that never came
         e->jit_unavailable = true;
-        return;
+        st.jit_failed = true;
+        if (job->want_std) st.var = pick_variant(e, st, nullptr);
     }
-    st.var = &job->k_std->var;
+    if (job->k_std) st.var = &job->k_std->var;
     if (job->k_ts) st.var_ts = &job->k_ts->var;
     if (job->k_tail) st.var_ts_tail = &job->k_tail->var;
 }
@@ -298,8 +343,10 @@ bool long_stage_wanted(const dspfx_engine *e) {
 
 int plan(dspfx_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
-    for (const Stage &st : e->stages)
+    for (const Stage &st : e->stages) {
         if (st.async) st.async->abandoned.store(true, std::memory_order_release);
+        if (st.async_mod) st.async_mod->abandoned.store(true, std::memory_order_release);
+    }
     e->stages.clear();
     e->jit_unavailable = false;
     e->has_fuzz = false;
@@ -349,7 +396,8 @@ int plan(dspfx_engine *e) {
     for (Stage &st : e->stages)
         if (st.type == ST_FUSED) {
             st.fast_div = stage_fast_div(e, st);
-            st.var = (e->graph_mode || st.count > MAX_SLOTS) ? graph_variant(e, st) : pick_variant(e, st);
+            bool pend_std = false, pend_ts = false, pend_tail = false;
+            st.var = (e->graph_mode || st.count > MAX_SLOTS) ? graph_variant(e, st) : pick_variant(e, st, &pend_std);
             if (!st.var && !e->graph_mode && st.count > MAX_SLOTS) {   // no run-time compiler: cut the run as usual
                 e->no_long = true;
                 return plan(e);
@@ -357,9 +405,9 @@ int plan(dspfx_engine *e) {
             if (!st.var)
                 return fail(e, DSPFX_ERR_UNSUPPORTED, e->graph_mode ? "the graph kernel could not be compiled (hiprtc / csrc headers unavailable)"
                                                                     : "no kernel variant for stage");
-            st.var_ts = e->graph_mode ? nullptr : pick_ts_variant(e, st);
-            st.var_ts_tail = e->graph_mode ? nullptr : pick_ts_tail_variant(e, st);
-            request_async_jit(e, st);
+            st.var_ts = (e->graph_mode || st.count > MAX_SLOTS) ? nullptr : pick_ts_variant(e, st, &pend_ts);
+            st.var_ts_tail = (e->graph_mode || st.count > MAX_SLOTS) ? nullptr : pick_ts_tail_variant(e, st, &pend_tail);
+            request_async_jit(e, st, pend_std, pend_ts, pend_tail);
         }
     for (const Node &nd : e->nodes) {
         if (nd.d.kind == DSPFX_DISTORT && nd.d.mode == DSPFX_DIST_FUZZ) e->has_fuzz = true;

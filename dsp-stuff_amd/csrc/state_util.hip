@@ -279,6 +279,8 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                 snprintf(buf, sizeof buf, "; channels left over, %d-frame blocks: %s", 4 * st.var_ts_tail->ts, st.var_ts_tail->name);
                 s += buf;
             }
+            if (st.async) s += "; specialised kernels being compiled in the background, adopted at a block boundary (dspfx_kernels_ready)";
+            if (st.async_mod) s += "; control-port kernel being compiled in the background";
             s += "):";
             for (int k = 0; k < st.count; ++k) {
                 s += " ";
@@ -307,6 +309,13 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                     s += buf;
                 }
         }
+    {
+        const std::string cdir = jit_cache_dir();
+        snprintf(buf, sizeof buf, "run-time kernels of this process: %llu compiled, %llu loaded from the disk cache, %llu written to it (%s)\n",
+                 (unsigned long long)g_jit_compiled.load(), (unsigned long long)g_jit_from_disk.load(), (unsigned long long)g_jit_disk_written.load(),
+                 cdir.empty() ? "no disk cache" : cdir.c_str());
+        s += buf;
+    }
     if (e->jit_unavailable)
         s += "note: a run-time specialised kernel was wanted but could not be compiled (chain_kernels.hip.h not found next to the "
              "library -- DSPFX_KERNEL_HEADERS names its directory -- or hiprtc unavailable): the interpreting kernels serve, 7-25 % slower\n";

@@ -132,6 +132,14 @@ impl Engine {
         self.check(rc)
     }
 
+    /// Kernels specialised for the chain's shape are compiled in the background and adopted at a block boundary (the engine
+    /// serves on its interpreting kernel meanwhile, same samples): wait up to `wait_ms` for them.  `Ok(true)`: nothing pending.
+    pub fn kernels_ready(&mut self, wait_ms: i32) -> Result<bool, Error> {
+        let rc = unsafe { dspfx_kernels_ready(self.h, wait_ms as c_int) };
+        if rc < 0 { self.check(rc)?; }
+        Ok(rc == 1)
+    }
+
     /// A whole saved graph (`DSPConfig`: runtime.rs:560-612) as ONE generated kernel: `nodes` in an order in which
     /// every link goes forward, `links` as (producer, consumer, port) with `DSPFX_GRAPH_INPUT` / `DSPFX_GRAPH_ZERO`
     /// producers and consumer == nodes.len() for the Output node.  `Err` with status `DSPFX_ERR_UNSUPPORTED` when

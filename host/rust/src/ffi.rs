@@ -156,6 +156,7 @@ extern "C" {
 
     pub fn dspfx_chain_set(e: *mut dspfx_engine, nodes: *const dspfx_node_desc, n_nodes: c_int) -> c_int;
     pub fn dspfx_chain_len(e: *const dspfx_engine) -> c_int;
+    pub fn dspfx_kernels_ready(e: *mut dspfx_engine, wait_ms: c_int) -> c_int;
     pub fn dspfx_set_param(e: *mut dspfx_engine, node: c_int, param: c_int, value: f32) -> c_int;
     pub fn dspfx_set_param_seq(e: *mut dspfx_engine, node: c_int, param: c_int, value: f32, seq: *mut u64) -> c_int;
     pub fn dspfx_set_mode(e: *mut dspfx_engine, node: c_int, mode: c_int) -> c_int;

@@ -39,10 +39,9 @@
  *   - there is NO CPU fallback: without a HIP device every entry point that
  *     needs one fails with DSPFX_ERR_NO_DEVICE.
  *   - kernels: which kernel serves a chain is the engine's business and never changes a sample
- *     (dspfx_describe names it).  Engines from 16384 channels on get kernels specialised for
- *     their chain's shape when the chain is set (about a second per new shape); smaller ones
- *     start on an interpreting kernel at once and adopt specialised ones at a block boundary
- *     when the library's background thread has compiled them.  N need not be a multiple of 64.
+ *     (dspfx_describe names it).  Kernels specialised for a chain's shape are taken from the
+ *     on-disk cache or compiled by the library's background thread while an interpreting kernel
+ *     serves, and adopted at a block boundary (dspfx_kernels_ready).  N need not be a multiple of 64.
  */
 #ifndef DSPFX_H
 #define DSPFX_H
@@ -195,6 +194,18 @@ const char *dspfx_last_error(const dspfx_engine *e);
  * (a linear graph of runtime.rs LinkInstances). */
 int dspfx_chain_set(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes);
 int dspfx_chain_len(const dspfx_engine *e);
+/* Kernels specialised for a chain's shape come from this process' table or the on-disk cache of code objects
+ * ($DSPFX_CACHE_DIR, else $XDG_CACHE_HOME/dspfx, else ~/.cache/dspfx; DSPFX_DISK_CACHE=0: none) in milliseconds; a shape seen
+ * for the first time is compiled by ONE background thread while the engine serves its blocks on the interpreting kernel, and
+ * adopted at a block boundary: dspfx_chain_set, dspfx_set_mode and the first connected control port never wait for the
+ * compiler (the reference re-creates nodes on every graph edit, runtime.rs:319-362).  Samples are the same bit for bit, and so
+ * is the bus (the interpreter runs with the coming kernel's rows of partial sums).  This call is for a host -- or a benchmark --
+ * that wants the specialised kernels BEFORE its first block: it adopts what is finished and waits up to wait_ms milliseconds
+ * for the rest.  Returns 1: nothing is pending (dspfx_describe names the kernels that are live), 0: still compiling, < 0: error.
+ * It does not hold the engine while it waits.  DSPFX_JIT=0: no run-time kernels; DSPFX_JIT=1 / DSPFX_JIT_ASYNC=0: compiled inside
+ * dspfx_chain_set (about a second per new shape), as in rounds 1-3.  A whole-graph kernel (dspfx_graph_set) has no interpreter to
+ * stand in for it: compiled in the call when neither cache has it. */
+int dspfx_kernels_ready(dspfx_engine *e, int wait_ms);
 
 /* Slider store + `after_settings_change` (dsp-stuff-derive/src/lib.rs:487-497, 560-568: the generated render() runs the
  * node's hook when ANY of its widgets changed):

@@ -155,6 +155,12 @@ class Engine {
         }
         chk(dspfx_chain_set(e_, d.data(), static_cast<int>(d.size())));
     }
+    // specialised kernels are compiled in the background and adopted at a block boundary: wait for them (dspfx.h)
+    bool kernels_ready(int wait_ms = 60000) {
+        const int rc = dspfx_kernels_ready(e_, wait_ms);
+        if (rc < 0) chk(rc);
+        return rc == 1;
+    }
     // a whole DAG as one generated kernel (dspfx.h, dspfx_graph_set); Error::status == DSPFX_ERR_UNSUPPORTED when it cannot be fused
     void set_graph(const std::vector<Node> &nodes, const std::vector<dspfx_graph_link> &links) {
         std::vector<dspfx_node_desc> d;

@@ -11,21 +11,18 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "fir_default: leave the FIR sweep at the engine's default (split precision) for this test")
-    config.addinivalue_line("markers", "jit_async: leave the background specialisation of small engines on for this test")
+    config.addinivalue_line("markers", "fir_f32: this test means the f32 FIR sweep (sets DSPFX_FIR_SPLIT=0; the product default is the split-precision sweep)")
+    config.addinivalue_line("markers", "jit_frozen: this test needs the kernel it starts on to stay (sets DSPFX_JIT_ASYNC=0; by default small engines adopt kernels compiled in the background)")
 
 
 @pytest.fixture(autouse=True)
-def _f32_fir_sweep_unless_asked(monkeypatch, request):
-    """The engine's default steady-state FIR sweep is the split-precision one (round 3).  The parity tests name the sweep they
-    mean -- f32 (`kernel = 1 / rect`) or split (`kernel = split`, dspfx_set_fir_precision) -- so DSPFX_FIR_SPLIT=0 is the
-    baseline of every test; tests marked `fir_default` see the default as a host would."""
-    if "fir_default" not in request.keywords:
+def _product_defaults_unless_a_test_opts_out(monkeypatch, request):
+    """The suite runs what ships: the split-precision FIR sweep and the background specialisation of small engines are ON,
+    as a host would see them (round 4; round 3 forced both off for every test).  A test that is ABOUT the f32 sweep or
+    about one particular kernel says so with a marker."""
+    if "fir_f32" in request.keywords:
         monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
-    # Small engines have their chain shape specialised in the background and switch kernels when it is ready (jit.hip): same
-    # samples, but WHEN the switch happens is a matter of timing, and the tests compare engines block for block (the bus'
-    # summation order follows the kernel).  Off by default here; tests marked `jit_async` exercise it.
-    if "jit_async" not in request.keywords and os.environ.get("DSPFX_TEST_JIT_ASYNC") != "1":   # (=1: the whole suite with it on)
+    if "jit_frozen" in request.keywords:
         monkeypatch.setenv("DSPFX_JIT_ASYNC", "0")
 
 

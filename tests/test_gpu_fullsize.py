@@ -46,7 +46,7 @@ def gather(dspfx, t, chans, n_frames, N, tile):
     return t.view(n_frames, N)[:, idx].cpu().numpy()
 
 
-def run_noise_engine(dspfx, tc, chain, N, B, n_calls, tile, chans, want_mix=False):
+def run_noise_engine(dspfx, tc, chain, N, B, n_calls, tile, chans, want_mix=False, info=None):
     eng = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
     eng.set_chain(chain)
     x = tc.empty(B * N, dtype=tc.float32, device="cuda")
@@ -64,6 +64,8 @@ def run_noise_engine(dspfx, tc, chain, N, B, n_calls, tile, chans, want_mix=Fals
             scale = float(ref.abs().max()) + 1.0
             mix_err = max(mix_err, float((mix.double() - ref).abs().max()) / scale)
     tc.cuda.synchronize()
+    if info is not None:
+        info["describe"] = eng.describe()
     eng.close()
     return got, mix_err
 
@@ -93,12 +95,20 @@ def test_config3_and_5_million_channels_chain5(dspfx, tc, B, tile):
     assert mix_err < 1e-5, mix_err
 
 
-def test_config4_fir_262144_channels(dspfx, tc):
-    """BASELINE config 4: 262 144 channels x 4096-tap FIR on MFMA, through warm-up into steady state."""
+@pytest.mark.parametrize("sweep", ["split", "f32"])
+def test_config4_fir_262144_channels(dspfx, tc, monkeypatch, sweep):
+    """BASELINE config 4: 262 144 channels x 4096-tap FIR on MFMA, through warm-up into steady state.  `split` is the sweep
+    that ships (fir_split_kernel, the kernel bench.py's cfg4 line times), `f32` the f32 matrix-pipe sweep (cfg4_f32)."""
     N, T, blocks = 1 << 18, 4096, 40
     chans = sample_channels(N)[::2]
     chain = [dspfx.Fir(fir_taps(T))]
-    got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 256, chans)
+    if sweep == "f32":
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
+    else:
+        monkeypatch.delenv("DSPFX_FIR_SPLIT", raising=False)
+    info = {}
+    got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 256, chans, info=info)
+    assert ("fir_split_kernel" if sweep == "split" else "fir_skew_kernel") in info["describe"], info["describe"]
     ref = oracle_channels(chain, chans, blocks)
     err = got.astype(np.float64) - ref.astype(np.float64)
     rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))

@@ -266,6 +266,7 @@ def test_fast_constant_division_is_exhaustively_exact(dspfx, torch_cuda, monkeyp
     assert ulp_diff(y_fast, run_oracle(ch, x, 3)).max() <= 1
 
 
+@pytest.mark.jit_frozen          # (it compares dspfx_describe before and after the stores: the kernel must not be swapped meanwhile)
 def test_distort_level_slider_moves_without_replanning(dspfx, torch_cuda):
     """Whether x / level may take the exact-product form is decided on the host: only even integers can have
     exact ties among their subnormal quotients.  Any level gives the oracle's bits; a slider store keeps the kernel
@@ -683,11 +684,14 @@ def fir_rel_rms(y, ref):
     return np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
 
 
-@pytest.mark.parametrize("kernel", ["0", "1"])
+@pytest.mark.parametrize("kernel", ["0", "1", "split"])
 @pytest.mark.parametrize("T", [3, 16, 100, 128, 129, 512])
 def test_fir_random_vs_oracle(dspfx, torch_cuda, monkeypatch, T, kernel):
-    """Both FIR kernels (0 = exact f64 VALU, 1 = MFMA f32) through the warm-up quirk and steady state."""
-    monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
+    """The FIR kernels (0 = exact f64 VALU, 1 = MFMA with the f32 sweep, split = MFMA with the default split-precision sweep)
+    through the warm-up quirk and steady state."""
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", "1" if kernel == "split" else kernel)
+    if kernel == "1":
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
     x = noise_block(64, 128 * 8)
     ch = [dspfx.Gain(0.9), dspfx.Fir(fir_taps(T)), dspfx.Gain(1.1)]
     y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
@@ -722,6 +726,7 @@ def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
     if skew == "split":
         monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
     else:
+        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
         monkeypatch.setenv("DSPFX_FIR_SKEW", skew)
     rng = np.random.default_rng(5)
     h = rng.integers(-4, 5, T).astype(np.float64)
@@ -732,6 +737,7 @@ def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
         assert np.array_equal(y, ref)
 
 
+@pytest.mark.fir_f32
 @pytest.mark.parametrize("block", [128, 256, 100, 64, 48, 16])
 @pytest.mark.parametrize("T", [33, 400])
 def test_fir_skewed_sweep_block_sizes_integer_exact(dspfx, torch_cuda, monkeypatch, T, block):
@@ -759,7 +765,6 @@ def test_fir_config4_taps_small_n(dspfx, torch_cuda):
     assert fir_rel_rms(y[:2048], ref[:2048]) < FIR_RMS_TOL      # warm-up alone
 
 
-@pytest.mark.fir_default
 def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_cuda):
     """A host that asks for nothing gets the split-precision sweep in steady state (whole 128-frame blocks, tables fit the
     LDS), the f32 sweep where it does not apply (short slices), the stated tolerance either way, integer data bit for bit;
@@ -1668,6 +1673,7 @@ def test_default_variant_selection_above_131072_channels_matches_small_engines(d
         def run(c0, n):
             eng = dspfx.Engine(n, B, channel_offset=c0, tile_channels=tile)
             eng.set_chain(chain)
+            eng.kernels_ready()              # the default choice once the background compiler is done with the shape
             stage = [l for l in eng.describe().splitlines() if l.startswith("stage")][0]
             outs, mixes = [], []
             for b in range(blocks):
