@@ -352,8 +352,10 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     a.n_launch = w1 - w0;
                     a.wave_base = (v->ts || rows_per_wave) ? w0 / per_wave : w0 / (per_wave * (WG / 64));   // rows of the windows before this one
                     ProfScope ps(e, si, stream);
-                    if (launch_variant(v, a, v->ts ? (w1 - w0) / per_wave : ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream))
+                    if (launch_variant(v, a, v->ts ? (w1 - w0) / per_wave : ((w1 - w0) / v->cpl + WG - 1) / WG, WG, (unsigned)(rows * WG * v->cpl * sizeof(float)), stream)) {
+                        if (tail_bus) (void)hipMemsetAsync(e->mt_tickets, 0, (MIX_SLICES + 1) * sizeof(unsigned), stream);
                         return fail(e, DSPFX_ERR_HIP, "kernel launch failed");
+                    }
                 }
             } else if (n_main) {
                 a.c_base = 0;
@@ -382,7 +384,15 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     (void)launch_variant(tail, a, (n_tail + 63) / 64, 64, (unsigned)(rows * WG * sizeof(float)), stream);
                 }
             }
-            HIPCHK(e, hipGetLastError());
+            {
+                const hipError_t lerr = hipGetLastError();
+                if (lerr != hipSuccess) {
+                    // one of the block's launches did not happen: the rows it would have ticketed never arrive, and the
+                    // counters the other launch bumped would stay non-zero for ever -- every later bus silently stale
+                    if (tail_bus) (void)hipMemsetAsync(e->mt_tickets, 0, (MIX_SLICES + 1) * sizeof(unsigned), stream);
+                    return fail(e, DSPFX_ERR_HIP, "kernel launch failed: %s", hipGetErrorString(lerr));
+                }
+            }
             if (deferred) {
                 e->part_stride[e->flip] = a.mix_stride;
                 e->part_frames[e->flip] = nframes;
@@ -795,6 +805,7 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     e->nodes.clear();
     e->nodes.resize((size_t)n_nodes);
     e->mp_count = 0;
+    if (e->mt_tickets) HIPCHK(e, hipMemset(e->mt_tickets, 0, (MIX_SLICES + 1) * sizeof(unsigned)));   // (the device is idle: quiesce above)
     int rc = DSPFX_OK;
     for (int i = 0; i < n_nodes && rc == DSPFX_OK; ++i) {
         Node &n = e->nodes[(size_t)i];
@@ -832,8 +843,13 @@ extern "C" int dspfx_graph_set(dspfx_engine *e, const dspfx_node_desc *nodes, in
     e->wiring.assign(links, links + n_links);
     const int rc = set_nodes(e, nodes, n_nodes);
     if (rc != DSPFX_OK) {   // leave a usable (empty) chain engine behind
-        const std::string msg = e->err;
+        std::string msg;
+        {
+            std::lock_guard<std::mutex> lk(e->err_mu);      // (a GUI thread's failing store may be writing it)
+            msg = e->err;
+        }
         (void)dspfx_chain_set(e, nullptr, 0);
+        std::lock_guard<std::mutex> lk(e->err_mu);
         e->err = msg;
     }
     return rc;
@@ -1014,6 +1030,9 @@ int reset_on(dspfx_engine *e, hipStream_t s) {
         if (n.d.kind == DSPFX_FIR) fir_reset(n.fir, s);
     }
     e->mp_count = 0;   // blocks still in the mix pipeline are dropped
+    // the in-launch bus' arrival counters are zero between launches only if every launch of a block ran to its end: put them
+    // back here (stream-ordered), so that a launch that failed half-way cannot leave every later bus stale
+    if (e->mt_tickets) HIPCHK(e, hipMemsetAsync(e->mt_tickets, 0, (MIX_SLICES + 1) * sizeof(unsigned), s));
     return DSPFX_OK;
 }
 }  // namespace dspfx_host

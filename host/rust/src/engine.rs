@@ -79,19 +79,25 @@ impl NodeDesc {
     pub fn envelope(attack: f32, release: f32) -> Self { Self::with(DSPFX_ENVELOPE, &[attack, release]) }
 }
 
+/// The C engine, destroyed when the LAST holder goes: the `Engine` and every `ParamHandle` made from it share it, so a GUI
+/// thread's handle can never point at freed memory (round 3's handle was a bare pointer with a comment).
+struct Raw(*mut dspfx_engine);
+unsafe impl Send for Raw {}
+unsafe impl Sync for Raw {}      // every C entry point may be called from any thread (include/dspfx.h, "threads")
+impl Drop for Raw {
+    fn drop(&mut self) {
+        unsafe { dspfx_engine_destroy(self.0) }
+    }
+}
+
 pub struct Engine {
-    h: *mut dspfx_engine,
+    raw: std::sync::Arc<Raw>,
+    h: *mut dspfx_engine,        // == raw.0
     channels: u32,
 }
 
 // The engine may be driven by one thread at a time (include/dspfx.h); callers wrap it in a Mutex.
 unsafe impl Send for Engine {}
-
-impl Drop for Engine {
-    fn drop(&mut self) {
-        unsafe { dspfx_engine_destroy(self.h) }
-    }
-}
 
 impl Engine {
     pub fn new(channels: u32, max_frames: u32, link_flags: u32, device: i32) -> Result<Self, Error> {
@@ -105,7 +111,7 @@ impl Engine {
             let msg = unsafe { CStr::from_ptr(dspfx_strerror(rc)) }.to_string_lossy().into_owned();
             return Err(Error { status: rc, message: msg });
         }
-        Ok(Engine { h, channels })
+        Ok(Engine { raw: std::sync::Arc::new(Raw(h)), h, channels })
     }
 
     fn check(&self, rc: c_int) -> Result<(), Error> {
@@ -167,7 +173,7 @@ impl Engine {
     /// `Mutex`) and is inside `process`: the reference's widgets store into atomics from the GUI thread
     /// (dsp-stuff-derive/src/lib.rs:487-492).  The C side queues the store and applies it at the next block boundary.
     pub fn params(&self) -> ParamHandle {
-        ParamHandle { h: self.h }
+        ParamHandle { raw: self.raw.clone() }
     }
     /// The stores applied so far with a sequence number above `after_seq`, oldest first.
     pub fn param_log(&mut self, after_seq: u64) -> Vec<dspfx_param_event> {
@@ -294,22 +300,20 @@ impl Drop for Comm {
 
 /// Slider / mode stores from a thread that does not own the `Engine` (see `Engine::params`).  Sound because
 /// `dspfx_set_param` / `dspfx_set_mode` are thread-safe by contract (include/dspfx.h, "threads"): they only queue.
-/// The handle must not outlive its engine (the node owns both).
-#[derive(Clone, Copy)]
+/// The handle keeps the C engine alive: it is destroyed when the `Engine` AND every handle are gone.
+#[derive(Clone)]
 pub struct ParamHandle {
-    h: *mut dspfx_engine,
+    raw: std::sync::Arc<Raw>,
 }
-unsafe impl Send for ParamHandle {}
-unsafe impl Sync for ParamHandle {}
 impl ParamHandle {
     /// Returns the store's sequence number.
     pub fn set_param(&self, node: usize, param: usize, value: f32) -> Result<u64, c_int> {
         let mut seq = 0u64;
-        let rc = unsafe { dspfx_set_param_seq(self.h, node as c_int, param as c_int, value, &mut seq) };
+        let rc = unsafe { dspfx_set_param_seq(self.raw.0, node as c_int, param as c_int, value, &mut seq) };
         if rc == 0 { Ok(seq) } else { Err(rc) }
     }
     pub fn set_mode(&self, node: usize, mode: c_int) -> Result<(), c_int> {
-        let rc = unsafe { dspfx_set_mode(self.h, node as c_int, mode) };
+        let rc = unsafe { dspfx_set_mode(self.raw.0, node as c_int, mode) };
         if rc == 0 { Ok(()) } else { Err(rc) }
     }
 }
