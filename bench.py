@@ -238,44 +238,59 @@ def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
     return res
 
 
-def make_comm(ctx):
-    """The mix bus' own communicator behind the C ABI (rank 0 makes the id, torch.distributed only carries the bytes)."""
+def make_comm(ctx, eng=None):
+    """The mix bus' own communicator behind the C ABI (rank 0 makes the id, torch.distributed only carries the bytes).
+    Backends are tried in order -- the one-shot mailbox all-reduce (peer writes over xGMI, rank-ordered sum), then RCCL behind
+    the same ABI -- and each is VALIDATED before it is trusted: 64 exchanges of known values, checked on every rank.  Any
+    failure on any rank sends ALL ranks on to the next backend, and in the end to torch.distributed's all_reduce; the line
+    says which one ran (config.collective): a run on N GPUs must not die on the plumbing of an alternative call path."""
     import torch
     import torch.distributed as dist
     if ctx.comm is not None or getattr(ctx, "comm_fallback", None) or not ctx.use_dist or os.environ.get("DSPFX_BENCH_COMM", "abi") != "abi":
         return
-    # Any failure on any rank (the library could not find RCCL, ncclCommInitRank refused ...) sends ALL ranks back to
-    # torch.distributed's all_reduce -- the same RCCL collective, called from Python -- and the line says so in
-    # config.collective: a run on N GPUs must not die on the plumbing of an alternative call path.
-    err = ""
-    idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=ctx.dev)
-    try:
-        if ctx.rank == 0:
-            idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id()), dtype=torch.uint8))
-    except Exception as ex:
-        err = "unique id: %s" % ex
-    dist.broadcast(idt, 0)
-    comm = None
-    if os.environ.get("DSPFX_BENCH_COMM_FAIL") == "1":       # exercise the fallback below
-        err = "forced by DSPFX_BENCH_COMM_FAIL"
-    elif not bool(idt.any().item()):
-        err = err or "rank 0 could not make a unique id"
-    else:
+    notes = []
+    for backend in [b for b in os.environ.get("DSPFX_BENCH_COMM_BACKENDS", "mailbox,rccl").split(",") if b]:
+        err = ""
+        idt = torch.zeros(ctx.pkg.COMM_ID_BYTES, dtype=torch.uint8, device=ctx.dev)
         try:
-            comm = ctx.pkg.Comm(ctx.local_rank, ctx.world, ctx.rank, bytes(idt.cpu().tolist()))
+            if ctx.rank == 0:
+                idt.copy_(torch.tensor(list(ctx.pkg.comm_unique_id(backend)), dtype=torch.uint8))
         except Exception as ex:
-            err = "comm create: %s" % ex
-    okt = torch.tensor([0.0 if err else 1.0], device=ctx.dev)
-    dist.all_reduce(okt, op=dist.ReduceOp.MIN)
-    if okt.item() >= 1.0:
-        ctx.comm = comm
-    else:
+            err = "unique id: %s" % ex
+        dist.broadcast(idt, 0)
+        comm = None
+        if os.environ.get("DSPFX_BENCH_COMM_FAIL") in ("1", backend):       # exercise the fallbacks below
+            err = "forced by DSPFX_BENCH_COMM_FAIL"
+        elif not bool(idt.any().item()):
+            err = err or "rank 0 could not make a unique id"
+        else:
+            try:
+                comm = ctx.pkg.Comm(ctx.local_rank, ctx.world, ctx.rank, bytes(idt.cpu().tolist()))
+                if eng is not None and not getattr(ctx, "dry", False):
+                    t = torch.empty(128, dtype=torch.float32, device=ctx.dev)
+                    for r in range(64):
+                        t.fill_(float((ctx.rank + 1) * (r + 1)))
+                        eng.mix_allreduce(comm, t, 128, 0, torch.cuda.current_stream().cuda_stream)
+                        want = float((r + 1) * ctx.world * (ctx.world + 1) // 2)
+                        if not bool((t == want).all().item()):
+                            raise RuntimeError("validation exchange %d gave %r, expected %r" % (r, t[:4].tolist(), want))
+            except Exception as ex:
+                err = "%s: %s" % (backend, ex)
+        okt = torch.tensor([0.0 if err else 1.0], device=ctx.dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if okt.item() >= 1.0:
+            ctx.comm = comm
+            ctx.comm_notes = notes
+            break
         if comm is not None:
             try:
                 comm.close()
             except Exception:
                 pass
-        ctx.comm_fallback = err or "another rank failed to create its communicator"
+        notes.append(err or "%s: another rank failed" % backend)
+        print("bench.py rank %d: communicator backend %s unavailable (%s)" % (ctx.rank, backend, notes[-1]), file=sys.stderr)
+    if ctx.comm is None:
+        ctx.comm_fallback = "; ".join(notes) or "no backend"
         print("bench.py rank %d: C-ABI communicator unavailable (%s); using torch.distributed all_reduce" % (ctx.rank, ctx.comm_fallback),
               file=sys.stderr)
     dist.barrier()
@@ -288,7 +303,7 @@ class Ctx:
     pass
 
 
-def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
+def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds, pbus=None, start_at=None):
     """Real-time operation: ONE block every block period (B / 48 kHz = 2.667 ms at B = 128) from a host timer, each block
     with the Output node's bus of the SAME block (dspfx_process_bus).  Per block: host time from the submit call to the
     moment the host sees the block's `out` AND `mix` complete (an event polled right behind the launch), and the GPU time
@@ -305,7 +320,7 @@ def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
     import gc
     gc_was = gc.isenabled()
     gc.disable()                                      # a collection in the middle of a block is the host's jitter, not the engine's
-    t_next = time.perf_counter() + 0.005
+    t_next = time.perf_counter() + (0.005 if start_at is None else max(0.005, start_at - time.time()))
     t_begin = t_next
     for k in range(n):
         while True:                                   # sleep most of the gap, spin the last 300 us
@@ -316,7 +331,10 @@ def paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, seconds):
                 time.sleep(1e-4)
         t_sub = time.perf_counter()
         ev[k][0].record()
-        eng.process_bus(xs[k % n_in], y, mixes[k & 3], B, n_connected=total_channels, stream=stream)
+        if pbus is not None:                          # several ranks: the block, then the exchange of its bus, on the compute stream
+            pbus.step(xs[k % n_in], y)
+        else:
+            eng.process_bus(xs[k % n_in], y, mixes[k & 3], B, n_connected=total_channels, stream=stream)
         ev[k][1].record()
         while not ev[k][1].query():
             pass
@@ -381,7 +399,10 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     mix_mode = os.environ.get("DSPFX_BENCH_MIX", "inline")
     mix_stream = ctx.mix_stream
     ms = mix_stream.cuda_stream
-    BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
+    # Blocks per exchange.  1 (default since round 4): the GLOBAL bus of every block, exchanged right behind the block's own
+    # launch on the compute stream -- the Output node as the reference has it, a few microseconds after the samples.  8 was
+    # rounds 1-3's default: one collective per 8 blocks on the second stream, the bus up to 21 ms late (a throughput option).
+    BATCH = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "1"))
     bus_world = 2 if (ctx.use_dist and world == 1) else world          # forced-dist: take the collective path
     bus = P.MixBus(total_channels, B, lambda m, nf, n: eng.mix_finish(m, nf, n, ms), world=bus_world)
     pipe_fill = [0]
@@ -440,7 +461,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
             for x_ in xs:
                 x_.zero_()
     if os.environ.get("DSPFX_BENCH_COMM_EARLY", "0") != "1":
-        make_comm(ctx)              # after the engine's large allocations and the tuning (A/B: DSPFX_BENCH_COMM_EARLY=1)
+        make_comm(ctx, eng)         # after the engine's large allocations and the tuning (A/B: DSPFX_BENCH_COMM_EARLY=1)
     pbus = (P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=BATCH, device=dev,
                               comm=ctx.comm, same_block=(mix_mode == "inline"))
             if (use_mix and dist_run and mix_mode in ("pipe", "inline")) else None)
@@ -630,13 +651,38 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
                        "frac": bps * N * B / (alt_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         if use_mix and args.paced_seconds > 0:
             paced = paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, args.paced_seconds)
+    # ---- several ranks: what one exchange of the bus costs (the kernel of dspfx_mix_allreduce alone, ranks in step), and the
+    # paced leg with the GLOBAL bus of every block
+    exchange = None
+    if dist_run and use_mix and ctx.comm is not None:
+        t = torch.zeros(B, dtype=torch.float32, device=dev)
+        fence()
+        xe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(200)]
+        for a_, b_ in xe:
+            a_.record()
+            eng.mix_allreduce(ctx.comm, t, B, total_channels, stream)
+            b_.record()
+        fence()
+        us = sorted(1e3 * a_.elapsed_time(b_) for a_, b_ in xe[20:])
+        exchange = {"what": "one dspfx_mix_allreduce of %d floats + Output hop, events around the call, ranks in step" % B, "backend": ctx.comm.backend,
+                    "us_p50": us[len(us) // 2], "us_p99": us[int(len(us) * 0.99)], "us_max": us[-1]}
+        if extras and args.paced_seconds > 0 and pbus is not None and pbus.inline:
+            t0 = torch.tensor([time.time() + 0.2], dtype=torch.float64, device=dev)
+            dist.broadcast(t0, 0)                     # all ranks start their block clock at the same wall-clock instant
+            paced = paced_run(torch, eng, xs, y, mixes, B, total_channels, stream, args.paced_seconds, pbus=pbus,
+                              start_at=float(t0.item()))
+            pbus.drain()
+            fence()
     res = {
         "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced, "alt_bus": alt_bus,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
                    "delay_len": cfg.get("delay"), "taps": cfg.get("taps"), "link_flags": args.link_flags, **({"zero_input": True} if os.environ.get("DSPFX_BENCH_ZERO_INPUT") == "1" else {}),
                    "mix_bus": (mix_mode if use_mix else False), "parallelism": f"channel-shard x{world}",
-                   "collective": (None if not dist_run else "dspfx_mix_allreduce (RCCL behind the C ABI)" if ctx.comm is not None
+                   "collective": (None if not dist_run else ("dspfx_mix_allreduce, backend %s, %d block(s) per exchange%s" % (
+                                      ctx.comm.backend, BATCH, "".join(" [not %s]" % n for n in getattr(ctx, "comm_notes", []))))
+                                  if ctx.comm is not None
                                   else "torch.distributed all_reduce" + (" (fallback: %s)" % ctx.comm_fallback if getattr(ctx, "comm_fallback", None) else "")),
+                   "bus_exchange": exchange,
                    "placement_probe": probe_log, "placement_tuning": tune_log,
                    "settle": {"steps": settle_steps, "ms_per_step": round(settle_ms, 4)},
                    "layout": f"channel-tiled [N/{tile}][B][{tile}]" if tile else "frame-major [B][N]",
@@ -715,7 +761,7 @@ def dry_run(args):
     N, B = args.channels or cfg["channels"], args.frames or cfg["frames"]
     shard = P.weak_shard(N, world, rank)
     mix_mode = os.environ.get("DSPFX_BENCH_MIX", "inline")
-    batch = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "8"))
+    batch = int(os.environ.get("DSPFX_BENCH_MIX_BATCH", "1"))
     div = float(ctx.pkg.link_divisor(shard.total_channels))
     eng = _DryEngine(torch, rank, B, div)
     pbus = P.PipelinedMixBus(eng, shard.total_channels, B, None, None, world, batch=batch, device="cpu",

@@ -55,7 +55,7 @@ EXPORTS = [
     "dspfx_process_partials", "dspfx_mix_collect", "dspfx_process_ctl",
     "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
-    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus", "dspfx_kernels_ready",
+    "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus", "dspfx_kernels_ready", "dspfx_comm_backend",
 ]
 COMM_ID_BYTES = 128
 
@@ -174,6 +174,8 @@ def lib():
     L.dspfx_comm_rank.argtypes = [vp]
     L.dspfx_comm_last_error.argtypes = [vp]
     L.dspfx_comm_last_error.restype = C.c_char_p
+    L.dspfx_comm_backend.argtypes = [vp]
+    L.dspfx_comm_backend.restype = C.c_char_p
     L.dspfx_mix_allreduce.argtypes = [vp, vp, f32p, C.c_uint32, C.c_uint64, vp]
     L.dspfx_algorithmic_bytes_per_sample.restype = C.c_double
     L.dspfx_algorithmic_bytes_per_sample.argtypes = [vp, C.c_uint32]
@@ -607,10 +609,21 @@ class Engine:
         return float(self.L.dspfx_algorithmic_bytes_per_sample(self.h, int(n_frames)))
 
 
-def comm_unique_id() -> bytes:
-    """The 128-byte id rank 0 creates and hands to every rank (dspfx_comm_unique_id)."""
+def comm_unique_id(backend: Optional[str] = None) -> bytes:
+    """The 128-byte id rank 0 creates and hands to every rank (dspfx_comm_unique_id).  backend: None = the library's default
+    (DSPFX_COMM_BACKEND, else "mailbox"), or "mailbox" / "rccl" for this id."""
     buf = C.create_string_buffer(COMM_ID_BYTES)
-    rc = lib().dspfx_comm_unique_id(buf)
+    old = os.environ.get("DSPFX_COMM_BACKEND")
+    if backend is not None:
+        os.environ["DSPFX_COMM_BACKEND"] = backend
+    try:
+        rc = lib().dspfx_comm_unique_id(buf)
+    finally:
+        if backend is not None:
+            if old is None:
+                os.environ.pop("DSPFX_COMM_BACKEND", None)
+            else:
+                os.environ["DSPFX_COMM_BACKEND"] = old
     if rc != 0:
         raise DspfxError(rc, lib().dspfx_comm_last_error(None).decode() or lib().dspfx_strerror(rc).decode())
     return buf.raw
@@ -628,6 +641,11 @@ class Comm:
         if rc != 0:
             self.h = C.c_void_p()
             raise DspfxError(rc, self.L.dspfx_comm_last_error(None).decode() or self.L.dspfx_strerror(rc).decode())
+
+    @property
+    def backend(self) -> str:
+        """"mailbox" (one-shot peer-write all-reduce, the default), "rccl" or "single"."""
+        return self.L.dspfx_comm_backend(self.h).decode()
 
     def close(self):
         h = getattr(self, "h", None)

@@ -147,6 +147,12 @@ class PipelinedMixBus:
     in steady state).  `results()` after `drain()` returns {block index: tensor view} for the blocks still in the rings.
     `order` = StreamOrder (GPU) or HostOrder (tests); `engine` needs process_bus / process_mixpipe / mixpipe_flush /
     mix_finish (/ mix_allreduce with a `comm`).
+
+    batch = 1 with same_block (the default of bench.py --gpus N since round 4) is the Output node as the reference has it: the
+    GLOBAL bus of every block, ready a few microseconds after the block's own samples -- the exchange (one kernel of one
+    workgroup with the mailbox backend of dspfx_mix_allreduce) is queued on the COMPUTE stream right behind the chain kernel:
+    no event, no second stream, no ring hand-over; north_star's "< 128-sample block latency" holds for the bus too.  Larger
+    batches trade that for throughput: the bus arrives up to `batch` blocks late (batch = 8: 21 ms at 48 kHz).
     """
 
     def __init__(self, engine, total_channels: int, n_frames: int, compute_stream, mix_stream, world: int,
@@ -156,9 +162,10 @@ class PipelinedMixBus:
         self.nf, self.batch = int(n_frames), int(batch)
         self.order = order if order is not None else StreamOrder(torch, compute_stream, mix_stream)
         self.same_block = bool(same_block)
+        self.inline = self.same_block and self.batch == 1      # one exchange per block, on the compute stream itself
         self.lag = 0 if self.same_block else 2       # calls between a block's submission and its bus
         self.rings = [torch.zeros(self.batch * self.nf, dtype=torch.float32, device=device) for _ in range(3)]
-        mh = self.order.mix_handle
+        mh = self.order.compute_handle if self.inline else self.order.mix_handle
         # comm (dsp_stuff_amd.Comm): the collective goes through the C ABI (dspfx_mix_allreduce: RCCL + Output hop on the
         # second stream); without one, torch.distributed's all_reduce on that stream
         allreduce = (lambda m, nf, n: engine.mix_allreduce(comm, m, nf, n, mh)) if comm is not None else None
@@ -175,6 +182,11 @@ class PipelinedMixBus:
         return self.rings[q % 3][r * self.nf:(r + 1) * self.nf]
 
     def _submit(self, q):
+        if self.inline:                              # stream order does it all: chain kernel, exchange + Output hop, next chain kernel
+            self.bus.submit(self.rings[q % 3])
+            self.bus.drain()
+            self.submitted = q + 1
+            return
         self.order.mix_after_compute()
         with self.order.on_mix():
             self.bus.submit(self.rings[q % 3])       # also completes batch q-1 (wait + Output hop)
@@ -188,7 +200,7 @@ class PipelinedMixBus:
         row = None
         if j >= 0:
             q, r = divmod(j, self.batch)
-            if r == 0 and (q - 2) in self.events:    # ring q % 3 last held batch q-3, finished by submit q-2
+            if not self.inline and r == 0 and (q - 2) in self.events:    # ring q % 3 last held batch q-3, finished by submit q-2
                 self.order.compute_after(self.events[q - 2])
             row = self._row(j)
         if self.same_block:

@@ -185,6 +185,7 @@ extern "C" {
     pub fn dspfx_comm_size(c: *const dspfx_comm) -> c_int;
     pub fn dspfx_comm_rank(c: *const dspfx_comm) -> c_int;
     pub fn dspfx_comm_last_error(c: *const dspfx_comm) -> *const c_char;
+    pub fn dspfx_comm_backend(c: *const dspfx_comm) -> *const c_char;
     pub fn dspfx_mix_allreduce(e: *mut dspfx_engine, c: *mut dspfx_comm, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;
 
     pub fn dspfx_process_mixpipe(e: *mut dspfx_engine, input: *const f32, side: *const f32, out: *mut f32, mix: *mut f32, n_frames: u32, n_connected: u64, stream: *mut c_void) -> c_int;

@@ -366,17 +366,29 @@ int dspfx_mix_finish(dspfx_engine *e, float *mix, uint32_t n_frames, uint64_t n_
 /* ---- the mix bus across GPUs ------------------------------------------------------------------------
  * Channels shard over the GPUs of a node with no data-path exchange; the one collective of the path is the mix bus:
  * the Output node's sum over ALL channels (nodes/output.rs:215-249 feeding node.rs:162-194).  Each rank owns one
- * engine; its un-normalised bus (dspfx_process(mix) / dspfx_process_mixpipe with n_connected = 0) is summed over
- * the ranks by ONE RCCL ncclAllReduce(sum, float, n_frames) over xGMI, then divided by f32(0.0001 + N_total).
+ * engine; its un-normalised bus (dspfx_process_bus / dspfx_process(mix) / dspfx_process_mixpipe with n_connected = 0) is summed
+ * over the ranks by ONE exchange of n_frames floats, then divided by f32(0.0001 + N_total).
  *
- * One process per GPU.  Rank 0 calls dspfx_comm_unique_id and hands the DSPFX_COMM_ID_BYTES bytes to the other ranks
- * over whatever channel the host already has (the Rust host's control socket, a file, MPI); every rank then calls
- * dspfx_comm_create(device, n_ranks, rank, id) -- collectively, it blocks until all ranks have joined.  RCCL is
- * loaded at run time (the copy already mapped into the process, else librccl.so.1): a host that never calls these
- * entry points needs no RCCL.  n_ranks = 1 is allowed (no collective runs; the calls still divide).
- * dspfx_mix_allreduce is asynchronous on `stream`, in place on `mix` (device, n_frames f32), deterministic for a
- * given rank count (RCCL's reduction order is fixed by the topology), and applies the Output hop when
- * n_connected != 0: mix[f] = (sum over ranks of mix[f]) / dspfx_link_divisor(n_connected). */
+ * One process per GPU (several ranks may also share one device).  Rank 0 calls dspfx_comm_unique_id and hands the
+ * DSPFX_COMM_ID_BYTES bytes to the other ranks over whatever channel the host already has (the Rust host's control socket, a
+ * file, MPI); every rank then calls dspfx_comm_create(device, n_ranks, rank, id) -- collectively, it blocks until all ranks
+ * have joined (DSPFX_COMM_TIMEOUT_MS, default 60 s).  Two backends, chosen by the rank that makes the id (DSPFX_COMM_BACKEND):
+ *   mailbox (default)  a one-shot all-reduce by direct peer writes: every rank owns a mailbox in its device memory, opened by
+ *                      its peers through hipIpc handles (exchanged via a shared-memory file named by the id: one node, which
+ *                      is all xGMI spans); an exchange is ONE kernel of one workgroup per rank that writes its n_frames
+ *                      {value, sequence} granules into every peer's mailbox over xGMI, then adds the n_ranks vectors of its
+ *                      own mailbox IN RANK ORDER, ((0 + x_0) + x_1) + ..., and applies the Output hop.  The sum is the same
+ *                      bits on every rank and from run to run by construction; latency is one peer write + one poll (a few
+ *                      microseconds), what the 512-byte, latency-bound exchange wants (a ring or tree only adds hops).  Every
+ *                      wait is bounded: a peer that never arrives gives NaNs and an error from the next call, not a hang.
+ *                      Up to 16 ranks, n_frames <= 2048.
+ *   rccl               ONE ncclAllReduce(sum, float, n_frames) in place + the Output hop.  RCCL is loaded at run time (the copy
+ *                      already mapped into the process, else librccl.so.1): a host that never asks for it needs no RCCL.
+ *                      Deterministic for a given rank count only as far as RCCL's topology search is.
+ * n_ranks = 1 is allowed (id may be NULL: no exchange runs, the calls still divide).
+ * dspfx_mix_allreduce is asynchronous on `stream`, in place on `mix` (device, n_frames f32), and applies the Output hop when
+ * n_connected != 0: mix[f] = (sum over ranks of mix[f]) / dspfx_link_divisor(n_connected).  Calls on one communicator must be
+ * made in the same order by every rank (they are counted). */
 typedef struct dspfx_comm dspfx_comm;
 #define DSPFX_COMM_ID_BYTES 128
 int dspfx_comm_unique_id(void *id_out);
@@ -385,6 +397,8 @@ void dspfx_comm_destroy(dspfx_comm *c);
 int dspfx_comm_size(const dspfx_comm *c);
 int dspfx_comm_rank(const dspfx_comm *c);
 const char *dspfx_comm_last_error(const dspfx_comm *c);
+/* "mailbox", "rccl" or "single" (one rank without an id). */
+const char *dspfx_comm_backend(const dspfx_comm *c);
 int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, uint32_t n_frames, uint64_t n_connected,
                         void *stream);
 

@@ -195,7 +195,7 @@ def _pipelined_worker(rank, world, port, total, blocks, batch, same_block, out_q
 
 
 @pytest.mark.parametrize("same_block", [False, True])
-@pytest.mark.parametrize("blocks,batch", [(1, 4), (2, 4), (7, 4), (8, 4), (13, 4), (26, 8), (33, 2)])
+@pytest.mark.parametrize("blocks,batch", [(1, 4), (2, 4), (7, 4), (8, 4), (13, 4), (26, 8), (33, 2), (1, 1), (9, 1)])
 def test_pipelined_mix_bus_world2_every_block_matches_the_oracle(blocks, batch, same_block):
     """Two ranks, different channel shards, the batched collective path of bench.py --gpus N: rings, batches, the
     partly filled last batch and the drain, with the engine's delivery (same block / two calls late) faked on the host.
