@@ -207,12 +207,34 @@ __device__ __forceinline__ ColdArgs cold_args() {
 // ONE lane bumps an agent-scope counter, and the workgroup that draws the last ticket reads them back with sc1 loads
 // (which the caches cannot serve stale).  No fences: a release fence would write back the XCD's whole L2, which at
 // this point is full of freshly stored samples.  Counters are reset by the last arriver, so they are zero between launches.
+// DSPFX_BUS_FENCE (make libdspfx_busfence.so): the same hand-over inside the HIP memory model -- plain stores, an agent-scope
+// RELEASE fence before a row's ticket, an agent-scope ACQUIRE fence behind the last ticket, plain loads -- for bisecting should a
+// compiler or firmware update break the default form (which rests on gfx950's documented write-through / sc1 behaviour, not on
+// the model).  Bit-identical results; slower: the release writes back the XCD's whole L2, full of freshly stored samples
+// (A/B table: profiles/r04_bus_fence_ab.txt; tests/test_gpu_threads.py runs both forms against each other).
 typedef __attribute__((address_space(1))) unsigned dspfx_gu32;   // every shared word is a GLOBAL agent-scope access, never flat
 __device__ __forceinline__ float ld_sc1(const float *p) {
     return __uint_as_float(__hip_atomic_load((const dspfx_gu32 *)reinterpret_cast<const unsigned *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ void st_sc1(float *p, float v) {
+#ifdef DSPFX_BUS_FENCE
+    *p = v;                                           // published by the release fence in bus_publish()
+#else
     __hip_atomic_store((dspfx_gu32 *)reinterpret_cast<unsigned *>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+// the writing wave, after its last store of a row / slice sum and before its ticket
+__device__ __forceinline__ void bus_publish() {
+#ifdef DSPFX_BUS_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (behind a release fence too: the compiler may drop the fence's own wait)
+}
+// the wave that drew the last ticket, before it reads what the others published
+__device__ __forceinline__ void bus_acquire() {
+#ifdef DSPFX_BUS_FENCE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
 }
 __device__ __forceinline__ unsigned ticket_take(unsigned *t, int lane) {
     unsigned v = 0;
@@ -232,7 +254,11 @@ typedef unsigned dspfx_u32x2 __attribute__((ext_vector_type(2)));
 // register instead of a 64-bit vector address per row (the atomic-load builtin's global sc1 loads: 64 VGPRs of addresses for
 // 32 rows in flight), and the descriptor's bounds check returns 0 for rows past n_valid -- no branches in the batch.
 // nf is even (the host takes this path for even block lengths only): a lane takes the frames 2 lane, 2 lane + 1.
+#ifdef DSPFX_BUS_FENCE
+constexpr int BUF_AUX_SC1 = 0;                        // plain loads behind the acquire fence
+#else
 constexpr int BUF_AUX_SC1 = 16;
+#endif
 __device__ __forceinline__ void tail_reduce_rows(const float *src, unsigned n, unsigned n_valid, unsigned nf, float *dst, float div, bool write_through, int lane) {
     const unsigned stride = nf * (unsigned)sizeof(float);           // n * stride stays far below 4 GiB (<= 8192 rows of <= a few thousand frames)
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(src), 0, (int)(n_valid * stride), 0x00020000);
@@ -271,18 +297,20 @@ __device__ __forceinline__ void tail_reduce_rows(const float *src, unsigned n, u
 }
 // Called by ONE wave per row (the wave that stored the row), all 64 lanes alive, after the row's last store.
 __device__ __forceinline__ void mix_tail(unsigned row, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the row has left this wave and is in memory
+    bus_publish();                                                    // the row has left this wave and is in memory
     const ColdArgs a = cold_args();
     const unsigned rows = a.mix_stride, nf = a.nframes;
     const unsigned per = mix_rows_per_slice(rows);
     const unsigned b = row / per, w0 = b * per, w1 = min(rows, w0 + per);
     if (ticket_take(a.mt_tickets + b, lane) + 1 != w1 - w0) return;
+    bus_acquire();
     // last row of slice b: the same sums in the same order as mix_slice_reduce
     tail_reduce_rows(a.mixpart + (size_t)w0 * nf, w1 - w0, w1 - w0, nf, a.mt_part2 + (size_t)b * nf, 0.0f, true, lane);
     if (lane == 0) __hip_atomic_store((dspfx_gu32 *)(a.mt_tickets + b), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bus_publish();
     const unsigned live = (rows + per - 1) / per;                     // slices that hold rows; the others count as the +0 their stage would have written
     if (ticket_take(a.mt_tickets + MIX_SLICES, lane) + 1 != live) return;
+    bus_acquire();
     // last slice: the same sums in the same order as mix_final_reduce
     tail_reduce_rows(a.mt_part2, MIX_SLICES, live, nf, a.mt_mix, a.mt_div, false, lane);      // (batches past `live` load nothing: bounds check)
     if (lane == 0) __hip_atomic_store((dspfx_gu32 *)(a.mt_tickets + MIX_SLICES), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -722,6 +750,9 @@ __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, 
 // reference's signs and NaNs).  A branch of its own so that the steady state pays one scalar compare per chunk.
 template <int F, int CPL>
 __device__ __forceinline__ void ring_zero_cleared(const SlotArgs &s, const Ctx &cx, float (&tap)[F][CPL]) {
+#ifdef DSPFX_NO_LAZY_CLEAR      // A/B builds only (what the steady state pays for the compare): the clear is NOT applied
+    return;
+#endif
     const unsigned zr = s.zero_rows;
     if (zr > cx.f0) {
 #pragma unroll

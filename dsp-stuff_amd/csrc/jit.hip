@@ -46,7 +46,11 @@ std::string csrc_dir() {
 // hiprtc version.  A second process loads it in a few milliseconds (hipModuleLoadData of ~100 KB).  Files are written to a
 // temporary name and renamed, so concurrent processes never see a partial object; a file that does not parse or load is
 // ignored and overwritten.
-static const char *const k_jit_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math"};
+static const char *const k_jit_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-fast-math",
+#ifdef DSPFX_BUS_FENCE
+                                         "-DDSPFX_BUS_FENCE",     // the run-time kernels of the fence build hand their bus rows over the same way
+#endif
+};
 std::atomic<uint64_t> g_jit_compiled{0}, g_jit_from_disk{0}, g_jit_disk_written{0};
 
 static void fnv(uint64_t &h, const void *p, size_t n) {

@@ -883,3 +883,87 @@ def test_a_missing_peer_is_an_error_not_a_hang(dspfx, torch_cuda, monkeypatch):
     torch_cuda.cuda.synchronize()
     assert np.array_equal(m.cpu().numpy(), (np.arange(128, dtype=F) / dspfx.link_divisor(4)).astype(F))
     c.close()
+
+
+# ---------------------------------------------------------------- the in-launch bus: soak, and the fence build against the default
+
+def _load_pkg_with_lib(lib_name, tag):
+    """A second copy of the Python binding over another build of the library (as tools/ab.py does)."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "dsp-stuff_amd", "csrc", lib_name)
+    if not os.path.exists(path):
+        return None
+    old = os.environ.get("DSPFX_LIB")
+    os.environ["DSPFX_LIB"] = path
+    try:
+        name = "dsp_stuff_amd_" + tag
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "dsp-stuff_amd", "__init__.py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        mod.lib()
+        return mod
+    finally:
+        if old is None:
+            os.environ.pop("DSPFX_LIB", None)
+        else:
+            os.environ["DSPFX_LIB"] = old
+
+
+def test_the_bus_inside_the_launch_soak_and_the_fence_build(dspfx, torch_cuda, monkeypatch):
+    """VERDICT r03 #8.  About 20 s of blocks with the bus finished inside the launch, under UNEVEN load (a second stream
+    hammering HBM with bursts of varying size, so that workgroups arrive at their tickets in every order), over ragged and
+    whole channel counts, both layouts, 128- and 256-frame blocks, the standard, the time-sliced and the interpreting kernels:
+      * the default hand-over (write-through rows, s_waitcnt, relaxed agent-scope tickets, sc1 reads: outside the HIP memory
+        model, resting on gfx950's documented behaviour),
+      * the fence build of the same library (libdspfx_busfence.so: plain rows, agent-scope release / acquire fences),
+      * the stand-alone reduction kernels behind the launch (DSPFX_MIX_TAIL=0),
+    must give the same bus, bit for bit, for every block."""
+    import time
+    torch = torch_cuda
+    from chains import chain3
+    fence = _load_pkg_with_lib("libdspfx_busfence.so", "busfence")
+    cases = [(1 << 20, 256, 128, "chain5", 4500), (262144, 256, 128, "chain5", 7000), (64 * 300 + 37, 0, 128, "chain5", 11000),
+             (65536, 256, 256, "chain3", 9000), (131072 + 64, 0, 256, "chain3", 5000), (4099, 0, 128, "mixed", 11000)]
+    junk = torch.empty(96 << 20, device="cuda")
+    s, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    rng = np.random.default_rng(4)
+    t0 = time.time()
+    total_blocks = 0
+    for N, tile, nf, which, blocks in cases:
+        mk = {"chain5": lambda p: chain5(p, 256), "chain3": lambda p: chain3(p, 256),
+              "mixed": lambda p: [p.Gain(0.8), p.Distort(2.0, p.TANH), p.LowPass(0.2), p.Reverb(delay_samples=256, decay=0.3)]}[which]
+        x = torch.empty((4, nf * N), device="cuda")
+        y = torch.empty(nf * N, device="cuda")
+        buses = {}
+        for form in ("tail", "fence", "standalone"):
+            if form == "fence" and fence is None:
+                continue
+            pkg = fence if form == "fence" else dspfx
+            monkeypatch.setenv("DSPFX_MIX_TAIL", "0" if form == "standalone" else "1")
+            eng = pkg.Engine(N, nf, link_flags=3, tile_channels=tile)
+            eng.set_chain(mk(pkg))
+            eng.kernels_ready()
+            for k in range(4):
+                eng.fill_noise(x[k], nf, k * nf)
+            dm = torch.zeros((blocks, nf), device="cuda")
+            torch.cuda.synchronize()
+            for k in range(blocks):
+                if form != "standalone" and rng.integers(0, 4) == 0:
+                    with torch.cuda.stream(s2):
+                        n = int(rng.integers(1, 96)) << 20
+                        junk[:n].mul_(1.0001)            # a burst of 8 .. 768 MiB of traffic beside the chain kernel
+                eng.process(x[k & 3], out=y, mix=dm[k], n_frames=nf, stream=s.cuda_stream)
+            torch.cuda.synchronize()
+            buses[form] = dm
+            eng.close()
+            total_blocks += blocks
+        for form in ("fence", "standalone"):
+            if form in buses:
+                bad = (buses["tail"].view(torch.int32) != buses[form].view(torch.int32)).nonzero()
+                assert bad.numel() == 0, (N, tile, nf, which, form, bad[:6].tolist())
+        assert bool(torch.isfinite(buses["tail"]).all()) and float(buses["tail"].abs().max()) > 0
+    assert fence is not None, "libdspfx_busfence.so was not built (make -C dsp-stuff_amd/csrc)"
+    print("in-launch bus soak: %d blocks in %.1f s, three forms bit-identical" % (total_blocks, time.time() - t0))
