@@ -3,11 +3,14 @@
 Follows nodes/fir.rs:86-173: decode the file to f64 samples, average the channels of every
 frame (`s.iter().sum::<f64>() / num_channels as f64`, fir.rs:140-144); the reversal
 (fir.rs:163,168) happens in `Fir(...)` / `dspfx_set_taps`.  The reference decodes through
-symphonia and sinc-resamples to 48 kHz through dasp when the file has another rate
-(fir.rs:153-171); neither crate is in the reference tree, so this reader handles RIFF/WAVE PCM
-(8/16/24/32-bit integer, 32/64-bit float) and REFUSES other sample rates instead of guessing
-the resampler.  Integer samples are scaled like symphonia's SampleBuffer<f64> conversion
-(u8: (x-128)/128, i16: /2^15, i24: /2^23, i32: /2^31).
+symphonia and, when the file is not 48 kHz, sinc-resamples it through dasp (fir.rs:153-171).
+Neither crate is in the reference tree: this reader handles RIFF/WAVE PCM (8/16/24/32-bit
+integer, 32/64-bit float; integer samples scaled like symphonia's SampleBuffer<f64> conversion:
+u8 (x-128)/128, i16 /2^15, i24 /2^23, i32 /2^31), and files of another rate go through
+`resample_dasp_sinc`, a restatement of dasp 0.11's Converter + 16-tap Sinc as recalled
+(oracle/dspfx_oracle.h writes the algorithm out; KAT-12 checks its closed forms); pass
+resample=False to refuse such files instead.  include/dspfx_ir.hpp is the C++ twin (bit-identical
+taps: tests/test_cpp_ir.py); tests/test_gpu_parity.py takes WAV files through to the FIR kernels.
 """
 from __future__ import annotations
 

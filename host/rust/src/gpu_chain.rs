@@ -64,13 +64,13 @@ pub struct Bank {
 }
 
 /// `len` f32 of page-locked host memory from `dspfx_host_alloc`.
-struct PinnedBlock {
+pub(crate) struct PinnedBlock {
     ptr: *mut f32,
     len: usize,
 }
 unsafe impl Send for PinnedBlock {}
 impl PinnedBlock {
-    fn new(len: usize) -> Result<Self, super::engine::Error> {
+    pub(crate) fn new(len: usize) -> Result<Self, super::engine::Error> {
         let mut p: *mut std::os::raw::c_void = std::ptr::null_mut();
         let rc = unsafe { super::ffi::dspfx_host_alloc(len * std::mem::size_of::<f32>(), &mut p) };
         if rc != super::ffi::DSPFX_OK {
@@ -80,8 +80,8 @@ impl PinnedBlock {
         unsafe { std::ptr::write_bytes(block.ptr, 0, len) };
         Ok(block)
     }
-    fn as_slice(&self) -> &[f32] { unsafe { std::slice::from_raw_parts(self.ptr, self.len) } }
-    fn as_mut_slice(&mut self) -> &mut [f32] { unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) } }
+    pub(crate) fn as_slice(&self) -> &[f32] { unsafe { std::slice::from_raw_parts(self.ptr, self.len) } }
+    pub(crate) fn as_mut_slice(&mut self) -> &mut [f32] { unsafe { std::slice::from_raw_parts_mut(self.ptr, self.len) } }
 }
 impl Drop for PinnedBlock {
     fn drop(&mut self) {

@@ -13,6 +13,7 @@
 #include <unistd.h>
 
 #include "../../include/dspfx.hpp"
+#include "../../include/dspfx_ir.hpp"
 #include "../../oracle/dspfx_oracle.h"
 
 static int ulp(float a, float b) {
@@ -42,6 +43,30 @@ int main(int argc, char **argv) {
     signal(SIGABRT, on_crash);
     setvbuf(stdout, nullptr, _IOLBF, 0);        // what was printed before a crash is in the report
     const bool expect_no_device = argc > 1 && std::strcmp(argv[1], "--expect-no-device") == 0;
+    if (argc > 2 && std::strcmp(argv[1], "--ir") == 0) {
+        // f3 from C++: test_host --ir file.wav [blocks] -- the impulse response through include/dspfx_ir.hpp (fir.rs:86-173:
+        // decode, channel average, resample to 48 kHz), Fir(...) of include/dspfx.hpp (reversal, fir.rs:163,168), 64 channels of
+        // hashed noise through the engine; prints the taps' count and every output sample of channels 0 and 63 as hex floats
+        try {
+            using namespace dspfx;
+            const std::vector<double> h = load_impulse_response(argv[2]);
+            const uint32_t N = 64, blocks = argc > 3 ? (uint32_t)std::atoi(argv[3]) : 6;
+            Engine eng(N, BUF_SIZE, 0);
+            eng.set_chain({Fir(h)});
+            std::vector<float> x(BUF_SIZE * N), y(BUF_SIZE * N);
+            std::printf("taps %zu\n", h.size());
+            for (uint32_t blk = 0; blk < blocks; ++blk) {
+                for (uint32_t f = 0; f < BUF_SIZE; ++f)
+                    for (uint32_t c = 0; c < N; ++c) x[f * N + c] = orc_noise(0x5EED0004u, c, blk * BUF_SIZE + f);
+                eng.process_host(x.data(), y.data(), BUF_SIZE);
+                for (uint32_t f = 0; f < BUF_SIZE; ++f) std::printf("%a %a\n", (double)y[f * N + 0], (double)y[f * N + 63]);
+            }
+            return 0;
+        } catch (const std::exception &e) {
+            std::printf("FAIL: %s\n", e.what());
+            return 1;
+        }
+    }
     try {
         using namespace dspfx;
         const uint32_t N = 200, blocks = 6;
@@ -109,10 +134,13 @@ int main(int argc, char **argv) {
         }
         // the mix bus across GPUs through the C ABI: a ONE-rank communicator made from a real unique id (so RCCL's
         // ncclCommInitRank / ncclAllReduce really run on this GPU), in place on a page-locked buffer, then the Output hop
-        {
+        for (const char *backend : {"mailbox", "rccl"}) {
+            setenv("DSPFX_COMM_BACKEND", backend, 1);            // read by the rank that makes the id
             Comm::Id id = Comm::unique_id();
+            unsetenv("DSPFX_COMM_BACKEND");
             Comm comm(0, 1, 0, &id);
             if (comm.size() != 1 || comm.rank() != 0) { std::printf("FAIL: comm size/rank\n"); return 1; }
+            if (std::strcmp(dspfx_comm_backend(comm.raw()), backend) != 0) { std::printf("FAIL: backend %s\n", dspfx_comm_backend(comm.raw())); return 1; }
             void *pinned = nullptr;
             if (dspfx_host_alloc(BUF_SIZE * sizeof(float), &pinned) != DSPFX_OK) { std::printf("FAIL: host_alloc\n"); return 1; }
             float *pm = static_cast<float *>(pinned);
@@ -130,7 +158,64 @@ int main(int argc, char **argv) {
             for (uint32_t f = 0; f < BUF_SIZE; ++f)
                 if (ulp(pm[f], mix[f] / div) != 0) { std::printf("FAIL: solo mix_allreduce at %u\n", f); return 1; }
             dspfx_host_free(pinned);
-            std::printf("mix_allreduce over a 1-rank RCCL communicator ok\n");
+            std::printf("mix_allreduce over a 1-rank %s communicator ok\n", backend);
+        }
+        // GpuBank (host/rust/src/gpu_bank.rs) -- the N-channel engine as a node of the reference graph -- makes exactly these C
+        // calls in this order; here they run from C++ against the oracle: N input ports gathered into one page-locked [128][N]
+        // block, ONE dspfx_process_host, N output ports scattered, the `mix` port = sum / f32(0.0001 + N) (node.rs:189-191).
+        {
+            const uint32_t NB = 64, nblk = 4;
+            dspfx_engine *be = nullptr;
+            const dspfx_engine_desc bd{DSPFX_ABI_VERSION, 0, NB, BUF_SIZE, DSPFX_LINK_INTERNAL, 0, 0};
+            if (dspfx_engine_create(&bd, &be) != DSPFX_OK) { std::printf("FAIL: bank engine\n"); return 1; }
+            const std::vector<Node> bchain = {BiQuad(1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f), Distort(3.0f, Mode::SoftClip), Reverb(0.5f, 0.5f),
+                                              BiQuad(1.0f, -1.98f, 0.9801f, 0.99f, -1.98f, 0.99f), Gain(0.5f)};
+            std::vector<dspfx_node_desc> bdesc;
+            for (const Node &n : bchain) bdesc.push_back(n.d);
+            if (dspfx_chain_set(be, bdesc.data(), (int)bdesc.size()) != DSPFX_OK) { std::printf("FAIL: bank chain: %s\n", dspfx_last_error(be)); return 1; }
+            void *pg = nullptr, *ps = nullptr;
+            if (dspfx_host_alloc((size_t)BUF_SIZE * NB * sizeof(float), &pg) != DSPFX_OK || dspfx_host_alloc((size_t)BUF_SIZE * NB * sizeof(float), &ps) != DSPFX_OK) { std::printf("FAIL: bank host_alloc\n"); return 1; }
+            const float bdiv = dspfx_link_divisor(NB);
+            float *gather = static_cast<float *>(pg), *scatter = static_cast<float *>(ps);
+            std::vector<std::vector<orc_node *>> bt(NB);
+            for (uint32_t c = 0; c < NB; ++c) {
+                orc_node *b0 = orc_node_new(ORC_BIQUAD), *b1 = orc_node_new(ORC_BIQUAD);
+                const float p0[6] = {1.0f, -1.8f, 0.81f, 0.0025f, 0.005f, 0.0025f}, p1[6] = {1.0f, -1.98f, 0.9801f, 0.99f, -1.98f, 0.99f};
+                for (int i = 0; i < 6; ++i) { orc_node_set_param(b0, i, p0[i]); orc_node_set_param(b1, i, p1[i]); }
+                orc_node *ds = orc_node_new(ORC_DISTORT); orc_node_init_param(ds, 0, 3.0f); orc_node_set_mode(ds, ORC_DIST_SOFT_CLIP);
+                orc_node *rv = orc_node_new(ORC_REVERB); orc_node_init_param(rv, 0, 0.5f); orc_node_init_param(rv, 1, 0.5f);
+                orc_node_after_settings_change(rv);                                   // a restored reverb: 24000 samples
+                orc_node *gn = orc_node_new(ORC_GAIN); orc_node_init_param(gn, 0, 0.5f);
+                bt[c] = {b0, ds, rv, b1, gn};
+            }
+            int bworst = 0;
+            double bmix_err = 0.0;
+            std::vector<float> port_in(BUF_SIZE), port_out(BUF_SIZE), bmix(BUF_SIZE), want(BUF_SIZE);
+            for (uint32_t blk = 0; blk < nblk; ++blk) {
+                for (uint32_t c = 0; c < NB; ++c)                                     // gather: port in{c} -> column c
+                    for (uint32_t f = 0; f < BUF_SIZE; ++f) gather[f * NB + c] = orc_noise(0x5EED0011u, c, blk * BUF_SIZE + f);
+                if (dspfx_process_host(be, gather, nullptr, scatter, bmix.data(), BUF_SIZE) != DSPFX_OK) { std::printf("FAIL: bank process: %s\n", dspfx_last_error(be)); return 1; }
+                std::vector<double> msum(BUF_SIZE, 0.0);
+                for (uint32_t c = 0; c < NB; ++c) {
+                    for (uint32_t f = 0; f < BUF_SIZE; ++f) port_in[f] = gather[f * NB + c];
+                    orc_chain_run(bt[c].data(), 5, 1, port_in.data(), nullptr, want.data(), BUF_SIZE, BUF_SIZE);   // hops BETWEEN the nodes only
+                    for (uint32_t f = 0; f < BUF_SIZE; ++f) {
+                        port_out[f] = scatter[f * NB + c];                            // scatter: column c -> port out{c}
+                        bworst = std::max(bworst, ulp(port_out[f], want[f]));
+                        msum[f] += want[f];
+                    }
+                }
+                for (uint32_t f = 0; f < BUF_SIZE; ++f) {
+                    const float mix_port = bmix[f] / bdiv;                            // the `mix` port
+                    bmix_err = std::max(bmix_err, std::fabs((double)mix_port - msum[f] / (double)bdiv));
+                }
+            }
+            dspfx_host_free(pg);
+            dspfx_host_free(ps);
+            dspfx_engine_destroy(be);
+            for (auto &v : bt) for (orc_node *n : v) orc_node_free(n);
+            if (bworst > 1 || bmix_err > 1e-5) { std::printf("FAIL: GpuBank sequence: max ulp %d, mix err %g\n", bworst, bmix_err); return 1; }
+            std::printf("GpuBank call sequence: %u ports, max ulp %d, mix err %.3g\n", NB, bworst, bmix_err);
         }
         // Two host threads, as in the reference: the audio task drives process (here the synchronous host form, block after
         // block) while the GUI thread stores a slider (dsp-stuff-derive/src/lib.rs:487-492).  No lock on the caller's side: the

@@ -36,5 +36,6 @@ def test_cpp_host_parity_on_gpu():
     r = subprocess.run([EXE], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "max ulp" in r.stdout
-    assert "mix_allreduce over a 1-rank RCCL communicator ok" in r.stdout
+    assert "mix_allreduce over a 1-rank mailbox communicator ok" in r.stdout and "mix_allreduce over a 1-rank rccl communicator ok" in r.stdout
+    assert "GpuBank call sequence: 64 ports" in r.stdout          # host/rust/src/gpu_bank.rs' C calls, in its order, against the oracle
     assert "slider stores from a second thread" in r.stdout

@@ -1928,3 +1928,48 @@ def test_reverb_store_inside_a_generated_graph_kernel(dspfx, torch_cuda):
             a = ns[3].process(hop(r), hop(h))
             ref[k * B:(k + 1) * B, c] = hop(a)
         assert ulp_diff(y[:, c], ref[:, c]).max() <= 1, c
+
+
+# ---------------------------------------------------------------- f3: a WAV impulse response all the way to the FIR kernels
+
+def test_wav_impulse_responses_through_the_fir_kernels(dspfx, torch_cuda, tmp_path):
+    """nodes/fir.rs:86-173 -> 179-225 end to end: a WAV file is decoded, its channels averaged, a file that is not 48 kHz
+    resampled (ir.load_impulse_response / include/dspfx_ir.hpp), the taps reversed (Fir(...), fir.rs:163,168) and handed to
+    dspfx_chain_set; the GPU's FIR kernels against the oracle fed the same taps -- bit for bit where the data is exact in f32
+    (16-bit taps k / 32768, small integer samples), within the stated 1e-6 relative RMS otherwise -- and the same file through
+    the C++ loader and engine wrapper (tests/cpp/test_host --ir), bit for bit against the Python path."""
+    import subprocess
+    from dsp_stuff_amd import ir
+    from test_config_ir_cpu import _wav
+    import test_cpp_host
+    test_cpp_host._build()
+    rng = np.random.default_rng(12)
+    N, blocks = 64, 6
+    xn = O.noise(0x5EED0004, np.arange(N), np.arange(128 * blocks))
+    cases = {
+        "mono16_exact": (1, 16, 48000, rng.integers(-4, 5, (200, 1)) / 32768.0, np.round(xn * 8).astype(F)),
+        "stereo_float": (3, 32, 48000, rng.uniform(-0.5, 0.5, (300, 2)).astype(np.float32).astype(np.float64), xn),
+        "mono16_44k1": (1, 16, 44100, np.round(rng.uniform(-0.9, 0.9, (150, 1)) * 32768) / 32768, xn),
+    }
+    for name, (tag, bits, rate, frames, x) in cases.items():
+        p = str(tmp_path / (name + ".wav"))
+        _wav(p, tag, bits, rate, frames)
+        h = ir.load_impulse_response(p)
+        assert len(h) == (len(frames) if rate == 48000 else len(ir.resample_dasp_sinc(frames.mean(axis=1), rate)))
+        if name == "stereo_float":
+            assert np.array_equal(h, (frames[:, 0] + frames[:, 1]) / 2.0)          # fir.rs:140-144
+        chain = [dspfx.Fir(h)]
+        y = run_gpu(dspfx, torch_cuda, chain, x, link_flags=0)
+        ref = run_oracle(chain, x, 0)
+        if name == "mono16_exact":
+            assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), name
+        else:
+            assert fir_rel_rms(y, ref) < FIR_RMS_TOL, (name, fir_rel_rms(y, ref))
+        if name != "mono16_exact":                                              # the C++ rig feeds the hashed noise itself
+            r = subprocess.run([test_cpp_host.EXE, "--ir", p, str(blocks)], capture_output=True, text=True)
+            assert r.returncode == 0, r.stdout + r.stderr
+            lines = r.stdout.strip().splitlines()
+            assert lines[0] == "taps %d" % len(h), lines[0]
+            got = np.array([[float.fromhex(v) for v in l.split()] for l in lines[1:]], F)
+            assert got.shape == (128 * blocks, 2)
+            assert np.array_equal(got[:, 0].view(np.uint32), y[:, 0].view(np.uint32)) and np.array_equal(got[:, 1].view(np.uint32), y[:, 63].view(np.uint32)), name

@@ -63,3 +63,44 @@ def test_constants_match():
         assert c[k] == v, (k, c[k], v)
     for k in c:                                       # every enum value / flag of the header is mirrored
         assert k in r, k
+
+
+def test_every_c_call_the_rust_sources_make_exists_with_that_arity():
+    """host/rust/src/{engine,gpu_chain,gpu_bank}.rs call the C ABI through `unsafe { dspfx_xxx(...) }`: every such call names an
+    entry point of include/dspfx.h and passes as many arguments as it takes (a typo or a stale signature would only show up in
+    a compiler this image does not have)."""
+    c = _c_protos()
+    src_dir = os.path.join(ROOT, "host", "rust", "src")
+    seen = set()
+    for fn in ("engine.rs", "gpu_chain.rs", "gpu_bank.rs"):
+        text = re.sub(r'"(?:[^"\\\\]|\\\\.)*"', '""', _strip_comments(open(os.path.join(src_dir, fn)).read()))     # (no string literals)
+        for m in re.finditer(r"\b(?:super::ffi::)?(dspfx_[a-z_]+)\s*\(", text):
+            name = m.group(1)
+            if name in ("dspfx_engine", "dspfx_comm"):
+                continue
+            # the argument list: up to the matching parenthesis
+            depth, k = 1, m.end()
+            while depth and k < len(text):
+                depth += {"(": 1, ")": -1}.get(text[k], 0)
+                k += 1
+            args = text[m.end():k - 1].strip()
+            n = 0
+            if args:
+                d = 0
+                n = 1
+                for ch in args:
+                    d += {"(": 1, "[": 1, "{": 1, ")": -1, "]": -1, "}": -1}.get(ch, 0)
+                    n += ch == "," and d == 0
+                if args.endswith(","):
+                    n -= 1
+            assert name in c, (fn, name)
+            assert n == c[name], (fn, name, n, c[name])
+            seen.add(name)
+    # GpuBank's documented sequence is really in its source
+    bank = open(os.path.join(src_dir, "gpu_bank.rs")).read()
+    for call in ("Engine::new", "set_chain", "PinnedBlock::new", "dspfx_link_divisor", "process_host", "engine.params()"):
+        assert call in bank, call
+    for trait in ("impl Node for GpuBank", "impl NodeStatic for GpuBank", "impl SimpleNode for GpuBank"):
+        assert trait in bank, trait
+    assert {"dspfx_engine_create", "dspfx_chain_set", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_engine_destroy",
+            "dspfx_set_param_seq", "dspfx_link_divisor"} <= seen, seen
