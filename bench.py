@@ -599,11 +599,33 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
             roof = {"bound": "mfma", "dtype": "bf16x3 (f32 operands split exactly into three bf16; f32 accumulation)",
                     "achieved": ex_rate, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex_rate / MFMA_BF16_PEAK_TFLOPS,
                     "algorithmic_tflops": achieved, "algorithmic_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
-                    "note": "power-limited: the shader clock sits near 1.8 GHz under this kernel (profiles/r02_fir_split_pmc.json)"}
+                    "note": "power-limited: the shader clock sits near 1.6 GHz under this kernel (profiles/r03_fir_split_pmc.json)"}
+        if kern_name == "fir_half_kernel":
+            # two-part f16: every f32 operand as f16 hi + f16 lo, THREE f16 MFMAs (32x32x16) per 16 taps and 32x32 tile.  Half the
+            # matrix-pipe time of the bf16 x 3 sweep: the sweep now sits between its two roofs, so both fractions are given and
+            # `bound` names the nearer one -- HBM: the sweep's own algorithmic bytes (the window's (T - 1 + B) rows re-read + the
+            # block written, per channel and block; the append is another kernel) over the 8 TB/s peak; matrix pipe: EXECUTED
+            # f16 flop/s over the dense f16 peak.  The algorithmic 2 T flop per sample rate of SURVEY 8d is beside them.
+            T = cfg["taps"]
+            koff = (1 - T) % 16
+            n_iter = (koff + T + 30) // 16 + 1
+            executed = ((N + 31) // 32) * ((B + 127) // 128) * n_iter * 12 * 32768.0
+            ex_rate = executed / (kern_ms * 1e-3) / 1e12
+            sweep_bytes = ((T - 1 + B) * 4.0 / B + 4.0) * N * B
+            hbm_rate = sweep_bytes / (kern_ms * 1e-3) / 1e9
+            f_hbm, f_mfma = hbm_rate / HBM_PEAK_GBPS, ex_rate / MFMA_BF16_PEAK_TFLOPS
+            roof = ({"bound": "hbm", "achieved": hbm_rate, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f_hbm} if f_hbm >= f_mfma else
+                    {"bound": "mfma", "achieved": ex_rate, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": f_mfma})
+            roof.update({"dtype": "f16x2 (f32 operands as f16 hi + f16 lo, three products per term; f32 accumulation; bf16 x 3 second pass "
+                                  "over the tiles outside f16's range)",
+                         "frac_hbm": f_hbm, "hbm_gbps": hbm_rate, "sweep_bytes_per_launch": sweep_bytes,
+                         "frac_f16_mfma": f_mfma, "executed_tflops": ex_rate,
+                         "algorithmic_tflops": achieved, "algorithmic_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS})
     else:
         achieved = bps * N * B / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS}
+    roof["frac_by_step"] = roof["frac"] * kern_ms / (dt * 1e3 / steps) if dt > 0 else None     # the same work over the whole step (launch gaps and the step's other kernels included)
     roof.update({"kernel": kern_name, "kernel_ms_avg": kern_ms, "launches": kern_launches, "timing": kern_method,
                  "algorithmic_bytes_per_sample": bps, "traffic": None})
     # HBM bytes per launch from the committed PMC pass of this same command, if one exists (not measured in this run)
@@ -611,7 +633,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     if os.path.exists(tr):
         try:
             t = json.load(open(tr))
-            ent = t.get(f"{cfg_name}{'split' if kern_name == 'fir_split_kernel' else ''}:{N}:{B}")
+            ent = t.get(f"{cfg_name}{'split' if kern_name == 'fir_split_kernel' else 'half' if kern_name == 'fir_half_kernel' else ''}:{N}:{B}")
             if ent:
                 roof["traffic"] = ent["hbm_bytes_per_launch"]
                 roof["traffic_source"] = ent.get("source")
@@ -911,6 +933,18 @@ def main():
             others["cfg4_f32"] = {"error": str(ex)[:300]}
         finally:
             os.environ.pop("DSPFX_FIR_SPLIT", None)
+        # ... and through the bf16 x 3 sweep (round 3's default; now the second pass of the two-part f16 sweep)
+        try:
+            os.environ["DSPFX_FIR_HALF"] = "0"
+            o = measure(ctx, args, "cfg4", args.steps, args.warmup)
+            timed_order.append("cfg4_split")
+            others["cfg4_split"] = {"workload": o["config"]["workload"] + " [DSPFX_FIR_HALF=0: bf16 x 3 sweep]", "value": o["value"], "unit": "samples/s",
+                                    "ms_per_step": o["ms_per_step"], "block_budget_ms": o["block_budget_ms"],
+                                    "roofline": o["roofline"], "plan": o["config"]["plan"]}
+        except Exception as ex:
+            others["cfg4_split"] = {"error": str(ex)[:300]}
+        finally:
+            os.environ.pop("DSPFX_FIR_HALF", None)
 
     if rank != 0:
         if ctx.use_dist:

@@ -33,7 +33,7 @@ SIG_SINE, SIG_TRIANGLE, SIG_SQUARE, SIG_CONSTANT = range(4)
 HARD_CLIP, SOFT_CLIP, TANH, RECIP_SOFT_CLIP, FUZZ, SIN, ATAN, SQUARE, CHEBYSHEV4 = range(9)
 DISTORT_MODES = ["HardClip", "SoftClip", "Tanh", "RecipSoftClip", "Fuzz", "Sin", "Atan", "Square", "Chebyshev4"]
 FIR_BALANCED, FIR_AVERAGE = 0, 1
-FIR_PRECISION_DEFAULT, FIR_PRECISION_F32, FIR_PRECISION_SPLIT = 0, 1, 2
+FIR_PRECISION_DEFAULT, FIR_PRECISION_F32, FIR_PRECISION_SPLIT, FIR_PRECISION_HALF = 0, 1, 2, 3
 LINK_INTERNAL, LINK_INPUT, LINK_SIDE_RAW = 1, 2, 4
 MAX_LINKS = 16
 GRAPH_MAX_NODES = 16

@@ -1014,7 +1014,7 @@ extern "C" int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision)
     if (api.rc) return api.rc;
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_FIR)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a FIR node", node);
-    if (precision < DSPFX_FIR_PRECISION_DEFAULT || precision > DSPFX_FIR_PRECISION_SPLIT)
+    if (precision < DSPFX_FIR_PRECISION_DEFAULT || precision > DSPFX_FIR_PRECISION_HALF)
         return fail(e, DSPFX_ERR_INVALID, "unknown FIR precision %d", precision);
     e->nodes[(size_t)node].fir.precision = precision;
     return DSPFX_OK;

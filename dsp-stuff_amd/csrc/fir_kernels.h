@@ -13,7 +13,10 @@
 //                         one set of weights per iteration, each on its own history chunk out of a register window;
 //       fir_mfma_kernel   the rectangular form (one history chunk per step shared by the tiles, per-tile weights): while the
 //                         deque fills (WARM: the reference's front-aligned pairing) and as the steady-state fallback;
-//       fir_split_kernel  opt-in: f32 operands as three bf16 parts each, six v_mfma_f32_32x32x16_bf16 per 16 taps and tile;
+//       fir_split_kernel  f32 operands as three bf16 parts each, six v_mfma_f32_32x32x16_bf16 per 16 taps and tile;
+//       fir_half_kernel   the default since round 4: f32 operands as f16 hi + f16 lo (x 2^14, taps x 2^p), THREE
+//                         v_mfma_f32_32x32x16_f16 per 16 taps and tile; tiles with a channel outside f16's range (peak >= 3.998, or
+//                         below 2^-13 without being silent) are listed by the sweep and redone by fir_split_kernel right behind it;
 //     non-finite (and huge) samples are replaced by 0 in the MFMA operands and their tiles redone by the exact kernel;
 //     when the FIR node ends the chain the sweeps' epilogue also leaves the Output node's mix-bus partials;
 //   - fir_warm_scan_kernel: while a deque that started empty is still filling, state[k] pairs with taps[k] (fir.rs:193-214)
@@ -40,6 +43,10 @@ struct FirState {
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path
     unsigned *taps_split = nullptr;   // split-precision sweep: [3][ntp4] bf16 pair tables of the same padded taps (or null)
+    unsigned *taps_half = nullptr;    // two-part f16 sweep: [2][ntp4] f16 pair tables of the padded taps x 2^p (or null)
+    float half_unscale = 0.0f;        // 2^-(14 + p): what that sweep's accumulators are multiplied by
+    unsigned *redo = nullptr;         // two-part sweep: [2] counts + [2][tiles] lists of the tiles its second pass redoes, used in turn
+    int redo_parity = 0;
     unsigned long long *nf_time = nullptr;   // [tiles]: 1 + absolute time of the newest non-finite sample of the tile (0: none)
     uint32_t T = 0, R = 0, N = 0, max_frames = 0, pad_lo = 0, pad_hi = 0, tiles = 0;
     int mode = 0;                 // 0 Balanced, 1 Average (fir.rs:187-190)
@@ -48,7 +55,7 @@ struct FirState {
     uint64_t seen_bias = 0;       // samples the deque had seen before a state import re-based time (reporting only)
     uint32_t dq_cap = 0, dq_head = 0;   // std VecDeque bookkeeping (a/b slice split of the exact kernel)
     int kernel = 0;               // 0 = exact f64 VALU, 1 = MFMA f32
-    int precision = 0;            // dspfx_fir_precision: 0 environment / f32, 1 f32, 2 split (bf16 x 3)
+    int precision = 0;            // dspfx_fir_precision: 0 default (two-part f16 / environment), 1 f32, 2 split (bf16 x 3), 3 two-part f16
     const char *last_kernel = nullptr;   // the sweep kernel of the last block (reporting)
     double *warm_acc = nullptr;   // [N] running f64 sums of the fill phase (fir_warm_scan_kernel)
     bool warm_ok = false;         // warm_acc holds the sums of everything pushed since the deque was last empty

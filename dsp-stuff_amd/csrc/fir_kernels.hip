@@ -216,6 +216,13 @@ struct FirMfmaArgs {
     const float *ring;
     const float *taps;     // [pad_lo + T + pad_hi], zeros in the pads
     const unsigned *taps_split;   // split-precision sweep: [3][ntp4] bf16 pair tables (entry m: parts of taps m, m + 1)
+    const unsigned *taps_half;    // two-part f16 sweep: [2][ntp4] f16 pair tables of the taps scaled by a power of two
+    float half_unscale;           // ... and what an accumulator of that sweep is multiplied by (exact: a power of two)
+    unsigned *redo_count;         // two-part sweep: tiles whose window it cannot serve are listed here (count, then the tiles) ...
+    unsigned *redo_tiles;
+    unsigned *redo_clear;         // ... and the NEXT block's count is zeroed by this launch
+    const unsigned *only_count;   // bf16 x 3 sweep as the two-part sweep's second pass: only the tiles listed (null: all tiles)
+    const unsigned *only_tiles;
     float *out;
     const unsigned long long *nf_time;
     uint32_t N, nframes, T, R;
@@ -581,16 +588,25 @@ __device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 &u) {
 }
 
 constexpr int SPLIT_WAVES = 8;                 // waves per workgroup of fir_split_kernel
+// LIST: the second pass of the two-part f16 sweep (tiles from its list, a persistent loop per workgroup)
+template <bool LIST>
 __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) fir_split_kernel(const FirMfmaArgs a) {
     constexpr int NJT = 4, WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + 1, D = 4;       // SLOTS % D == 0: both rings repeat with the unrolled body
     static_assert(FLUSH % SLOTS == 0 && SLOTS % D == 0, "unroll period");
     if (a.mp.stage) fir_mixpipe_prologue(a);
     extern __shared__ unsigned tps[];          // [3][ntp4] pair tables, then the totals of tiles 1..3 per wave
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // second pass behind the two-part f16 sweep: the tiles come from that sweep's list (usually empty: the workgroups leave
+    // before they have staged anything); workgroup b takes the listed tiles 8 b .. 8 b + 7
+    unsigned n_only = 0;
+    if constexpr (LIST) {
+        n_only = *(const volatile unsigned *)a.only_count;
+        if (blockIdx.x * SPLIT_WAVES >= n_only) return;
+    }
     const int ntp = (int)(PAD_LO + a.T + PAD_HI), ntp4 = (ntp + 3) & ~3;
     for (int i = tid; i < 3 * ntp4; i += 64 * SPLIT_WAVES) tps[i] = a.taps_split[i];
     __syncthreads();
-    const uint32_t tile = blockIdx.x * SPLIT_WAVES + wave;
+  auto sweep_tile = [&](const uint32_t tile) __attribute__((always_inline)) {
     if ((size_t)tile * TILE_C >= a.N) return;
     const int cl = lane & 31, kh = lane >> 5;
     const uint32_t c = tile * TILE_C + cl;
@@ -696,6 +712,219 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
     flush();
     fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
                       [&](int jt, int r) { return jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]; });
+  };
+  // (LIST as a persistent loop over the list -- a launch of 256 workgroups instead of one per eight tiles -- made the compiler
+  // spill 136 registers in the sweep; one workgroup per eight LISTED tiles it is, the others leave at once)
+  if constexpr (LIST) {
+      if (blockIdx.x * SPLIT_WAVES + wave < n_only) sweep_tile(a.only_tiles[blockIdx.x * SPLIT_WAVES + wave]);
+  } else {
+      sweep_tile(blockIdx.x * SPLIT_WAVES + wave);
+  }
+}
+
+
+// ---- steady state, two-part split: f32 operands as f16 hi + f16 lo, THREE products per term ----------------------------
+// The bf16 x 3 sweep above is bound by the matrix pipe at the socket's power limit (71 % busy at 1.63 GHz: six MFMAs per 16
+// taps and tile).  f16 keeps 11 significant bits where bf16 keeps 8, so TWO parts hold 22: with x' = x 2^14 and h' = h 2^p
+// (p: the largest tap lands in [2^14, 2^15)),  x' = xh + xl,  h' = hh + hl  (each the round-to-nearest f16 of what is left),
+//     x' h' = xh hh + xh hl + xl hh   (+ xl hl, below 2^-22 of the product: dropped)
+// -- three v_mfma_f32_32x32x16_f16 per 16 taps and tile instead of six, each product exact in f32, the sum scaled back by the
+// exact power of two.  Representation error 8e-8 relative RMS at 4096 taps (numpy model, tools/fir_accuracy.py); with the f32
+// accumulation the sweep measures the same ~3e-7 against the f64 oracle as the other two.  f16 has five exponent bits where
+// bf16 has f32's eight, which is why this needs a RANGE: samples up to 3.998 in magnitude (x' <= 65504), and an absolute floor
+// of 2^-39 below which nothing is resolved (the smallest f16 subnormal / 2^14; the MFMA honours f16 subnormals: measured,
+// tools/micro/mfma_f16_denorm.hip).  Every wave therefore tracks the peak |x| of each of its channels over the window it
+// actually swept; a tile with a channel whose peak is >= 3.998 or (non-zero and) < 2^-13 is LISTED, and the bf16 x 3 sweep --
+// launched right behind, over the listed tiles only, usually none -- redoes it.  Audio at ordinary levels never leaves the
+// fast path; integers beyond 3, fades into the noise floor and denormal dust take the slower sweep: same bar either way.
+// Schedule, window, weights-in-LDS and epilogue are fir_split_kernel's with two parts instead of three.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifndef DSPFX_HALF_D
+#define DSPFX_HALF_D 4
+#endif
+constexpr int HALF_D = DSPFX_HALF_D;          // history chunks in flight per wave behind the window (A/B builds: 4 or 8)
+constexpr float HALF_X_SCALE = 0x1p14f, HALF_PEAK_MAX = 3.998046875f * 0x1p14f, HALF_PEAK_MIN = 0x1p-13f * 0x1p14f;   // in units of x'
+
+__device__ __forceinline__ unsigned pack_f16(float a, float b) {      // v_cvt_pk_f16_f32: round to nearest even (measured)
+    const f16x2 p = __builtin_convertvector(f32x2{a, b}, f16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &p, 4);
+    return u;
+}
+__device__ __forceinline__ f32x2 unpack_f16(unsigned u) {
+    f16x2 p;
+    __builtin_memcpy(&p, &u, 4);
+    return __builtin_convertvector(p, f32x2);
+}
+// four f32 (one 16-byte piece, K order) -> two pairs of dwords (hi, lo of x 2^14); the lane's running peak |x 2^14|.
+// lo = x' - hi is formed by ONE mixed-precision fma per element (v_fma_mix_f32: the f16 operand is widened inside the
+// instruction) instead of a conversion and a subtraction; it is exact either way (<= 13 significant bits).
+// (`half` = which piece of the chunk: elements 2 half, 2 half + 1 of the two part vectors)
+// lo = x' - hi: v_fma_mix_f32 d, hi.{lo,hi half as f16}, -1.0, x' -- the f16 operand is widened inside the instruction; spelled
+// in assembly because the compiler turns fma(ext(h), -1, a) back into a conversion and a (packed) subtraction.
+__device__ __forceinline__ float sub_f16_lo(float a, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ float sub_f16_hi(float a, unsigned h) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(a));
+    return r;
+}
+__device__ __forceinline__ void split4h(const f32x4 &v, u32x4 (&p)[2], const int half, float &peak) {
+    const float a = v[0] * HALF_X_SCALE, b = v[1] * HALF_X_SCALE, c = v[2] * HALF_X_SCALE, d = v[3] * HALF_X_SCALE;
+    const unsigned h0 = pack_f16(a, b), h1 = pack_f16(c, d);
+    const unsigned l0 = pack_f16(sub_f16_lo(a, h0), sub_f16_hi(b, h0)), l1 = pack_f16(sub_f16_lo(c, h1), sub_f16_hi(d, h1));
+    peak = __builtin_fmaxf(__builtin_fmaxf(peak, __builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b))), __builtin_fmaxf(__builtin_fabsf(c), __builtin_fabsf(d)));
+    p[0][2 * half] = h0;
+    p[0][2 * half + 1] = h1;
+    p[1][2 * half] = l0;
+    p[1][2 * half + 1] = l1;
+}
+// eight f32 (K order) -> two vectors of eight f16
+__device__ __forceinline__ void split8h(const f32x4 (&v)[2], u32x4 (&p)[2], float &peak) {
+    split4h(v[0], p, 0, peak);
+    split4h(v[1], p, 1, peak);
+}
+__device__ __forceinline__ f16x8 as_f16x8(const u32x4 &u) {
+    f16x8 r;
+    __builtin_memcpy(&r, &u, 16);
+    return r;
+}
+
+__global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) fir_half_kernel(const FirMfmaArgs a) {
+    constexpr int NJT = 4, WIN = 2 * (NJT - 1) + 1, SLOTS = WIN + 1, D = HALF_D;       // SLOTS % D == 0: both rings repeat with the unrolled body
+    static_assert(FLUSH % SLOTS == 0 && SLOTS % D == 0, "unroll period");
+    if (a.mp.stage) fir_mixpipe_prologue(a);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.redo_clear = 0u;                  // the next block's list starts empty
+    extern __shared__ unsigned tps[];          // [2][ntp4] pair tables, then the totals of tiles 1..3 per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntp = (int)(PAD_LO + a.T + PAD_HI), ntp4 = (ntp + 3) & ~3;
+    for (int i = tid; i < 2 * ntp4; i += 64 * SPLIT_WAVES) tps[i] = a.taps_half[i];
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * SPLIT_WAVES + wave;
+    if ((size_t)tile * TILE_C >= a.N) return;
+    const int cl = lane & 31, kh = lane >> 5;
+    const uint32_t c = tile * TILE_C + cl;
+    const bool c_ok = c < a.N;
+    const bool dirty = a.nf_time[tile] > (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
+    const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;      // table index of (iteration i, K element e) = wofs + 16 i + e
+    const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
+
+    f32x16 acc[NJT], tot0;
+    f32x4 *tl = (f32x4 *)(tps + 2 * (size_t)ntp4) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot0[r] = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < (NJT - 1) * 4; ++q) tl[q * 64] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    const float *hlane = a.ring + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
+    auto load_chunk = [&](uint32_t m, f32x4 (&h)[2]) {     // unconditional: past the sweep's end some unused rows of the ring
+        uint32_t row0 = a.rb + m * KC;                     // < 2R
+        row0 = row0 >= a.R ? row0 - a.R : row0;
+        const f32x4 *p = (const f32x4 *)(hlane + (size_t)row0 * TILE_C);
+        h[0] = __builtin_nontemporal_load(p);
+        h[1] = __builtin_nontemporal_load(p + 64);
+    };
+    auto arrive = [&](uint32_t m, f32x4 (&h)[2]) {
+        const uint32_t kc = m * KC;
+        if (kc + KC > a.kvalid) {                          // rows past the block's newest sample are stale
+#pragma unroll
+            for (int e = 0; e < KC / 2; ++e) h[e >> 2][e & 3] = kc + 8 * kh + e < a.kvalid ? h[e >> 2][e & 3] : 0.0f;
+        }
+        if (dirty) {                                       // (non-finite or huge samples: zero here, the tile is redone exactly)
+#pragma unroll
+            for (int e = 0; e < KC / 2; ++e) h[e >> 2][e & 3] = finite_f32(h[e >> 2][e & 3]) ? h[e >> 2][e & 3] : 0.0f;
+        }
+    };
+    auto wload = [&](uint32_t i, u32x4 (&w)[2]) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[sp][e] = tps[sp * ntp4 + wofs + (int)(i * KC) + 2 * e];
+    };
+    u32x4 win[SLOTS][2];
+    f32x4 fly[D][2];
+    float peak = 0.0f;
+    {   // chunks 0 .. WIN-1 split into the window, WIN .. WIN+D-1 in flight
+        f32x4 t[WIN][2];
+        static_for<0, WIN>([&](auto m) { load_chunk(m.value, t[m.value]); });
+        static_for<0, D>([&](auto m) { load_chunk(WIN + m.value, fly[(WIN + m.value) % D]); });
+        static_for<0, WIN>([&](auto m) {
+            arrive(m.value, t[m.value]);
+            split8h(t[m.value], win[m.value], peak);
+        });
+    }
+    u32x4 wq[2][2];
+    wload(0, wq[0]);
+
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 1; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
+                tl[((jt - 1) * 4 + q) * 64] = t;
+            }
+    };
+    // iteration i, i mod SLOTS == P: three groups of NJT MFMAs (one per product term), the other work pinned between them
+    auto iter = [&](auto p_c, uint32_t i) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_c)::value;
+        if constexpr (P == 0) {                            // the flush inside the unrolled body: see fir_skew_kernel
+            if (i != 0 && i % FLUSH == 0) flush();
+        }
+        constexpr int TX[3] = {0, 0, 1}, TH[3] = {0, 1, 0};                        // x part, h part of the three terms
+        f32x4 (&in)[2] = fly[(P + WIN) % D];                                       // chunk i + WIN: lands in window slot (P + WIN) % SLOTS
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            // (the chunk split here is first used by the NEXT iteration: its work can sit anywhere among this one's groups)
+            u32x4 (&nw)[2] = win[(P + WIN) % SLOTS];
+            if (t == 0) {
+                arrive(i + WIN, in);
+                split4h(in[0], nw, 0, peak);
+            }
+            if (t == 1) {
+                asm volatile("" : "+v"(in[1][0]), "+v"(in[1][1]), "+v"(in[1][2]), "+v"(in[1][3]));      // (keeps this half's split HERE: the compiler merges it into the first otherwise)
+                split4h(in[1], nw, 1, peak);
+                load_chunk(i + WIN + D, in);
+            }
+            if (t == 2) wload(i + 1, wq[(P + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(wq[P & 1][TH[t]]), as_f16x8(win[(P + 2 * jt) % SLOTS][TX[t]]),
+                                                                 acc[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    uint32_t i = 0;
+    for (; i + SLOTS <= n_iter; i += SLOTS) static_for<0, SLOTS>([&](auto p) { iter(p, i + p.value); });
+    if (i < n_iter) {                                      // fewer than SLOTS left
+        const uint32_t rest = n_iter - i;
+        static_for<0, SLOTS - 1>([&](auto p) {
+            if ((uint32_t)p.value < rest) iter(p, i + p.value);
+        });
+    }
+    flush();
+    // Could this sweep serve every channel of the tile?  (The peak covers the rows the window really held, a few chunks past
+    // the sweep's end included: conservative.)  NaN compares false: such a tile is listed too (and redone exactly besides).
+    peak = __builtin_fmaxf(peak, __shfl_xor(peak, 32));                            // the channel's two lanes
+    const bool ok = peak == 0.0f || (peak >= HALF_PEAK_MIN && peak <= HALF_PEAK_MAX);
+    if (__ballot(ok) != ~0ull && lane == 0) a.redo_tiles[atomicAdd(a.redo_count, 1u)] = tile;
+    const float us = a.half_unscale;
+    fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
+                      [&](int jt, int r) { return (jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]) * us; });
 }
 
 // old ring -> new ring for the sample times [t_begin, t_end): a tap reload that needs more rows
@@ -763,6 +992,10 @@ static size_t split_lds_bytes(uint32_t n_taps) {
     const size_t ntp4 = ((size_t)PAD_LO + n_taps + PAD_HI + 3) & ~(size_t)3;
     return 3 * ntp4 * sizeof(unsigned) + (size_t)SPLIT_WAVES * 3 * 4 * 64 * sizeof(f32x4);
 }
+static size_t half_lds_bytes(uint32_t n_taps) {
+    const size_t ntp4 = ((size_t)PAD_LO + n_taps + PAD_HI + 3) & ~(size_t)3;
+    return 2 * ntp4 * sizeof(unsigned) + (size_t)SPLIT_WAVES * 3 * 4 * 64 * sizeof(f32x4);
+}
 static size_t tap_table_bytes(uint32_t n_taps) { return ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float); }
 static size_t skew_lds_bytes(uint32_t n_taps, int) { return tap_table_bytes(n_taps); }
 
@@ -770,9 +1003,11 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
     if (s.taps_split) (void)hipFree(s.taps_split);
+    if (s.taps_half) (void)hipFree(s.taps_half);
     s.taps64 = nullptr;
     s.taps32 = nullptr;
     s.taps_split = nullptr;
+    s.taps_half = nullptr;
     s.T = n_taps;
     s.pad_lo = PAD_LO;
     s.pad_hi = PAD_HI;
@@ -801,7 +1036,38 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
             for (size_t m = 0; m < ntp; ++m) tab[k * ntp4 + m] = part[k][m] | (part[k][m + 1] << 16);
         FIRCHK(hipMalloc((void **)&s.taps_split, tab.size() * sizeof(uint32_t)));
         FIRCHK(hipMemcpy(s.taps_split, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        FIRCHK(hipFuncSetAttribute((const void *)fir_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes(n_taps)));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes(n_taps)));
+        FIRCHK(hipFuncSetAttribute((const void *)fir_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)split_lds_bytes(n_taps)));
+    }
+    // two-part f16 tables: each padded tap times 2^p as f16 hi + f16 lo (22 significant bits), stored as pairs (m, m + 1); p puts
+    // the largest tap into [2^14, 2^15).  Needs the bf16 tables too (its second pass) and an unscale factor that is a normal f32.
+    {
+        float tmax = 0.0f;
+        for (float t : t32) tmax = std::max(tmax, std::fabs(t));
+        const int E = tmax > 0.0f ? std::ilogb(tmax) : 0;
+        if (s.taps_split && tmax > 0.0f && E >= -96 && E <= 126 && half_lds_bytes(n_taps) <= LDS_PER_CU) {
+            const float P = std::ldexp(1.0f, 14 - E);
+            s.half_unscale = std::ldexp(1.0f, E - 28);
+            const size_t ntp = t32.size(), ntp4 = (ntp + 3) & ~(size_t)3;
+            std::vector<uint32_t> part[2];
+            for (auto &v : part) v.assign(ntp + 1, 0);
+            for (size_t m = 0; m < ntp; ++m) {
+                const float hs = t32[m] * P;               // exact (a power of two; tiny taps may go subnormal: below every bar)
+                const _Float16 hh = (_Float16)hs;
+                const _Float16 hl = (_Float16)(hs - (float)hh);
+                uint16_t b0, b1;
+                memcpy(&b0, &hh, 2);
+                memcpy(&b1, &hl, 2);
+                part[0][m] = b0;
+                part[1][m] = b1;
+            }
+            std::vector<uint32_t> tab(2 * ntp4, 0);
+            for (int k = 0; k < 2; ++k)
+                for (size_t m = 0; m < ntp; ++m) tab[k * ntp4 + m] = part[k][m] | (part[k][m + 1] << 16);
+            FIRCHK(hipMalloc((void **)&s.taps_half, tab.size() * sizeof(uint32_t)));
+            FIRCHK(hipMemcpy(s.taps_half, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)half_lds_bytes(n_taps)));
+        }
     }
     // DSPFX_FIR_KERNEL: 0 = exact f64 VALU kernel, 1 = MFMA; default MFMA unless the filter is tiny
     const char *k = getenv("DSPFX_FIR_KERNEL");
@@ -845,6 +1111,9 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
     FIRCHK(hipMemset(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long)));
     FIRCHK(hipMalloc((void **)&s.warm_acc, (size_t)N * sizeof(double)));
     FIRCHK(hipMemset(s.warm_acc, 0, (size_t)N * sizeof(double)));
+    FIRCHK(hipMalloc((void **)&s.redo, (2 + 2 * (size_t)s.tiles) * sizeof(unsigned)));
+    FIRCHK(hipMemset(s.redo, 0, (2 + 2 * (size_t)s.tiles) * sizeof(unsigned)));
+    s.redo_parity = 0;
     s.warm_ok = true;
     return upload_taps(s, taps_reversed, n_taps);
 }
@@ -888,8 +1157,12 @@ void fir_free(FirState &s) {
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
     if (s.taps_split) (void)hipFree(s.taps_split);
+    if (s.taps_half) (void)hipFree(s.taps_half);
+    if (s.redo) (void)hipFree(s.redo);
     if (s.nf_time) (void)hipFree(s.nf_time);
     if (s.warm_acc) (void)hipFree(s.warm_acc);
+    s.taps_half = nullptr;
+    s.redo = nullptr;
     s.warm_acc = nullptr;
     s.warm_ok = false;
     s.ring = nullptr;
@@ -1049,18 +1322,42 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             const char *split_env = getenv("DSPFX_FIR_SPLIT");
             const bool want_split = s.precision == DSPFX_FIR_PRECISION_SPLIT ||
                                     (s.precision == DSPFX_FIR_PRECISION_DEFAULT && !(split_env && atoi(split_env) == 0));
-            const bool split = steady && nf > 64 && s.taps_split && want_split;
-            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
-            const unsigned grid_sweep = split ? (s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES : grid;
+            // two-part f16 (three f16 products per term + a bf16 x 3 second pass over the tiles it lists): the DEFAULT since round 4
+            // -- same bar, bit-exact on data that is exact in f16's 22 bits, config 4 1.33 -> see DESIGN 5; DSPFX_FIR_HALF=0 (for
+            // nodes left at the default) or dspfx_set_fir_precision(SPLIT / F32) select the others.
+            const char *half_env = getenv("DSPFX_FIR_HALF");
+            const bool want_half = s.precision == DSPFX_FIR_PRECISION_HALF ||
+                                   (s.precision == DSPFX_FIR_PRECISION_DEFAULT && want_split && !(half_env && atoi(half_env) == 0));
+            const bool half = steady && nf > 64 && s.taps_half && s.taps_split && s.redo && want_half;
+            const bool split = !half && steady && nf > 64 && s.taps_split && want_split;
+            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : half ? "fir_half_kernel" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
+            const unsigned grid_sweep = (split || half) ? (s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES : grid;
             if (mp_pending) {
-                if (steady && (split || skew) && grid_sweep > MIX_SLICES) a.mp = *mixpipe;     // rides in the sweep's first workgroups
+                if (steady && (split || skew || half) && grid_sweep > MIX_SLICES) a.mp = *mixpipe;     // rides in the sweep's first workgroups
                 else fir_mixpipe_standalone(*mixpipe, nframes, stream);
             }
             if (!steady) {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<true, 2>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_mfma_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, a);
+            } else if (half) {
+                const int par = s.redo_parity;
+                s.redo_parity ^= 1;
+                a.taps_half = s.taps_half;
+                a.half_unscale = s.half_unscale;
+                a.redo_count = s.redo + par;
+                a.redo_tiles = s.redo + 2 + (size_t)par * s.tiles;
+                a.redo_clear = s.redo + (par ^ 1);
+                hipLaunchKernelGGL(fir_half_kernel, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), half_lds_bytes(s.T), stream, a);
+                if (ev_end && f0 + SLICE >= nframes) {      // (the dominant kernel ends here; the second pass is usually empty)
+                    (void)hipEventRecord(ev_end, stream);
+                    ev_end = nullptr;
+                }
+                a.mp = FirMixPipe{};                        // hosted by the first pass
+                a.only_count = a.redo_count;
+                a.only_tiles = a.redo_tiles;
+                hipLaunchKernelGGL(fir_split_kernel<true>, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), split_lds_bytes(s.T), stream, a);
             } else if (split) {
-                hipLaunchKernelGGL(fir_split_kernel, dim3((s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES), dim3(64 * SPLIT_WAVES), split_lds_bytes(s.T), stream, a);
+                hipLaunchKernelGGL(fir_split_kernel<false>, dim3((s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES), dim3(64 * SPLIT_WAVES), split_lds_bytes(s.T), stream, a);
             } else if (skew) {
                 // history chunks requested 5 iterations before their first use (11 in flight or in use per wave); with 1
                 // the sweep waits for HBM: 1.997 vs 1.949 ms at config 4, 3: 1.986, 7 / 9: 1.962-1.979 (DSPFX_FIR_DIST=1 for A/B)

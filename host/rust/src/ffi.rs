@@ -140,6 +140,7 @@ pub const DSPFX_FIR_AVERAGE: c_int = 1;
 pub const DSPFX_FIR_PRECISION_DEFAULT: c_int = 0;
 pub const DSPFX_FIR_PRECISION_F32: c_int = 1;
 pub const DSPFX_FIR_PRECISION_SPLIT: c_int = 2;
+pub const DSPFX_FIR_PRECISION_HALF: c_int = 3;
 
 #[link(name = "dspfx")]
 extern "C" {

@@ -256,18 +256,24 @@ int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
  * dspfx_reset (or a new dspfx_chain_set) starts from an empty history. */
 int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode);
 /* How the FIR node's steady-state sweep multiplies (the reference accumulates in f64, fir.rs:201-216; every form below meets
- * the stated 1e-6 relative RMS bar and is bit-exact on data whose products and sums are exact in f32):
- *   DSPFX_FIR_PRECISION_SPLIT    every f32 operand split exactly into three bf16 parts, six bf16 products per term on the
- *                                bf16 matrix pipe, f32 accumulation: as accurate as the f32 products (measured 2.9e-7 against
- *                                3.3e-7 relative RMS at 4096 taps) and 1.5 x faster; used for whole 128-frame slices while
- *                                the tap tables fit the LDS (<= ~5000 taps), the f32 sweep otherwise;
+ * the stated 1e-6 relative RMS bar and is bit-exact on data whose products and sums are exact in its operand width):
+ *   DSPFX_FIR_PRECISION_HALF     every f32 operand as f16 hi + f16 lo (samples x 2^14, taps x a power of two: 22 significant
+ *                                bits), THREE f16 products per term on the matrix pipe, f32 accumulation: 3e-7 relative RMS at
+ *                                4096 taps like the others, and the fastest (the sweep becomes HBM-bound).  f16's range is
+ *                                narrow: the sweep tracks every channel's peak over the window it swept and lists the tiles with
+ *                                a channel at 3.998 or above, or below 2^-13 (-78 dBFS) without being silent; the SPLIT sweep,
+ *                                launched right behind it over the listed tiles only (usually none), redoes those.  Whole
+ *                                128-frame slices while the tap tables fit the LDS (<= ~5000 taps);
+ *   DSPFX_FIR_PRECISION_SPLIT    every f32 operand split exactly into three bf16 parts, six bf16 products per term: any f32
+ *                                range (bf16 has f32's exponent), 1.5 x faster than F32, 1.5 x slower than HALF;
  *   DSPFX_FIR_PRECISION_F32      f32 products on the f32 matrix pipe (v_mfma_f32_32x32x2_f32), always;
- *   DSPFX_FIR_PRECISION_DEFAULT  the split form (round 3; DSPFX_FIR_SPLIT=0 in the environment makes it the f32 form).
+ *   DSPFX_FIR_PRECISION_DEFAULT  HALF (round 4; DSPFX_FIR_HALF=0 in the environment makes it SPLIT, DSPFX_FIR_SPLIT=0 F32).
  * Takes effect from the next block; history and taps are untouched. */
 typedef enum dspfx_fir_precision {
     DSPFX_FIR_PRECISION_DEFAULT = 0,
     DSPFX_FIR_PRECISION_F32 = 1,
-    DSPFX_FIR_PRECISION_SPLIT = 2
+    DSPFX_FIR_PRECISION_SPLIT = 2,
+    DSPFX_FIR_PRECISION_HALF = 3
 } dspfx_fir_precision;
 int dspfx_set_fir_precision(dspfx_engine *e, int node, int precision);
 /* Zero every node's DSP state (fresh nodes); parameters are kept.  Asynchronous: the clears are queued on the stream

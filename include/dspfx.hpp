@@ -186,7 +186,7 @@ class Engine {
     }
     std::uint64_t frames_submitted() const { return dspfx_frames_submitted(e_); }
     void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }
-    /// DSPFX_FIR_PRECISION_DEFAULT / _F32 / _SPLIT: how a FIR node's steady-state sweep multiplies (dspfx.h)
+    /// DSPFX_FIR_PRECISION_DEFAULT / _F32 / _SPLIT / _HALF: how a FIR node's steady-state sweep multiplies (dspfx.h)
     void set_fir_precision(int node, dspfx_fir_precision p) { chk(dspfx_set_fir_precision(e_, node, static_cast<int>(p))); }
     void reset() { chk(dspfx_reset(e_)); }
     // device buffers, asynchronous on `stream`

@@ -95,20 +95,23 @@ def test_config3_and_5_million_channels_chain5(dspfx, tc, B, tile):
     assert mix_err < 1e-5, mix_err
 
 
-@pytest.mark.parametrize("sweep", ["split", "f32"])
+@pytest.mark.parametrize("sweep", ["half", "split", "f32"])
 def test_config4_fir_262144_channels(dspfx, tc, monkeypatch, sweep):
-    """BASELINE config 4: 262 144 channels x 4096-tap FIR on MFMA, through warm-up into steady state.  `split` is the sweep
-    that ships (fir_split_kernel, the kernel bench.py's cfg4 line times), `f32` the f32 matrix-pipe sweep (cfg4_f32)."""
+    """BASELINE config 4: 262 144 channels x 4096-tap FIR on MFMA, through warm-up into steady state.  `half` is the sweep
+    that ships (fir_half_kernel, two-part f16: the kernel bench.py's cfg4 line times), `split` the bf16 x 3 sweep (its second
+    pass, and round 3's default), `f32` the f32 matrix-pipe sweep (cfg4_f32)."""
     N, T, blocks = 1 << 18, 4096, 40
     chans = sample_channels(N)[::2]
     chain = [dspfx.Fir(fir_taps(T))]
+    monkeypatch.delenv("DSPFX_FIR_SPLIT", raising=False)
+    monkeypatch.delenv("DSPFX_FIR_HALF", raising=False)
     if sweep == "f32":
         monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
-    else:
-        monkeypatch.delenv("DSPFX_FIR_SPLIT", raising=False)
+    if sweep == "split":
+        monkeypatch.setenv("DSPFX_FIR_HALF", "0")
     info = {}
     got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 256, chans, info=info)
-    assert ("fir_split_kernel" if sweep == "split" else "fir_skew_kernel") in info["describe"], info["describe"]
+    assert {"half": "fir_half_kernel", "split": "fir_split_kernel", "f32": "fir_skew_kernel"}[sweep] in info["describe"], info["describe"]
     ref = oracle_channels(chain, chans, blocks)
     err = got.astype(np.float64) - ref.astype(np.float64)
     rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))

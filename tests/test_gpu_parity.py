@@ -679,19 +679,29 @@ def test_fir_identity_and_small(dspfx, torch_cuda):
     assert np.array_equal(run_gpu(dspfx, torch_cuda, ch, xi, 0), run_oracle(ch, xi, 0))
 
 
+def fir_sweep(monkeypatch, which):
+    """Name the steady-state FIR sweep a test means: "f32" (fir_skew_kernel / fir_mfma_kernel), "split" (bf16 x 3) or "half"
+    (two-part f16 with its bf16 x 3 second pass: the product default)."""
+    monkeypatch.setenv("DSPFX_FIR_SPLIT", "0" if which == "f32" else "1")
+    if which == "split":
+        monkeypatch.setenv("DSPFX_FIR_HALF", "0")
+    else:
+        monkeypatch.delenv("DSPFX_FIR_HALF", raising=False)
+
+
 def fir_rel_rms(y, ref):
     err = y.astype(np.float64) - ref.astype(np.float64)
     return np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "split"])
+@pytest.mark.parametrize("kernel", ["0", "1", "split", "half"])
 @pytest.mark.parametrize("T", [3, 16, 100, 128, 129, 512])
 def test_fir_random_vs_oracle(dspfx, torch_cuda, monkeypatch, T, kernel):
     """The FIR kernels (0 = exact f64 VALU, 1 = MFMA with the f32 sweep, split = MFMA with the default split-precision sweep)
     through the warm-up quirk and steady state."""
-    monkeypatch.setenv("DSPFX_FIR_KERNEL", "1" if kernel == "split" else kernel)
-    if kernel == "1":
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
+    monkeypatch.setenv("DSPFX_FIR_KERNEL", "1" if kernel in ("split", "half") else kernel)
+    if kernel != "0":
+        fir_sweep(monkeypatch, "f32" if kernel == "1" else kernel)
     x = noise_block(64, 128 * 8)
     ch = [dspfx.Gain(0.9), dspfx.Fir(fir_taps(T)), dspfx.Gain(1.1)]
     y, ref = run_gpu(dspfx, torch_cuda, ch, x, 3), run_oracle(ch, x, 3)
@@ -714,7 +724,7 @@ def test_fir_mfma_ragged_shapes(dspfx, torch_cuda, monkeypatch, N, block):
     assert np.abs(y - ref).max() < 2e-5
 
 
-@pytest.mark.parametrize("skew", ["1", "0", "split"])
+@pytest.mark.parametrize("skew", ["1", "0", "split", "half"])
 @pytest.mark.parametrize("T", [300, 17, 64, 500, 1000])
 def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
     """Integer taps and samples are exact in f32: the MFMA path must equal the oracle bit for bit,
@@ -723,10 +733,10 @@ def test_fir_mfma_integer_exact(dspfx, torch_cuda, monkeypatch, skew, T):
     (fir_skew_kernel); 0: the rectangular sweep throughout; split: the split-precision sweep (fir_split_kernel: every
     operand as three bf16 parts, six bf16 MFMAs per 16 taps -- small integers have one part, so it is exact too)."""
     monkeypatch.setenv("DSPFX_FIR_KERNEL", "1")
-    if skew == "split":
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    if skew in ("split", "half"):                  # (half: samples of magnitude up to 8 are beyond f16's range at the sweep's
+        fir_sweep(monkeypatch, skew)               #  scale -- its second pass redoes those tiles on the bf16 x 3 sweep: exact either way)
     else:
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")
+        fir_sweep(monkeypatch, "f32")
         monkeypatch.setenv("DSPFX_FIR_SKEW", skew)
     rng = np.random.default_rng(5)
     h = rng.integers(-4, 5, T).astype(np.float64)
@@ -766,16 +776,16 @@ def test_fir_config4_taps_small_n(dspfx, torch_cuda):
 
 
 def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_cuda):
-    """A host that asks for nothing gets the split-precision sweep in steady state (whole 128-frame blocks, tables fit the
-    LDS), the f32 sweep where it does not apply (short slices), the stated tolerance either way, integer data bit for bit;
-    DSPFX_FIR_PRECISION_F32 is the opt-out."""
+    """A host that asks for nothing gets the two-part f16 sweep in steady state (whole 128-frame blocks, tables fit the
+    LDS), the f32 sweep where it does not apply (short slices), the stated tolerance either way, integer data bit for bit
+    (its samples of magnitude > 3 go through the sweep's bf16 x 3 second pass); DSPFX_FIR_PRECISION_F32 is the opt-out."""
     T, N, blocks = 1024, 64, 20
     x = noise_block(N, 128 * blocks)
     ch = [dspfx.Fir(fir_taps(T))]
     eng = dspfx.Engine(N, 128, link_flags=3)
     eng.set_chain(ch)
     y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
-    assert "fir_split_kernel" in eng.describe(), eng.describe()
+    assert "fir_half_kernel" in eng.describe(), eng.describe()
     ref = run_oracle(ch, x, 3)
     assert fir_rel_rms(y[T:], ref[T:]) < FIR_RMS_TOL
     _run_fir_blocks(dspfx, torch_cuda, eng, x[:64], block=64)            # a 64-frame slice: the f32 sweep serves
@@ -789,8 +799,58 @@ def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_c
     ei = dspfx.Engine(96, 128, link_flags=0)
     ei.set_chain([dspfx.Fir(h)])
     yi = _run_fir_blocks(dspfx, torch_cuda, ei, xi)
-    assert "fir_split_kernel" in ei.describe()
+    assert "fir_half_kernel" in ei.describe()
     assert np.array_equal(yi, run_oracle([dspfx.Fir(h)], xi, 0))
+
+
+def test_fir_two_part_f16_sweep_range_and_accuracy_per_channel(dspfx, torch_cuda):
+    """fir_half_kernel: f32 operands as f16 hi + f16 lo, three products per term.  f16's range is narrow, so the sweep lists
+    the tiles it cannot serve and the bf16 x 3 sweep redoes them right behind it.  Config 4's filter, 96 channels in three
+    tiles whose channels are, per CHANNEL: ordinary noise; loud (peaks of 6: beyond 3.998); quiet (2^-15: below the 2^-13
+    floor); silent; noise that fades from full scale into the floor and comes back; a huge finite sample (exact kernel).
+    The bar holds for EVERY channel on its own -- relative RMS over its own output -- not only in aggregate, block after
+    block as channels cross the thresholds in both directions."""
+    T, N, blocks = 4096, 96, 44
+    x = noise_block(N, 128 * blocks)
+    x[:, 3] *= 6.0                                   # tile 0: one loud channel -> the whole tile takes the second pass
+    x[:, 40] *= F(2.0 ** -15)                        # tile 1: one quiet channel
+    x[:, 41] = 0.0                                   #         and a silent one (fine for the fast path by itself)
+    env = np.ones(128 * blocks, F)
+    env[128 * 6:128 * 24] = np.logspace(0, -7, 128 * 18).astype(F)
+    env[128 * 24:128 * 34] = F(1e-7)
+    x[:, 70] *= env                                  # tile 2: fades from full scale to 1e-7 and back: fast -> second pass -> fast
+    x[128 * 40 + 9, 71] = 3.0e38                     #         and a sample the bf16 split cannot hold either: the exact kernel
+    ch = [dspfx.Fir(fir_taps(T))]
+    eng = dspfx.Engine(N, 128, link_flags=0)
+    eng.set_chain(ch)
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_HALF)
+    y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
+    assert "fir_half_kernel" in eng.describe(), eng.describe()
+    ref = run_oracle(ch, x, 0)
+    assert np.array_equal(np.isfinite(y), np.isfinite(ref))
+    steady = slice(T, None)
+    for c in range(N):
+        if c == 71:
+            continue
+        r = ref[steady, c].astype(np.float64)
+        e = y[steady, c].astype(np.float64) - r
+        if c == 41:
+            assert not y[:, c].any()
+            continue
+        # (the fading channel: judged over windows in which it has a level of its own, as the bar is a relative one)
+        for w in range(0, len(r), 128 * 4):
+            rw, ew = r[w:w + 128 * 4], e[w:w + 128 * 4]
+            assert np.sqrt(np.mean(ew ** 2)) <= FIR_RMS_TOL * np.sqrt(np.mean(rw ** 2)) + 1e-30, (c, w, np.sqrt(np.mean(ew ** 2)) / np.sqrt(np.mean(rw ** 2)))
+    fin = np.isfinite(ref[:, 71])
+    assert np.allclose(y[fin, 71], ref[fin, 71], rtol=1e-5, atol=1e-5 * np.abs(ref[fin, 71]).max())
+    # the same blocks on the bf16 x 3 sweep alone and on the f32 sweep: the three agree to the bar as well
+    for prec in (dspfx.FIR_PRECISION_SPLIT, dspfx.FIR_PRECISION_F32):
+        e2 = dspfx.Engine(N, 128, link_flags=0)
+        e2.set_chain(ch)
+        e2.set_fir_precision(0, prec)
+        y2 = _run_fir_blocks(dspfx, torch_cuda, e2, x)
+        ok = [c for c in range(N) if c not in (41, 71)]
+        assert fir_rel_rms(y2[steady][:, ok], ref[steady][:, ok]) < FIR_RMS_TOL
 
 
 def test_fir_split_precision_sweep_config4_accuracy(dspfx, torch_cuda, monkeypatch):
@@ -911,7 +971,7 @@ def test_fir_exact_kernel_is_bit_exact_and_mfma_within_tolerance(dspfx, torch_cu
                 assert fir_rel_rms(y, ref) < FIR_RMS_TOL, (T, mode)
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split", "half"])
 def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel):
     """dspfx_set_taps = the impulse-response reload of fir.rs:153-171: the taps change, `state` does not.  A history
     longer than the new tap count stays longer (one pop per step, fir.rs:193-197): the output is the new convolution
@@ -921,8 +981,8 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")      # the f32 sweeps unless asked otherwise (the engine's default is the split one)
-    if kernel == "split":       # the split-precision sweep in steady state
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    if kernel in ("split", "half"):       # the split-precision sweeps in steady state
+        fir_sweep(monkeypatch, kernel)
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     rng = np.random.default_rng(8)
@@ -956,7 +1016,7 @@ def test_fir_tap_reload_keeps_the_history(dspfx, torch_cuda, monkeypatch, kernel
     assert eng.describe()
 
 
-@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split"])
+@pytest.mark.parametrize("kernel", ["0", "1", "rect", "split", "half"])
 def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cuda, monkeypatch, kernel):
     """inf / NaN samples: the reference's sums turn inf / NaN exactly while the sample is inside the deque (T outputs)
     and only in that channel.  The MFMA sweep multiplies the zero corners of its Toeplitz band with the history, where
@@ -967,8 +1027,8 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_SPLIT", "0")      # the f32 sweeps unless asked otherwise (the engine's default is the split one)
-    if kernel == "split":       # the split-precision sweep in steady state
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    if kernel in ("split", "half"):       # the split-precision sweeps in steady state
+        fir_sweep(monkeypatch, kernel)
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     T, N, nf = 200, 100, 128 * 8
@@ -993,7 +1053,7 @@ def test_fir_non_finite_samples_stay_in_their_channel_and_window(dspfx, torch_cu
             assert np.array_equal(y[fin].view(np.uint32), ref[fin].view(np.uint32))
 
 
-@pytest.mark.parametrize("kernel", ["1", "rect", "0", "split"])
+@pytest.mark.parametrize("kernel", ["1", "rect", "0", "split", "half"])
 @pytest.mark.parametrize("N,tile,B", [(70, 0, 128), (4096 + 256, 256, 128), (300, 0, 256), (96, 0, 48)])
 def test_fir_that_ends_the_chain_feeds_the_mix_bus_itself(dspfx, torch_cuda, monkeypatch, kernel, N, tile, B):
     """When the FIR node ends the chain the sweep's epilogue (and the exact kernel) leave the Output node's mix-bus partials
@@ -1004,8 +1064,8 @@ def test_fir_that_ends_the_chain_feeds_the_mix_bus_itself(dspfx, torch_cuda, mon
     if kernel == "rect":
         monkeypatch.setenv("DSPFX_FIR_SKEW", "0")
         kernel = "1"
-    if kernel == "split":
-        monkeypatch.setenv("DSPFX_FIR_SPLIT", "1")
+    if kernel in ("split", "half"):
+        fir_sweep(monkeypatch, kernel)
         kernel = "1"
     monkeypatch.setenv("DSPFX_FIR_KERNEL", kernel)
     T, blocks = 100, 6

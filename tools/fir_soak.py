@@ -17,10 +17,12 @@ for T, N, B in ((333, 40, 128), (64, 70, 256), (1500, 33, 128)):
         h = rng.integers(-4, 5, T).astype(np.float64) if integers else rng.uniform(-1, 1, T) * np.exp(-np.arange(T) / (T / 5.0))
         x = rng.integers(-8, 9, (blocks * B, N)).astype(np.float32) if integers else rng.uniform(-1, 1, (blocks * B, N)).astype(np.float32)
         ref = O.run_channels([fx.Fir(h).oracle_desc()], x, 0)
-        for mode in ("skew", "rect", "split"):
-            for k in ("DSPFX_FIR_SKEW", "DSPFX_FIR_SPLIT"):
+        for mode in ("skew", "rect", "split", "half"):
+            for k in ("DSPFX_FIR_SKEW", "DSPFX_FIR_SPLIT", "DSPFX_FIR_HALF"):
                 os.environ.pop(k, None)
-            os.environ["DSPFX_FIR_SPLIT"] = "1" if mode == "split" else "0"     # (the engine's default is the split sweep)
+            os.environ["DSPFX_FIR_SPLIT"] = "1" if mode in ("split", "half") else "0"     # (the engine's default is the two-part f16 sweep)
+            if mode == "split":
+                os.environ["DSPFX_FIR_HALF"] = "0"
             if mode == "rect":
                 os.environ["DSPFX_FIR_SKEW"] = "0"
             eng = fx.Engine(N, B, link_flags=0)
