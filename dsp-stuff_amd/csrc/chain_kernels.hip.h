@@ -1402,9 +1402,31 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
     if (a.mixpart) mixbus_partial<F, CPL>(ms, v, true, f0, lane, wave);
 }
 
+// DSPFX_TS_TRACE (tools/wg_timeline.py, a debug build only): per wave of the last launch, wall-clock stamps (100 MHz) at entry and
+// after its last store has been acknowledged, and where it ran (HW_ID: SIMD, CU, shader engine; XCC_ID)
+#ifdef DSPFX_TS_TRACE
+constexpr unsigned WG_TRACE_WAVES = 32768;
+static __device__ unsigned long long dspfx_wg_trace[WG_TRACE_WAVES * 3];
+#define DSPFX_WG_IN const unsigned long long wg_t_in = wall_clock64();
+#define DSPFX_WG_OUT(WB, WAVE)                                                                                      \
+    {                                                                                                               \
+        __builtin_amdgcn_s_waitcnt(0);                                                                              \
+        const unsigned wi = (WB) * (WG / 64) + (WAVE);                                                              \
+        if (lane == 0 && wi < WG_TRACE_WAVES) {                                                                     \
+            dspfx_wg_trace[wi * 3] = wg_t_in;                                                                       \
+            dspfx_wg_trace[wi * 3 + 1] = wall_clock64();                                                            \
+            dspfx_wg_trace[wi * 3 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) |  \
+                                         (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);                      \
+        }                                                                                                           \
+    }
+#else
+#define DSPFX_WG_IN
+#define DSPFX_WG_OUT(WB, WAVE)
+#endif
 // Covers channels a.c_base + [0, a.n_launch), n_launch % (64*CPL) == 0 (whole waves).
 template <int F, int CPL, class SL, bool MOD = false>
 __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
+    DSPFX_WG_IN
     __shared__ MixStage ms;
     if (a.mp_stage) mixpipe_prologue(a);
     const unsigned wb = work_block(a.xcd_remap);
@@ -1433,6 +1455,7 @@ __global__ void __launch_bounds__(WG) chain_kernel(const ChainArgs a) {
     store_state<SL::v[I], CPL, false>(a.slot[I], st[I], c, a.N, true);
     DSPFX_FOR_SLOTS(DSPFX_ST)
 #undef DSPFX_ST
+    DSPFX_WG_OUT(wb, wave)
     if (a.mt_tickets) mix_tail_rows(work_block(a.xcd_remap), wave, lane);
 }
 

@@ -32,4 +32,13 @@ extern "C" int dspfx_debug_ts_trace5(unsigned long long *host, size_t count, int
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     return hipMemcpyFromSymbol(host, HIP_SYMBOL(dspfx::dspfx_ts_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
+extern "C" int dspfx_debug_wg_trace5(unsigned long long *host, size_t count, int clear) {
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(dspfx::dspfx_wg_trace)) != hipSuccess) return -1;
+        return hipMemset(p, 0, sizeof(dspfx::dspfx_wg_trace)) == hipSuccess ? 0 : -1;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(dspfx::dspfx_wg_trace), count * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 #endif
