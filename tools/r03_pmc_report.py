@@ -7,6 +7,7 @@ import csv
 import glob
 import json
 import os
+ROUND = os.environ.get("DSPFX_ROUND", "r03")
 import statistics
 import sys
 
@@ -16,7 +17,7 @@ dest = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")     
 os.makedirs(dest, exist_ok=True)
 traffic = {}
 for cfg in ("cfg5", "cfg3", "cfg2"):
-    rec = {"round": "r03", "command": "python3 tools/r03_pmc_workload.py %s 40 (under rocprofv3 --kernel-trace --pmc <counter>)" % cfg,
+    rec = {"round": ROUND, "command": "python3 tools/r03_pmc_workload.py %s 40 (under rocprofv3 --kernel-trace --pmc <counter>)" % cfg,
            "units": "counter values are KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "counters": {}}
     info = None
     ok = True
@@ -65,13 +66,13 @@ for cfg in ("cfg5", "cfg3", "cfg2"):
     alg = bps * n * b
     rec.update({"kernel": kern, "channels": n, "frames": b, "bus": "same block, inside the launch (dspfx_process_bus)",
                 "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": hbm / alg})
-    path = os.path.join(dest, "r03_pmc_%s.json" % cfg)
+    path = os.path.join(dest, "%s_pmc_%s.json" % (ROUND, cfg))
     json.dump(rec, open(path, "w"), indent=1)
     print("%s %s: %.4f GB per launch = %.4f x algorithmic (FETCH x%.4f, WRITE x%.4f)" % (
         cfg, kern, hbm / 1e9, hbm / alg, rec["counters"]["FETCH_SIZE"]["correction_factor"], rec["counters"]["WRITE_SIZE"]["correction_factor"]))
     traffic["%s:%d:%d" % (cfg, n, b)] = {
         "hbm_bytes_per_launch": hbm,
-        "source": "profiles/r03_pmc_%s.json (%s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, each calibrated on the empty-chain "
+        "source": "profiles/" + ROUND + "_pmc_%s.json (%s; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, each calibrated on the empty-chain "
                   "kernel %s of the same pass); from the committed PMC pass of this build, not measured in this run" % (cfg, kern, cal)}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 old = json.load(open(tp)) if os.path.exists(tp) else {}

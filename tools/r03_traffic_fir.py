@@ -7,7 +7,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 t = json.load(open(tp))
-for key, f, kern in (("cfg4:262144:128", "r03_fir_pmc.json", "fir_skew_kernel"), ("cfg4split:262144:128", "r03_fir_split_pmc.json", "fir_split_kernel")):
+ROUND = os.environ.get("DSPFX_ROUND", "r03")
+for key, f, kern in (("cfg4:262144:128", ROUND + "_fir_pmc.json", "fir_skew_kernel"), ("cfg4split:262144:128", ROUND + "_fir_split_pmc.json", "fir_split_kernel"),
+                     ("cfg4half:262144:128", ROUND + "_fir_half_pmc.json", "fir_half_kernel")):
     p = os.path.join(ROOT, "profiles", f)
     if not os.path.exists(p):
         print("missing", p, file=sys.stderr)
