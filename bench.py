@@ -79,7 +79,7 @@ def parse():
                          "a line marked dry_run -- what tests/test_bench_dryrun_cpu.py executes under torch.distributed.run")
     ap.add_argument("--tile", type=int, default=None,
                     help="channel-tiled HBM layout [N/W][B][W]; 0 = frame-major [B][N].  Default: the config's own `tile` entry, else 256 (the "
-                         "engine-native tiling; tools/r03_cfg2_layout_ab.sh, r03_cfg5_layout_ab.sh sweep it)")
+                         "engine-native tiling; tools/archive/r03_cfg2_layout_ab.sh, r03_cfg5_layout_ab.sh sweep it)")
     return ap.parse_args()
 
 
@@ -833,7 +833,7 @@ def main():
 
     ctx = Ctx()
     world, rank = launch_env(args, ctx)
-    # DSPFX_BENCH_SHARE_GPU=1 (a test rig for one-GPU boxes, tools/r03_two_ranks_one_gpu.sh): every rank uses GPU 0 and the
+    # DSPFX_BENCH_SHARE_GPU=1 (a test rig for one-GPU boxes, tools/r04_two_ranks_one_gpu.sh): every rank uses GPU 0 and the
     # process group runs over gloo -- RCCL refuses two ranks on one device.  Everything else is the N > 1 path as the driver
     # launches it: sharding, per-rank engines and tuning, the batched bus with its collective on the second stream, barriers,
     # MAX over ranks, one line from rank 0.  The numbers of such a run mean nothing (the ranks time-slice one chip).
@@ -886,7 +886,7 @@ def main():
     # Config 2 is timed BEFORE the headline config.  After seconds of the large configs the chip runs this light, latency-
     # sensitive kernel 2-4 % slower for about three seconds (23.4-24.0 us against the 23.1 us it holds for as long as it runs
     # alone: profiles/r03_small_n.txt) -- the previous workload's power state, not config 2's.  DSPFX_BENCH_EARLY= (empty)
-    # restores the old order (tools/r03_cfg2_order.sh).
+    # restores the old order (tools/archive/r03_cfg2_order.sh).
     want_others = args.config == "cfg5" and world == 1 and not over and not args.no_others
     other_names = [n for n in os.environ.get("DSPFX_BENCH_OTHERS", "cfg3,cfg2,cfg4").split(",") if n]
     early_names = [n for n in os.environ.get("DSPFX_BENCH_EARLY", "cfg2").split(",") if n and n in other_names] if want_others else []

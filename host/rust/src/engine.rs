@@ -77,6 +77,33 @@ impl NodeDesc {
     }
     /// nodes/envelope.rs: attack / release in frames
     pub fn envelope(attack: f32, release: f32) -> Self { Self::with(DSPFX_ENVELOPE, &[attack, release]) }
+
+    /// The node as JSON -- what `GpuChain` / `GpuBank` put under "chain" in the saved graph (runtime.rs:560-564 saves whatever
+    /// `Node::save` returns): kind, mode, the eight slider slots, the delay length, the impulse response in natural order.
+    pub fn to_json(&self) -> serde_json::Value {
+        let ir: Vec<f64> = self.taps.iter().rev().copied().collect();
+        serde_json::json!({ "kind": self.d.kind, "mode": self.d.mode, "params": self.d.params.to_vec(),
+                            "delay_len": self.d.delay_len, "impulse_response": ir })
+    }
+    /// Inverse of `to_json`; `None` for anything that is not a node of this library (an unknown kind, a missing field).
+    pub fn from_json(v: &serde_json::Value) -> Option<Self> {
+        let kind = v.get("kind")?.as_i64()? as c_int;
+        if !(0..DSPFX_N_KINDS).contains(&kind) {
+            return None;
+        }
+        let mut n = Self::defaults(kind);
+        n.d.mode = v.get("mode")?.as_i64()? as c_int;
+        for (slot, p) in n.d.params.iter_mut().zip(v.get("params")?.as_array()?) {
+            *slot = p.as_f64()? as f32;
+        }
+        n.d.delay_len = v.get("delay_len")?.as_u64()? as u32;
+        n.taps = v.get("impulse_response")?.as_array()?.iter().rev().filter_map(|t| t.as_f64()).collect();
+        Some(n)
+    }
+    /// A saved "chain" array; `None` if any entry is not a node.
+    pub fn chain_from_json(v: &serde_json::Value) -> Option<Vec<Self>> {
+        v.as_array()?.iter().map(Self::from_json).collect()
+    }
 }
 
 /// The C engine, destroyed when the LAST holder goes: the `Engine` and every `ParamHandle` made from it share it, so a GUI

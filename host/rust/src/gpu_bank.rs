@@ -21,8 +21,8 @@
 //!   drop          : dspfx_host_free(p) x 2 -> dspfx_engine_destroy(e)
 //! NOT compiled in the build container (no rustc).
 use super::engine::{Engine, NodeDesc, ParamHandle};
-use super::ffi::{dspfx_link_divisor, DSPFX_DIST_SOFT_CLIP, DSPFX_LINK_INTERNAL};
-use super::gpu_chain::PinnedBlock;
+use super::ffi::{dspfx_link_divisor, DSPFX_LINK_INTERNAL};
+use super::gpu_chain::{default_chain, PinnedBlock};
 use crate::{
     ids::{NodeId, PortId},
     node::*,
@@ -49,26 +49,17 @@ pub struct GpuBank {
     out_names: Vec<String>,
     divisor: f32,           // f32(0.0001 + N): the Output node's collect_and_average over N pipes
     params: ParamHandle,    // the GUI thread's slider handle (queued stores: lib.rs:487-492 across the FFI)
+    chain: Mutex<Vec<NodeDesc>>, // what every channel runs: saved under "chain", replaceable while the graph runs
     state: Mutex<BankState>,
 }
 
 impl GpuBank {
-    /// The chain every channel runs: BASELINE's 5-node chain; the hops BETWEEN its nodes are the engine's (the hop INTO
-    /// the bank is applied by the Perform wrapper per input port).
-    fn default_chain() -> Vec<NodeDesc> {
-        vec![
-            NodeDesc::biquad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025),
-            NodeDesc::distort(3.0, DSPFX_DIST_SOFT_CLIP),
-            NodeDesc::reverb(0.5, 0.5),
-            NodeDesc::biquad(1.0, -1.98, 0.9801, 0.99, -1.98, 0.99),
-            NodeDesc::gain(0.5),
-        ]
-    }
-
-    fn build(id: NodeId, channels: usize, inputs: PortStorage, outputs: PortStorage) -> Self {
+    /// `chain`: what every channel runs; the hops BETWEEN its nodes are the engine's (the hop INTO the bank is applied by the
+    /// Perform wrapper per input port).
+    fn build(id: NodeId, channels: usize, inputs: PortStorage, outputs: PortStorage, chain: Vec<NodeDesc>) -> Self {
         // a missing GPU is fatal, like every other failure on the reference's hot path (node.rs:173,271)
         let mut engine = Engine::new(channels as u32, BUF_SIZE as u32, DSPFX_LINK_INTERNAL, 0).expect("libdspfx engine");
-        engine.set_chain(&Self::default_chain()).expect("chain");
+        engine.set_chain(&chain).expect("chain");
         let n = channels * BUF_SIZE;
         let params = engine.params();
         let state = BankState {
@@ -86,6 +77,7 @@ impl GpuBank {
             out_names: (0..channels).map(|c| format!("out{c}")).collect(),
             divisor: unsafe { dspfx_link_divisor(channels as u64) },
             params,
+            chain: Mutex::new(chain),
             state: Mutex::new(state),
         }
     }
@@ -97,6 +89,17 @@ impl GpuBank {
         (PortStorage::new(ins), PortStorage::new(outs))
     }
 
+    /// A bank of `channels` channels of a chain of the host's choosing.
+    pub fn with_chain(id: NodeId, channels: usize, chain: Vec<NodeDesc>) -> Self {
+        let (ins, outs) = Self::fresh_ports(channels);
+        Self::build(id, channels, ins, outs, chain)
+    }
+    /// Replace the chain while the graph runs (dspfx_chain_set never waits for the run-time compiler; state starts from zero).
+    pub fn set_chain(&self, chain: Vec<NodeDesc>) -> Result<(), super::engine::Error> {
+        self.state.lock().unwrap().engine.set_chain(&chain)?;
+        *self.chain.lock().unwrap() = chain;
+        Ok(())
+    }
     /// Slider stores from the GUI thread: queued by libdspfx, applied at the next block boundary.
     pub fn params(&self) -> ParamHandle {
         self.params.clone()
@@ -107,7 +110,7 @@ impl Node for GpuBank {
     fn title(&self) -> &'static str { "GPU bank" }
     fn cfg_name(&self) -> &'static str { "gpu_bank" }
     fn description(&self) -> &'static str {
-        "N channels of biquad > soft clip > delay > biquad > gain in one launch of libdspfx on an MI355X, plus their mix"
+        "N channels of one effect chain in one launch of libdspfx on an MI355X, plus their mix"
     }
     fn id(&self) -> NodeId { self.id }
     fn inputs(&self) -> &PortStorage { &self.inputs }
@@ -116,21 +119,22 @@ impl Node for GpuBank {
         ui.label(format!("{} channels on the GPU", self.channels));
     }
     fn save(&self) -> serde_json::Value {
-        serde_json::json!({ "id": self.id, "inputs": self.inputs, "outputs": self.outputs, "channels": self.channels })
+        let chain: Vec<serde_json::Value> = self.chain.lock().unwrap().iter().map(NodeDesc::to_json).collect();
+        serde_json::json!({ "id": self.id, "inputs": self.inputs, "outputs": self.outputs, "channels": self.channels, "chain": chain })
     }
 }
 
 impl NodeStatic for GpuBank {
     fn new(id: NodeId) -> Self {
-        let (ins, outs) = Self::fresh_ports(DEFAULT_BANK_CHANNELS);
-        Self::build(id, DEFAULT_BANK_CHANNELS, ins, outs)
+        Self::with_chain(id, DEFAULT_BANK_CHANNELS, default_chain())
     }
     fn restore(value: serde_json::Value) -> Self {
         let id = serde_json::from_value(value["id"].clone()).unwrap();
         let channels = value["channels"].as_u64().unwrap() as usize;
         let ins: PortStorage = serde_json::from_value(value["inputs"].clone()).unwrap();
         let outs: PortStorage = serde_json::from_value(value["outputs"].clone()).unwrap();
-        Self::build(id, channels, ins, outs)
+        let chain = NodeDesc::chain_from_json(&value["chain"]).unwrap_or_else(default_chain);
+        Self::build(id, channels, ins, outs, chain)
     }
 }
 

@@ -8,39 +8,77 @@ use super::ffi::{DSPFX_DIST_SOFT_CLIP, DSPFX_LINK_INTERNAL};
 use crate::{ids::NodeId, node::*};
 use std::sync::Mutex;
 
-#[derive(dsp_stuff_derive::DspNode)]
-#[dsp(
-    input = "in",
-    output = "out",
-    title = "GPU chain",
-    cfg_name = "gpu_chain",
-    description = "biquad > soft clip > delay > biquad > gain, evaluated by libdspfx on an MI355X"
-)]
-pub struct GpuChain {
-    #[dsp(id)]
-    id: NodeId,
-    #[dsp(inputs)]
-    inputs: PortStorage,
-    #[dsp(outputs)]
-    outputs: PortStorage,
+/// BASELINE's 5-node chain: what a node made from the menu starts with (a saved node restores its own chain).
+pub fn default_chain() -> Vec<NodeDesc> {
+    vec![
+        NodeDesc::biquad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025),
+        NodeDesc::distort(3.0, DSPFX_DIST_SOFT_CLIP),
+        NodeDesc::reverb(0.5, 0.5),
+        NodeDesc::biquad(1.0, -1.98, 0.9801, 0.99, -1.98, 0.99),
+        NodeDesc::gain(0.5),
+    ]
+}
 
-    #[dsp(default = "GpuChain::make_engine()")]
+/// One mono channel through ANY fusable chain.  `Node` is implemented by hand rather than derived: the chain is data of the
+/// node (saved under "chain", restored, replaceable while the graph runs), which `#[derive(DspNode)]`'s field attributes
+/// cannot express.
+pub struct GpuChain {
+    id: NodeId,
+    inputs: PortStorage,
+    outputs: PortStorage,
+    chain: Mutex<Vec<NodeDesc>>,
     engine: Mutex<Engine>,
 }
 
 impl GpuChain {
-    fn make_engine() -> Mutex<Engine> {
+    fn build(id: NodeId, inputs: PortStorage, outputs: PortStorage, chain: Vec<NodeDesc>) -> Self {
         // a missing GPU is fatal, like every other failure on the reference's hot path (node.rs:173,271)
         let mut e = Engine::new(1, BUF_SIZE as u32, DSPFX_LINK_INTERNAL, 0).expect("libdspfx engine");
-        e.set_chain(&[
-            NodeDesc::biquad(1.0, -1.8, 0.81, 0.0025, 0.005, 0.0025),
-            NodeDesc::distort(3.0, DSPFX_DIST_SOFT_CLIP),
-            NodeDesc::reverb(0.5, 0.5),
-            NodeDesc::biquad(1.0, -1.98, 0.9801, 0.99, -1.98, 0.99),
-            NodeDesc::gain(0.5),
-        ])
-        .expect("chain");
-        Mutex::new(e)
+        e.set_chain(&chain).expect("chain");
+        GpuChain { id, inputs, outputs, chain: Mutex::new(chain), engine: Mutex::new(e) }
+    }
+    /// A node for a chain of the host's choosing (the k effect nodes it replaces, in order).
+    pub fn with_chain(id: NodeId, chain: Vec<NodeDesc>) -> Self {
+        let (inputs, outputs) = (PortStorage::default(), PortStorage::default());    // like the derived `new` (lib.rs:213-219)
+        inputs.add("in".to_owned());
+        outputs.add("out".to_owned());
+        Self::build(id, inputs, outputs, chain)
+    }
+    /// Replace the chain while the graph runs: dspfx_chain_set never waits for the run-time compiler (ABI 2), the new chain's
+    /// state starts from zero like freshly created reference nodes (runtime.rs:319-362 re-creates nodes on a graph edit).
+    pub fn set_chain(&self, chain: Vec<NodeDesc>) -> Result<(), super::engine::Error> {
+        self.engine.lock().unwrap().set_chain(&chain)?;
+        *self.chain.lock().unwrap() = chain;
+        Ok(())
+    }
+}
+
+impl Node for GpuChain {
+    fn title(&self) -> &'static str { "GPU chain" }
+    fn cfg_name(&self) -> &'static str { "gpu_chain" }
+    fn description(&self) -> &'static str { "a chain of effect nodes evaluated as one kernel by libdspfx on an MI355X" }
+    fn id(&self) -> NodeId { self.id }
+    fn inputs(&self) -> &PortStorage { &self.inputs }
+    fn outputs(&self) -> &PortStorage { &self.outputs }
+    fn render(&self, ui: &mut eframe::egui::Ui) {
+        ui.label(format!("{} nodes on the GPU", self.chain.lock().unwrap().len()));
+    }
+    fn save(&self) -> serde_json::Value {
+        let chain: Vec<serde_json::Value> = self.chain.lock().unwrap().iter().map(NodeDesc::to_json).collect();
+        serde_json::json!({ "id": self.id, "inputs": self.inputs, "outputs": self.outputs, "chain": chain })
+    }
+}
+
+impl NodeStatic for GpuChain {
+    fn new(id: NodeId) -> Self {
+        Self::with_chain(id, default_chain())
+    }
+    fn restore(value: serde_json::Value) -> Self {
+        let id = serde_json::from_value(value["id"].clone()).unwrap();
+        let ins: PortStorage = serde_json::from_value(value["inputs"].clone()).unwrap();
+        let outs: PortStorage = serde_json::from_value(value["outputs"].clone()).unwrap();
+        let chain = NodeDesc::chain_from_json(&value["chain"]).unwrap_or_else(default_chain);
+        Self::build(id, ins, outs, chain)
     }
 }
 

@@ -45,6 +45,13 @@
  *     44.1 -> 48 kHz a sinusoid below 10 kHz is interpolated to within 2.5e-3 of sin(2 pi f t) (measured 1.2e-3: the
  *     16-tap Hann window's passband ripple), and the output equals the direct evaluation of the formula above.
  *
+ *   - Rust std `impl Sum for f64` (nodes/fir.rs:143, 206, 211): the reference pins `channel = "nightly"` with no date
+ *     (rust-toolchain.toml:3).  Up to Rust 1.82 the fold starts from +0.0; since 1.83 it starts from -0.0, the true additive
+ *     identity.  The two differ in ONE case only: a sum whose every term is -0.0 (or an empty one) gives -0.0 on a new toolchain
+ *     and +0.0 on an old one.  This restatement (orc_fir_*: accumulators from +0.0), oracle/numpy_model.py and the exact f64 GPU
+ *     kernel all take the OLD convention, the one current when the reference was written (2022); "bit-identical to the oracle"
+ *     for FIR is a statement about that convention.  Nothing but the sign of such a zero depends on it (no bar does).
+ *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (Rust never contracts a*b+c).
  * All citations are relative to /root/reference/.
  */

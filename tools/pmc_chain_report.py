@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""HBM bytes per launch from the round-3 counter passes (tools/r03_pmc.sh): FETCH_SIZE and WRITE_SIZE of the config's kernel,
+"""HBM bytes per launch from the counter passes (tools/pmc_chain.sh): FETCH_SIZE and WRITE_SIZE of the config's kernel,
 each scaled by the factor that makes the empty-chain kernel of the same pass report the N*B*4 bytes it is known to move in that
-direction.  Writes profiles/r03_pmc_<cfg>.json and profiles/traffic.json."""
+direction.  Writes profiles/<round>_pmc_<cfg>.json (round = $DSPFX_ROUND) and profiles/traffic.json."""
 import collections
 import csv
 import glob
@@ -17,7 +17,7 @@ dest = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles")     
 os.makedirs(dest, exist_ok=True)
 traffic = {}
 for cfg in ("cfg5", "cfg3", "cfg2"):
-    rec = {"round": ROUND, "command": "python3 tools/r03_pmc_workload.py %s 40 (under rocprofv3 --kernel-trace --pmc <counter>)" % cfg,
+    rec = {"round": ROUND, "command": "python3 tools/pmc_chain_workload.py %s 40 (under rocprofv3 --kernel-trace --pmc <counter>)" % cfg,
            "units": "counter values are KiB per dispatch (rocprofv3 FETCH_SIZE / WRITE_SIZE)", "counters": {}}
     info = None
     ok = True

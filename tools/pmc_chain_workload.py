@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Workload of the round-3 counter passes (tools/r03_pmc.sh): for one BASELINE chain config, launches of a kernel whose
+"""Workload of the counter passes (tools/pmc_chain.sh): for one BASELINE chain config, launches of a kernel whose
 traffic is KNOWN -- the empty chain with the same access width (copy_f8_c<cpl>: reads N*B*4 bytes, writes N*B*4 bytes) --
 followed by launches of the config's own kernel exactly as bench.py launches it (same engine settings, same bus form).
 Run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and, separately, `--pmc WRITE_SIZE`."""

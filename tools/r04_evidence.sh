@@ -33,12 +33,12 @@ rm -rf $OUT/trace/*/*.db $OUT/paced_trace/*/*.db 2>/dev/null
 rm -rf $OUT/paced_trace
 find $OUT/trace -name "*kernel_trace.csv" -size +20M -delete
 cd $ROOT
-bash tools/r03_pmc.sh > $OUT/pmc.txt 2>&1
+bash tools/pmc_chain.sh > $OUT/pmc.txt 2>&1
 tail -3 $OUT/timed_regions.txt; cat $OUT/paced_kernel.txt; tail -4 $OUT/pmc.txt
 bash tools/fir_pmc.sh r04half > $OUT/firpmc_half.txt 2>&1
 python3 tools/fir_pmc_report.py gpurun_out/firpmc_r04half r04 --kernel fir_half_kernel > $OUT/r04_fir_half_pmc.json 2>$OUT/firpmc_half_report.err
 find gpurun_out/firpmc_r04half -name "*kernel_trace.csv" -size +8M -delete 2>/dev/null
-find gpurun_out/firpmc_r04half gpurun_out/r03pmc -name "*.db" -delete 2>/dev/null
+find gpurun_out/firpmc_r04half gpurun_out/pmc_chain -name "*.db" -delete 2>/dev/null
 head -12 $OUT/r04_fir_half_pmc.json
 python3 - <<PY
 import json
