@@ -49,7 +49,7 @@
  *     (rust-toolchain.toml:3).  Up to Rust 1.82 the fold starts from +0.0; since 1.83 it starts from -0.0, the true additive
  *     identity.  The two differ in ONE case only: a sum whose every term is -0.0 (or an empty one) gives -0.0 on a new toolchain
  *     and +0.0 on an old one.  This restatement (orc_fir_*: accumulators from +0.0), oracle/numpy_model.py and the exact f64 GPU
- *     kernel all take the OLD convention, the one current when the reference was written (2022); "bit-identical to the oracle"
+ *     kernel all take the OLD convention (which toolchain the reference is built with is not recorded anywhere in its tree); "bit-identical to the oracle"
  *     for FIR is a statement about that convention.  Nothing but the sign of such a zero depends on it (no bar does).
  *
  * Build: gcc -O2 -ffp-contract=off -fno-fast-math  (Rust never contracts a*b+c).
