@@ -22,19 +22,31 @@ namespace dspfx_host {
 std::mutex g_jit_mu;
 std::map<std::string, JitKernel *> g_jit;     // key -> kernel
 
-// Where chain_kernels.hip.h / graph_kernel.hip.h are: next to the library, or DSPFX_KERNEL_HEADERS when they are installed
-// elsewhere (read per compile).
+// The text of chain_kernels.hip.h / graph_kernel.hip.h the run-time compiler instantiates: the very headers this library was
+// built from, EMBEDDED in it (kernel_headers.inc, made by the Makefile) -- a deployed libdspfx.so needs no source file beside it
+// (round 3 read them from the library's directory and fell back to the interpreter without a word when they were missing).
+// DSPFX_KERNEL_HEADERS=<dir> reads them from <dir> instead (kernel development; an empty <dir> is how the tests take the
+// compiler away).  Read per compile.
 // (the background compiler's thread never calls getenv -- a host may be changing its environment at that moment: it is given
 // the directory the submitting thread saw)
+#include "kernel_headers.inc"        // k_hdr_chain[], k_hdr_graph[]
 static thread_local const std::string *t_dir_override = nullptr;
-std::string csrc_dir() {
+std::string csrc_dir() {             // "" = the embedded text
     if (t_dir_override) return *t_dir_override;
     if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
-    Dl_info info;
-    if (!dladdr((const void *)&dspfx_abi_version, &info) || !info.dli_fname) return "";
-    std::string p(info.dli_fname);
-    const size_t k = p.find_last_of('/');
-    return k == std::string::npos ? "." : p.substr(0, k);
+    return "";
+}
+static bool read_file(const std::string &path, std::string &out);
+// the two headers as the compiler will see them; false: an override directory without chain_kernels.hip.h
+static bool kernel_headers(const std::string &dir, std::string &chain, std::string &graph) {
+    if (dir.empty()) {
+        chain.assign(k_hdr_chain, sizeof k_hdr_chain - 1);
+        graph.assign(k_hdr_graph, sizeof k_hdr_graph - 1);
+        return true;
+    }
+    if (!read_file(dir + "/chain_kernels.hip.h", chain)) return false;
+    (void)read_file(dir + "/graph_kernel.hip.h", graph);
+    return true;
 }
 
 // ---- the on-disk cache of code objects ---------------------------------------------------------------------------------
@@ -94,10 +106,9 @@ static void mkdirs(const std::string &dir) {
 // name of the cache file for (translation unit, kernel expression) given the headers in `hdr_dir`; "" when there is no cache
 static std::string cache_file(const std::string &hdr_dir, const std::string &src, const std::string &expr) {
     const std::string dir = cache_dir_now();
-    if (dir.empty() || hdr_dir.empty()) return "";
+    if (dir.empty()) return "";
     std::string h1, h2;
-    if (!read_file(hdr_dir + "/chain_kernels.hip.h", h1)) return "";
-    (void)read_file(hdr_dir + "/graph_kernel.hip.h", h2);
+    if (!kernel_headers(hdr_dir, h1, h2)) return "";
     uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
     int ver_major = 0, ver_minor = 0;
     (void)hiprtcVersion(&ver_major, &ver_minor);
@@ -210,10 +221,12 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
     if (mode == JIT_DISK) return nullptr;
     JitKernel *res = nullptr;
     hiprtcProgram prog = nullptr;
-    if (!dir.empty() && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 0, nullptr, nullptr) == HIPRTC_SUCCESS) {
-        const std::string inc = "-I" + dir;
+    std::string h_chain, h_graph;
+    const char *const h_names[2] = {"chain_kernels.hip.h", "graph_kernel.hip.h"};
+    const bool have = kernel_headers(dir, h_chain, h_graph);
+    const char *const h_text[2] = {h_chain.c_str(), h_graph.c_str()};
+    if (have && hiprtcCreateProgram(&prog, src.c_str(), "dspfx_jit.hip", 2, (const char **)h_text, (const char **)h_names) == HIPRTC_SUCCESS) {
         std::vector<const char *> opts(k_jit_opts, k_jit_opts + sizeof k_jit_opts / sizeof k_jit_opts[0]);
-        opts.push_back(inc.c_str());
         if (hiprtcAddNameExpression(prog, expr.c_str()) == HIPRTC_SUCCESS &&
             hiprtcCompileProgram(prog, (int)opts.size(), opts.data()) == HIPRTC_SUCCESS) {
             const char *lowered = nullptr;

@@ -317,8 +317,8 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
         s += buf;
     }
     if (e->jit_unavailable)
-        s += "note: a run-time specialised kernel was wanted but could not be compiled (chain_kernels.hip.h not found next to the "
-             "library -- DSPFX_KERNEL_HEADERS names its directory -- or hiprtc unavailable): the interpreting kernels serve, 7-25 % slower\n";
+        s += "note: a run-time specialised kernel was wanted but could not be compiled (hiprtc unavailable, or DSPFX_KERNEL_HEADERS "
+             "names a directory without chain_kernels.hip.h): the interpreting kernels serve, 7-25 % slower\n";
     snprintf(dst, cap, "%s", s.c_str());
     return DSPFX_OK;
 }

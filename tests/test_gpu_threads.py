@@ -747,6 +747,32 @@ def test_a_damaged_cache_file_is_ignored_and_rewritten(dspfx, torch_cuda, monkey
     assert all(f.stat().st_size > 1000 for f in sorted(cdir.glob("*.co")))
 
 
+def test_the_library_alone_is_enough_for_the_run_time_compiler(dspfx, torch_cuda, tmp_path):
+    """A deployed libdspfx.so carries the text of its kernel headers (kernel_headers.inc): copied ALONE into an empty directory --
+    no chain_kernels.hip.h, no graph_kernel.hip.h beside it -- a fresh process still gets a specialised kernel for a chain shape
+    the library has none for, and a generated graph kernel (round 3 fell back to the interpreter / DSPFX_ERR_UNSUPPORTED there)."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lone = tmp_path / "deploy"
+    lone.mkdir()
+    shutil.copy(os.path.join(root, "dsp-stuff_amd", "csrc", "libdspfx.so"), lone / "libdspfx.so")
+    assert sorted(os.listdir(lone)) == ["libdspfx.so"]
+    script = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests')\nimport torch\nfrom __graft_entry__ import load_package\nfx = load_package()\n"
+              "import graphs\nfrom dsp_stuff_amd import graph as G\n"
+              "assert fx.LIB_PATH.startswith(%r), fx.LIB_PATH\n"
+              "e = fx.Engine(4096, 128, link_flags=3)\n"
+              "e.set_chain([fx.Gain(0.41), fx.HighPass(0.21), fx.Gain(0.67), fx.LowPass(0.5)])\n"
+              "assert e.kernels_ready(120000), e.describe()\n"
+              "d = e.describe(); assert 'jit_' in d and 'could not be compiled' not in d, d\n"
+              "g = G.GraphEngine(graphs.fan_in_three(), 256, 128)\nassert g.fused is not None\nprint('ok')\n" % (root, root, str(lone)))
+    env = dict(os.environ, DSPFX_LIB=str(lone / "libdspfx.so"), DSPFX_CACHE_DIR=str(tmp_path / "cache"))
+    env.pop("DSPFX_KERNEL_HEADERS", None)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 # ---------------------------------------------------------------- the mix bus across ranks: two PROCESSES, one exchange per block
 
 _RANK_SCRIPT = r"""
