@@ -104,3 +104,29 @@ def test_every_c_call_the_rust_sources_make_exists_with_that_arity():
         assert trait in bank, trait
     assert {"dspfx_engine_create", "dspfx_chain_set", "dspfx_process_host", "dspfx_host_alloc", "dspfx_host_free", "dspfx_engine_destroy",
             "dspfx_set_param_seq", "dspfx_link_divisor"} <= seen, seen
+
+
+def test_rust_sources_are_lexically_well_formed():
+    """No rustc here: the least a file must be is balanced -- every bracket closed by its own kind, outside comments, strings
+    and character literals.  (It caught nothing so far; it is there for the edit that forgets a brace.)"""
+    import glob
+    src_dir = os.path.join(ROOT, "host", "rust")
+    files = sorted(glob.glob(os.path.join(src_dir, "src", "*.rs")) + glob.glob(os.path.join(src_dir, "*.rs")))
+    assert len(files) >= 5
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for f in files:
+        s = open(f).read()
+        s = re.sub(r"//[^\n]*", "", s)
+        s = re.sub(r"/\*.*?\*/", "", s, flags=re.S)
+        s = re.sub(r'"(\\.|[^"\\])*"', '""', s)
+        s = re.sub(r"'(\\.|[^'\\])'", "''", s)
+        stack, line = [], 1
+        for ch in s:
+            if ch == "\n":
+                line += 1
+            elif ch in "([{":
+                stack.append((ch, line))
+            elif ch in ")]}":
+                assert stack and stack[-1][0] == pairs[ch], "%s:%d: unexpected %r" % (f, line, ch)
+                stack.pop()
+        assert not stack, "%s: unclosed %r" % (f, stack[-1])
