@@ -250,6 +250,7 @@ __device__ __forceinline__ unsigned ticket_take(unsigned *t, int lane) {
 #endif
 constexpr int TAIL_BATCH = DSPFX_TAIL_BATCH;   // even
 typedef unsigned dspfx_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned dspfx_u32x4 __attribute__((ext_vector_type(4)));
 // sc1 loads through a buffer descriptor (`buffer_load_dwordx2 v, v_off, s[rsrc], 0 offen sc1`): one running 32-bit offset
 // register instead of a 64-bit vector address per row (the atomic-load builtin's global sc1 loads: 64 VGPRs of addresses for
 // 32 rows in flight), and the descriptor's bounds check returns 0 for rows past n_valid -- no branches in the batch.
@@ -632,9 +633,14 @@ __device__ __forceinline__ float chebyshev1(float sample, float lp, float ln, fl
 // specialised kernel issues them together with the sample loads at the top of the chunk instead of after
 // the nodes in front of the delay: one exposed memory latency per chunk instead of two, which is what
 // bounds launches with few channels (one wave per SIMD, nothing else to switch to).
+// (filled by ring_groups / ring_groups_host below)
+struct RingGroups {
+    float *ga, *gb, *g0;
+    unsigned gia;
+};
 template <int F, int CPL> struct RingPre {
     float tap[F][CPL];
-    float *row[F];     // wave-uniform row base (scalar registers); the lane adds cx.ring_off
+    float *row[F];     // wave-uniform row base (scalar registers): the base of the row's buffer descriptor, the lane adds cx.ring_off
 };
 // signal_gen.rs:57-104, one sample: `total` is the block-local phase advance, `clock` the phase carried
 // between 128-frame blocks.  Square compares `total` (not the phase) with 0.5, like the reference.
@@ -706,10 +712,6 @@ __device__ __forceinline__ float *uniform_ptr(float *p) {
 // row, the one after it, and group 0 (rows after the wrap at D).  Three scalar loads issued together -- one table read PER
 // ROW, each waited for before the row's address could be formed, cost a wave 32 x ~90 ns before its first tap load was
 // even issued (tools/ts_timeline.py: 2.9 us at the head of the time-sliced kernel).
-struct RingGroups {
-    float *ga, *gb, *g0;
-    unsigned gia;
-};
 // (the time-sliced kernel, whose blocks are exactly 128 frames, takes the three pointers from its arguments instead: ring_groups_host)
 __device__ __forceinline__ RingGroups ring_groups_host(const SlotArgs &s) { return RingGroups{s.g_a, s.g_b, s.g_0, s.g_ia}; }
 __device__ __forceinline__ RingGroups ring_groups(const SlotArgs &s, const Ctx &cx) {
@@ -735,14 +737,85 @@ __device__ __forceinline__ float *ring_row(const SlotArgs &s, const Ctx &cx, con
     float *gb = gi == g.gia ? g.ga : (gi == g.gia + 1 ? g.gb : g.g0);
     return uniform_ptr(gb + cx.ring_base0 + (size_t)(r & 127u) * cx.ld);
 }
+// ---- rows through a buffer descriptor -------------------------------------------------------------------------------------
+// A wave of the time-sliced kernel touches 4 x 32 rows (samples in, taps, ring rows out, samples out) whose addresses are a
+// wave-uniform row base + one per-lane byte offset.  As 64-bit pointers the compiler formed every row's address with a vector
+// 64-bit add, kept the 64 row bases alive in SGPR pairs across the whole chain for the stores, and spilled them into VGPR
+// lanes: ~570 of the 3-node kernel's 3800 vector-ALU slots and ~470 of the 5-node kernel's 2750 were v_lshl_add_u64 /
+// v_writelane / v_readlane (round 4, ISA count).  A buffer instruction takes the base as a descriptor in SGPRs, the lane's
+// offset in ONE VGPR for all rows and the row's byte offset as a scalar operand: no vector ALU work per row at all.
+// Lanes of a guarded launch that are out of range get an offset beyond the descriptor's extent: their loads return 0 and
+// their stores are dropped, branch-free.  Row offsets are 32-bit and relative to the chunk's (slice's) first row: at most
+// 32 rows x 4 N bytes in the frame-major layout, i.e. fine up to 16 M channels per engine; 128 KiB in the tiled one.
+constexpr unsigned ROW_OOB = 0x80000000u;
+constexpr int BUF_AUX_NT = 2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float *base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, 0x7fffffff, 0x00020000);
+}
+template <int CPL, int STREAM>
+__device__ __forceinline__ void load_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, float (&v)[CPL]) {
+    static_assert(CPL == 1 || CPL == 2 || CPL == 4, "one, two or four channels per lane");
+    constexpr int aux = nt_for(STREAM) ? BUF_AUX_NT : 0;
+    if constexpr (CPL == 1) {
+        v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, aux));
+    } else if constexpr (CPL == 2) {
+        const dspfx_u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, aux);
+        v[0] = __uint_as_float(t.x);
+        v[1] = __uint_as_float(t.y);
+    } else {
+        const dspfx_u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, aux);
+        v[0] = __uint_as_float(t.x);
+        v[1] = __uint_as_float(t.y);
+        v[2] = __uint_as_float(t.z);
+        v[3] = __uint_as_float(t.w);
+    }
+}
+template <int CPL, int STREAM>
+__device__ __forceinline__ void store_row(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float (&v)[CPL]) {
+    constexpr int aux = nt_for(STREAM) ? BUF_AUX_NT : 0;
+    if constexpr (CPL == 1) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[0]), r, (int)voff, (int)soff, aux);
+    } else if constexpr (CPL == 2) {
+        dspfx_u32x2 t;
+        t.x = __float_as_uint(v[0]);
+        t.y = __float_as_uint(v[1]);
+        __builtin_amdgcn_raw_buffer_store_b64(t, r, (int)voff, (int)soff, aux);
+    } else {
+        dspfx_u32x4 t;
+        t.x = __float_as_uint(v[0]);
+        t.y = __float_as_uint(v[1]);
+        t.z = __float_as_uint(v[2]);
+        t.w = __float_as_uint(v[3]);
+        __builtin_amdgcn_raw_buffer_store_b128(t, r, (int)voff, (int)soff, aux);
+    }
+}
+// ring row (pos + f0 + f) as (descriptor of its group at this wave's first channel, byte offset of the row inside the group)
+struct RowRef {
+    __amdgpu_buffer_rsrc_t rsrc;
+    unsigned soff;
+};
+// pos0: s.pos + cx.f0, handed in by the caller -- once as it is for the loads and once through opaque_u32 for the stores, so that
+// the compiler forms the 32 descriptors AGAIN at the stores instead of keeping them alive across the whole chain
+__device__ __forceinline__ unsigned opaque_u32(unsigned x) {
+    asm volatile("" : "+s"(x));
+    return x;
+}
+__device__ __forceinline__ RowRef ring_row_ref(const SlotArgs &s, const Ctx &cx, const RingGroups &g, unsigned pos0, int f) {
+    unsigned r = pos0 + f;
+    r = r >= s.D ? r - s.D : r;
+    const unsigned gi = r >> 7;
+    float *gb = gi == g.gia ? g.ga : (gi == g.gia + 1 ? g.gb : g.g0);
+    return RowRef{row_rsrc(gb + cx.ring_base0), (r & 127u) * (unsigned)cx.ld * 4u};
+}
 template <int F, int CPL, bool GUARD>
 __device__ __forceinline__ void ring_prefetch(const SlotArgs &s, const Ctx &cx, RingPre<F, CPL> &pre) {
     static_assert(F <= 128, "ring_groups covers spans of at most one group length");
     const RingGroups g = ring_groups(s, cx);
+    const unsigned voff = (GUARD && !cx.active) ? ROW_OOB : cx.ring_off;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
         pre.row[f] = ring_row(s, cx, g, f);
-        load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(pre.row[f], cx.ring_off), pre.tap[f], cx.active);
+        load_row<CPL, S_RING_LD>(row_rsrc(pre.row[f]), voff, 0u, pre.tap[f]);
     }
 }
 // A tap of frame cx.f0 + f that was written before the ring's last clear reads as the +0.0 the reference's new ring holds
@@ -767,11 +840,12 @@ template <int F, int CPL, bool GUARD>
 __device__ __forceinline__ void ring_apply(const SlotArgs &s, float (&v)[F][CPL], RingPre<F, CPL> &pre, const Ctx &cx) {
     const float decay = s.p[0];
     ring_zero_cleared<F, CPL>(s, cx, pre.tap);
+    const unsigned voff = (GUARD && !cx.active) ? ROW_OOB : cx.ring_off;
 #pragma unroll
     for (int f = 0; f < F; ++f) {
 #pragma unroll
         for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + pre.tap[f][j] * decay;
-        store_vec<CPL, GUARD, S_RING_ST>(lane_ptr(pre.row[f], cx.ring_off), v[f], cx.active);
+        store_row<CPL, S_RING_ST>(row_rsrc(pre.row[f]), voff, 0u, v[f]);
     }
 }
 
@@ -1380,7 +1454,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
                                             unsigned f0, int lane, MixStage &ms, int wave) {
     float v[F][CPL];
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
+    for (int f = 0; f < F; ++f) load_row<CPL, S_IN>(row_rsrc(a.in + w.io_base0 + (size_t)f0 * a.ld), w.io_off, (unsigned)f * (a.ld * 4u), v[f]);
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, true};
     // delay taps first (see RingPre), then the nodes in order
     RingPre<F, CPL> pre[MAX_SLOTS];
@@ -1398,7 +1472,7 @@ __device__ __forceinline__ void chain_chunk(const ChainArgs &a, float (&st)[MAX_
 #undef DSPFX_RUN
 #pragma unroll
     for (int f = 0; f < F; ++f)
-        if (!a.skip_store) store_vec<CPL, false, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], true);
+        if (!a.skip_store) store_row<CPL, S_OUT>(row_rsrc(a.out + w.io_base0 + (size_t)f0 * a.ld), w.io_off, (unsigned)f * (a.ld * 4u), v[f]);
     if (a.mixpart) mixbus_partial<F, CPL>(ms, v, true, f0, lane, wave);
 }
 
@@ -1504,6 +1578,10 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
                                        int q, int lane, size_t c, unsigned group, MixStage &ms, unsigned f_begin, bool active) {
     constexpr int FS = ts_first_stateful<SL>(), FR = ts_first_reverb<SL>();
     constexpr bool late = LATE && FS < FR && FR < MAX_SLOTS;
+    // rows through buffer descriptors (load_row / store_row): the lane's byte offsets, out of range for lanes past the last channel
+    const unsigned io_voff = (GUARD && !active) ? ROW_OOB : w.io_off, ring_voff = (GUARD && !active) ? ROW_OOB : w.ring_off;
+    const unsigned row_bytes = a.ld * 4u;
+    const __amdgpu_buffer_rsrc_t r_out = row_rsrc(a.out + w.io_base0 + (size_t)f_begin * a.ld);
     // delay taps of every delay node of the chain (nframes <= D: they never depend on this block's outputs)
 #define DSPFX_TAPS_DECL(I)                                                                                       \
     float tap##I[sig_is<K_REVERB>(SL::v[I]) ? S : 1][CPL];                                                       \
@@ -1513,8 +1591,13 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
 #define DSPFX_TAPS(I)                                                                                            \
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         rg##I = ring_groups_host(a.slot[I]);   /* blocks of exactly 128 frames: the host named the groups (no table read) */ \
+        const unsigned pos_ld = opaque_u32(a.slot[I].pos + cx.f0);   /* formed HERE, not at the top of the kernel */  \
         _Pragma("unroll") for (int f = 0; f < S; ++f)                                                            \
-            load_vec<CPL, GUARD, S_RING_LD>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), tap##I[f], active); \
+        {                                                                                                        \
+            const RowRef rr = ring_row_ref(a.slot[I], cx, rg##I, pos_ld, f);                                         \
+            load_row<CPL, S_RING_LD>(rr.rsrc, ring_voff, rr.soff, tap##I[f]);                                        \
+            __builtin_amdgcn_sched_barrier(0);   /* one row's scalar operands at a time */                          \
+        }                                                                                                        \
     }
     auto load_taps = [&]() __attribute__((always_inline)) { DSPFX_FOR_SLOTS(DSPFX_TAPS) };
     // Slice 0's own copy of the body (LATE) also requests the state of the first stateful node right here, behind its samples:
@@ -1528,10 +1611,13 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     if constexpr (sig_is<K_REVERB>(SL::v[I])) {                                                                  \
         if constexpr (sig_hop(SL::v[I])) apply_hop<S, CPL, true>(v, cx.hop_div, cx.hop_rc);                      \
         const float decay = a.slot[I].p[0];                                                                      \
+        const unsigned pos_st = opaque_u32(a.slot[I].pos + cx.f0);                                               \
         ring_zero_cleared<sig_is<K_REVERB>(SL::v[I]) ? S : 1, CPL>(a.slot[I], cx, tap##I);   /* taps from before the ring's last clear: +0.0 */ \
         _Pragma("unroll") for (int f = 0; f < S; ++f) {                                                          \
             _Pragma("unroll") for (int j = 0; j < CPL; ++j) v[f][j] = v[f][j] + tap##I[f][j] * decay;            \
-            store_vec<CPL, GUARD, S_RING_ST>(lane_ptr(ring_row(a.slot[I], cx, rg##I, f), cx.ring_off), v[f], active); \
+            const RowRef rr = ring_row_ref(a.slot[I], cx, rg##I, pos_st, f);                                         \
+            store_row<CPL, S_RING_ST>(rr.rsrc, ring_voff, rr.soff, v[f]);                                            \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
         }                                                                                                        \
     } else if constexpr (SL::v[I] != SIG_NONE && kind_nstate(sig_kind(SL::v[I])) == 0) {                         \
         float none[4][CPL];                                                                                      \
@@ -1569,7 +1655,10 @@ __device__ __forceinline__ void ts_run(const ChainArgs &a, float (&lds_st)[4][CP
     DSPFX_TS_STAMP(12)
 #pragma unroll
     for (int f = 0; f < S; ++f)
-        if (!a.skip_store) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], active);
+        if (!a.skip_store) {
+            store_row<CPL, S_OUT>(r_out, io_voff, (unsigned)f * row_bytes, v[f]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     DSPFX_TS_STAMP(13)
     if (a.mixpart) mixbus_partial<S, CPL>(ms, v, active, f_begin, lane, 0);      // the four slices of ONE row
     DSPFX_TS_STAMP(14)
@@ -1602,8 +1691,15 @@ __global__ void __launch_bounds__(WG) chain_ts_kernel(const ChainArgs a) {
     const unsigned f_begin = (unsigned)q * S;
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f_begin, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     float v[S][CPL];
+    {
+        const unsigned io_voff = (GUARD && !active) ? ROW_OOB : w.io_off, row_bytes = a.ld * 4u;
+        const __amdgpu_buffer_rsrc_t r_in = row_rsrc(a.in + w.io_base0 + (size_t)f_begin * a.ld);
 #pragma unroll
-    for (int f = 0; f < S; ++f) load_vec<CPL, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f_begin + f) * a.ld, w.io_off), v[f], active);
+        for (int f = 0; f < S; ++f) {
+            load_row<CPL, S_IN>(r_in, io_voff, (unsigned)f * row_bytes, v[f]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     // slice 0's late taps cost registers (the second copy of the body): 3-node chain 119 -> 153 (one channel per lane, still
     // three workgroups per CU where that form is used), 218 -> 243 (two); the 5-node chain would drop from four workgroups
     // per CU to three (108 -> 155) and ran 36 -> 42 us at 65536 channels: short chains only.  (Late taps for EVERY slice --
@@ -1632,7 +1728,8 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
                                           int lane, MixStage &ms, int wave) {
     float v[F][CPL];
 #pragma unroll
-    for (int f = 0; f < F; ++f) load_vec<CPL, GUARD, S_IN>(lane_ptr(a.in + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+    for (int f = 0; f < F; ++f)
+        load_row<CPL, S_IN>(row_rsrc(a.in + w.io_base0 + (size_t)f0 * a.ld), (GUARD && !active) ? ROW_OOB : w.io_off, (unsigned)f * (a.ld * 4u), v[f]);
     const Ctx cx{c, a.N, w.io_base0, w.io_off, w.ring_base0, w.ring_off, a.ld, f0, a.hop_div, a.hop_rc, a.third_rc, a.side, a.side_hop, active};
     // (Prefetching the first delay node's taps here, as the static kernels do, was measured: +18 VGPRs cost a wave
     // of occupancy and the 5-node chain went from 0.4255 to 0.4565 ms.  The interpreter loads them in the node's slot.)
@@ -1657,7 +1754,8 @@ __device__ __forceinline__ void dyn_chunk(const ChainArgs &a, float *lds, size_t
     }
 #pragma unroll
     for (int f = 0; f < F; ++f)
-        if (!a.skip_store) store_vec<CPL, GUARD, S_OUT>(lane_ptr(a.out + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), v[f], active);
+        if (!a.skip_store)
+            store_row<CPL, S_OUT>(row_rsrc(a.out + w.io_base0 + (size_t)f0 * a.ld), (GUARD && !active) ? ROW_OOB : w.io_off, (unsigned)f * (a.ld * 4u), v[f]);
     if (a.mixpart) mixbus_partial<F, CPL>(ms, v, !GUARD || active, f0, lane, wave);
 }
 

@@ -219,9 +219,10 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pen
         if (!ok) continue;
         // two channels per lane (half the load / store instructions per byte) once there are still two workgroups per CU
         // at that width and the chain is short enough for the doubled registers: 3-node chain at 65536 channels 29.0 -> 27.6 us
-        // (one channel per lane holds one resident round up to 49152 channels -- three workgroups per CU; beyond that two per
-        // lane: 53248 channels 27.8 us at one, 21.1 at two; 49152: 19.0 / 21.6; tools sweep in profiles/r03_small_n.txt)
-        const int want_cpl = pref.cpl > 0 ? pref.cpl : (st.count <= 3 && N > 49152u ? 2 : 1);
+        // (one channel per lane holds one resident round up to 49152 channels -- three workgroups per CU; from there two per
+        // lane: 53248 channels 27.8 us at one, 21.1 at two; 49152 itself, since the rows go through buffer descriptors: 20.5-21.1
+        // at one, 19.2 at two; 32768: 13.8 / 16.8 -- profiles/r04_midn.txt, section G)
+        const int want_cpl = pref.cpl > 0 ? pref.cpl : (st.count <= 3 && N >= 49152u ? 2 : 1);
         if (!best || (v->cpl == want_cpl && best->cpl != want_cpl)) best = v;
     }
     if (best) return best;
