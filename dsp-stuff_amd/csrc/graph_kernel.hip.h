@@ -140,7 +140,8 @@ __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAP
         if ((PROG::in_mask >> k) & 1u) {
             const float *src = k == 0 ? a.in : k == 1 ? a.side : g.xin[k >= 2 ? k - 2 : 0];
 #pragma unroll
-            for (int f = 0; f < F; ++f) load_vec<CPL, false, S_IN>(lane_ptr(src + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), xs[k][f], true);
+            for (int f = 0; f < F; ++f)      // rows through a buffer descriptor (chain_kernels.hip.h, load_row)
+                load_row<CPL, S_IN>(row_rsrc(src + w.io_base0 + (size_t)f0 * a.ld), w.io_off, (unsigned)f * (a.ld * 4u), xs[k][f]);
         } else {
             g_zero<F, CPL>(xs[k]);
         }
@@ -153,7 +154,7 @@ __device__ __forceinline__ void graph_chunk(const GraphArgs &g, float (&st)[GRAP
             float *dst = m == 0 ? a.out : g.xout[m >= 1 ? m - 1 : 0];
 #pragma unroll
             for (int f = 0; f < F; ++f)
-                store_vec<CPL, false, S_OUT>(lane_ptr(dst + w.io_base0 + (size_t)(f0 + f) * a.ld, w.io_off), ys[m][f], true);
+                store_row<CPL, S_OUT>(row_rsrc(dst + w.io_base0 + (size_t)f0 * a.ld), w.io_off, (unsigned)f * (a.ld * 4u), ys[m][f]);
         }
     }
     if (a.mixpart) mixbus_partial<F, CPL>(ms, ys[0], true, f0, lane, wave);
