@@ -273,7 +273,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     // else the control-port interpreter: two channels per lane above 131072 channels -- or, while the
                     // specialised kernel is on its way, the channels per lane of THAT kernel (the same rows of bus partials)
                     if (!st.var_mod_tried) request_mod_kernel(e, st);
-                    const bool two = st.async_mod ? jit_std_cpl(e) == 2 : N > 131072u;
+                    const bool two = st.async_mod ? jit_std_cpl(e, st.count) == 2 : N > 131072u;
                     v = st.var_mod ? st.var_mod : ((e->dyn_mod2 && two && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod);
                     tail = e->tail_mod;
                 }

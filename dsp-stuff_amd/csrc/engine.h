@@ -299,8 +299,8 @@ enum JitPolicy { JP_OFF = 0, JP_SYNC = 1, JP_ASYNC = 2 };
 JitPolicy jit_policy(const dspfx_engine *e);
 const JitKernel *jit_get(int device, const int (&sigs)[MAX_SLOTS], int n_slots, int f, int cpl, bool mod, bool ts, bool guard, int mode);
 void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]);
-int jit_std_cpl(const dspfx_engine *e);
-int jit_std_f(const dspfx_engine *e, bool mod);
+int jit_std_cpl(const dspfx_engine *e, int n_slots);
+int jit_std_f(const dspfx_engine *e, bool mod, int n_slots);
 std::string jit_cache_dir();
 void jit_arm_exit_guard();   // the calling thread waits for a background compile in flight when it ends (jit.hip: ExitGuard)
 extern std::atomic<uint64_t> g_jit_compiled, g_jit_from_disk, g_jit_disk_written;

@@ -434,11 +434,21 @@ void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]) 
     }
 }
 // channels per lane / frames per chunk of the run-time specialised standard kernel of an engine of N channels (plan.hip has the sweeps)
-int jit_std_cpl(const dspfx_engine *e) {
+// Two channels per lane: from STATIC_CPL2_MIN_CHANNELS on -- and, for chains of up to three nodes, between the time-sliced
+// kernels' one resident round (65536 channels) and 131072 channels, where two channels per lane are at most ONE workgroup per CU
+// (81920 channels: 35.4 -> 34.9 us against the time-sliced kernel's two rounds, 98304: 38.2 -> 37.2, 114688: 47 -> 42.6-44.4,
+// 131072: 47.9 -> 46.6; the 5-node chain is slower that way: its single wave per SIMD has too much arithmetic to hide;
+// profiles/r04_midn.txt, section B).
+int jit_std_cpl(const dspfx_engine *e, int n_slots) {
     const uint32_t N = e->desc.channels;
-    return (e->desc.tile_channels && N >= STATIC_CPL2_MIN_CHANNELS && N % 2u == 0) ? 2 : 1;
+    if (!e->desc.tile_channels || N % 2u) return 1;
+    if (N >= STATIC_CPL2_MIN_CHANNELS) return 2;
+    return (n_slots <= 3 && N > 65536u && N <= 131072u && N % 128u == 0) ? 2 : 1;
 }
-int jit_std_f(const dspfx_engine *e, bool mod) { return (e->desc.channels < 131072u && !mod) ? 16 : 8; }   // few channels: more loads in flight per wave
+int jit_std_f(const dspfx_engine *e, bool mod, int n_slots) {     // few channels: more loads in flight per wave
+    if (jit_std_cpl(e, n_slots) == 2) return 8;
+    return (e->desc.channels < 131072u && !mod) ? 16 : 8;
+}
 
 // How run-time specialised kernels are obtained (DSPFX_JIT / DSPFX_JIT_ASYNC / DSPFX_VARIANT, read per call):
 //   JP_OFF     never: the interpreter serves (DSPFX_JIT=0; below JIT_MIN_CHANNELS also with DSPFX_JIT_ASYNC=0 or DSPFX_VARIANT set:
@@ -463,9 +473,9 @@ const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod, int
     if (st.count < 1 || st.count > MAX_SLOTS || !st.fast_div) return nullptr;
     int sigs[MAX_SLOTS];
     stage_sigs(e, st, sigs);
-    const int cpl = jit_std_cpl(e);
+    const int cpl = jit_std_cpl(e, st.count);
     if (N < 64u * (unsigned)cpl) return nullptr;
-    const JitKernel *k = jit_get(e->device, sigs, st.count, jit_std_f(e, mod), cpl, mod, false, false, mode);
+    const JitKernel *k = jit_get(e->device, sigs, st.count, jit_std_f(e, mod, st.count), cpl, mod, false, false, mode);
     if (!k && mode == JIT_COMPILE) e->jit_unavailable = true;       // dspfx_describe says so: the interpreter serves, 7-25 % slower
     return k ? &k->var : nullptr;
 }

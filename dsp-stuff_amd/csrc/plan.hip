@@ -141,7 +141,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pendin
                         !(st.fast_div && pref.stat != 0 && has_static_variant(e, st, all));
     if (jit_ok) {
         if (const Variant *j = jit_variant(e, st, false, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK)) return j;
-        pend = policy == JP_ASYNC && !st.jit_failed && N >= 64u * (unsigned)jit_std_cpl(e);
+        pend = policy == JP_ASYNC && !st.jit_failed && N >= 64u * (unsigned)jit_std_cpl(e, st.count);
     }
     if (pending) *pending = pend;
     for (const Variant *v : all) {
@@ -177,10 +177,10 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pendin
         // F 16, 53.6 at F 8), and one channel per lane up to ~229000 (163840 channels: 74.0 us at CPL 2, 63.3 at CPL 1;
         // 196608: 79.8 / 75.7; 262144: 92.5 / 95.2 -- from there two channels per lane win).
         const bool few = N <= 131072u;
-        const int want_f = (N < 131072u && !is_dyn) ? 16 : 8;
+        const int want_f = is_dyn ? 8 : jit_std_f(e, false, st.count);
         // interpreter: two channels per lane halve the per-chunk interpretive overhead per sample (0.4275 -> 0.383 ms on
         // the 5-node chain, 0.487 -> 0.415 on an 8-node one, 0.612 -> 0.490 with a Tanh node)
-        const int want_cpl = is_dyn ? (pend ? jit_std_cpl(e) : (few ? 1 : 2)) : ((!e->desc.tile_channels || N < STATIC_CPL2_MIN_CHANNELS) ? 1 : 2);
+        const int want_cpl = is_dyn ? (pend ? jit_std_cpl(e, st.count) : (few ? 1 : 2)) : jit_std_cpl(e, st.count);
         if (pref.f > 0 ? v->f == pref.f : v->f == want_f) score += 10;   // A/B: profiles/r01_ab_dyn.txt
         if (pref.cpl > 0 ? v->cpl == pref.cpl : v->cpl == want_cpl) score += 5;
         if (score > best_score) {
@@ -202,7 +202,9 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pen
     // Measured crossover against the standard kernels (tools/r03_ts_threshold.py, placement tuned, three engines each;
     // profiles/r03_small_n.txt): 98304 channels for chains of up to three nodes (38.5 against 44.2 us there, a tie at 114688),
     // 65536 for longer ones (more registers per wave, fewer co-resident workgroups: 32.8 against 33.7 us, a tie at 73728).
-    const uint32_t ts_max = st.count <= 3 ? TS_MAX_CHANNELS : 65536u;
+    // (round 4: where the standard kernel takes two channels per lane -- tiled engines of a whole number of 128-channel waves,
+    // short chains -- it is one workgroup per CU from 65536 channels on and beats the time-sliced kernel's second round: jit_std_cpl)
+    const uint32_t ts_max = (st.count <= 3 && !(N > 65536u && jit_std_cpl(e, st.count) == 2)) ? TS_MAX_CHANNELS : 65536u;
     if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     const Pref pref = read_pref();
     std::vector<const Variant *> all;
@@ -277,8 +279,8 @@ void request_async_jit(const dspfx_engine *e, const Stage &st, bool want_std, bo
     job->n_slots = st.count;
     stage_sigs(e, st, job->sigs);
     job->want_std = want_std;
-    job->f_std = jit_std_f(e, false);
-    job->cpl_std = jit_std_cpl(e);
+    job->f_std = jit_std_f(e, false, st.count);
+    job->cpl_std = jit_std_cpl(e, st.count);
     job->want_ts = want_ts;
     job->want_tail = want_tail;
     st.async = job;
@@ -293,14 +295,14 @@ void request_mod_kernel(dspfx_engine *e, const Stage &st) {
     const JitPolicy policy = jit_policy(e);
     if ((vp && strstr(vp, "static=0")) || policy == JP_OFF || e->graph_mode) return;
     st.var_mod = jit_variant(e, st, true, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
-    if (st.var_mod || policy != JP_ASYNC || st.count < 1 || st.count > MAX_SLOTS || !st.fast_div || e->desc.channels < 64u * (unsigned)jit_std_cpl(e)) return;
+    if (st.var_mod || policy != JP_ASYNC || st.count < 1 || st.count > MAX_SLOTS || !st.fast_div || e->desc.channels < 64u * (unsigned)jit_std_cpl(e, st.count)) return;
     auto job = std::make_shared<AsyncJit>();
     job->device = e->device;
     job->n_slots = st.count;
     stage_sigs(e, st, job->sigs);
     job->want_mod = true;
-    job->f_mod = jit_std_f(e, true);
-    job->cpl_std = jit_std_cpl(e);
+    job->f_mod = jit_std_f(e, true, st.count);
+    job->cpl_std = jit_std_cpl(e, st.count);
     st.async_mod = job;
     async_jit_submit(job);
 }
