@@ -65,6 +65,18 @@ static const char *const k_jit_opts[] = {"--offload-arch=gfx950", "-O3", "-std=c
 };
 std::atomic<uint64_t> g_jit_compiled{0}, g_jit_from_disk{0}, g_jit_disk_written{0};
 
+// The hiprtc version is part of every cache key.  hiprtc serialises ALL its entry points behind one lock, so asking for it while
+// the background thread is inside hiprtcCompileProgram waits for that compile: the second new chain shape within a second blocked
+// its dspfx_chain_set for 220-250 ms (tools/micro/jit_contention.py; round 4).  Asked once, when the first engine is created
+// (jit_arm_exit_guard) -- before this process can have a compile in flight.
+static std::pair<int, int> hiprtc_version() {
+    static const std::pair<int, int> v = [] {
+        int major = 0, minor = 0;
+        (void)hiprtcVersion(&major, &minor);
+        return std::make_pair(major, minor);
+    }();
+    return v;
+}
 static void fnv(uint64_t &h, const void *p, size_t n) {
     const unsigned char *b = (const unsigned char *)p;
     for (size_t i = 0; i < n; ++i) {
@@ -110,8 +122,7 @@ static std::string cache_file(const std::string &hdr_dir, const std::string &src
     std::string h1, h2;
     if (!kernel_headers(hdr_dir, h1, h2)) return "";
     uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
-    int ver_major = 0, ver_minor = 0;
-    (void)hiprtcVersion(&ver_major, &ver_minor);
+    const int ver_major = hiprtc_version().first, ver_minor = hiprtc_version().second;
     for (uint64_t *h : {&a, &b}) {
         fnv(*h, h1.data(), h1.size());
         fnv(*h, "\x01", 1);
@@ -367,7 +378,10 @@ struct ExitGuard {
 thread_local ExitGuard t_exit_guard;
 }  // namespace
 
-void jit_arm_exit_guard() { t_exit_guard.armed = true; }   // (touching it constructs it on this thread: its destructor runs when the thread ends)
+void jit_arm_exit_guard() {
+    t_exit_guard.armed = true;
+    (void)hiprtc_version();
+}   // (touching it constructs it on this thread: its destructor runs when the thread ends)
 
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     t_exit_guard.armed = true;

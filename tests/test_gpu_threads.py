@@ -294,23 +294,34 @@ def test_fir_state_round_trip_after_tap_reloads(dspfx, torch_cuda, monkeypatch):
 # ---- the same-block mix bus inside the chain launch (chain_kernels.hip.h, mix_tail) ---------------------------------
 
 def _bus_blocks(dspfx, torch, N, chain, nf, blocks, tile=0, graph=None, seed=3):
-    """`blocks` blocks of nf frames with the mix bus requested in the same call; returns (outputs, buses)."""
+    """`blocks` blocks of nf frames with the mix bus requested in the same call; returns (outputs, buses, describe()).
+    Large engines keep everything on the device (noise made there, outputs returned as one device tensor per block)."""
     eng = dspfx.Engine(N, nf, link_flags=3, tile_channels=tile)
     if graph is None:
         eng.set_chain(chain)
     else:
         eng.set_graph(chain, graph)
-    x = O.noise(seed, np.arange(N), np.arange(nf * blocks))
     s = torch.cuda.Stream()
-    dx = [torch.from_numpy(dspfx.to_layout(x[k * nf:(k + 1) * nf], tile)).cuda() for k in range(blocks)]
+    on_device = N >= 100000
+    if on_device:
+        dx = [torch.empty(nf * N, device="cuda") for _ in range(blocks)]
+        for k, d in enumerate(dx):
+            eng.fill_noise(d, nf, k * nf, seed)
+    else:
+        x = O.noise(seed, np.arange(N), np.arange(nf * blocks))
+        dx = [torch.from_numpy(dspfx.to_layout(x[k * nf:(k + 1) * nf], tile)).cuda() for k in range(blocks)]
     dy = [torch.empty_like(d) for d in dx]
     dm = torch.zeros((blocks, nf), device="cuda")
     torch.cuda.synchronize()
     for k in range(blocks):                          # back to back, no host synchronisation: the arrival counters must be
         eng.process(dx[k], out=dy[k], mix=dm[k], n_frames=nf, stream=s.cuda_stream)   # back at zero when the next launch starts
     s.synchronize()
+    desc = eng.describe()
+    eng.close()
+    if on_device:
+        return dy, dm.cpu().numpy(), desc
     ys = np.stack([dspfx.from_layout(d.cpu().numpy(), nf, N, tile) for d in dy])
-    return ys, dm.cpu().numpy(), eng.describe()
+    return ys, dm.cpu().numpy(), desc
 
 
 @pytest.mark.parametrize("N,nf,tile,which", [
@@ -347,9 +358,17 @@ def test_the_bus_inside_the_launch_equals_the_stand_alone_reduction(dspfx, torch
     y1, m1, desc = _bus_blocks(dspfx, torch_cuda, N, chain, nf, blocks, tile, links)
     monkeypatch.setenv("DSPFX_MIX_TAIL", "0")
     y0, m0, _ = _bus_blocks(dspfx, torch_cuda, N, chain, nf, blocks, tile, links)
-    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
     assert np.array_equal(m1.view(np.uint32), m0.view(np.uint32)), (desc, np.abs(m1 - m0).max())
-    want = y1.astype(np.float64).sum(axis=2)
+    if isinstance(y1, list):                         # a large engine: the blocks stayed on the device
+        torch = torch_cuda
+        want = np.empty((blocks, nf))
+        for k in range(blocks):
+            assert torch.equal(y1[k].view(torch.int32), y0[k].view(torch.int32)), k
+            y = y1[k].double()
+            want[k] = (y.view(N // tile, nf, tile).sum(dim=(0, 2)) if tile else y.view(nf, N).sum(dim=1)).cpu().numpy()
+    else:
+        assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+        want = y1.astype(np.float64).sum(axis=2)
     assert np.allclose(m1, want, rtol=1e-5, atol=1e-4 * np.abs(want).max())
 
 
@@ -471,7 +490,10 @@ def test_channels_left_over_go_through_the_guarded_time_sliced_kernel(dspfx, tor
     monkeypatch.setenv("DSPFX_TS_TAIL", "0")
     y0, m0, desc0 = _bus_blocks(dspfx, torch_cuda, N, mk(), nf, blocks)
     assert "channels left over" not in desc0
-    assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
+    if isinstance(y1, list):                         # a large engine: the blocks stayed on the device
+        assert all(torch_cuda.equal(a.view(torch_cuda.int32), b.view(torch_cuda.int32)) for a, b in zip(y1, y0))
+    else:
+        assert np.array_equal(y1.view(np.uint32), y0.view(np.uint32))
     assert np.array_equal(m1.view(np.uint32), m0.view(np.uint32))
     if N <= 4099:
         from chains import ulp_diff
@@ -747,6 +769,35 @@ def test_a_damaged_cache_file_is_ignored_and_rewritten(dspfx, torch_cuda, monkey
     assert all(f.stat().st_size > 1000 for f in sorted(cdir.glob("*.co")))
 
 
+def test_new_shapes_do_not_wait_for_each_others_compiles(dspfx, torch_cuda, monkeypatch, tmp_path):
+    """hiprtc serialises all its entry points behind one lock: a second new chain shape installed while the background thread was
+    compiling the first one waited 220-250 ms for it inside dspfx_chain_set -- in a call to hiprtcVersion for the cache key --
+    and so did the block that polled for the finished kernels (round 4, found by a slow test).  Four new shapes in a row, blocks
+    running in between: every call returns in milliseconds while the compiler is busy."""
+    import time
+    monkeypatch.setenv("DSPFX_CACHE_DIR", str(tmp_path / "cache"))            # nothing to find on disk
+    B, N = 128, 1000
+    x = torch_cuda.zeros(B * N, device="cuda")
+    y = torch_cuda.empty_like(x)
+    engs, worst_set, worst_block = [], 0.0, 0.0
+    for k in range(4):
+        e = dspfx.Engine(N, B, link_flags=3)
+        t = time.time()
+        e.set_chain([dspfx.Gain(0.31 + 0.07 * k), dspfx.LowPass(0.23), dspfx.HighPass(0.11 * (k + 1)), dspfx.Gain(1.07)] + [dspfx.Gain(0.93)] * k)
+        worst_set = max(worst_set, time.time() - t)
+        engs.append(e)
+        for eng in engs:                              # the engines keep playing (and polling for their kernels) meanwhile
+            t = time.time()
+            eng.process(x, out=y, n_frames=B)
+            worst_block = max(worst_block, time.time() - t)
+    busy = not all(e.kernels_ready(0) for e in engs)
+    for e in engs:
+        assert e.kernels_ready(120000)
+    if not busy or "jit_" not in engs[-1].describe():
+        pytest.skip("the compiler was not busy (no run-time compiler on this box, or an extraordinarily fast one)")
+    assert worst_set < 0.05 and worst_block < 0.05, (worst_set, worst_block)
+
+
 def test_the_library_alone_is_enough_for_the_run_time_compiler(dspfx, torch_cuda, tmp_path):
     """A deployed libdspfx.so carries the text of its kernel headers (kernel_headers.inc): copied ALONE into an empty directory --
     no chain_kernels.hip.h, no graph_kernel.hip.h beside it -- a fresh process still gets a specialised kernel for a chain shape
@@ -939,7 +990,7 @@ def _load_pkg_with_lib(lib_name, tag):
 
 
 def test_the_bus_inside_the_launch_soak_and_the_fence_build(dspfx, torch_cuda, monkeypatch):
-    """VERDICT r03 #8.  About 20 s of blocks with the bus finished inside the launch, under UNEVEN load (a second stream
+    """VERDICT r03 #8.  About 10 s (31 000 launches per form) of blocks with the bus finished inside the launch, under UNEVEN load (a second stream
     hammering HBM with bursts of varying size, so that workgroups arrive at their tickets in every order), over ragged and
     whole channel counts, both layouts, 128- and 256-frame blocks, the standard, the time-sliced and the interpreting kernels:
       * the default hand-over (write-through rows, s_waitcnt, relaxed agent-scope tickets, sc1 reads: outside the HIP memory
@@ -951,8 +1002,8 @@ def test_the_bus_inside_the_launch_soak_and_the_fence_build(dspfx, torch_cuda, m
     torch = torch_cuda
     from chains import chain3
     fence = _load_pkg_with_lib("libdspfx_busfence.so", "busfence")
-    cases = [(1 << 20, 256, 128, "chain5", 4500), (262144, 256, 128, "chain5", 7000), (64 * 300 + 37, 0, 128, "chain5", 11000),
-             (65536, 256, 256, "chain3", 9000), (131072 + 64, 0, 256, "chain3", 5000), (4099, 0, 128, "mixed", 11000)]
+    cases = [(1 << 20, 256, 128, "chain5", 3000), (262144, 256, 128, "chain5", 4500), (64 * 300 + 37, 0, 128, "chain5", 7000),
+             (65536, 256, 256, "chain3", 6000), (131072 + 64, 0, 256, "chain3", 3500), (4099, 0, 128, "mixed", 7000)]
     junk = torch.empty(96 << 20, device="cuda")
     s, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     rng = np.random.default_rng(4)
