@@ -278,11 +278,12 @@ def test_distort_level_slider_moves_without_replanning(dspfx, torch_cuda):
         ch = [dspfx.Distort(3.0, mode), dspfx.Gain(1.0)]
         eng = dspfx.Engine(128, 128)
         eng.set_chain(ch)
-        plan0 = eng.describe()
+        plan = lambda: [l for l in eng.describe().splitlines() if l.startswith("stage")]   # (the counters of the process-wide
+        plan0 = plan()                                # compiler in the last line move while earlier tests' shapes are still compiling)
         dx = torch_cuda.from_numpy(x).cuda()
         for level in (0.37, 30.0 - 2 ** -19, 7.0, 0.0005, 2.5, 1e-3, 4.0, 16.0) + tuple(failing[:1]) + (3.0,):
             eng.set_param(0, 0, level)
-            assert (eng.describe() == plan0) == (level not in failing), level
+            assert (plan() == plan0) == (level not in failing), level
             y = eng.process(dx, out=torch_cuda.empty_like(dx), n_frames=128).cpu().numpy()
             ref = run_oracle([dspfx.Distort(level, mode), dspfx.Gain(1.0)], x, 3)
             assert ulp_diff(y, ref).max() == 0, (mode, level)
