@@ -683,15 +683,17 @@ def test_a_new_chain_shape_never_waits_for_the_compiler_and_a_second_process_fin
     if "could not be compiled" in a["d1"]:
         pytest.skip("no run-time compiler on this box")
     # first process: nothing blocked on the compiler, the interpreter served the first block, then the kernels arrived
-    assert a["t_set"] < 0.05, a["t_set"]
+    # (a compile takes 0.3-1.5 s, a wait for the compiler's lock 0.2 s or more: 0.15 s tells them from a call that did not wait,
+    # with room for a slow host; measured: 1-5 ms)
+    assert a["t_set"] < 0.15, a["t_set"]
     assert "being compiled in the background" in a["d0"] and "dyn" in a["d0"], a["d0"]
     assert a["ready"] and "jit_" in a["d1"] and "being compiled" not in a["d1"], a["d1"]
     assert " 0 loaded from the disk cache" in a["d1"] and "0 compiled" not in a["d1"], a["d1"]
     # second process: from the disk cache, at once
-    assert b["t_set"] < 0.05, b["t_set"]
+    assert b["t_set"] < 0.15, b["t_set"]
     assert "jit_" in b["d0"] and "being compiled" not in b["d0"], b["d0"]
     assert " 0 compiled" in b["d1"] and " 0 loaded from the disk cache" not in b["d1"], b["d1"]
-    assert b["t_wait"] < 0.05
+    assert b["t_wait"] < 0.15
     # the same bits from the interpreter (a, first block), the fresh kernel (a, after the reset) and the cached one (b)
     assert a["first"] == a["second"] == b["first"] == b["second"]
     print("chain_set: %.1f ms first process, %.1f ms second; background compile %.2f s" % (1e3 * a["t_set"], 1e3 * b["t_set"], a["t_wait"]))
@@ -795,7 +797,7 @@ def test_new_shapes_do_not_wait_for_each_others_compiles(dspfx, torch_cuda, monk
         assert e.kernels_ready(120000)
     if not busy or "jit_" not in engs[-1].describe():
         pytest.skip("the compiler was not busy (no run-time compiler on this box, or an extraordinarily fast one)")
-    assert worst_set < 0.05 and worst_block < 0.05, (worst_set, worst_block)
+    assert worst_set < 0.15 and worst_block < 0.15, (worst_set, worst_block)     # (measured: 1-2 ms; a wait for the compiler: >= 0.2 s)
 
 
 def test_the_library_alone_is_enough_for_the_run_time_compiler(dspfx, torch_cuda, tmp_path):
