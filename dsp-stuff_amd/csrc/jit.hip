@@ -461,7 +461,10 @@ int jit_std_cpl(const dspfx_engine *e, int n_slots) {
 }
 int jit_std_f(const dspfx_engine *e, bool mod, int n_slots) {     // few channels: more loads in flight per wave
     if (jit_std_cpl(e, n_slots) == 2) return 8;
-    return (e->desc.channels < 131072u && !mod) ? 16 : 8;
+    // (16 frames per chunk only below 65536 channels since the rows go through buffer descriptors: the 5-node chain at 81920 /
+    // 98304 / 114688 channels 43.2 / 44.9 / 46.3 us at F = 16, 40.9 / 43.4 / 44.4 at F = 8; the 3-node chain one channel per lane
+    // 39.6 / 42.4 vs 37.2 / 40.2 at 81920 / 98304, but 22.1 vs 23.9 at 32768: profiles/r04_midn.txt, section I)
+    return (e->desc.channels < 65536u && !mod) ? 16 : 8;
 }
 
 // How run-time specialised kernels are obtained (DSPFX_JIT / DSPFX_JIT_ASYNC / DSPFX_VARIANT, read per call):

@@ -174,7 +174,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pendin
         // spread over all SIMDs (CPL 1) and keep more loads in flight per wave (F 16): profiles/r01_small_n.txt
         // Round 3 sweep of every compiled (F, CPL) at 114688 ... 262144 channels with tuned placement
         // (tools/r03_midn_variants.py, profiles/r03_small_n.txt): F 16 only BELOW 131072 (5-node chain at 131072: 60.4 us at
-        // F 16, 53.6 at F 8), and one channel per lane up to ~229000 (163840 channels: 74.0 us at CPL 2, 63.3 at CPL 1;
+        // F 16, 53.6 at F 8; round 4: only below 65536, jit_std_f), and one channel per lane up to ~229000 (163840 channels: 74.0 us at CPL 2, 63.3 at CPL 1;
         // 196608: 79.8 / 75.7; 262144: 92.5 / 95.2 -- from there two channels per lane win).
         const bool few = N <= 131072u;
         const int want_f = is_dyn ? 8 : jit_std_f(e, false, st.count);

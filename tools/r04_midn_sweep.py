@@ -15,7 +15,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "both"
 nmax = int(sys.argv[2]) if len(sys.argv) > 2 and which != "table" else 262144
 blocks = 1500
 ARMS = [("default", None), ("ts c1", "ts=1,cpl=1"), ("ts c2", "ts=1,cpl=2"),
-        ("std f16 c1", "ts=0,f=16,cpl=1"), ("std f8 c1", "ts=0,f=8,cpl=1"), ("std f8 c2", "ts=0,f=8,cpl=2")]
+        ("std f32 c1", "ts=0,f=32,cpl=1"), ("std f16 c1", "ts=0,f=16,cpl=1"), ("std f8 c1", "ts=0,f=8,cpl=1"), ("std f8 c2", "ts=0,f=8,cpl=2")]
 if os.environ.get("SWEEP_ARMS"):
     ARMS = [a for a in ARMS if a[0] in os.environ["SWEEP_ARMS"].split(";")]
 
