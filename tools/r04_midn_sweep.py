@@ -92,7 +92,7 @@ for cname, mk, bps, wcap in (("chain3", lambda: chain3(dspfx, 24000), 16.25, 4),
     if which not in ("both", cname):
         continue
     print("== %s: us per block incl. launch gaps (fraction of 8 TB/s) [kernel]" % cname, flush=True)
-    for N in range(32768, nmax + 1, 16384):
+    for N in range(int(os.environ.get("SWEEP_NMIN", "32768")), nmax + 1, 16384):
         row = []
         for label, var in ARMS:
             v = var % wcap if var and "%d" in var else var
