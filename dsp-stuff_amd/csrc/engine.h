@@ -206,11 +206,14 @@ struct GLink {
     bool raw;
 };
 
-// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
-// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
-// 128-frame block of a chain of up to three nodes goes through the time-sliced kernel (profiles/r03_small_n.txt).
+// JIT_MIN_CHANNELS: from here on DSPFX_JIT_ASYNC=0 / DSPFX_VARIANT mean "compile inside dspfx_chain_set" (below: "interpreter only");
+// by default every engine gets its kernels from the background compiler (jit.hip: jit_policy).  TS_MAX_CHANNELS: up to here a
+// whole 128-frame block of a chain of up to three nodes MAY go through the time-sliced kernel (pick_ts_variant: 65536 for longer
+// chains, and for short ones where the standard kernel takes two channels per lane) -- and up to here the bus' first stage
+// leaves one row per wave, whatever kernel runs (dspfx.hip: rows_per_wave).
 constexpr uint32_t JIT_MIN_CHANNELS = 16384, TS_MAX_CHANNELS = 98304;
-// from here on the specialised standard kernels take two channels per lane in the tiled layout (below: one; plan.hip has the sweep)
+// from here on the specialised standard kernels take two channels per lane in the tiled layout (below: one, except short chains
+// between 65536 and 131072 channels: jit_std_cpl; plan.hip has the sweep)
 constexpr uint32_t STATIC_CPL2_MIN_CHANNELS = 229376;
 
 // ---- errors

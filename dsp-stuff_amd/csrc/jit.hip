@@ -433,10 +433,9 @@ int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned
     return hipModuleLaunchKernel(k->fn, grid, 1, 1, block, 1, 1, 0, s, params, nullptr) == hipSuccess ? 0 : -1;
 }
 
-// Engines from this many channels on get their chain's kernel specialised at run time (about a second per distinct chain
-// shape, cached per process); smaller ones run the interpreter unless DSPFX_JIT=1.  TS_MAX_CHANNELS: up to here a whole
-// 128-frame block goes through the time-sliced kernel (measured on the 3-node chain, rocprofv3 kernel averages:
-// 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt).
+// (JIT_MIN_CHANNELS, TS_MAX_CHANNELS: engine.h.  Where the time-sliced kernel came from, 3-node chain, rocprofv3 kernel averages of
+// round 2: 16384 ch 34.7 -> 16.2 us, 32768 37.0 -> 18.2, 65536 34.3 -> 29.2, 131072 50.2 -> 56.0: profiles/r02_small_n.txt; today
+// 13.8 / 23.0 us at 32768 / 65536 by step: profiles/r04_midn.txt.)
 
 // The shape of a fused chain stage as template arguments of the chain kernels.
 void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]) {
