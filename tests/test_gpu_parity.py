@@ -2034,3 +2034,28 @@ def test_wav_impulse_responses_through_the_fir_kernels(dspfx, torch_cuda, tmp_pa
             got = np.array([[float.fromhex(v) for v in l.split()] for l in lines[1:]], F)
             assert got.shape == (128 * blocks, 2)
             assert np.array_equal(got[:, 0].view(np.uint32), y[:, 0].view(np.uint32)) and np.array_equal(got[:, 1].view(np.uint32), y[:, 63].view(np.uint32)), name
+
+
+def test_kernel_selection_by_engine_size(dspfx, torch_cuda):
+    """Which kernel serves whole 128-frame blocks of the BASELINE chains at which size (plan.hip / jit.hip: the measured rules of
+    profiles/r04_midn.txt), read from dspfx_describe: the time-sliced kernel holds one resident round (one channel per lane up to
+    49152 channels for the 3-node chain, two from there); beyond it short chains in the tiled layout take the standard kernel
+    at two channels per lane (at most one workgroup per CU up to 131072 channels), long chains and other layouts one channel per
+    lane with 8-frame chunks; from 229376 channels on everything takes two channels per lane."""
+    from chains import chain3
+    expect = [
+        ("chain3", 32768, 256, "time-sliced s3h_ts32_c1"), ("chain3", 49152, 256, "time-sliced s3h_ts32_c2"),
+        ("chain3", 65536, 256, "time-sliced s3h_ts32_c2"), ("chain3", 81920, 256, "s3h_f8_c2"), ("chain3", 131072, 256, "s3h_f8_c2"),
+        ("chain3", 81920, 0, "time-sliced s3h_ts32_c2"), ("chain3", 147456, 256, "s3h_f8_c1"), ("chain3", 229376, 256, "s3h_f8_c2"),
+        ("chain5", 32768, 256, "time-sliced s5h_ts32_c1"), ("chain5", 65536, 256, "time-sliced s5h_ts32_c1"),
+        ("chain5", 81920, 256, "s5h_f8_c1"), ("chain5", 131072, 256, "s5h_f8_c1"), ("chain5", 229376, 256, "s5h_f8_c2"),
+    ]
+    for which, N, tile, want in expect:
+        eng = dspfx.Engine(N, 128, link_flags=3, tile_channels=tile)
+        eng.set_chain(chain3(dspfx, 128) if which == "chain3" else chain5(dspfx, 128))
+        stage = [l for l in eng.describe().splitlines() if l.startswith("stage")][-1]
+        if "time-sliced" in want:
+            assert want in stage, (which, N, tile, stage)
+        else:
+            assert ("fused kernel " + want) in stage and "time-sliced" not in stage, (which, N, tile, stage)
+        eng.close()
