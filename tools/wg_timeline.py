@@ -26,6 +26,8 @@ xs = [torch.empty(128 * N, device="cuda") for _ in range(2)]
 for k, x in enumerate(xs):
     eng.fill_noise(x, 128, k * 128)
 y = torch.empty(128 * N, device="cuda")
+if os.environ.get("WG_TUNE"):
+    eng.tune_placement(xs[0], y, 128)
 for k in range(300):
     eng.process(xs[k & 1], out=y, n_frames=128)
 torch.cuda.synchronize()
