@@ -115,8 +115,10 @@ def test_slider_store_from_another_thread_with_blocks_in_flight(dspfx, torch_cud
     got = dy.cpu().numpy()[:, sample]
     ref = _oracle_blocks(chain, x[:, sample], stores)
     assert ulp_diff(got, ref).max() <= 1, (stores, ulp_diff(got, ref).max())
-    # ... and it is not the same as ignoring the stores or resetting early
-    assert ulp_diff(got, _oracle_blocks(chain, x[:, sample], {})).max() > 1000
+    # ... and it is not the same as ignoring the stores or resetting early (unless the other thread only got its turn after the
+    # last block had been queued -- a host confined to one core -- so that every store landed behind the whole stream)
+    if min(stores) < blocks:
+        assert ulp_diff(got, _oracle_blocks(chain, x[:, sample], {})).max() > 1000
 
 
 def test_store_made_while_idle_is_ordered_behind_the_blocks_in_flight(dspfx, torch_cuda):
