@@ -460,7 +460,9 @@ def test_many_stores_under_contention_replayed_from_the_log(dspfx, torch_cuda):
     got = dy.cpu().numpy()[:, sample]
     ref = _oracle_blocks(chain, x[:, sample], stores)
     assert ulp_diff(got, ref).max() <= 1, ulp_diff(got, ref).max()
-    assert len(stores) > 1                           # the stores really were spread over several block boundaries
+    # the stores really were spread over several block boundaries -- unless the storing thread only got the processor after the
+    # last block had been queued (a host confined to one core): then every store landed behind the stream, which is just as valid
+    assert len(stores) > 1 or frames[0] >= blocks * B
 
 
 @pytest.mark.parametrize("N,which", [
