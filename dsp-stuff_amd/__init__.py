@@ -56,6 +56,7 @@ EXPORTS = [
     "dspfx_process_io", "dspfx_comm_unique_id", "dspfx_comm_create", "dspfx_comm_destroy", "dspfx_comm_size", "dspfx_comm_rank",
     "dspfx_comm_last_error", "dspfx_mix_allreduce",
     "dspfx_set_param_seq", "dspfx_param_log", "dspfx_frames_submitted", "dspfx_process_bus", "dspfx_kernels_ready", "dspfx_comm_backend",
+    "dspfx_reserve_delay_len", "dspfx_ring_trim",
 ]
 COMM_ID_BYTES = 128
 
@@ -138,6 +139,8 @@ def lib():
     L.dspfx_frames_submitted.restype = C.c_uint64
     L.dspfx_frames_submitted.argtypes = [vp]
     L.dspfx_set_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
+    L.dspfx_reserve_delay_len.argtypes = [vp, C.c_int, C.c_uint32]
+    L.dspfx_ring_trim.argtypes = [vp]
     L.dspfx_set_taps.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.c_uint32, C.c_int]
     L.dspfx_set_fir_precision.argtypes = [vp, C.c_int, C.c_int]
     L.dspfx_reset.argtypes = [vp]
@@ -295,13 +298,14 @@ def Reverb(seconds: Optional[float] = None, decay: float = 0.5, delay_samples: O
            page_round: bool = False) -> NodeSpec:
     """nodes/reverb.rs: feedback delay; params = [decay, seconds], mode bit 0 = page_round.
       Reverb(seconds=s)         a restored node: refresh_seconds has run, the ring is reverb.rs:58's length for s;
-      Reverb()                  a node fresh from the menu: make_buffer()'s 128-sample ring (reverb.rs:44-52) under the default
+      Reverb()                  a node fresh from the menu: make_buffer()'s 128-sample ring (reverb.rs:44-52; 1024 under
+                                page_round -- the same rivulet calls as refresh_seconds, so the same reading) under the default
                                 0.5 s slider -- its first slider change makes it a 24000-sample delay, like the reference's;
       Reverb(delay_samples=D)   an explicit ring and no seconds slider: a slider change swaps in a zero ring of the same D.
     Any set_param on the node -- decay included -- swaps in a NEW ZERO ring (reverb.rs:19, 55-71; include/dspfx.h)."""
     if delay_samples is None:
         if seconds is None:
-            return NodeSpec(REVERB, [decay, 0.5], mode=int(page_round), delay_len=128)
+            return NodeSpec(REVERB, [decay, 0.5], mode=int(page_round), delay_len=delay_len(0.0, page_round))
         delay_samples = delay_len(seconds, page_round)
     return NodeSpec(REVERB, [decay, 0.0 if seconds is None else float(seconds)], mode=int(page_round), delay_len=int(delay_samples))
 
@@ -466,6 +470,13 @@ class Engine:
 
     def set_delay_len(self, node: int, d: int):
         self._chk(self.L.dspfx_set_delay_len(self.h, node, int(d)))
+
+    def reserve_delay_len(self, node: int, d: int):
+        """Capacity hint (any thread, takes no engine lock): the groups a ring of d samples would need are allocated now."""
+        self._chk(self.L.dspfx_reserve_delay_len(self.h, node, int(d)))
+
+    def ring_trim(self):
+        self._chk(self.L.dspfx_ring_trim(self.h))
 
     def set_taps(self, node: int, impulse_response, mode: int = FIR_BALANCED):
         t = np.ascontiguousarray(np.asarray(impulse_response, np.float64)[::-1])

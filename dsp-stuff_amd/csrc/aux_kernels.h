@@ -51,6 +51,9 @@ int verify_libm_on_device(int func, unsigned long long *d_out, hipStream_t s);
 // dense[k][c] <-> ring row (r0 + k) mod D of channel c, k < nrows  (state export / import)
 void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W, unsigned D, unsigned r0,
                       unsigned nrows, bool to_dense, hipStream_t s);
+// table[first + k] = ptrs[k], k < count, in stream order.  The pointers travel in the kernel arguments (32 per launch): no host
+// staging buffer has to outlive the call, and no copy engine -- whose pageable-memory path waits for the stream -- is involved.
+void launch_table_write(float **table, unsigned first, unsigned count, float *const *ptrs, hipStream_t s);
 // dst[f][c] = noise(seed, c0 + c, n_abs0 + f)
 void launch_noise(float *dst, unsigned N, unsigned nframes, uint32_t c0, uint32_t n_abs0, uint32_t seed,
                   const Layout &lay, hipStream_t s);

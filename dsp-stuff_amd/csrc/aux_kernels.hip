@@ -226,6 +226,18 @@ void launch_ring_copy(float *const *groups, float *dense, unsigned N, unsigned W
                        to_dense ? 1 : 0);
 }
 
+struct PtrPack { float *p[32]; };
+__global__ void table_write_kernel(float **table, unsigned first, unsigned count, PtrPack pk) {
+    if (threadIdx.x < count) table[first + threadIdx.x] = pk.p[threadIdx.x];
+}
+void launch_table_write(float **table, unsigned first, unsigned count, float *const *ptrs, hipStream_t s) {
+    for (unsigned k = 0; k < count; k += 32) {
+        PtrPack pk{};
+        const unsigned n = count - k < 32u ? count - k : 32u;
+        for (unsigned j = 0; j < n; ++j) pk.p[j] = ptrs[k + j];
+        hipLaunchKernelGGL(table_write_kernel, dim3(1), dim3(64), 0, s, table, first + k, n, pk);
+    }
+}
 
 void launch_fuzz(const FuzzArgs &a, hipStream_t s) {
     hipLaunchKernelGGL(fuzz_kernel, dim3((a.N + FUZZ_CH - 1) / FUZZ_CH), dim3(WG), 0, s, a);

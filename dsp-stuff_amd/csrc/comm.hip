@@ -125,6 +125,8 @@ struct MbxShm {                                    // the rendezvous file in /de
         uint32_t stage;                            // 0 empty, 1 handle published, 2 peers opened, 3 leaving
         uint32_t pid;
         uint64_t ptr;                              // the mailbox' address in its owner's process (ranks of ONE process share it directly)
+        uint64_t proc_token;                       // random per process: pid equality alone is fooled by pid namespaces that share /dev/shm
+        int32_t device, pad;                       // the owner's device (ranks of one process on different devices need peer access)
         char handle[64];                           // hipIpcMemHandle_t
     } r[MBX_MAX_RANKS];
 };
@@ -134,9 +136,21 @@ struct Mailbox {
     bool opened[MBX_MAX_RANKS] = {};
     unsigned *status = nullptr;                    // pinned host memory: the kernel's error bits, readable without a sync
     unsigned seq = 0;
+    unsigned spin = 1u << 22;                      // DSPFX_COMM_SPIN, read when the communicator is made: polls before a missing peer becomes an error (~ seconds)
+    bool coarse = false;                           // DSPFX_COMM_COARSE=1 (test rigs only): the mailbox is ordinary device memory
     MbxShm *shm = nullptr;
     std::string shm_path;
 };
+static uint64_t process_token() {
+    static const uint64_t t = [] {
+        uint64_t v = 0;
+        FILE *f = fopen("/dev/urandom", "rb");
+        if (!f || fread(&v, 1, sizeof v, f) != sizeof v) v = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count() ^ ((uint64_t)getpid() << 32);
+        if (f) fclose(f);
+        return v | 1;
+    }();
+    return t;
+}
 static uint32_t shm_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 static void shm_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 }  // namespace
@@ -202,23 +216,38 @@ int mailbox_join(dspfx_comm *c, const char *id) {
         return code;
     };
     if (hipSetDevice(c->device) != hipSuccess) return bail(DSPFX_ERR_HIP, "hipSetDevice failed");
-    // fine-grained memory: remote writes must become visible to the owner's polling loads without any cache maintenance
-    if (hipExtMallocWithFlags((void **)&m->own, box_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-        (void)hipGetLastError();
+    // fine-grained memory: remote writes must become visible to the owner's polling loads without any cache maintenance.  There
+    // is NO silent fallback to ordinary (coarse-grained) device memory: the owner's L2 may serve its polling loads stale, which
+    // shows up as timeouts and NaNs, never as an error at the place that caused it.  DSPFX_COMM_COARSE=1 asks for
+    // exactly that memory on purpose -- a test rig's switch (tests/test_gpu_multidevice.py), not a deployment option.
+    if (const char *sp = getenv("DSPFX_COMM_SPIN")) m->spin = (unsigned)atoi(sp);
+    if (const char *cg = getenv("DSPFX_COMM_COARSE")) m->coarse = atoi(cg) == 1;
+    if (m->coarse) {
         if (hipMalloc((void **)&m->own, box_bytes) != hipSuccess) return bail(DSPFX_ERR_OOM, "no memory for the mailbox");
+    } else if (hipExtMallocWithFlags((void **)&m->own, box_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+        (void)hipGetLastError();
+        return bail(DSPFX_ERR_UNSUPPORTED, "no fine-grained device memory for the mailbox (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed); "
+                                           "use the rccl backend (DSPFX_COMM_BACKEND=rccl)");
     }
     if (hipMemset(m->own, 0, box_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return bail(DSPFX_ERR_HIP, "clearing the mailbox failed");
     if (hipHostMalloc((void **)&m->status, sizeof(unsigned), hipHostMallocMapped) != hipSuccess) return bail(DSPFX_ERR_OOM, "hipHostMalloc failed");
     *m->status = 0;
     m->peer[c->rank] = m->own;
     if (c->n_ranks == 1) return DSPFX_OK;
+    // the id came over the host's control channel: exactly 32 lower-case hex digits behind the magic, or it names no file of ours
+    // (a '/' or ".." in there would make this library truncate and scribble on whatever the caller may write to)
     char name[80];
     snprintf(name, sizeof name, "/dev/shm/dspfx_comm_");
     size_t off = strlen(name);
-    for (int k = 8; k < 40 && off + 1 < sizeof name; ++k) name[off++] = id[k];       // 32 hex digits behind the magic
+    for (int k = 8; k < 40; ++k) {
+        const char ch = id[k];
+        if (!((ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'f'))) return bail(DSPFX_ERR_INVALID, "malformed communicator id");
+        name[off++] = ch;
+    }
+    if (id[40] != 0) return bail(DSPFX_ERR_INVALID, "malformed communicator id");
     name[off] = 0;
     m->shm_path = name;
-    const int fd = open(name, O_CREAT | O_RDWR, 0600);
+    const int fd = open(name, O_CREAT | O_RDWR | O_NOFOLLOW | O_CLOEXEC, 0600);
     if (fd < 0) return bail(DSPFX_ERR_HIP, std::string("cannot open ") + name);
     if (ftruncate(fd, sizeof(MbxShm)) != 0) {
         close(fd);
@@ -235,9 +264,12 @@ int mailbox_join(dspfx_comm *c, const char *id) {
     memcpy(me.handle, &h, sizeof h);
     me.pid = (uint32_t)getpid();
     me.ptr = (uint64_t)(uintptr_t)m->own;
+    me.proc_token = process_token();
+    me.device = c->device;
     shm_store(&me.stage, 1);
     const auto t0 = std::chrono::steady_clock::now();
-    auto timed_out = [&] { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > comm_timeout_ms(); };
+    const int timeout_ms = comm_timeout_ms();
+    auto timed_out = [&] { return std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count() > timeout_ms; };
     for (int p = 0; p < c->n_ranks; ++p) {
         if (p == c->rank) continue;
         while (shm_load(&m->shm->r[p].stage) < 1) {
@@ -245,7 +277,16 @@ int mailbox_join(dspfx_comm *c, const char *id) {
             std::this_thread::sleep_for(std::chrono::microseconds(200));
         }
         const MbxShm::Slot &o = m->shm->r[p];
-        if (o.pid == (uint32_t)getpid()) {           // a rank of this very process (threads): its pointer is ours too
+        if (o.pid == (uint32_t)getpid() && o.proc_token == process_token()) {   // a rank of this very process (threads): its pointer is ours too
+            if (o.device != c->device) {             // ... on another device: this device must be allowed to write there
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->device, o.device) != hipSuccess || !can)
+                    return bail(DSPFX_ERR_UNSUPPORTED, "device " + std::to_string(c->device) + " cannot access device " + std::to_string(o.device) + " (rank " + std::to_string(p) + ")");
+                const hipError_t pe = hipDeviceEnablePeerAccess(o.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+                    return bail(DSPFX_ERR_HIP, std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
             m->peer[p] = (unsigned long long *)(uintptr_t)o.ptr;
         } else {
             hipIpcMemHandle_t ph;
@@ -405,8 +446,7 @@ extern "C" int dspfx_mix_allreduce(dspfx_engine *e, dspfx_comm *c, float *mix, u
         a.seq = ++m->seq;
         a.slot = m->seq % MBX_SLOTS;
         a.nf = n_frames;
-        const char *sp = getenv("DSPFX_COMM_SPIN");
-        a.spin = sp ? (unsigned)atoi(sp) : (1u << 22);      // ~ seconds of polling before a missing peer becomes an error
+        a.spin = m->spin;
         a.in = mix;
         a.out = mix;
         a.div = div;

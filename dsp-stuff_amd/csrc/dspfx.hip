@@ -51,6 +51,7 @@ void free_ring(Node &n) {
     n.groups.clear();
     if (n.d_groups) (void)hipFree(n.d_groups);
     n.d_groups = nullptr;
+    n.table_cap = 0;
 }
 
 void free_node(Node &n) {
@@ -85,21 +86,15 @@ int alloc_node_state(dspfx_engine *e, Node &n) {
     n.state_bytes = bytes;
     if (bytes) HIPCHK(e, hipMemset(n.state, 0, bytes));
     n.pos = 0;
-    n.zero_left = 0;          // (a ring allocated below is zero-filled for real)
-    if (n.d.kind == DSPFX_REVERB) {   // reverb.rs:55-71: a brand-new zero-filled ring
+    n.zero_left = 0;
+    if (n.d.kind == DSPFX_REVERB) {   // reverb.rs:55-71: a brand-new zero ring (setup time: the device is idle, see set_nodes)
+        const uint32_t D = n.D;
         free_ring(n);
-        const size_t ngroups = ((size_t)n.D + RING_GROUP_ROWS - 1) / RING_GROUP_ROWS;
-        n.group_floats = (size_t)RING_GROUP_ROWS * N;
-        n.groups.assign(ngroups, nullptr);
-        for (size_t g = 0; g < ngroups; ++g) {
-            HIPCHK(e, big_alloc((void **)&n.groups[g], n.group_floats * sizeof(float)));
-            HIPCHK(e, hipMemset(n.groups[g], 0, n.group_floats * sizeof(float)));
-        }
-        HIPCHK(e, hipMalloc((void **)&n.d_groups, ngroups * sizeof(float *)));
-        HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), ngroups * sizeof(float *), hipMemcpyHostToDevice));
-        n.state_bytes = (size_t)n.D * N * sizeof(float);   // canonical (exported) size
-        const int rc = tune_ring(e, n);
+        n.D = 0;
+        const int rc = ring_resize(e, (int)(&n - e->nodes.data()), D, nullptr);   // nothing is written: the ring starts as `zero_left = D`
         if (rc) return rc;
+        const int rt = tune_ring(e, n);
+        if (rt) return rt;
     }
     if (n.d.kind == DSPFX_FIR) {
         const int rc = fir_configure(n.fir, n.taps.data(), (uint32_t)n.taps.size(), n.d.mode, (uint32_t)N,
@@ -249,9 +244,9 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             a.hop_rc = 1.0 / (double)e->hop_div;
             a.third_rc = 1.0 / 3.0;
             a.fast_div = st.fast_div ? 1 : 0;
-            // DSPFX_XCD_REMAP=0 / 1 switches the XCD-contiguous block mapping off / on (A/B runs); read per launch
-            const char *xcd_env = getenv("DSPFX_XCD_REMAP");
-            a.xcd_remap = xcd_env ? atoi(xcd_env) : 1;
+            // DSPFX_XCD_REMAP=0 / 1 switches the XCD-contiguous block mapping off / on (A/B runs; EnvSwitches)
+            const bool xcd_env = e->env.xcd_remap >= 0;
+            a.xcd_remap = xcd_env ? e->env.xcd_remap : 1;
             a.n_slots = st.count;
             a.skip_store = (st.count == 0 && src == out) ? 1 : 0;   // an empty stage in place exists only for the mix bus
             // hop flag of the side input and of control links (both are ordinary links between nodes);
@@ -260,8 +255,11 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             if (e->desc.link_flags & DSPFX_LINK_INTERNAL) a.side_hop = (e->desc.link_flags & DSPFX_LINK_SIDE_RAW) ? 2 : 3;
             int rows = 0;
             for (int k = 0; k < st.count; ++k) {
+                const Node &nk = e->nodes[st.first + k];
+                if (nk.d.kind == DSPFX_REVERB && (!nk.d_groups || nk.groups.size() < ring_groups_for(nk.D) || !nk.D))
+                    return fail(e, DSPFX_ERR_STATE, "REVERB node %d has no delay ring (an allocation failed earlier)", st.first + k);
                 fill_slot(e, st.first + k, k < MAX_SLOTS ? a.slot[k] : ga.more[k - MAX_SLOTS], nframes);
-                rows += state_rows(e->nodes[st.first + k]);
+                rows += state_rows(nk);
             }
             if (st.async || st.async_mod) adopt_async_jit(e, st);      // kernels the background compiler has finished: from this block on
             const Variant *v = st.var, *tail = e->tail;
@@ -273,7 +271,8 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
                     // else the control-port interpreter: two channels per lane above 131072 channels -- or, while the
                     // specialised kernel is on its way, the channels per lane of THAT kernel (the same rows of bus partials)
                     if (!st.var_mod_tried) request_mod_kernel(e, st);
-                    const bool two = st.async_mod ? jit_std_cpl(e, st.count) == 2 : N > 131072u;
+                    // (fixed when the job was submitted and kept when it comes back empty-handed: the bus' rows must not change in mid-stream)
+                    const bool two = st.mod_two >= 0 ? st.mod_two == 1 : N > 131072u;
                     v = st.var_mod ? st.var_mod : ((e->dyn_mod2 && two && N % 2u == 0) ? e->dyn_mod2 : e->dyn_mod);
                     tail = e->tail_mod;
                 }
@@ -314,8 +313,7 @@ int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out
             // Same-block bus: the slice and final stages ride in the tail of this very launch (mix_tail) instead of two more
             // kernels behind it.  DSPFX_MIX_TAIL=0: the stand-alone kernels (A/B runs, tests: bit-identical).
             // (even block lengths: the tail reads two frames per lane with one 8-byte load)
-            const bool tail_bus = last && mix && !deferred && !e->mp_building && e->mt_tickets && nframes % 2u == 0 &&
-                                  !(getenv("DSPFX_MIX_TAIL") && atoi(getenv("DSPFX_MIX_TAIL")) == 0);
+            const bool tail_bus = last && mix && !deferred && !e->mp_building && e->mt_tickets && nframes % 2u == 0 && e->env.mix_tail != 0;
             if (tail_bus) {
                 a.mt_tickets = e->mt_tickets;
                 a.mt_part2 = e->mixpart_b;
@@ -509,10 +507,26 @@ int settle_null_stream(dspfx_engine *e) {
 }
 
 void publish_kinds(dspfx_engine *e) {
-    std::lock_guard<std::mutex> lk(e->pend_mu);
-    e->pub_kinds.clear();
-    for (const Node &n : e->nodes) e->pub_kinds.push_back(n.d.kind);
-    e->pending.clear();                 // stores aimed at the nodes that no longer exist
+    std::vector<float *> drop;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        e->pub_kinds.clear();
+        e->pub_rev.assign(e->nodes.size(), dspfx_engine::PubReverb{});
+        for (size_t i = 0; i < e->nodes.size(); ++i) {
+            const Node &n = e->nodes[i];
+            e->pub_kinds.push_back(n.d.kind);
+            if (n.d.kind == DSPFX_REVERB) e->pub_rev[i] = dspfx_engine::PubReverb{n.d.params[1], n.d.mode, n.D, n.groups.size()};
+        }
+        e->pending.clear();                 // stores aimed at the nodes that no longer exist
+        ++e->chain_gen;                     // ... and ring capacity being allocated for them is dropped by its allocator
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        for (auto &pool : e->ring_pool)
+            for (float *g : pool) drop.push_back(g);
+        e->ring_pool.assign(e->nodes.size(), {});
+    }
+    for (float *g : drop) (void)hipFree(g);     // (never part of a ring: no block has seen them)
 }
 
 // One slider / mode store takes effect (api_mu held).  State writes go to `s` in stream order.  *replan: the stage split or a
@@ -558,23 +572,159 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
 uint32_t reverb_refresh_len(const Node &n) {
     return n.d.params[1] > 0.0f ? dspfx_delay_len(n.d.params[1], n.d.mode & 1) : n.D;
 }
-// A NEW zero ring of D samples for node n.  Same length as the ring it has: O(1) -- the next D frames read their taps as +0.0
-// (Node::zero_left), nothing is written, freed or re-placed, blocks in flight are untouched (they carry their own count).  A
-// different length frees and re-allocates the ring's groups: waits for the device, like dspfx_chain_set.
-int reverb_new_ring(dspfx_engine *e, Node &n, uint32_t D, bool &replan) {
+// A NEW zero ring of D samples for node n -- Reverb::refresh_seconds (reverb.rs:55-71), which in the reference is an
+// allocation of at most 192 KB and a pointer swap under the node's mutex, made on every frame a drag moves a slider
+// (dsp-stuff-derive/src/lib.rs:487-497, 560-568).  Here it is a change of three scalars whatever the lengths:
+//   * the ring is a table of 128-row groups and a ring of D rows uses the first ceil(D / 128) of them; groups are never freed
+//     or moved by a length change (a shorter ring keeps the surplus as capacity), so blocks in flight -- which carry their own
+//     D, position and clear count in their kernel arguments -- are untouched: NO wait for the device;
+//   * nothing is zeroed: `zero_left = D` makes the next D frames read their taps as +0.0 (SlotArgs::zero_rows) and every row is
+//     written before it is read unmasked, so groups fresh from hipMalloc (whatever they hold) are as good as zeroed ones;
+//   * a LONGER ring than the node has capacity for takes the groups the storing thread allocated for it (ring_reserve: the
+//     thread that moves the slider pays for the memory, like the reference's GUI thread) and appends their addresses to the
+//     device table in stream order; only when none were provided (a racing chain set, dspfx_set_delay_len) does this thread
+//     allocate -- without memset, without a device-wide wait;
+//   * no placement probe (dspfx_tune_placement is the explicit call), no re-plan (the kernels do not depend on D; only the
+//     sub-block split does: recompute_min_delay).
+// On failure (out of memory) the node keeps the ring, length and position it had.
+int ring_resize(dspfx_engine *e, int idx, uint32_t D, hipStream_t s) {
+    Node &n = e->nodes[(size_t)idx];
     if (D < DSPFX_BUF_SIZE) D = DSPFX_BUF_SIZE;
-    if (D == n.D && !n.groups.empty()) {
-        n.zero_left = n.D;
-        return DSPFX_OK;
+    const size_t N = e->desc.channels;
+    const size_t need = ring_groups_for(D), have = n.groups.size();
+    n.group_floats = (size_t)RING_GROUP_ROWS * N;
+    std::vector<float *> fresh;
+    auto give_back = [&] {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        if (e->ring_pool.size() <= (size_t)idx) e->ring_pool.resize((size_t)idx + 1);
+        for (float *g : fresh) e->ring_pool[(size_t)idx].push_back(g);
+        fresh.clear();
+    };
+    if (need > have) {
+        {
+            std::lock_guard<std::mutex> lk(e->pool_mu);
+            if ((size_t)idx < e->ring_pool.size()) {
+                auto &pool = e->ring_pool[(size_t)idx];
+                while (fresh.size() < need - have && !pool.empty()) {
+                    fresh.push_back(pool.back());
+                    pool.pop_back();
+                }
+            }
+        }
+        while (fresh.size() < need - have) {
+            float *g = nullptr;
+            const hipError_t err = big_alloc((void **)&g, n.group_floats * sizeof(float));
+            if (err != hipSuccess) {
+                (void)hipGetLastError();
+                give_back();
+                return fail(e, DSPFX_ERR_OOM, "delay ring of %u samples: no room for %zu more groups of %zu MiB (the ring keeps its %u samples)", D,
+                            need - have, (n.group_floats * sizeof(float)) >> 20, n.D);
+            }
+            fresh.push_back(g);
+        }
     }
-    int rc = quiesce(e);
-    if (rc) return rc;
+    float **table = n.d_groups;
+    size_t cap = n.table_cap;
+    if (need > cap) {             // room for every length the seconds slider can ask for (0..=1 s, page-rounded: 376 groups)
+        cap = std::max<size_t>(need, 384);
+        if (hipMalloc((void **)&table, cap * sizeof(float *)) != hipSuccess) {
+            (void)hipGetLastError();
+            give_back();
+            return fail(e, DSPFX_ERR_OOM, "delay ring of %u samples: no room for its group table", D);
+        }
+    }
+    // ---- nothing below fails
+    n.groups.insert(n.groups.end(), fresh.begin(), fresh.end());
+    if (table != n.d_groups) {
+        if (n.d_groups) e->retired.push_back(n.d_groups);       // blocks in flight still read it
+        n.d_groups = table;
+        n.table_cap = cap;
+        launch_table_write(n.d_groups, 0, (unsigned)n.groups.size(), n.groups.data(), s);
+    } else if (n.groups.size() > have) {
+        launch_table_write(n.d_groups, (unsigned)have, (unsigned)(n.groups.size() - have), n.groups.data() + have, s);
+    }
+    (void)hipGetLastError();
     n.D = D;
     n.d.delay_len = D;
-    rc = alloc_node_state(e, n);
-    replan = true;                       // the shortest delay line bounds the sub-block length
-    const int rs = settle_null_stream(e);
-    return rc ? rc : rs;
+    n.pos = 0;
+    n.zero_left = D;
+    n.state_bytes = (size_t)D * N * sizeof(float);   // canonical (exported) size
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if ((size_t)idx < e->pub_rev.size()) {
+            e->pub_rev[(size_t)idx].D = D;
+            e->pub_rev[(size_t)idx].have = n.groups.size();
+        }
+    }
+    return DSPFX_OK;
+}
+
+// Capacity for a ring of want_groups groups at node `node`, allocated by the CALLING thread into the node's pool (see
+// engine.h).  No api_mu: a process call in progress is not held up, and the blocks it queues are not either (hipMalloc does
+// not wait for the device).  keep_free: leave that many bytes of device memory alone (0: take what is needed).  gen: the
+// chain generation the caller looked at -- groups made for a chain that was replaced meanwhile are freed again.
+int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free) {
+    std::lock_guard<std::mutex> alloc_lk(e->alloc_mu);
+    if (hipSetDevice(e->device) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    const size_t gbytes = (size_t)RING_GROUP_ROWS * e->desc.channels * sizeof(float);
+    size_t have = 0;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (e->chain_gen != gen || node < 0 || (size_t)node >= e->pub_rev.size()) return DSPFX_OK;   // the chain was replaced: nothing to do
+        have = e->pub_rev[(size_t)node].have;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        if ((size_t)node < e->ring_pool.size()) have += e->ring_pool[(size_t)node].size();
+    }
+    if (have >= want_groups) return DSPFX_OK;
+    const size_t short_by = want_groups - have;
+    // all or nothing: a reservation that cannot be completed holds no memory
+    size_t fb = 0, tb = 0;
+    if (hipMemGetInfo(&fb, &tb) == hipSuccess && fb < keep_free + short_by * gbytes)
+        return fail(e, DSPFX_ERR_OOM, "no room for a delay ring of %zu groups of %zu MiB at node %d: %zu more needed, %zu MiB free", want_groups, gbytes >> 20,
+                    node, short_by, fb >> 20);
+    std::vector<float *> got;
+    for (size_t k = 0; k < short_by; ++k) {
+        float *g = nullptr;
+        if (big_alloc((void **)&g, gbytes) != hipSuccess) {
+            (void)hipGetLastError();
+            for (float *x : got) (void)hipFree(x);        // (nobody ever saw them)
+            return fail(e, DSPFX_ERR_OOM, "no room for a delay ring of %zu groups of %zu MiB at node %d (%zu short)", want_groups, gbytes >> 20, node,
+                        short_by - got.size());
+        }
+        got.push_back(g);
+    }
+    bool stale = false;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        stale = e->chain_gen != gen;
+    }
+    if (stale) {                                           // made for a chain that was replaced meanwhile
+        for (float *x : got) (void)hipFree(x);
+        return DSPFX_OK;
+    }
+    std::lock_guard<std::mutex> lk(e->pool_mu);
+    if (e->ring_pool.size() <= (size_t)node) e->ring_pool.resize((size_t)node + 1);
+    e->ring_pool[(size_t)node].insert(e->ring_pool[(size_t)node].end(), got.begin(), got.end());
+    return DSPFX_OK;
+}
+
+void recompute_min_delay(dspfx_engine *e) {
+    e->min_delay = 0xffffffffu;
+    for (const Node &nd : e->nodes)
+        if (nd.d.kind == DSPFX_REVERB) e->min_delay = std::min(e->min_delay, nd.D);
+}
+
+int reverb_new_ring(dspfx_engine *e, Node &n, uint32_t D, hipStream_t s) {
+    if (D < DSPFX_BUF_SIZE) D = DSPFX_BUF_SIZE;
+    if (D == n.D && !n.groups.empty()) {
+        n.zero_left = n.D;               // the same rows go on being overwritten: only their past is forgotten
+        return DSPFX_OK;
+    }
+    const int rc = ring_resize(e, (int)(&n - e->nodes.data()), D, s);
+    recompute_min_delay(e);              // the shortest delay line bounds the sub-block length
+    return rc;
 }
 
 // Apply every queued store, in order, at this block boundary (api_mu held); biquad resets are queued on `s` -- the
@@ -599,7 +749,7 @@ int drain_pending(dspfx_engine *e, hipStream_t s) {
             HIPCHK(e, hipMemsetAsync(e->nodes[i].state, 0, e->nodes[i].state_bytes, s));
     for (size_t i = 0; i < reverb_refresh.size(); ++i)      // once per node and boundary: every store leaves a zero ring behind
         if (reverb_refresh[i]) {
-            const int r = reverb_new_ring(e, e->nodes[i], reverb_refresh_len(e->nodes[i]), replan);
+            const int r = reverb_new_ring(e, e->nodes[i], reverb_refresh_len(e->nodes[i]), s);
             if (r && !rc) rc = r;
         }
     if (replan) {
@@ -703,6 +853,7 @@ extern "C" int dspfx_engine_create(const dspfx_engine_desc *desc, dspfx_engine *
     if (hipSetDevice(desc->device) != hipSuccess) return DSPFX_ERR_HIP;
     jit_arm_exit_guard();
     dspfx_engine *e = new dspfx_engine();
+    e->env = read_env_switches();
     e->desc = *desc;
     e->device = desc->device;
     e->hop_div = dspfx_link_divisor(1);
@@ -740,6 +891,15 @@ extern "C" void dspfx_engine_destroy(dspfx_engine *e) {
         if (st.async_mod) st.async_mod->abandoned.store(true, std::memory_order_release);
     }
     for (Node &n : e->nodes) free_node(n);
+    {
+        std::lock_guard<std::mutex> alloc_lk(e->alloc_mu);      // (a thread still allocating ring capacity finishes its group first)
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        for (auto &pool : e->ring_pool)
+            for (float *g : pool) (void)hipFree(g);
+        e->ring_pool.clear();
+    }
+    for (void *t : e->retired) (void)hipFree(t);
+    e->retired.clear();
     if (e->mixpart) (void)hipFree(e->mixpart);
     if (e->mixpart_b) (void)hipFree(e->mixpart_b);
     if (e->mixpart_b2) (void)hipFree(e->mixpart_b2);
@@ -793,6 +953,7 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     if (n_nodes < 0 || n_nodes > DSPFX_MAX_NODES || (n_nodes > 0 && !nodes))
         return fail(e, DSPFX_ERR_INVALID, "chain length %d out of range", n_nodes);
     HIPCHK(e, hipSetDevice(e->device));
+    e->env = read_env_switches();        // a setup call: the one place (with engine creation) where the environment is looked at
     for (int i = 0; i < n_nodes; ++i) {
         const int rc = validate_node(e, nodes[i]);
         if (rc) return rc;
@@ -802,6 +963,8 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
         if (rc) return rc;
     }
     for (Node &n : e->nodes) free_node(n);
+    for (void *t : e->retired) (void)hipFree(t);       // group tables replaced under blocks that have finished by now
+    e->retired.clear();
     e->nodes.clear();
     e->nodes.resize((size_t)n_nodes);
     e->mp_count = 0;
@@ -825,6 +988,21 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     }
     rc = plan(e);
     publish_kinds(e);
+    // A node fresh from the menu sits on make_buffer()'s short ring under a seconds slider that asks for a longer one
+    // (reverb.rs:44-52): its first slider change -- any slider -- jumps to that length (reverb.rs:55-71).  The groups for it are
+    // reserved now, while nothing is running (best effort, leaving 8 GiB alone: a failed reservation only means the store
+    // allocates), so that first touch is the same O(1) swap as every later one.
+    uint64_t gen = 0;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        gen = e->chain_gen;
+    }
+    for (int i = 0; i < n_nodes && rc == DSPFX_OK; ++i) {
+        const Node &n = e->nodes[(size_t)i];
+        if (n.d.kind != DSPFX_REVERB) continue;
+        const uint32_t want = reverb_refresh_len(n);
+        if (ring_groups_for(want) > n.groups.size()) (void)ring_reserve(e, i, gen, ring_groups_for(want), (size_t)8 << 30);
+    }
     const int rs = settle_null_stream(e);
     return rc ? rc : rs;
 }
@@ -897,6 +1075,8 @@ extern "C" int dspfx_chain_len(const dspfx_engine *e) {
 // with its state write (the biquad reset) queued in stream order behind the blocks already in flight.
 namespace dspfx_host {
 int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *seq_out) {
+    size_t want_groups = 0;
+    uint64_t gen = 0;
     {
         std::lock_guard<std::mutex> lk(e->pend_mu);
         if (node < 0 || node >= (int)e->pub_kinds.size() || param < -1 || param >= 8)
@@ -911,6 +1091,33 @@ int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *s
             d.taps = &one;
             const int rc = validate_node(e, d);
             if (rc) return rc;
+        }
+        if (e->pub_kinds[(size_t)node] == DSPFX_REVERB && param >= 0) {
+            // the seconds slider is 0..=1 (reverb.rs:34-37); anything else is not a value the reference's widget can hold --
+            // and would ask for a ring of up to 2^32 samples per channel
+            if (param == 1 && !(value >= 0.0f && value <= 1.0f))
+                return fail(e, DSPFX_ERR_INVALID, "REVERB seconds %g outside the slider's range 0..=1 (reverb.rs:34-37)", (double)value);
+            // the ring this store will swap in (reverb_refresh_len, with the stores queued before it applied)
+            const dspfx_engine::PubReverb &pr = e->pub_rev[(size_t)node];
+            const float seconds = param == 1 ? value : pr.seconds;
+            if (seconds > 0.0f) want_groups = ring_groups_for(dspfx_delay_len(seconds, pr.mode & 1));
+            if (want_groups <= pr.have) want_groups = 0;
+            gen = e->chain_gen;
+        }
+    }
+    // Reverb::refresh_seconds allocates the new ring on the thread that moved the slider (reverb.rs:55-71).  So does this: a
+    // ring longer than the node's capacity gets its groups HERE, before the store is queued -- the thread that drives the blocks
+    // finds them at the block boundary and only swaps.  Out of memory: the store is not made, the node keeps ring and slider.
+    if (want_groups) {
+        const int rc = ring_reserve(e, node, gen, want_groups, 0);
+        if (rc) return rc;
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (node >= (int)e->pub_kinds.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);   // (the chain was replaced meanwhile)
+        if (e->pub_kinds[(size_t)node] == DSPFX_REVERB) {
+            if (param == 1) e->pub_rev[(size_t)node].seconds = value;
+            if (param < 0) e->pub_rev[(size_t)node].mode = (int)value;
         }
         const uint64_t seq = e->next_seq++;
         e->pending.push_back(dspfx_engine::Store{seq, node, param, value});
@@ -969,17 +1176,54 @@ extern "C" int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len
     if (node < 0 || node >= (int)e->nodes.size() || e->nodes[(size_t)node].d.kind != DSPFX_REVERB)
         return fail(e, DSPFX_ERR_INVALID, "node %d is not a REVERB node", node);
     if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
-    // reverb.rs:55-71: a brand-new zero-filled ring.  An unchanged length takes the O(1) path (reverb_new_ring): no wait
-    // for the device, nothing re-allocated; a new length frees the old ring first, so nothing may still be reading it.
-    bool replan = false;
-    int rc = reverb_new_ring(e, e->nodes[(size_t)node], delay_len, replan);
-    if (rc) return rc;
-    if (replan) {
-        rc = plan(e);
-        const int rs = settle_null_stream(e);
-        if (!rc) rc = rs;
+    // reverb.rs:55-71: a brand-new zero ring -- three scalars change (reverb_new_ring); a ring longer than the node's capacity
+    // has its missing groups allocated here, by the calling thread, without a wait for the device (dspfx_reserve_delay_len from
+    // another thread beforehand keeps even that off the thread that drives the blocks).
+    return reverb_new_ring(e, e->nodes[(size_t)node], delay_len, e->cur_stream_set ? e->cur_stream : nullptr);
+}
+
+extern "C" int dspfx_reserve_delay_len(dspfx_engine *e, int node, uint32_t delay_len) {
+    if (!e) return DSPFX_ERR_INVALID;
+    uint64_t gen = 0;
+    {
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (node < 0 || node >= (int)e->pub_kinds.size() || e->pub_kinds[(size_t)node] != DSPFX_REVERB)
+            return fail(e, DSPFX_ERR_INVALID, "node %d is not a REVERB node", node);
+        gen = e->chain_gen;
     }
-    return rc;
+    if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
+    return ring_reserve(e, node, gen, ring_groups_for(delay_len), 0);
+}
+
+extern "C" int dspfx_ring_trim(dspfx_engine *e) {
+    if (!e) return DSPFX_ERR_INVALID;
+    ApiScope api(e);
+    if (api.rc) return api.rc;
+    const int rc = quiesce(e);              // blocks in flight may still be on a longer ring of the same groups
+    if (rc) return rc;
+    std::vector<float *> drop;
+    {
+        std::lock_guard<std::mutex> lk(e->pool_mu);
+        for (auto &pool : e->ring_pool) {
+            drop.insert(drop.end(), pool.begin(), pool.end());
+            pool.clear();
+        }
+    }
+    for (size_t i = 0; i < e->nodes.size(); ++i) {
+        Node &n = e->nodes[i];
+        if (n.d.kind != DSPFX_REVERB) continue;
+        const size_t need = ring_groups_for(n.D);
+        while (n.groups.size() > need) {
+            drop.push_back(n.groups.back());
+            n.groups.pop_back();
+        }
+        std::lock_guard<std::mutex> lk(e->pend_mu);
+        if (i < e->pub_rev.size()) e->pub_rev[i].have = n.groups.size();
+    }
+    for (float *g : drop) (void)hipFree(g);
+    for (void *t : e->retired) (void)hipFree(t);
+    e->retired.clear();
+    return DSPFX_OK;
 }
 
 extern "C" int dspfx_set_taps(dspfx_engine *e, int node, const double *taps_reversed, uint32_t n_taps, int mode) {

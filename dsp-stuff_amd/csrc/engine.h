@@ -53,8 +53,12 @@ struct Node {
     float a1 = 0, a2 = 0, b0 = 0, b1 = 0, b2 = 0;
     float *state = nullptr;   // BIQUAD [4][N], LOW/HIGH_PASS [1][N]
     // REVERB: the ring as separately allocated 128-row groups + the device copy of the pointer table
+    // `groups` is the ring's CAPACITY: a ring of D rows uses the first ceil(D / 128) of them; groups once allocated stay
+    // (a shorter ring keeps them for the next longer one), and entry g of the device table never changes once written,
+    // so a length change appends -- in stream order, behind the blocks in flight, which only read the entries of THEIR ring.
     std::vector<float *> groups;
     float **d_groups = nullptr;
+    size_t table_cap = 0;           // entries d_groups has room for
     float *probe_group = nullptr;   // placement probes: the node stands in as a one-group ring made of this group
     size_t group_floats = 0;
     int ring_replaced = 0;    // groups re-allocated by the placement probe
@@ -92,6 +96,30 @@ struct AsyncJit {
     std::string cache_dir;               // ... and the on-disk cache of code objects ("": none)
 };
 
+// DSPFX_VARIANT="f=8,cpl=2,static=1" narrows the choice (tuning / A-B runs).
+struct Pref {
+    int f = -1, cpl = -1, stat = -1;
+};
+
+// Every DSPFX_* switch that bears on planning or on the per-block path, read from the environment ONCE per setup call
+// (dspfx_engine_create, dspfx_chain_set / dspfx_graph_set) and kept on the engine: nothing a process call, a slider
+// store or the background compiler's hand-over does calls getenv -- a host may be changing its environment at that
+// moment, and the calls are not free (tests/test_abi_cpu.py greps for it).  -1 = not set.
+struct EnvSwitches {
+    int xcd_remap = -1;          // DSPFX_XCD_REMAP
+    int mix_tail = -1;           // DSPFX_MIX_TAIL (0: stand-alone bus kernels)
+    int fast_div = -1;           // DSPFX_FAST_DIV (0: IEEE division everywhere)
+    int jit = -1, jit_async = -1;   // DSPFX_JIT, DSPFX_JIT_ASYNC
+    int ts_tail = -1;            // DSPFX_TS_TAIL
+    bool has_variant = false;    // DSPFX_VARIANT set at all
+    int variant_ts = -1;         // its ts= field
+    bool variant_static0 = false;   // it contains "static=0"
+    Pref pref;                   // its f= / cpl= / static= fields
+    std::string headers_dir;     // DSPFX_KERNEL_HEADERS ("": the embedded text)
+    std::string cache_dir;       // the on-disk cache of code objects as resolved from DSPFX_DISK_CACHE / DSPFX_CACHE_DIR / XDG_CACHE_HOME / HOME ("": none)
+};
+EnvSwitches read_env_switches();
+
 struct Stage {
     StageType type;
     int first, count;
@@ -103,6 +131,7 @@ struct Stage {
     mutable const Variant *var_mod = nullptr;   // ST_FUSED, control ports connected: specialised kernel, asked for on first use
     mutable bool var_mod_tried = false;
     mutable std::shared_ptr<AsyncJit> async_mod;   // ... being compiled in the background
+    mutable int mod_two = -1;                   // ... 1 / 0: the control-port interpreter's channels per lane (2 / 1) fixed for the life of this plan when such a job was submitted
     bool fast_div = false;          // all constant divisors of the stage verified (see divisor_is_fast)
 };
 
@@ -112,6 +141,7 @@ using namespace dspfx_host;
 struct dspfx_engine {
     dspfx_engine_desc desc{};
     int device = 0;
+    EnvSwitches env;                          // the environment as of the last setup call (engine.h: EnvSwitches)
     std::vector<Node> nodes;
     std::vector<Stage> stages;
     bool graph_mode = false;                  // dspfx_graph_set: the nodes form a DAG evaluated by one generated kernel
@@ -181,15 +211,22 @@ struct dspfx_engine {
     hipStream_t cur_stream = nullptr;
     bool cur_stream_set = true;               // the null stream to begin with: setup-time writes go there
     hipEvent_t ev_order = nullptr;
+    // ---- delay-ring capacity (dspfx.hip: ring_reserve / ring_resize) ------------------------------------------------
+    // A slider store that lengthens a ring needs groups the ring does not have yet.  The thread that MAKES the store (the
+    // reference's GUI thread, which allocates the new ring itself: reverb.rs:55-71) allocates them into ring_pool[node]
+    // before it queues the store; the thread that drives the blocks only takes them over at the block boundary.
+    // alloc_mu serialises allocating threads (held across hipMalloc calls), pool_mu guards the containers (never held
+    // across a HIP call), pub_rev (under pend_mu) is what a storing thread may know about a REVERB node without api_mu.
+    std::mutex alloc_mu, pool_mu;
+    std::vector<std::vector<float *>> ring_pool;      // [node]: allocated groups not yet part of the node's ring
+    std::vector<void *> retired;                      // group tables replaced while blocks were in flight: freed when the device is idle
+    struct PubReverb { float seconds = 0.0f; int mode = 0; uint32_t D = 0; size_t have = 0; };
+    std::vector<PubReverb> pub_rev;                   // [node] (REVERB nodes only carry meaning)
+    uint64_t chain_gen = 0;                           // bumped by every chain / graph set (under pend_mu)
     mutable std::mutex err_mu;                        // err (also kept per calling thread: dspfx_last_error)
 };
 
 namespace dspfx_host {
-
-// DSPFX_VARIANT="f=8,cpl=2,static=1" narrows the choice (tuning / A-B runs).
-struct Pref {
-    int f = -1, cpl = -1, stat = -1;
-};
 
 struct JitKernel {
     Variant var;            // launch == nullptr: launched through `fn`
@@ -257,12 +294,12 @@ struct ProfScope {   // brackets one kernel launch with events on its own stream
     }
 };
 
-bool divisor_is_fast(float c, bool have_device = true);
-bool node_divisors_fast(const Node &n, bool have_device = true);
+bool divisor_is_fast(float c, bool have_device = true, bool forced_off = false);
+bool node_divisors_fast(const Node &n, bool have_device = true, bool forced_off = false);
 bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device = true);
 bool fusable(const Node &n);
 int node_hop(const dspfx_engine *e, int idx);
-Pref read_pref();
+inline const Pref &read_pref(const dspfx_engine *e) { return e->env.pref; }
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job);   // jit.hip: background specialisation for small engines
 bool async_jit_wait(const std::shared_ptr<AsyncJit> &job, int wait_ms);   // ... until the compiler is done with `job` (bounded)
 int validate_node(dspfx_engine *e, const dspfx_node_desc &d);
@@ -271,6 +308,10 @@ void collect_variants(std::vector<const Variant *> &out);
 void adopt_async_jit(dspfx_engine *e, const Stage &st);      // plan.hip: run_subblock calls it at a block boundary
 void request_mod_kernel(dspfx_engine *e, const Stage &st);   // plan.hip: the stage's control-port kernel, on first use
 int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *host, bool to_host);
+inline size_t ring_groups_for(uint32_t D) { return ((size_t)D + RING_GROUP_ROWS - 1) / RING_GROUP_ROWS; }
+int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free);   // any thread, no api_mu
+int ring_resize(dspfx_engine *e, int node, uint32_t D, hipStream_t s);          // api_mu held
+void recompute_min_delay(dspfx_engine *e);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
                  hipStream_t stream);
 int bind_stream(dspfx_engine *e, hipStream_t s);
@@ -305,6 +346,14 @@ void stage_sigs(const dspfx_engine *e, const Stage &st, int (&sigs)[MAX_SLOTS]);
 int jit_std_cpl(const dspfx_engine *e, int n_slots);
 int jit_std_f(const dspfx_engine *e, bool mod, int n_slots);
 std::string jit_cache_dir();
+std::string jit_headers_dir();
+// While alive, this thread's run-time compiler look-ups take their header / cache directories from the engine's snapshot
+// instead of the environment (the background thread is handed them with its job in the same way).
+struct JitDirScope {
+    const std::string *old_hdr, *old_cache;
+    explicit JitDirScope(const dspfx_engine *e);
+    ~JitDirScope();
+};
 void jit_arm_exit_guard();   // the calling thread waits for a background compile in flight when it ends (jit.hip: ExitGuard)
 extern std::atomic<uint64_t> g_jit_compiled, g_jit_from_disk, g_jit_disk_written;
 int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s);

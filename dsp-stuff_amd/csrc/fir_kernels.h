@@ -38,7 +38,20 @@
 
 namespace dspfx {
 
+// The DSPFX_FIR_* switches, read ONCE when the node is configured (fir_configure: dspfx_chain_set) -- fir_process, on the per-block
+// path, never calls getenv.  -1 = not set.
+struct FirEnv {
+    int kernel = -1;   // DSPFX_FIR_KERNEL: 0 exact f64 VALU kernel, 1 MFMA
+    int scan = -1;     // DSPFX_FIR_SCAN=0: the warm-up sweep instead of the running sums while the deque fills
+    int njt = -1;      // DSPFX_FIR_NJT=2|4: tiles per wave
+    int skew = -1;     // DSPFX_FIR_SKEW=0: the rectangular sweep in steady state too
+    int split = -1;    // DSPFX_FIR_SPLIT=0: nodes left at the default precision take the f32 sweep
+    int half = -1;     // DSPFX_FIR_HALF=0: ... the bf16 x 3 sweep
+    int dist = -1;     // DSPFX_FIR_DIST=1: history chunks requested one iteration ahead (A/B)
+};
+
 struct FirState {
+    FirEnv env;
     float *ring = nullptr;        // [ceil(N/32)] tiles of R * 32 + 32 floats
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path

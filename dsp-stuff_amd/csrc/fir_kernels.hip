@@ -1075,8 +1075,7 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
         }
     }
     // DSPFX_FIR_KERNEL: 0 = exact f64 VALU kernel, 1 = MFMA; default MFMA unless the filter is tiny
-    const char *k = getenv("DSPFX_FIR_KERNEL");
-    s.kernel = k ? atoi(k) : (n_taps >= 16 ? 1 : 0);
+    s.kernel = s.env.kernel >= 0 ? s.env.kernel : (n_taps >= 16 ? 1 : 0);
     const size_t lds = tap_table_bytes(n_taps);
     if (lds > LDS_PER_CU - 1024) s.kernel = 0;         // tap table must fit the CU's LDS
     if (s.kernel == 1) {
@@ -1100,6 +1099,19 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
 int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int mode, uint32_t N,
                   uint32_t max_frames) {
     fir_free(s);
+    {   // setup time: the one place the FIR switches are read (FirEnv)
+        auto env_int = [](const char *name) {
+            const char *v = getenv(name);
+            return v ? atoi(v) : -1;
+        };
+        s.env.kernel = env_int("DSPFX_FIR_KERNEL");
+        s.env.scan = env_int("DSPFX_FIR_SCAN");
+        s.env.njt = env_int("DSPFX_FIR_NJT");
+        s.env.skew = env_int("DSPFX_FIR_SKEW");
+        s.env.split = env_int("DSPFX_FIR_SPLIT");
+        s.env.half = env_int("DSPFX_FIR_HALF");
+        s.env.dist = env_int("DSPFX_FIR_DIST");
+    }
     s.N = N;
     s.max_frames = max_frames;
     s.mode = mode;
@@ -1273,8 +1285,7 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         }
         const dim3 ex_grid(s.tiles, (nf + 7) / 8);
         // the fill phase of a deque that started empty: running sums (exact); DSPFX_FIR_SCAN=0 keeps the warm-up sweep (A/B, tests)
-        const char *scan_env = getenv("DSPFX_FIR_SCAN");
-        const bool fill = mfma && s.warm_ok && front0 == 0 && s.front == 0 && n0 + nf <= s.T && !(scan_env && atoi(scan_env) == 0);
+        const bool fill = mfma && s.warm_ok && front0 == 0 && s.front == 0 && n0 + nf <= s.T && s.env.scan != 0;
         if (!steady && !fill) s.warm_ok = false;             // a filling slice the running sums did not see
         if (fill) {
             s.last_kernel = "fir_warm_scan_kernel";
@@ -1312,27 +1323,22 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             // slice is at most 64 frames, which is one wave's two tiles.  DSPFX_FIR_NJT=2|4 forces either.  (With the
             // rectangular sweep two tiles per wave were faster up to 384 taps -- a narrower band; the skewed sweep has no
             // band overhead and four tiles win at every length: profiles/r02_fir.txt.)
-            const char *njt_env = getenv("DSPFX_FIR_NJT");
-            const bool two = nf <= 64 || (njt_env && atoi(njt_env) == 2);
-            const char *skew_env = getenv("DSPFX_FIR_SKEW");     // 0: the rectangular sweep in steady state too (A/B, cross-checks)
+            const bool two = nf <= 64 || s.env.njt == 2;
+            // DSPFX_FIR_SKEW=0: the rectangular sweep in steady state too (A/B, cross-checks)
             // (the skewed kernel wants its workgroup's LDS twice per CU for NJT = 4 -- two waves per SIMD -- else the rectangular sweep serves)
             const size_t lds_skew = skew_lds_bytes(s.T, two ? 2 : 4);
-            const bool skew = steady && !(skew_env && atoi(skew_env) == 0) && lds_skew * 2 <= LDS_PER_CU;
+            const bool skew = steady && s.env.skew != 0 && lds_skew * 2 <= LDS_PER_CU;
             const unsigned grid = two ? (s.tiles + 1) / 2 : (s.tiles + 3) / 4;
             const size_t lds = skew ? lds_skew : tap_table_bytes(s.T);
             // split precision (bf16 x 3 on the bf16 matrix pipe): whole 128-frame slices in steady state.  The DEFAULT since round
             // 3 (as accurate as the f32 sweep against the f64 oracle -- 2.9e-7 vs 3.3e-7 relative RMS at 4096 taps -- bit-exact on
             // integer data, x 1.5); dspfx_set_fir_precision(F32) or DSPFX_FIR_SPLIT=0 in the environment (for nodes left at the
             // default) select the f32 sweep.
-            const char *split_env = getenv("DSPFX_FIR_SPLIT");
-            const bool want_split = s.precision == DSPFX_FIR_PRECISION_SPLIT ||
-                                    (s.precision == DSPFX_FIR_PRECISION_DEFAULT && !(split_env && atoi(split_env) == 0));
+            const bool want_split = s.precision == DSPFX_FIR_PRECISION_SPLIT || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && s.env.split != 0);
             // two-part f16 (three f16 products per term + a bf16 x 3 second pass over the tiles it lists): the DEFAULT since round 4
             // -- same bar, bit-exact on data that is exact in f16's 22 bits, config 4 1.33 -> see DESIGN 5; DSPFX_FIR_HALF=0 (for
             // nodes left at the default) or dspfx_set_fir_precision(SPLIT / F32) select the others.
-            const char *half_env = getenv("DSPFX_FIR_HALF");
-            const bool want_half = s.precision == DSPFX_FIR_PRECISION_HALF ||
-                                   (s.precision == DSPFX_FIR_PRECISION_DEFAULT && want_split && !(half_env && atoi(half_env) == 0));
+            const bool want_half = s.precision == DSPFX_FIR_PRECISION_HALF || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && want_split && s.env.half != 0);
             const bool half = steady && nf > 64 && s.taps_half && s.taps_split && s.redo && want_half;
             const bool split = !half && steady && nf > 64 && s.taps_split && want_split;
             s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : half ? "fir_half_kernel" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
@@ -1366,9 +1372,8 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             } else if (skew) {
                 // history chunks requested 5 iterations before their first use (11 in flight or in use per wave); with 1
                 // the sweep waits for HBM: 1.997 vs 1.949 ms at config 4, 3: 1.986, 7 / 9: 1.962-1.979 (DSPFX_FIR_DIST=1 for A/B)
-                const char *dist_env = getenv("DSPFX_FIR_DIST");
                 if (two) hipLaunchKernelGGL((fir_skew_kernel<2, 1>), dim3(grid), dim3(256), lds, stream, a);
-                else if (dist_env && atoi(dist_env) == 1) hipLaunchKernelGGL((fir_skew_kernel<4, 1>), dim3(grid), dim3(256), lds, stream, a);
+                else if (s.env.dist == 1) hipLaunchKernelGGL((fir_skew_kernel<4, 1>), dim3(grid), dim3(256), lds, stream, a);
                 else hipLaunchKernelGGL((fir_skew_kernel<4, 5>), dim3(grid), dim3(256), lds, stream, a);
             } else {
                 if (two) hipLaunchKernelGGL((fir_mfma_kernel<false, 2>), dim3(grid), dim3(256), lds, stream, a);

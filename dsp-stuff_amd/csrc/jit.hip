@@ -31,10 +31,14 @@ std::map<std::string, JitKernel *> g_jit;     // key -> kernel
 // the directory the submitting thread saw)
 #include "kernel_headers.inc"        // k_hdr_chain[], k_hdr_graph[]
 static thread_local const std::string *t_dir_override = nullptr;
-std::string csrc_dir() {             // "" = the embedded text
-    if (t_dir_override) return *t_dir_override;
+static const bool g_jit_debug = getenv("DSPFX_JIT_DEBUG") != nullptr;      // read once, when the library is loaded
+std::string jit_headers_dir() {      // setup calls only (read_env_switches)
     if (const char *d = getenv("DSPFX_KERNEL_HEADERS")) return d;
     return "";
+}
+std::string csrc_dir() {             // "" = the embedded text
+    if (t_dir_override) return *t_dir_override;
+    return jit_headers_dir();
 }
 static bool read_file(const std::string &path, std::string &out);
 // the two headers as the compiler will see them; false: an override directory without chain_kernels.hip.h
@@ -107,6 +111,14 @@ std::string jit_cache_dir() {
     return "";
 }
 static std::string cache_dir_now() { return t_cache_override ? *t_cache_override : jit_cache_dir(); }
+JitDirScope::JitDirScope(const dspfx_engine *e) : old_hdr(t_dir_override), old_cache(t_cache_override) {
+    t_dir_override = &e->env.headers_dir;
+    t_cache_override = &e->env.cache_dir;
+}
+JitDirScope::~JitDirScope() {
+    t_dir_override = old_hdr;
+    t_cache_override = old_cache;
+}
 static void mkdirs(const std::string &dir) {
     std::string cur;
     for (size_t i = 0; i <= dir.size(); ++i)
@@ -253,7 +265,7 @@ const JitKernel *jit_compile(const std::string &key, const std::string &src, con
                     }
                 }
             }
-        } else if (!t_dir_override && getenv("DSPFX_JIT_DEBUG")) {
+        } else if (g_jit_debug) {
             size_t ls = 0;
             (void)hiprtcGetProgramLogSize(prog, &ls);
             std::vector<char> log(ls + 1, 0);
@@ -385,8 +397,8 @@ void jit_arm_exit_guard() {
 
 void async_jit_submit(const std::shared_ptr<AsyncJit> &job) {
     t_exit_guard.armed = true;
-    job->headers_dir = csrc_dir();
-    job->cache_dir = jit_cache_dir();
+    job->headers_dir = csrc_dir();          // (the submitting thread's view: the engine's snapshot, plan() holds a JitDirScope)
+    job->cache_dir = cache_dir_now();
     std::call_once(g_async_once, [] {
         g_async = new AsyncCompiler();
         // hiprtc loads the compiler (comgr, with LLVM inside) lazily, at the first compile -- on the worker thread, i.e. AFTER
@@ -474,11 +486,10 @@ int jit_std_f(const dspfx_engine *e, bool mod, int n_slots) {     // few channel
 //   JP_ASYNC   the default, at every size: this process' table and the disk cache at once (milliseconds), else the engine starts
 //              on the interpreter, the background thread compiles, and the kernels are adopted at a block boundary.
 JitPolicy jit_policy(const dspfx_engine *e) {
-    const char *jit_env = getenv("DSPFX_JIT"), *async_env = getenv("DSPFX_JIT_ASYNC");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const int jit_mode = e->env.jit;
     if (jit_mode == 0) return JP_OFF;
     if (jit_mode == 1) return JP_SYNC;
-    if ((async_env && atoi(async_env) == 0) || getenv("DSPFX_VARIANT")) return e->desc.channels >= JIT_MIN_CHANNELS ? JP_SYNC : JP_OFF;
+    if (e->env.jit_async == 0 || e->env.has_variant) return e->desc.channels >= JIT_MIN_CHANNELS ? JP_SYNC : JP_OFF;
     return JP_ASYNC;
 }
 
@@ -559,7 +570,7 @@ std::string graph_source(const dspfx_engine *e, int first, int n, const std::vec
         }
         if (!srcs.empty()) {
             const float div = dspfx_link_divisor(srcs.size());
-            body += std::string(" g_div<") + (divisor_is_fast(div, have_device) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
+            body += std::string(" g_div<") + (divisor_is_fast(div, have_device, e->env.fast_div == 0) ? "true" : "false") + ", F, CPL>(" + dst + ", " + hexf(div) + ", " +
                     hexd(1.0 / (double)div) + ");";
         }
         body += "\n";
@@ -643,7 +654,7 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     }
     const std::string src = graph_source(e, st.first, st.count, links, st.fast_div, gsigs);
     for (int i = 0; i < MAX_SLOTS; ++i) sigs[i] = gsigs[i];
-    if (getenv("DSPFX_JIT_DEBUG")) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
+    if (g_jit_debug) fprintf(stderr, "dspfx graph kernel source:\n%s\n", src.c_str());
     auto build = [&](int cpl) {
         const std::string expr = "dspfx::graph_kernel<" + std::to_string(f) + ", " + std::to_string(cpl) + ", dspfx::Prog>";
         const std::string key = "graph_d" + std::to_string(e->device) + "_f" + std::to_string(f) + "_c" + std::to_string(cpl) + "_" +
@@ -653,7 +664,7 @@ const Variant *graph_variant(const dspfx_engine *e, const Stage &st) {
     // Two channels per lane as the chain kernels do (large tiled engines), as long as the graph's live values fit:
     // every node output still needed is F x CPL registers, and past 128 VGPRs the lost occupancy costs more than
     // the wider accesses gain (profiles/r01_graph_one_kernel.txt).  DSPFX_VARIANT="cpl=1|2" forces either (A/B runs).
-    const Pref pref = read_pref();
+    const Pref pref = read_pref(e);
     const bool can2 = N % 128u == 0;
     if (pref.cpl == 2 && can2) { const JitKernel *k = build(2); return k ? &k->var : nullptr; }
     if (pref.cpl == 1) { const JitKernel *k = build(1); return k ? &k->var : nullptr; }
@@ -732,6 +743,7 @@ extern "C" int dspfx_graph_source(const dspfx_node_desc *nodes, int n_nodes, con
     st.count = n_nodes;
     int sigs[GRAPH_SLOTS];
     tmp.hop_div = dspfx_link_divisor(1);
+    tmp.env = read_env_switches();
     // no device is touched: divisions already proven in this process are written in their exact-product form, all others
     // in the IEEE form (nothing is verified, nothing is cached)
     const std::string src = graph_source(&tmp, 0, n_nodes, gl, stage_fast_div(&tmp, st, false), sigs, false);

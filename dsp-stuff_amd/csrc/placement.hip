@@ -152,7 +152,7 @@ int tune_ring(dspfx_engine *e, Node &n) {
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
     if (rc) return rc;
-    for (float *g : n.groups) HIPCHK(e, hipMemset(g, 0, gbytes));   // probing wrote into the groups
+    n.zero_left = n.D;                 // probing wrote into the groups: the ring is still the zero ring it was (Node::zero_left)
     HIPCHK(e, hipMemcpy(n.d_groups, n.groups.data(), n.groups.size() * sizeof(float *), hipMemcpyHostToDevice));
     return DSPFX_OK;
 }

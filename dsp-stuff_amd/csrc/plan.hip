@@ -16,12 +16,11 @@ namespace dspfx_host {
 //     the exhaustive 2^32-input check decides, on the CURRENT device (plan() selects the engine's device first).  Only
 //     COMPLETED checks are cached: a HIP failure answers "not fast" for this call and is asked again next time;
 //     have_device = false only consults the cache.
-// DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; read per call so a test can flip it between engines).
-bool divisor_is_fast(float c, bool have_device) {
+// DSPFX_FAST_DIV=0 forces the IEEE path (A/B runs; part of the engine's environment snapshot: forced_off).
+bool divisor_is_fast(float c, bool have_device, bool forced_off) {
     static std::mutex mu;
     static std::map<uint32_t, bool> cache;
-    if (const char *fd = getenv("DSPFX_FAST_DIV"))
-        if (atoi(fd) == 0) return false;
+    if (forced_off) return false;
     if (!(c == c) || c == 0.0f || std::isinf(c)) return false;
     const float ac = fabsf(c), half = ac * 0.5f;
     int ex = 0;
@@ -52,11 +51,11 @@ bool divisor_is_fast(float c, bool have_device) {
     return ok;
 }
 
-bool node_divisors_fast(const Node &n, bool have_device) {
+bool node_divisors_fast(const Node &n, bool have_device, bool forced_off) {
     if (n.d.kind == DSPFX_DISTORT && (n.d.mode == DSPFX_DIST_HARD_CLIP || n.d.mode == DSPFX_DIST_SOFT_CLIP)) {
         if (n.d.params[0] < 0.001f) return true;   // bypassed: never divides
-        if (!divisor_is_fast(n.d.params[0], have_device)) return false;
-        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f, have_device)) return false;
+        if (!divisor_is_fast(n.d.params[0], have_device, forced_off)) return false;
+        if (n.d.mode == DSPFX_DIST_SOFT_CLIP && !divisor_is_fast(3.0f, have_device, forced_off)) return false;
     }
     return true;
 }
@@ -82,21 +81,38 @@ void collect_variants(std::vector<const Variant *> &out) {
     for (int i = 0; i < n; ++i) out.push_back(v + i);
 }
 
-Pref read_pref() {
-    Pref p;
-    const char *s = getenv("DSPFX_VARIANT");
-    if (!s) return p;
-    const char *q;
-    if ((q = strstr(s, "f="))) p.f = atoi(q + 2);
-    if ((q = strstr(s, "cpl="))) p.cpl = atoi(q + 4);
-    if ((q = strstr(s, "static="))) p.stat = atoi(q + 7);
-    return p;
+static int env_int(const char *name) {
+    const char *v = getenv(name);
+    return v ? atoi(v) : -1;
+}
+// The ONE place (with jit.hip's directory helpers it calls) where the planning / per-block switches are read: setup calls only.
+EnvSwitches read_env_switches() {
+    EnvSwitches s;
+    s.xcd_remap = env_int("DSPFX_XCD_REMAP");
+    s.mix_tail = env_int("DSPFX_MIX_TAIL");
+    s.fast_div = env_int("DSPFX_FAST_DIV");
+    s.jit = env_int("DSPFX_JIT");
+    s.jit_async = env_int("DSPFX_JIT_ASYNC");
+    s.ts_tail = env_int("DSPFX_TS_TAIL");
+    if (const char *v = getenv("DSPFX_VARIANT")) {
+        s.has_variant = true;
+        const char *q;
+        if ((q = strstr(v, "f="))) s.pref.f = atoi(q + 2);
+        if ((q = strstr(v, "cpl="))) s.pref.cpl = atoi(q + 4);
+        if ((q = strstr(v, "static="))) s.pref.stat = atoi(q + 7);
+        if ((q = strstr(v, "ts="))) s.variant_ts = atoi(q + 3);
+        s.variant_static0 = strstr(v, "static=0") != nullptr;
+    }
+    s.headers_dir = jit_headers_dir();
+    s.cache_dir = jit_cache_dir();
+    return s;
 }
 
 bool stage_fast_div(const dspfx_engine *e, const Stage &st, bool have_device) {
-    if (!divisor_is_fast(e->hop_div, have_device)) return false;
+    const bool off = e->env.fast_div == 0;
+    if (!divisor_is_fast(e->hop_div, have_device, off)) return false;
     for (int i = 0; i < st.count; ++i)
-        if (!node_divisors_fast(e->nodes[st.first + i], have_device)) return false;
+        if (!node_divisors_fast(e->nodes[st.first + i], have_device, off)) return false;
     return true;
 }
 
@@ -128,7 +144,7 @@ static bool has_static_variant(const dspfx_engine *e, const Stage &st, const std
 const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     std::vector<const Variant *> all;
     collect_variants(all);
-    const Pref pref = read_pref();
+    const Pref pref = read_pref(e);
     const uint32_t N = e->desc.channels;
     const Variant *best = nullptr;
     int best_score = -1;
@@ -196,9 +212,7 @@ const Variant *pick_variant(const dspfx_engine *e, const Stage &st, bool *pendin
 const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     const uint32_t N = e->desc.channels;
     if (pending) *pending = false;
-    int want = -1;
-    if (const char *sv = getenv("DSPFX_VARIANT"))
-        if (const char *q = strstr(sv, "ts=")) want = atoi(q + 3);
+    const int want = e->env.variant_ts;
     // Measured crossover against the standard kernels (tools/r03_ts_threshold.py, placement tuned, three engines each;
     // profiles/r03_small_n.txt): 98304 channels for chains of up to three nodes (38.5 against 44.2 us there, a tie at 114688),
     // 65536 for longer ones (more registers per wave, fewer co-resident workgroups: 32.8 against 33.7 us, a tie at 73728).
@@ -206,7 +220,7 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pen
     // short chains -- it is one workgroup per CU from 65536 channels on and beats the time-sliced kernel's second round: jit_std_cpl)
     const uint32_t ts_max = (st.count <= 3 && !(N > 65536u && jit_std_cpl(e, st.count) == 2)) ? TS_MAX_CHANNELS : 65536u;
     if (want == 0 || (want < 0 && N > ts_max) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
-    const Pref pref = read_pref();
+    const Pref pref = read_pref(e);
     std::vector<const Variant *> all;
     collect_variants(all);
     const Variant *best = nullptr;
@@ -246,8 +260,7 @@ const Variant *pick_ts_variant(const dspfx_engine *e, const Stage &st, bool *pen
 const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st, bool *pending) {
     const uint32_t N = e->desc.channels;
     if (pending) *pending = false;
-    const char *off = getenv("DSPFX_TS_TAIL");
-    if ((off && atoi(off) == 0) || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
+    if (e->env.ts_tail == 0 || !st.fast_div || st.count < 1 || st.count > MAX_SLOTS) return nullptr;
     unsigned cpl = st.var ? (unsigned)st.var->cpl : 1u;
     if (st.var_ts) cpl = std::max(cpl, (unsigned)st.var_ts->cpl);
     if (N % (64u * cpl) == 0) return nullptr;          // no launch of this engine leaves channels over
@@ -262,7 +275,7 @@ const Variant *pick_ts_tail_variant(const dspfx_engine *e, const Stage &st, bool
         if (ok) return v;
     }
     const JitPolicy policy = jit_policy(e);
-    const Pref pref = read_pref();
+    const Pref pref = read_pref(e);
     if (policy == JP_OFF || pref.stat == 0 || e->graph_mode) return nullptr;
     const JitKernel *k = jit_get(e->device, sigs, st.count, 32, 1, false, true, true, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
     if (!k && pending) *pending = policy == JP_ASYNC && !st.jit_failed;
@@ -291,9 +304,9 @@ void request_async_jit(const dspfx_engine *e, const Stage &st, bool want_std, bo
 // (JP_SYNC), or by the background thread -- the control-port interpreter serves meanwhile.
 void request_mod_kernel(dspfx_engine *e, const Stage &st) {
     st.var_mod_tried = true;
-    const char *vp = getenv("DSPFX_VARIANT");
     const JitPolicy policy = jit_policy(e);
-    if ((vp && strstr(vp, "static=0")) || policy == JP_OFF || e->graph_mode) return;
+    if (e->env.variant_static0 || policy == JP_OFF || e->graph_mode) return;
+    JitDirScope dirs(e);                 // (run_subblock calls this on a stage's first connected control port: no getenv from here)
     st.var_mod = jit_variant(e, st, true, policy == JP_SYNC ? JIT_COMPILE : JIT_DISK);
     if (st.var_mod || policy != JP_ASYNC || st.count < 1 || st.count > MAX_SLOTS || !st.fast_div || e->desc.channels < 64u * (unsigned)jit_std_cpl(e, st.count)) return;
     auto job = std::make_shared<AsyncJit>();
@@ -303,6 +316,7 @@ void request_mod_kernel(dspfx_engine *e, const Stage &st) {
     job->want_mod = true;
     job->f_mod = jit_std_f(e, true, st.count);
     job->cpl_std = jit_std_cpl(e, st.count);
+    st.mod_two = job->cpl_std == 2 ? 1 : 0;      // the control-port interpreter runs with THAT kernel's channels per lane, whether it ever arrives or not
     st.async_mod = job;
     async_jit_submit(job);
 }
@@ -320,11 +334,11 @@ void adopt_async_jit(dspfx_engine *e, const Stage &st) {
     const std::shared_ptr<AsyncJit> job = st.async;
     st.async.reset();
     if (job->ready.load(std::memory_order_acquire) < 0 || (job->want_std && !job->k_std)) {
-        // no run-time compiler here: the interpreter stays -- from now on its best instantiation for this size, not the one that
-        // mimics the kernel that never came
+        // no run-time compiler here: the interpreter stays -- the SAME instantiation the stage started on (the coming kernel's
+        // channels per lane), for the life of this plan: another one would cut the bus' rows differently and change its f32
+        // summation order at a block nobody can predict; the next dspfx_chain_set picks the best one for the size
         e->jit_unavailable = true;
         st.jit_failed = true;
-        if (job->want_std) st.var = pick_variant(e, st, nullptr);
     }
     if (job->k_std) st.var = &job->k_std->var;
     if (job->k_ts) st.var_ts = &job->k_ts->var;
@@ -337,15 +351,15 @@ void adopt_async_jit(dspfx_engine *e, const Stage &st) {
 bool long_stage_wanted(const dspfx_engine *e) {
     if (e->no_long) return false;
     const uint32_t N = e->desc.channels;
-    const char *jit_env = getenv("DSPFX_JIT");
-    const int jit_mode = jit_env ? atoi(jit_env) : -1;
+    const int jit_mode = e->env.jit;
     if (!(jit_mode == 1 || (jit_mode != 0 && N > 131072u))) return false;
-    if (read_pref().stat == 0) return false;
+    if (read_pref(e).stat == 0) return false;
     return N % 64u == 0;
 }
 
 int plan(dspfx_engine *e) {
     HIPCHK(e, hipSetDevice(e->device));   // divisor checks run there, run-time compiled modules are loaded there
+    JitDirScope dirs(e);                  // a re-plan at a block boundary (mode store) reads the engine's snapshot, not the environment
     for (const Stage &st : e->stages) {
         if (st.async) st.async->abandoned.store(true, std::memory_order_release);
         if (st.async_mod) st.async_mod->abandoned.store(true, std::memory_order_release);

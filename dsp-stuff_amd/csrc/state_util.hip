@@ -300,8 +300,14 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
     }
     for (size_t i = 0; i < e->nodes.size(); ++i)
         if (!e->nodes[i].groups.empty()) {
-            snprintf(buf, sizeof buf, "node %zu delay ring: %zu groups x %zu MiB, %d re-placed by the placement probe\n", i,
-                     e->nodes[i].groups.size(), (e->nodes[i].group_floats * sizeof(float)) >> 20, e->nodes[i].ring_replaced);
+            size_t reserved = 0;
+            {
+                std::lock_guard<std::mutex> lk(const_cast<dspfx_engine *>(e)->pool_mu);
+                if (i < e->ring_pool.size()) reserved = e->ring_pool[i].size();
+            }
+            snprintf(buf, sizeof buf, "node %zu delay ring: %u samples in %zu of %zu groups x %zu MiB (+%zu reserved), %d re-placed by the placement probe\n", i,
+                     e->nodes[i].D, ring_groups_for(e->nodes[i].D), e->nodes[i].groups.size(), (e->nodes[i].group_floats * sizeof(float)) >> 20, reserved,
+                     e->nodes[i].ring_replaced);
             s += buf;
             if (getenv("DSPFX_DESCRIBE_GROUPS"))
                 for (size_t g = 0; g < e->nodes[i].groups.size(); ++g) {
@@ -310,7 +316,7 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                 }
         }
     {
-        const std::string cdir = jit_cache_dir();
+        const std::string &cdir = e->env.cache_dir;
         snprintf(buf, sizeof buf, "run-time kernels of this process: %llu compiled, %llu loaded from the disk cache, %llu written to it (%s)\n",
                  (unsigned long long)g_jit_compiled.load(), (unsigned long long)g_jit_from_disk.load(), (unsigned long long)g_jit_disk_written.load(),
                  cdir.empty() ? "no disk cache" : cdir.c_str());

@@ -164,6 +164,8 @@ extern "C" {
     pub fn dspfx_param_log(e: *mut dspfx_engine, dst: *mut dspfx_param_event, cap: c_int, after_seq: u64) -> c_int;
     pub fn dspfx_frames_submitted(e: *const dspfx_engine) -> u64;
     pub fn dspfx_set_delay_len(e: *mut dspfx_engine, node: c_int, delay_len: u32) -> c_int;
+    pub fn dspfx_reserve_delay_len(e: *mut dspfx_engine, node: c_int, delay_len: u32) -> c_int;
+    pub fn dspfx_ring_trim(e: *mut dspfx_engine) -> c_int;
     pub fn dspfx_set_taps(e: *mut dspfx_engine, node: c_int, taps_reversed: *const f64, n_taps: u32, mode: c_int) -> c_int;
     pub fn dspfx_set_fir_precision(e: *mut dspfx_engine, node: c_int, precision: c_int) -> c_int;
     pub fn dspfx_reset(e: *mut dspfx_engine) -> c_int;

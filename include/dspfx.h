@@ -34,8 +34,8 @@
  *     in flight and ahead of the next one -- with any kind of stream (torch's and most hosts'
  *     streams are non-blocking: the null stream orders nothing against them).  A process call
  *     on a DIFFERENT stream first waits (on the device) for the previous stream.  Calls that
- *     free or re-allocate state (dspfx_chain_set, dspfx_graph_set, dspfx_set_delay_len,
- *     dspfx_set_taps, dspfx_state_import / _export) wait for the device first.
+ *     free or re-allocate state (dspfx_chain_set, dspfx_graph_set, dspfx_set_taps, dspfx_ring_trim,
+ *     dspfx_state_import / _export) wait for the device first.  A delay-ring length change does NOT (dspfx_set_param).
  *   - there is NO CPU fallback: without a HIP device every entry point that
  *     needs one fails with DSPFX_ERR_NO_DEVICE.
  *   - kernels: which kernel serves a chain is the engine's business and never changes a sample
@@ -145,7 +145,8 @@ typedef struct dspfx_engine_desc {
  *   LOW_PASS   params[0]=ratio (0..=1, default 0.5)                   low_pass.rs:20-21
  *   HIGH_PASS  params[0]=ratio                                        high_pass.rs:20-21
  *   REVERB     params[0]=decay (0..=1, default .5), params[1]=seconds (0..=1, default .5; 0 = not given);
- *              delay_len=D, the ring the node STARTS with; mode bit 0: the page-rounded reading of seconds -> samples
+ *              delay_len=D, the ring the node STARTS with (restored: dspfx_delay_len(seconds, r); fresh from the menu:
+ *              dspfx_delay_len(0, r) -- make_buffer); mode bit 0 = r: the page-rounded reading of seconds -> samples
  *              (see dspfx_set_param for what a slider store does to the ring)   reverb.rs:29-38, 44-71
  *   DISTORT    params[0]=level (0..=30, default 0); mode              distort.rs:46-50
  *   OVERDRIVE  params[0]=boost, [1]=drive, [2]=level                  overdrive.rs:21-28
@@ -176,8 +177,16 @@ const char *dspfx_strerror(int status);
 int dspfx_device_count(void);
 /* Fill `d` with the reference's defaults for `kind` (derive `default=`, lib.rs:196-210). */
 int dspfx_node_defaults(int kind, dspfx_node_desc *d);
-/* reverb.rs:58 `((seconds * 48000.0) as usize).max(128)`; page_round != 0 rounds
- * up to whole 4 KiB pages (1024 f32), the other reading of rivulet's ring size. */
+/* reverb.rs:58 `((seconds * 48000.0) as usize).max(128)`; page_round != 0 rounds up to whole 4 KiB pages (1024 f32).
+ * Two readings of ONE fact that the reference tree does not contain (rivulet is a git dependency, Cargo.toml:42): both
+ * refresh_seconds (reverb.rs:60-68) and make_buffer (reverb.rs:44-49) call circular_buffer::<f32>(n), try_grant(n) and then
+ * release(view().len()) zeros -- the delay is however long the granted view is.
+ *   page_round = 0  the view is exactly the n asked for: the delay is n samples (what the slider's "s" suffix promises);
+ *   page_round = 1  the view is all the free space of a buffer whose capacity is whole pages: n rounded up to 1024 f32.
+ * Evidence, as far as it goes: rivulet's circular buffer is a virtual-memory mirror (page-granular capacity) and its `grant`
+ * contract is "at least count" -- both favour 1; the label "Delay ... s" and the 0.5 s default say what the author MEANT -- 0.
+ * Neither can be pinned here, so the reading is the caller's choice (mode bit 0 of a REVERB node) and it is applied to BOTH
+ * call sites alike: a node fresh from the menu sits on dspfx_delay_len(0, page_round) = 128 or 1024 samples. */
 uint32_t dspfx_delay_len(float seconds, int page_round);
 /* node.rs:166,179: f32 0.0001 incremented by 1.0 per connected pipe. */
 float dspfx_link_divisor(uint64_t n_connected);
@@ -213,11 +222,17 @@ int dspfx_kernels_ready(dspfx_engine *e, int wait_ms);
  *   REVERB -- ANY slider, `decay` included -- swaps in a NEW ZERO-FILLED ring (reverb.rs:19, 55-71: refresh_seconds): the echo
  *          tail is cut.  Its length is what the seconds slider says, max((seconds * 48000) as usize, 128) (mode bit 0: rounded up
  *          to whole 4 KiB pages), when the node was given one (params[1] > 0) -- so a node fresh from the menu (dspfx_node_defaults:
- *          make_buffer's 128-sample ring under a 0.5 s slider, reverb.rs:44-52) becomes a 24000-sample delay at its first slider
- *          change, like the reference's -- and the ring's current length otherwise.  An unchanged length costs NOTHING: no
- *          memset, no re-allocation, placement kept -- the next D frames simply read their taps as +0.0 (a per-node frame
- *          counter in the kernel arguments), in order with the blocks in flight.  A changed length re-allocates the ring at
- *          that block boundary (waits for the device, like dspfx_set_delay_len);
+ *          make_buffer's 128-sample ring -- 1024 page-rounded -- under a 0.5 s slider, reverb.rs:44-52) becomes a 24000-sample delay at its first slider
+ *          change, like the reference's -- and the ring's current length otherwise.  The swap costs NOTHING on the thread
+ *          that drives the blocks, whatever the two lengths: no wait for the device, no memset, no re-allocation, placement
+ *          kept.  The ring is a table of separately allocated 128-row groups of which a ring of D samples uses the first
+ *          ceil(D / 128); the swap sets D, restarts the position and makes the next D frames read their taps as +0.0 (a per-node
+ *          frame counter in the kernel arguments), in order with the blocks in flight, which carry their own copies.  Groups a
+ *          LONGER ring needs are allocated -- not zeroed: every row is written before it is read unmasked -- by the thread
+ *          that MAKES the store, before the store is queued (the reference's GUI thread allocates the new ring too,
+ *          reverb.rs:55-71); dspfx_chain_set reserves them up front for a menu-fresh node; a shorter ring keeps the surplus
+ *          as capacity (dspfx_ring_trim returns it).  DSPFX_ERR_OOM: the store was NOT made, the node keeps ring and slider.
+ *          params[1] outside 0..=1 (the slider's range, reverb.rs:34-37) is DSPFX_ERR_INVALID;
  *   other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
  * exactness of a DISTORT level as a constant divisor is decided on the host; only a level that is an even integer
  * other than a power of two runs the 2 ms device check, once per value and process).
@@ -245,10 +260,17 @@ typedef struct dspfx_param_event {
 int dspfx_param_log(dspfx_engine *e, dspfx_param_event *dst, int cap, uint64_t after_seq);
 /* Frames handed to the process calls since the engine was created (all sub-blocks counted). */
 uint64_t dspfx_frames_submitted(const dspfx_engine *e);
-/* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring.  With the length the ring already has this is
- * the O(1) clear of dspfx_set_param (no wait for the device); a new length frees and re-allocates the ring (waits for the
- * device first).  The node's seconds slider (params[1]) is left as it is. */
+/* Reverb::refresh_seconds (reverb.rs:55-71) with D explicit: a NEW zero ring, the same O(1) swap as a slider store (no wait
+ * for the device).  A ring longer than the node's capacity has its missing groups allocated inside the call, on the calling
+ * thread (DSPFX_ERR_OOM leaves the ring as it was); dspfx_reserve_delay_len beforehand, from any thread, moves that cost off
+ * the thread that drives the blocks.  The node's seconds slider (params[1]) is left as it is. */
 int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
+/* Capacity hint: allocate (not zero, not yet use) the 128-row groups a ring of delay_len samples at `node` would need beyond
+ * what the node already has -- e.g. dspfx_delay_len(1.0f, page_round) once after dspfx_chain_set, and no seconds store can
+ * allocate again.  Callable from any thread while blocks are running; takes no engine lock, launches nothing. */
+int dspfx_reserve_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
+/* Give back delay-ring capacity beyond the rings' current lengths (and reservations not yet used).  Waits for the device. */
+int dspfx_ring_trim(dspfx_engine *e);
 /* Fir tap reload (fir.rs:153-171).  Like the reference it replaces the taps ONLY: the history is kept (`state`,
  * fir.rs:64-65, is never cleared), and because at most one sample is popped per step (fir.rs:193-197) a history longer
  * than the new tap count STAYS longer -- its oldest samples pair with the taps, i.e. the output is the new convolution

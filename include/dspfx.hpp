@@ -65,8 +65,14 @@ inline Node Reverb(float seconds = 0.5f, float decay = 0.5f, bool page_round = f
     n.d.delay_len = dspfx_delay_len(seconds, page_round ? 1 : 0);
     return n;
 }
-// a node fresh from the menu: make_buffer()'s 128-sample ring under the 0.5 s slider (reverb.rs:44-52) = dspfx_node_defaults
-inline Node ReverbFresh() { return make(DSPFX_REVERB); }
+// a node fresh from the menu: make_buffer()'s ring under the 0.5 s slider (reverb.rs:44-52) = dspfx_node_defaults: 128 samples,
+// or 1024 under the page-rounded reading of rivulet (make_buffer() is refresh_seconds' three calls with 128 for num_samples)
+inline Node ReverbFresh(bool page_round = false) {
+    Node n = make(DSPFX_REVERB);
+    n.d.mode = page_round ? 1 : 0;
+    n.d.delay_len = dspfx_delay_len(0.0f, page_round ? 1 : 0);
+    return n;
+}
 // an explicit ring and no seconds slider: a slider store swaps in a zero ring of the same length
 inline Node ReverbSamples(std::uint32_t delay_len, float decay = 0.5f) {
     Node n = make(DSPFX_REVERB);
@@ -186,6 +192,8 @@ class Engine {
     }
     std::uint64_t frames_submitted() const { return dspfx_frames_submitted(e_); }
     void set_delay_len(int node, std::uint32_t d) { chk(dspfx_set_delay_len(e_, node, d)); }
+    void reserve_delay_len(int node, std::uint32_t d) { chk(dspfx_reserve_delay_len(e_, node, d)); }   // capacity hint (any thread)
+    void ring_trim() { chk(dspfx_ring_trim(e_)); }
     /// DSPFX_FIR_PRECISION_DEFAULT / _F32 / _SPLIT / _HALF: how a FIR node's steady-state sweep multiplies (dspfx.h)
     void set_fir_precision(int node, dspfx_fir_precision p) { chk(dspfx_set_fir_precision(e_, node, static_cast<int>(p))); }
     void reset() { chk(dspfx_reset(e_)); }

@@ -199,6 +199,14 @@ uint32_t orc_delay_len(float seconds, int page_round) {
     return d;
 }
 
+/* make_buffer() (reverb.rs:44-52) is the SAME three rivulet calls as refresh_seconds (reverb.rs:60-68) with 128 for num_samples:
+ * circular_buffer::<f32>(n), try_grant(n), release(view().len()).  Whatever a reading of rivulet makes of those calls it
+ * makes of both: under the page-rounded reading (mode bit 0) a node fresh from the menu delays by orc_delay_len(0, 1) = 1024
+ * samples, not 128 (one hypothesis, one answer).  Call after the mode is set. */
+void orc_reverb_make_buffer(orc_node *n) {
+    if (n->kind == ORC_REVERB) orc_reverb_set_len(n, orc_delay_len(0.0f, n->mode & 1));
+}
+
 void orc_reverb_set_len(orc_node *n, uint32_t d) {
     /* reverb.rs:60-68: new ring, grant, fill(0.0), release(view.len()) => D zeros queued */
     free(n->ring);

@@ -184,6 +184,9 @@ void orc_node_after_settings_change(orc_node *n);
 void orc_node_set_mode(orc_node *n, int mode);
 /* reverb.rs:55-71 with D explicit: fresh zero-filled ring of D samples. */
 void orc_reverb_set_len(orc_node *n, uint32_t d);
+/* make_buffer() under the reading the node's mode bit 0 selects: 128 samples, or 1024 (= orc_delay_len(0, 1)) page-rounded.
+ * orc_node_new leaves the unrounded 128; a fresh node whose mode says page-rounded calls this once after orc_node_set_mode. */
+void orc_reverb_make_buffer(orc_node *n);
 /* reverb.rs:58 helper: max((seconds*48000f32) as usize, 128); page_round!=0
  * additionally rounds up to whole 4 KiB pages (1024 f32) -- the two candidate
  * readings of rivulet's capacity rounding. */

@@ -404,7 +404,8 @@ class NodeModel:
         elif kind == K_REVERB:                                    # make_buffer(): 128 zeros (reverb.rs:44-52) unless D is named
             if params is None or len(params) < 2:                 # no seconds slider given: the default one (0.5 s) for a fresh
                 self.p[1] = F(0.0) if delay_len else F(0.5)       # node, none to refresh from beside an explicit ring
-            self.impl = Reverb(delay_len or 128, self.p[0])
+            # ... 128 zeros, or the 1024 of the page-rounded reading (mode bit 0): make_buffer() is refresh_seconds' three calls
+            self.impl = Reverb(delay_len or delay_len_from_seconds(0.0, bool(self.mode & 1)), self.p[0])
         elif kind == K_FIR:
             self.impl = Fir(taps_reversed if taps_reversed is not None else [1.0], average=self.mode == 1)
         elif kind == K_SIGNAL_GEN:

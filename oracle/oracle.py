@@ -63,6 +63,7 @@ def _bind(L):
     L.orc_node_after_settings_change.argtypes = [vp]
     L.orc_node_set_mode.argtypes = [vp, C.c_int]
     L.orc_reverb_set_len.argtypes = [vp, C.c_uint32]
+    L.orc_reverb_make_buffer.argtypes = [vp]
     L.orc_delay_len.restype = C.c_uint32
     L.orc_delay_len.argtypes = [C.c_float, C.c_int]
     L.orc_fir_set_taps.argtypes = [vp, f64p, C.c_uint32]
@@ -108,6 +109,8 @@ class Node:
         self.h = C.c_void_p(self.L.orc_node_new(kind))
         if mode is not None:
             self.L.orc_node_set_mode(self.h, int(mode))
+            if kind == REVERB:
+                self.L.orc_reverb_make_buffer(self.h)      # make_buffer() under the mode's reading of rivulet: 128 / 1024 samples
         if params:
             for i, v in enumerate(params):
                 if v is not None:

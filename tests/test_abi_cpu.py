@@ -82,3 +82,45 @@ def test_product_never_imports_oracle():
                 assert not re.search(r"#\s*include[^\n]*oracle", src), f
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", src, re.M), f
                 assert "load_oracle" not in src, f
+
+
+def test_no_getenv_on_the_per_block_path():
+    """every DSPFX_* switch is read at a setup call (library load, dspfx_engine_create, dspfx_chain_set /
+    dspfx_graph_set -> EnvSwitches / FirEnv, dspfx_comm_create), never by a process call, a slider store, dspfx_mix_allreduce
+    or the FIR launch path -- a host may be changing its environment at that moment.  Structural check: in the translation
+    units of libdspfx.so, `getenv(` may appear only inside the functions named here."""
+    allowed = {
+        "dspfx.hip": set(),
+        "host_pipe.hip": {"dspfx_process_host"},        # two `static const` locals: read once per process
+        "plan.hip": {"env_int", "read_env_switches"},
+        "jit.hip": {"jit_headers_dir", "jit_cache_dir", "<file scope>"},
+        "comm.hip": {"rccl", "want_rccl", "comm_timeout_ms", "mailbox_join"},
+        "fir_kernels.hip": {"fir_configure"},
+        "placement.hip": {"big_alloc", "tune_ring", "dspfx_tune_placement"},      # setup-time calls
+        "state_util.hip": {"dspfx_describe"},
+        "aux_kernels.hip": set(),
+    }
+    csrc = os.path.join(ROOT, "dsp-stuff_amd", "csrc")
+    head = re.compile(r"^(?:extern \"C\" |static |inline )*[A-Za-z_][\w:<>\*&\s]*?\b([A-Za-z_]\w*)\s*\([^;]*$")
+    for name, ok in allowed.items():
+        func = "<file scope>"
+        depth = 0
+        for ln, line in enumerate(open(os.path.join(csrc, name), errors="ignore"), 1):
+            code = line.split("//")[0]
+            if re.match(r"^(namespace\b.*\{|\}\s*//\s*namespace)", line):      # namespaces do not nest functions
+                continue
+            if depth == 0 and not line.startswith((" ", "\t", "}", "#", "/")):
+                m = head.match(code.rstrip())
+                if m and "(" in code:
+                    func = m.group(1)
+            if "getenv(" in code:
+                where = func if depth > 0 or "{" in code else "<file scope>"
+                if depth == 0 and "=" in code and not code.rstrip().endswith("{"):
+                    where = "<file scope>"
+                assert where in ok, f"{name}:{ln}: getenv inside {where}() -- read it at setup into EnvSwitches / FirEnv"
+            depth += code.count("{") - code.count("}")
+            if depth == 0 and "}" in code:
+                func = "<file scope>"
+    # ... and the two functions every block goes through mention the snapshot, not the environment
+    src = open(os.path.join(csrc, "dspfx.hip")).read()
+    assert "e->env.mix_tail" in src and "e->env.xcd_remap" in src and "read_env_switches()" in src

@@ -264,3 +264,103 @@ def test_config5_as_specified_eight_shards_against_the_monolith(dspfx, tc):
         yc, _ = O.run_noise_channels(descs, SEED, c, 1, 0, blocks, link_flags=3)
         ref[:, i] = yc[:, 0]
     assert ulp_diff(got, ref).max() <= 1
+
+
+def test_seconds_slider_dragged_on_config5_shard_with_blocks_in_flight(dspfx, tc):
+    """Reverb::refresh_seconds (reverb.rs:55-71; run by the generated render() on every frame a drag moves the slider,
+    dsp-stuff-derive/src/lib.rs:560-568) on BASELINE config 5's shard: 1 048 576 channels x 5 nodes, the seconds slider
+    dragged 0.5 -> 0.25 -> 0.75 -> 0.5 -> 0.75 (24000 -> 12000 -> 36000 -> 24000 -> 36000 samples: a shrink, a growth BEYOND
+    the ring's capacity -- 94 more groups of 512 MiB, allocated by the storing thread --, a shrink, a growth WITHIN capacity)
+    from a second thread while 64 blocks are queued behind a busy stream.  Every store lands at a block boundary without the
+    thread that drives the blocks waiting for the device (the stream is still busy when the call that applied it returns);
+    sampled channels equal the oracle, with the stores at the blocks the engine logged, to <= 1 ulp."""
+    import threading
+    import time
+    from test_gpu_threads import _hold
+    torch = tc
+    N, B, tile = 1 << 20, 128, 256
+    chain = chain5(dspfx)
+    chain[2] = dspfx.Reverb(seconds=0.5, decay=0.5)
+    assert chain[2].delay_len == 24000
+    chans = sample_channels(N)
+    idx = torch.tensor(chans, device="cuda", dtype=torch.long)
+    eng = dspfx.Engine(N, B, link_flags=3, tile_channels=tile)
+    eng.set_chain(chain)
+    s = torch.cuda.Stream()
+    x = torch.empty(B * N, dtype=torch.float32, device="cuda")
+    y = torch.empty_like(x)
+    drag = [0.25, 0.75, 0.5, 0.75]
+    after = [110, 300, 200, 300]                      # blocks after each store: past one period of the new ring
+    total = 200 + sum(a + 128 for a in after)
+    got_dev = torch.empty((total, B, len(chans)), dtype=torch.float32, device="cuda")
+    busy_after, call_ms = [], []
+    k = 0
+
+    def block():
+        nonlocal k
+        eng.fill_noise(x, B, k * B, SEED, stream=s.cuda_stream)
+        t0 = time.perf_counter()
+        eng.process(x, out=y, n_frames=B, stream=s.cuda_stream)
+        call_ms.append((time.perf_counter() - t0) * 1e3)
+        busy_after.append(not s.query())
+        with torch.cuda.stream(s):
+            got_dev[k] = y.view(N // tile, B, tile)[idx // tile, :, idx % tile].transpose(0, 1)
+        k += 1
+
+    for _ in range(200):
+        block()
+    store_ms, seqs = [], []
+    for seconds, n_after in zip(drag, after):
+        go = threading.Event()
+
+        def gui_thread():
+            go.wait()
+            t0 = time.perf_counter()
+            seqs.append(eng.set_param_seq(2, 1, seconds))
+            store_ms.append((time.perf_counter() - t0) * 1e3)
+
+        t = threading.Thread(target=gui_thread)
+        t.start()
+        s.synchronize()
+        _hold(torch, s, 120)
+        for j in range(128):
+            block()
+            if j == 63:
+                go.set()                               # 64 blocks queued, none has run: now the other thread moves the slider
+        t.join()
+        for _ in range(n_after):
+            block()
+    s.synchronize()
+    assert k == total
+    log = eng.param_log()
+    assert [ev[0] for ev in log] == seqs and len(log) == 4
+    stores = {}
+    for (seq, frame, node, param, value), seconds in zip(log, drag):
+        assert (node, param, value) == (2, 1, np.float32(seconds)) and frame % B == 0
+        stores[frame // B] = seconds
+    # the call that applied a store did not wait for the device: the stream it queued on was still busy when it returned
+    # (the growth beyond capacity spends its time in the storing thread; by the time it is queued the hold may have run out)
+    for i, blk in enumerate(sorted(stores)):
+        if i != 1 and blk < total:
+            assert busy_after[blk], (i, blk)
+    landing = [call_ms[blk] for blk in sorted(stores) if blk < total]
+    print("\nseconds drag at 1 048 576 channels: store calls (storing thread) %s ms; the process calls that applied them %s ms; slowest process "
+          "call of all %.2f ms (block %d; median %.3f)" % (", ".join("%.2f" % m for m in store_ms), ", ".join("%.3f" % m for m in landing),
+                                                          max(call_ms), int(np.argmax(call_ms)), float(np.median(call_ms))))
+    assert max(landing) < 20.0, landing                # the call that swaps the ring in neither allocates nor waits for the device
+    assert "36000 samples in 282 of 282 groups" in eng.describe(), eng.describe()      # capacity: the longest ring so far
+    eng.close()
+    got = got_dev.cpu().numpy().reshape(total * B, len(chans))
+    descs = [n.oracle_desc() for n in chain]
+    ref = np.empty_like(got)
+    for i, c in enumerate(chans):
+        xs = O.noise(SEED, np.array([c]), np.arange(total * B))[:, 0]
+        nodes = [O.node_from_desc(d) for d in descs]
+        for blk in range(total):
+            if blk in stores:
+                nodes[2].set_param(1, stores[blk])
+            ref[blk * B:(blk + 1) * B, i] = O.chain_run(nodes, xs[blk * B:(blk + 1) * B], 3)
+    assert ulp_diff(got, ref).max() <= 1, ulp_diff(got, ref).max()
+    # the stores mattered: the echo of the 36000-sample ring is in the last phase
+    last = max(stores)
+    assert np.abs(ref[(last + 282) * B:]).max() > 0

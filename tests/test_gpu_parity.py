@@ -1942,7 +1942,7 @@ def test_reverb_fresh_node_and_seconds_slider_resize_the_ring(dspfx, torch_cuda)
     N, B = 96, 128
     for page_round in (False, True):
         chain = [dspfx.Gain(0.9), dspfx.Reverb(page_round=page_round), dspfx.LowPass(0.3)]
-        assert chain[1].delay_len == 128 and list(chain[1].params) == [0.5, 0.5]
+        assert chain[1].delay_len == (1024 if page_round else 128) and list(chain[1].params) == [0.5, 0.5]   # make_buffer(), either reading
         x = noise_block(N, B * 24)
         eng = dspfx.Engine(N, B, link_flags=3)
         eng.set_chain(chain)
@@ -1959,6 +1959,78 @@ def test_reverb_fresh_node_and_seconds_slider_resize_the_ring(dspfx, torch_cuda)
     assert len(eng.state_export(0)) == 4 * 64 * 128
     eng.set_param(0, 0, 0.5)
     assert len(eng.state_export(0)) == 4 * 64 * 24000
+    eng.close()
+
+
+@pytest.mark.parametrize("N,tile,variant,block", [
+    (192, 0, "static=0,f=8,cpl=1", 128),             # the interpreter
+    (512, 256, "static=1,f=8,cpl=2", 128),           # the statically specialised kernels, tiled
+    (256, 0, "static=1,f=16,cpl=1", 100),            # ragged blocks
+    (64 * 9, 64, "ts=1", 128),                       # the time-sliced kernel (group pointers from the host)
+    (64 * 5 + 17, 0, "ts=1", 128),                   # ... and its guarded form
+    (131, 0, None, 128),                             # defaults
+])
+def test_reverb_length_changes_reuse_the_rings_groups(dspfx, torch_cuda, monkeypatch, N, tile, variant, block):
+    """A ring is the first ceil(D / 128) of the node's 128-row groups (include/dspfx.h, dspfx_set_param): growing appends
+    groups (never zeroed: the lazy clear masks whatever they hold), shrinking keeps the surplus, growing again re-uses
+    groups still FULL of the longer ring's old echoes -- which must read as the zeros of refresh_seconds' new ring
+    (reverb.rs:55-71).  203 -> 1000 -> 300 -> 700 (inside the first clear's countdown) -> 2000 samples against the oracle,
+    in every kernel family; nothing waits for the device and the capacity only ever grows."""
+    if variant:
+        monkeypatch.setenv("DSPFX_VARIANT", variant)
+    chain = chain5(dspfx, 203)
+    ridx = 2
+    lens = [1000, 300, 700, 2000]
+    at, k = {}, 4
+    for i, D in enumerate(lens):
+        at[k] = D
+        k += (2 if i == 1 else D // block + 3)       # the third change lands while the second one's clear is still counting
+    nblocks = k + 4
+    x = noise_block(N, block * nblocks)
+    eng = dspfx.Engine(N, block, link_flags=3, tile_channels=tile)
+    eng.set_chain(chain)
+    gpu = {kk: (lambda e, D=D: e.set_delay_len(ridx, D)) for kk, D in at.items()}
+    orc = {kk: (lambda ns, D=D: ns[ridx].set_delay_len(D)) for kk, D in at.items()}
+    y = _run_with_stores(dspfx, torch_cuda, eng, x, gpu, block, tile)
+    ref = _oracle_with_stores(chain, x, orc, block)
+    assert ulp_diff(y, ref).max() <= 1, (ulp_diff(y, ref).max(), np.argwhere(ulp_diff(y, ref) > 1)[:4])
+    assert "2000 samples in 16 of 16 groups" in eng.describe(), eng.describe()
+    eng.set_delay_len(ridx, 128)
+    assert "128 samples in 1 of 16 groups" in eng.describe(), eng.describe()
+    eng.ring_trim()
+    assert "128 samples in 1 of 1 groups" in eng.describe(), eng.describe()
+    eng.close()
+
+
+def test_reverb_seconds_store_that_cannot_be_had_leaves_the_node_alone(dspfx, torch_cuda):
+    """a seconds store whose ring does not fit the device fails on the STORING thread with DSPFX_ERR_OOM, before
+    anything is queued: the node keeps ring, length and slider, and goes on processing; a value outside the slider's 0..=1
+    (reverb.rs:34-37) is DSPFX_ERR_INVALID.  4 194 304 channels: one 128-row group is 2 GiB, one second would be 750 GiB."""
+    torch = torch_cuda
+    N, B = 1 << 22, 128
+    eng = dspfx.Engine(N, B, link_flags=0)
+    eng.set_chain([dspfx.Reverb()])                    # menu-fresh: 128 samples under a 0.5 s slider; 376 GiB cannot be reserved
+    assert "128 samples in 1 of 1 groups" in eng.describe() and "(+0 reserved)" in eng.describe(), eng.describe()
+    x = torch.zeros((B, N), dtype=torch.float32, device="cuda")
+    x[0, :] = 1.0
+    y = torch.empty_like(x)
+    eng.process(x, out=y, n_frames=B)
+    with pytest.raises(dspfx.DspfxError) as ei:
+        eng.set_param(0, 1, 1.0)
+    assert ei.value.status == -4 and "no room" in str(ei.value), ei.value
+    for bad in (1.5, -0.1, float("nan")):
+        with pytest.raises(dspfx.DspfxError) as ei:
+            eng.set_param(0, 1, bad)
+        assert ei.value.status == -1
+    assert eng.param_log() == []
+    x.zero_()
+    eng.process(x, out=y, n_frames=B)                  # the 128-sample ring is still there: the impulse comes back halved
+    torch.cuda.synchronize()
+    assert float(y[0].min()) == 0.5 and float(y[0].max()) == 0.5 and float(y[1:].abs().max()) == 0.0
+    with pytest.raises(dspfx.DspfxError):              # `decay` on this node asks for the half-second ring too (lib.rs:560-568)
+        eng.set_param(0, 0, 0.25)
+    eng.set_param(0, 1, 0.004)                         # a ring that fits: 192 samples, two groups
+    assert "192 samples in 2 of 2 groups" in eng.describe(), eng.describe()
     eng.close()
 
 

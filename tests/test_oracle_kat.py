@@ -476,6 +476,10 @@ def test_kat13_reverb_fresh_node_becomes_a_half_second_delay_at_its_first_slider
         assert list(echo_at(node, 3)) == [3, 131, 259]               # a 128-sample delay
         node.set_param(0, 0.5)                                       # "changed" even to the same value: a new ring, 24000 long
         assert list(echo_at(node, 190)) == [3, 24003]
+    for node in _both(O.REVERB, [0.5, 0.5], mode=1):                 # fresh from the menu under the page-rounded reading: make_buffer()
+        assert list(echo_at(node, 17)) == [3, 1027, 2051]            # is refresh_seconds' three rivulet calls with 128 -> 1024 samples
+        node.set_param(0, 0.5)
+        assert list(echo_at(node, 193)) == [3, 24579]                # ... and the half second is 24576
     for node in _both(O.REVERB, [0.5, 0.01], restored=True):         # restored with seconds = 0.01: 480 samples
         assert list(echo_at(node, 5)) == [3, 483]
     for node in _both(O.REVERB, [0.5, 0.01], mode=1, restored=True):  # the page-rounded reading: 1024
