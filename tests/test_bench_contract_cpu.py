@@ -43,3 +43,35 @@ def test_headline_record_names_the_baseline_metric():
     assert d["unit"] == "samples/s" and "samples/sec" in d["metric"]
     assert d["roofline"]["traffic"] and 0.9 < d["roofline"]["traffic"] / (16.5 * (1 << 20) * 128) < 1.1
     assert isinstance(base, dict)
+
+
+def test_the_printed_line_fits_the_drivers_stdout_tail():
+    """The driver keeps the last 8 KB of stdout (BENCH_r04: the line was 16 KB and cfg3 fell off the front).  bench.py prints
+    compact_line(full record): every contract field unchanged, every config's numbers, under 7 KB; the full record goes to
+    stderr and gpurun_out/."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = 0
+    for path, d in _records():
+        if "other_configs" not in d:
+            continue
+        seen += 1
+        c = bench.compact_line(d)
+        text = json.dumps(c)
+        assert len(text) < 7000, (path, len(text))
+        for k in REQUIRED:
+            assert k in c, (path, k)
+            if not isinstance(d[k], (dict, list)):
+                assert c[k] == d[k], (path, k)
+        assert c["roofline"]["frac"] == pytest_approx(d["roofline"]["frac"]) and c["roofline"]["bound"] == d["roofline"]["bound"]
+        assert set(c["other_configs"]) == set(d["other_configs"])
+        for name, o in d["other_configs"].items():
+            if "error" not in o:
+                assert c["other_configs"][name]["roofline"]["kernel"] == o["roofline"]["kernel"]
+    assert seen >= 1
+
+
+def pytest_approx(v):
+    import pytest
+    return pytest.approx(v, rel=1e-6)

@@ -841,12 +841,15 @@ from __graft_entry__ import load_package
 import chains
 fx = load_package()
 rank, world, uid, outdir, N, blocks, exact = int(sys.argv[1]), int(sys.argv[2]), bytes.fromhex(sys.argv[3]), sys.argv[4], int(sys.argv[5]), int(sys.argv[6]), sys.argv[7] == "1"
+dev = int(sys.argv[8]) if len(sys.argv) > 8 else 0      # all ranks on device 0 (the mailbox backend does not mind), or one device each
+backend = sys.argv[9] if len(sys.argv) > 9 else "mailbox"
+torch.cuda.set_device(dev)
 B = 128
 n_loc = N // world
-eng = fx.Engine(n_loc, B, link_flags=0 if exact else 3, channel_offset=rank * n_loc, tile_channels=256)
+eng = fx.Engine(n_loc, B, link_flags=0 if exact else 3, channel_offset=rank * n_loc, tile_channels=256, device=dev)
 eng.set_chain([fx.Gain(1.0)] if exact else chains.chain5(fx, 256))
-comm = fx.Comm(0, world, rank, uid)                     # both ranks on device 0: the mailbox backend does not mind
-assert comm.backend == "mailbox", comm.backend
+comm = fx.Comm(dev, world, rank, uid)
+assert comm.backend == backend, comm.backend
 s = torch.cuda.Stream()
 x = torch.empty(B * n_loc, device="cuda"); y = torch.empty_like(x)
 bus = torch.zeros((blocks, B), device="cuda")
@@ -865,7 +868,7 @@ with torch.cuda.stream(s):
 s.synchronize()
 np.save("%s/bus%d.npy" % (outdir, rank), bus.cpu().numpy())
 us = sorted(1e3 * a.elapsed_time(b) for a, b in ev[4:])
-print(json.dumps(dict(rank=rank, backend=comm.backend, us_p50=us[len(us) // 2], us_min=us[0])))
+print(json.dumps(dict(rank=rank, device=dev, backend=comm.backend, us_p50=us[len(us) // 2], us_min=us[0], us_max=us[-1])))
 comm.close()
 """
 
