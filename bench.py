@@ -608,7 +608,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
                     "achieved": ex_rate, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ex_rate / MFMA_BF16_PEAK_TFLOPS,
                     "algorithmic_tflops": achieved, "algorithmic_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
                     "note": "power-limited: shader clock 1.79-1.82 GHz under this kernel, matrix pipe 70-71 % busy (profiles/r03_fir_split_pmc.json)"}
-        if kern_name == "fir_half_kernel":
+        if kern_name in ("fir_half_kernel", "fir_halfp_kernel"):
             # two-part f16: every f32 operand as f16 hi + f16 lo, THREE f16 MFMAs (32x32x16) per 16 taps and 32x32 tile.  Half the
             # matrix-pipe time of the bf16 x 3 sweep: the sweep now sits between its two roofs, so both fractions are given and
             # `bound` names the nearer one -- HBM: the sweep's own algorithmic bytes (the window's (T - 1 + B) rows re-read + the
@@ -629,8 +629,8 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
                          "frac_hbm": f_hbm, "hbm_gbps": hbm_rate, "sweep_bytes_per_launch": sweep_bytes,
                          "frac_f16_mfma": f_mfma, "executed_tflops": ex_rate,
                          "algorithmic_tflops": achieved, "algorithmic_over_f32_mfma_peak": achieved / MFMA_F32_PEAK_TFLOPS,
-                         "note": "power-limited: shader clock 1.57 GHz under this kernel, matrix pipe 58 % busy, HBM traffic 1.05 x the sweep's "
-                                 "algorithmic bytes (profiles/r04_fir_half_pmc.json: counter passes of this build)"})
+                         "note": "fir_halfp_kernel = the sweep over the packed {f16 hi, f16 lo} history the append pass writes (round 5); "
+                                 "counters: profiles/r05_fir_halfp_pmc.json"})
     else:
         achieved = bps * N * B / (kern_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -643,7 +643,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     if os.path.exists(tr):
         try:
             t = json.load(open(tr))
-            ent = t.get(f"{cfg_name}{'split' if kern_name == 'fir_split_kernel' else 'half' if kern_name == 'fir_half_kernel' else ''}:{N}:{B}")
+            ent = t.get(f"{cfg_name}{'split' if kern_name == 'fir_split_kernel' else 'half' if kern_name in ('fir_half_kernel', 'fir_halfp_kernel') else ''}:{N}:{B}")
             if ent:
                 roof["traffic"] = ent["hbm_bytes_per_launch"]
                 roof["traffic_source"] = ent.get("source")

@@ -48,11 +48,24 @@ struct FirEnv {
     int split = -1;    // DSPFX_FIR_SPLIT=0: nodes left at the default precision take the f32 sweep
     int half = -1;     // DSPFX_FIR_HALF=0: ... the bf16 x 3 sweep
     int dist = -1;     // DSPFX_FIR_DIST=1: history chunks requested one iteration ahead (A/B)
+    int slots = -1;    // DSPFX_FIR_SLOTS=12|16: register slots of the packed sweep's chunk ring (A/B)
+    int packed = -1;   // DSPFX_FIR_PACKED=0: the two-part f16 sweep splits the f32 history itself (round 4's form; A/B, bisecting)
 };
 
 struct FirState {
     FirEnv env;
     float *ring = nullptr;        // [ceil(N/32)] tiles of R * 32 + 32 floats
+    // The two-part f16 sweep's own copy of the history (round 5): every sample ALREADY split into f16 hi + f16 lo of x 2^14, laid out
+    // like `ring` (same tile stride, same 2 KiB chunks) but in MFMA operand order -- chunk = [part hi | lo][kh][channel][4 dwords],
+    // a dword = the parts of two consecutive rows -- so the sweep's two 16-byte loads per lane and chunk ARE its B operands; and
+    // the per-channel peak |x 2^14| of every 128 sample times (an "epoch": slot = epoch mod peak_slots), which the sweep reduces
+    // over its window (<= 34 entries) instead of scanning every sample.  Written by the append pass (fir_append2_kernel); any other
+    // writer of `ring` (state import, a tap reload that re-bases the ring, placement tuning's unpark) clears packed_ok and the next
+    // block rebuilds both from `ring` (fir_repack_kernel).  Null when the two-part sweep cannot serve this filter.
+    unsigned *ringh = nullptr;
+    float *peaks = nullptr;       // [tiles][peak_slots][32]
+    uint32_t peak_slots = 0;
+    bool packed_ok = false;
     double *taps64 = nullptr;     // [T] reversed, as fir.rs stores them
     float *taps32 = nullptr;      // [pad_lo + T + pad_hi] zero-padded f32 copy for the MFMA path
     unsigned *taps_split = nullptr;   // split-precision sweep: [3][ntp4] bf16 pair tables of the same padded taps (or null)

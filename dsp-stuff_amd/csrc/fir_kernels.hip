@@ -97,6 +97,157 @@ __global__ void __launch_bounds__(256) fir_append_kernel(const float *in, float 
 // pieces that can hold rows of a block of nframes starting anywhere in a 16-row group
 static uint32_t append_pieces(uint32_t row0, uint32_t nframes) { return (((row0 & 15u) + nframes + KC - 1) / KC) * 4; }
 
+// ---- the append pass of the two-part f16 sweep: f32 ring + packed {hi, lo} ring + per-epoch peaks ----------------------
+// the sweep re-split every sample into f16 hi / lo and re-scanned it for its peak in EVERY block it stayed in
+// the window -- 33 times at 4096 taps -- inside a kernel that runs at the socket's power limit.  The experiment build that fed the
+// matrix pipe unsplit bits ran 15 % faster (0.873 -> 0.742 ms, 0.77 of the HBM peak: profiles/r05_fir_packed.txt).  So the
+// split happens ONCE, here: beside the f32 ring (which the bf16 x 3 / exact passes, state export and tap reloads keep using) the
+// block's samples go into a second ring already in the sweep's operand form (FirState::ringh), and each channel's peak over the
+// 128 sample times of an "epoch" into a small table.  +4 bytes per sample for this pass, -(33 x the split) for the sweep.
+// One thread = one channel x one epoch's part of the block (<= 128 consecutive sample times), walked in half chunks of 8 rows:
+// the f32 ring gets two 16-byte pieces, the packed ring the lane's 16 bytes of hi parts and 16 bytes of lo parts per half chunk.
+constexpr uint32_t EPOCH = 128;
+__host__ __device__ __forceinline__ size_t ringh_at(uint32_t tile, uint32_t row8, uint32_t cl, uint32_t R) {   // dword index of the hi parts of rows row8 .. row8 + 7 (row8 % 8 == 0)
+    return (size_t)tile * ring_tile_stride(R) + (size_t)(row8 >> 4) * (KC * TILE_C) + ((row8 >> 3) & 1) * 128 + cl * 4;
+}
+constexpr float HALF_APPEND_SCALE = 0x1p14f;
+typedef float ap_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ap_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned pack_f16_pair(float a, float b) {     // v_cvt_pk_f16_f32: round to nearest even
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const h2 p = __builtin_convertvector(f2{a, b}, h2);
+    unsigned u;
+    __builtin_memcpy(&u, &p, 4);
+    return u;
+}
+__device__ __forceinline__ float f16_lo_value(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u & 0xffffu)); }
+__device__ __forceinline__ float f16_hi_value(unsigned u) { return (float)__builtin_bit_cast(_Float16, (unsigned short)(u >> 16)); }
+// eight scaled samples (K order) -> hi[4], lo[4] dwords; non-finite / huge samples (already replaced by 0 by the caller) never get here
+__device__ __forceinline__ void split8_packed(const float (&x)[8], unsigned (&hi)[4], unsigned (&lo)[4]) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const float a = x[2 * d] * HALF_APPEND_SCALE, b = x[2 * d + 1] * HALF_APPEND_SCALE;
+        const unsigned h = pack_f16_pair(a, b);
+        hi[d] = h;
+        lo[d] = pack_f16_pair(a - f16_lo_value(h), b - f16_hi_value(h));      // exact differences (<= 13 significant bits)
+    }
+}
+struct FirAppend2Args {
+    const float *in;
+    float *ring;
+    unsigned *ringh;
+    float *peaks;
+    unsigned long long *nf_time;
+    uint32_t N, nframes, R, peak_slots;
+    unsigned long long n0;        // absolute time of the block's first frame
+    int hop;
+    float hop_div;
+    Layout lay;
+};
+// A workgroup = 64 consecutive channels x four waves; wave w takes the epoch part's half chunks w, w + 4, w + 8, ... (so the four
+// waves stream neighbouring rows at the same time and there are four times the loads in flight of one thread per channel: the
+// first form of this kernel, one thread per channel walking all 128 rows, moved 4.6 TB/s); the four partial peaks meet in LDS.
+constexpr int APPEND2_CH = 64;
+__global__ void __launch_bounds__(256) fir_append2_kernel(const FirAppend2Args a) {
+    __shared__ float part_peak[4][APPEND2_CH];
+    const uint32_t w = threadIdx.x >> 6, ch = threadIdx.x & 63;
+    const uint32_t c = blockIdx.x * APPEND2_CH + ch;
+    const bool c_ok = c < a.N;
+    const unsigned long long E = a.n0 / EPOCH + blockIdx.y;
+    const unsigned long long t_end = a.n0 + a.nframes;
+    const unsigned long long ta = E * EPOCH > a.n0 ? E * EPOCH : a.n0, tb = (E + 1) * EPOCH < t_end ? (E + 1) * EPOCH : t_end;
+    const uint32_t tile = c >> 5, cl = c & 31;
+    const float *__restrict__ in = a.in;
+    float *__restrict__ ring = a.ring;
+    unsigned *__restrict__ ringh = a.ringh;
+    float peak = 0.0f;
+    if (c_ok)
+    for (unsigned long long h = (ta & ~7ull) + 8 * w; h < tb; h += 32) {
+        float x[8];
+        bool ok[8];
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned long long t = h + k;
+            ok[k] = t >= ta && t < tb;
+            all = all && ok[k];
+            x[k] = ok[k] ? __builtin_nontemporal_load(in + a.lay.at((uint32_t)(t - a.n0), c)) : 0.0f;
+        }
+        float xs[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (a.hop) x[k] = (0.0f + x[k]) / a.hop_div;
+            const bool fin = finite_f32(x[k]);
+            if (ok[k] && !fin) atomicMax(&a.nf_time[tile], h + k + 1);
+            xs[k] = fin ? x[k] : 0.0f;                    // the packed ring never holds a non-finite part: such tiles are redone exactly
+            if (ok[k]) peak = __builtin_fmaxf(peak, fin ? __builtin_fabsf(x[k]) * HALF_APPEND_SCALE : __builtin_inff());
+        }
+        const uint32_t r = (uint32_t)(h % a.R);          // R % 16 == 0 and h % 8 == 0: the eight rows share a chunk
+        float *dst = ring + ring_at(c, r, a.R);          // rows r .. r+3, and r+4 .. r+7 one piece (256 floats) further
+        unsigned hi[4], lo[4];
+        split8_packed(xs, hi, lo);
+        unsigned *ph = ringh + ringh_at(tile, r, cl, a.R);
+        if (all) {
+            __builtin_nontemporal_store(ap_f32x4{x[0], x[1], x[2], x[3]}, (ap_f32x4 *)dst);
+            __builtin_nontemporal_store(ap_f32x4{x[4], x[5], x[6], x[7]}, (ap_f32x4 *)(dst + 256));
+            __builtin_nontemporal_store(ap_u32x4{hi[0], hi[1], hi[2], hi[3]}, (ap_u32x4 *)ph);
+            __builtin_nontemporal_store(ap_u32x4{lo[0], lo[1], lo[2], lo[3]}, (ap_u32x4 *)(ph + 256));
+        } else {                                         // a block that starts or ends inside the half chunk: element by element
+            unsigned short *ph16 = (unsigned short *)ph, *pl16 = (unsigned short *)(ph + 256);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (ok[k]) {
+                    dst[(k >> 2) * 256 + (k & 3)] = x[k];
+                    ph16[k] = (unsigned short)(hi[k >> 1] >> (16 * (k & 1)));
+                    pl16[k] = (unsigned short)(lo[k >> 1] >> (16 * (k & 1)));
+                }
+        }
+    }
+    part_peak[w][ch] = peak;
+    __syncthreads();
+    if (w != 0 || !c_ok || ta >= tb) return;
+    peak = __builtin_fmaxf(__builtin_fmaxf(part_peak[0][ch], part_peak[1][ch]), __builtin_fmaxf(part_peak[2][ch], part_peak[3][ch]));
+    // the epoch's peak: begun by the call that holds its first sample time, merged by the calls that continue it
+    float *pk = a.peaks + ((size_t)tile * a.peak_slots + (uint32_t)(E % a.peak_slots)) * TILE_C + cl;
+    if (E * EPOCH < a.n0) peak = __builtin_fmaxf(peak, *pk);
+    *pk = peak;
+}
+// `ring` -> `ringh` + `peaks` for the sample times [t_lo, t_hi): after anything but the append pass wrote the f32 ring
+__global__ void __launch_bounds__(256) fir_repack_kernel(const float *ring, unsigned *ringh, float *peaks, uint32_t N, uint32_t R, uint32_t peak_slots,
+                                                         unsigned long long t_lo, unsigned long long t_hi) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    const uint32_t tile = c >> 5, cl = c & 31;
+    for (unsigned long long E = t_lo / EPOCH + blockIdx.y; E * EPOCH < t_hi; E += gridDim.y) {
+        const unsigned long long ta = E * EPOCH > t_lo ? E * EPOCH : t_lo, tb = (E + 1) * EPOCH < t_hi ? (E + 1) * EPOCH : t_hi;
+        float peak = 0.0f;
+        for (unsigned long long h = ta & ~7ull; h < tb; h += 8) {
+            const uint32_t r = (uint32_t)(h % R);
+            const float *src = ring + ring_at(c, r, R);
+            float xs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float v = src[(k >> 2) * 256 + (k & 3)];
+                const bool in = h + k >= ta && h + k < tb, fin = finite_f32(v);
+                xs[k] = in && fin ? v : 0.0f;
+                if (in) peak = __builtin_fmaxf(peak, fin ? __builtin_fabsf(v) * HALF_APPEND_SCALE : __builtin_inff());
+            }
+            unsigned hi[4], lo[4];
+            split8_packed(xs, hi, lo);
+            unsigned *ph = ringh + ringh_at(tile, r, cl, R);
+            unsigned short *ph16 = (unsigned short *)ph, *pl16 = (unsigned short *)(ph + 256);
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (h + k >= ta && h + k < tb) {
+                    ph16[k] = (unsigned short)(hi[k >> 1] >> (16 * (k & 1)));
+                    pl16[k] = (unsigned short)(lo[k >> 1] >> (16 * (k & 1)));
+                }
+        }
+        peaks[((size_t)tile * peak_slots + (uint32_t)(E % peak_slots)) * TILE_C + cl] = peak;
+    }
+}
+
 // ---- exact path ---------------------------------------------------------------------------------------------
 // One lane per (frame, channel); a workgroup = one 32-channel tile x 8 frames.  Output f of the slice sees the
 // deque with front F = front0 + dfront[f] and n - F + 1 samples (n = n0 + f); its first physical slice holds
@@ -219,6 +370,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct FirMfmaArgs {
     const float *ring;
+    const unsigned *ringh; // two-part f16 sweep: the packed {hi, lo} history (FirState::ringh), or null: split the f32 history in the sweep
+    const float *peaks;    // ... and the per-epoch channel peaks [tiles][peak_slots][32]
+    uint32_t peak_slots;
     const float *taps;     // [pad_lo + T + pad_hi], zeros in the pads
     const unsigned *taps_split;   // split-precision sweep: [3][ntp4] bf16 pair tables (entry m: parts of taps m, m + 1)
     const unsigned *taps_half;    // two-part f16 sweep: [2][ntp4] f16 pair tables of the taps scaled by a power of two
@@ -779,6 +933,15 @@ __device__ __forceinline__ float sub_f16_hi(float a, unsigned h) {
     return r;
 }
 __device__ __forceinline__ void split4h(const f32x4 &v, u32x4 (&p)[2], const int half, float &peak) {
+#ifdef DSPFX_HALF_NOSPLIT      // experiment build ONLY (tools/r05_fir_nosplit_ab.sh): what would the sweep cost if the history arrived already split
+    // into packed f16 parts (a second ring written by the append pass)?  The f32 bits are fed to the matrix pipe as they are --
+    // the results are garbage, the instruction stream is the packed-ring sweep's: an upper bound on what that design can gain.
+    p[0][2 * half] = __float_as_uint(v[0]);
+    p[0][2 * half + 1] = __float_as_uint(v[1]);
+    p[1][2 * half] = __float_as_uint(v[2]);
+    p[1][2 * half + 1] = __float_as_uint(v[3]);
+    return;
+#endif
     const float a = v[0] * HALF_X_SCALE, b = v[1] * HALF_X_SCALE, c = v[2] * HALF_X_SCALE, d = v[3] * HALF_X_SCALE;
     const unsigned h0 = pack_f16(a, b), h1 = pack_f16(c, d);
     const unsigned l0 = pack_f16(sub_f16_lo(a, h0), sub_f16_hi(b, h0)), l1 = pack_f16(sub_f16_lo(c, h1), sub_f16_hi(d, h1));
@@ -932,6 +1095,140 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
                       [&](int jt, int r) { return (jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]) * us; });
 }
 
+// ---- the same sweep over the PACKED history (round 5) -------------------------------------------------------------------------
+// The history arrives already split (FirState::ringh, written by fir_append2_kernel): a chunk's two 16-byte loads per lane ARE the two
+// B operands -- no conversion, no subtraction, no peak scan in the loop (fir_half_kernel does ~30 vector-ALU instructions per lane
+// and chunk for them, 33 times per sample at 4096 taps, inside a power-limited kernel); the window's peak per channel comes from
+// the append pass' epoch table.  With nothing to do to a chunk when it arrives, the window and the chunks in flight share ONE ring
+// of NS register slots that the loads write directly: chunk m lives in slot m % NS from its load (iteration m - NS + 1) to its
+// last use (iteration m), the unrolled body has NS iterations, and D = NS - 8 chunks are in flight behind the seven live ones.
+template <int NS>
+__global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) fir_halfp_kernel(const FirMfmaArgs a) {
+    constexpr int NJT = 4, WIN = 2 * (NJT - 1) + 1, D = NS - WIN - 1;
+    constexpr int HF = (FLUSH + NS - 1) / NS * NS;          // chunks per accumulator flush: a multiple of the unroll period (36 / 32)
+    static_assert(D >= 2 && NS % 2 == 0, "ring of chunk slots");
+    if (a.mp.stage) fir_mixpipe_prologue(a);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.redo_clear = 0u;                  // the next block's list starts empty
+    extern __shared__ unsigned tps[];          // [2][ntp4] pair tables, then the totals of tiles 1..3 per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntp = (int)(PAD_LO + a.T + PAD_HI), ntp4 = (ntp + 3) & ~3;
+    for (int i = tid; i < 2 * ntp4; i += 64 * SPLIT_WAVES) tps[i] = a.taps_half[i];
+    __syncthreads();
+    const uint32_t tile = blockIdx.x * SPLIT_WAVES + wave;
+    if ((size_t)tile * TILE_C >= a.N) return;
+    const int cl = lane & 31, kh = lane >> 5;
+    const uint32_t c = tile * TILE_C + cl;
+    const bool c_ok = c < a.N;
+    const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;      // table index of (iteration i, K element e) = wofs + 16 i + e
+    const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
+
+    // the window's peak per channel: the epochs that hold the sample times [max(t_k0, 0), t_k0 + kvalid) -- at most 34 entries of
+    // 128 bytes per tile; the channel's two lanes take every other one
+    float peak = 0.0f;
+    {
+        const long long t_last = a.t_k0 + (long long)a.kvalid - 1;
+        if (t_last >= 0) {
+            const unsigned long long e_lo = (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0) / EPOCH, e_hi = (unsigned long long)t_last / EPOCH;
+            const float *pk = a.peaks + (size_t)tile * a.peak_slots * TILE_C + cl;
+            for (unsigned long long e = e_lo + kh; e <= e_hi; e += 2) peak = __builtin_fmaxf(peak, pk[(size_t)(e % a.peak_slots) * TILE_C]);
+        }
+    }
+
+    f32x16 acc[NJT], tot0;
+    f32x4 *tl = (f32x4 *)(tps + 2 * (size_t)ntp4) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot0[r] = 0.0f;
+#pragma unroll
+    for (int jt = 0; jt < NJT; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[jt][r] = 0.0f;
+#pragma unroll
+    for (int q = 0; q < (NJT - 1) * 4; ++q) tl[q * 64] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // (the two rings share tile stride and chunk geometry: the lane's offset inside a chunk is the same in both)
+    const unsigned *hlane = a.ringh + (size_t)tile * ring_tile_stride(a.R) + (size_t)(kh * 32 + cl) * 4;
+    auto load_chunk = [&](uint32_t m, u32x4 (&h)[2]) {     // unconditional: past the sweep's end some unused rows of the ring
+        uint32_t row0 = a.rb + m * KC;                     // < 2R
+        row0 = row0 >= a.R ? row0 - a.R : row0;
+        const u32x4 *p = (const u32x4 *)(hlane + (size_t)row0 * TILE_C);
+        h[0] = __builtin_nontemporal_load(p);              // the hi parts of the lane's eight rows
+        h[1] = __builtin_nontemporal_load(p + 64);         // the lo parts
+    };
+    auto mask_tail = [&](uint32_t m, u32x4 (&h)[2]) {      // rows past the block's newest sample are stale: dword d holds K elements 2 d, 2 d + 1
+        const uint32_t kc = m * KC;
+        if (kc + KC > a.kvalid) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const unsigned keep = (kc + 8 * kh + 2 * d < a.kvalid ? 0x0000ffffu : 0u) | (kc + 8 * kh + 2 * d + 1 < a.kvalid ? 0xffff0000u : 0u);
+                h[0][d] &= keep;
+                h[1][d] &= keep;
+            }
+        }
+    };                                                      // (non-finite samples were written as zeros by the append pass)
+    auto wload = [&](uint32_t i, u32x4 (&w)[2]) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w[sp][e] = tps[sp * ntp4 + wofs + (int)(i * KC) + 2 * e];
+    };
+    u32x4 buf[NS][2];
+    static_for<0, NS - 1>([&](auto m) { load_chunk(m.value, buf[m.value]); });          // chunks 0 .. WIN + D - 1
+    static_for<0, WIN>([&](auto m) { mask_tail(m.value, buf[m.value]); });
+    u32x4 wq[2][2];
+    wload(0, wq[0]);
+
+    auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { tot0[r] = tot0[r] + acc[0][r]; acc[0][r] = 0.0f; }
+#pragma unroll
+        for (int jt = 1; jt < NJT; ++jt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 t = tl[((jt - 1) * 4 + q) * 64];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { t[e] = t[e] + acc[jt][q * 4 + e]; acc[jt][q * 4 + e] = 0.0f; }
+                tl[((jt - 1) * 4 + q) * 64] = t;
+            }
+    };
+    // iteration i, i mod NS == P: three groups of NJT MFMAs (one per product term) on the chunks i, i + 2, i + 4, i + 6
+    auto iter = [&](auto p_c, uint32_t i) __attribute__((always_inline)) {
+        constexpr int P = decltype(p_c)::value;
+        if constexpr (P == 0) {                            // the flush inside the unrolled body: see fir_skew_kernel
+            if (i != 0 && i % HF == 0) flush();
+        }
+        constexpr int TX[3] = {0, 0, 1}, TH[3] = {0, 1, 0};                        // x part, h part of the three terms
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 0) mask_tail(i + WIN, buf[(P + WIN) % NS]);                   // chunk i + WIN is first used by the next iteration
+            if (t == 1) load_chunk(i + NS - 1, buf[(P + NS - 1) % NS]);            // into the slot chunk i - 1 has just left
+            if (t == 2) wload(i + 1, wq[(P + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int jt = 0; jt < NJT; ++jt)
+                acc[jt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(wq[P & 1][TH[t]]), as_f16x8(buf[(P + 2 * jt) % NS][TX[t]]), acc[jt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    uint32_t i = 0;
+    for (; i + NS <= n_iter; i += NS) static_for<0, NS>([&](auto p) { iter(p, i + p.value); });
+    if (i < n_iter) {                                      // fewer than NS left
+        const uint32_t rest = n_iter - i;
+        static_for<0, NS - 1>([&](auto p) {
+            if ((uint32_t)p.value < rest) iter(p, i + p.value);
+        });
+    }
+    flush();
+    // Could this sweep serve every channel of the tile?  (The peak covers whole 128-sample epochs, up to 127 samples older than
+    // the window: conservative.)  A non-finite sample makes its epoch's peak infinite: listed too (and redone exactly besides).
+    peak = __builtin_fmaxf(peak, __shfl_xor(peak, 32));                            // the channel's two lanes
+    const bool ok = peak == 0.0f || (peak >= HALF_PEAK_MIN && peak <= HALF_PEAK_MAX);
+    if (__ballot(ok) != ~0ull && lane == 0) a.redo_tiles[atomicAdd(a.redo_count, 1u)] = tile;
+    const float us = a.half_unscale;
+    fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
+                      [&](int jt, int r) { return (jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]) * us; });
+}
+
 // old ring -> new ring for the sample times [t_begin, t_end): a tap reload that needs more rows
 __global__ void __launch_bounds__(256) fir_rebase_kernel(const float *src, float *dst, uint32_t tiles, uint32_t R_src, uint32_t R_dst,
                                                          unsigned long long t_begin, unsigned long long t_end) {
@@ -1004,6 +1301,27 @@ static size_t half_lds_bytes(uint32_t n_taps) {
 static size_t tap_table_bytes(uint32_t n_taps) { return ((size_t)PAD_LO + n_taps + PAD_HI) * sizeof(float); }
 static size_t skew_lds_bytes(uint32_t n_taps, int) { return tap_table_bytes(n_taps); }
 
+static void free_packed(FirState &s) {
+    if (s.ringh) (void)hipFree(s.ringh);
+    if (s.peaks) (void)hipFree(s.peaks);
+    s.ringh = nullptr;
+    s.peaks = nullptr;
+    s.peak_slots = 0;
+    s.packed_ok = false;
+}
+// the packed history + peak table for a ring of s.R rows (zeroed: consistent with an empty or all-zero f32 ring only)
+static int alloc_packed(FirState &s) {
+    free_packed(s);
+    if (s.env.packed == 0) return 0;
+    const size_t bytes = ring_bytes_for(s.tiles, s.R);
+    s.peak_slots = s.R / EPOCH + 3;
+    FIRCHK(hipMalloc((void **)&s.ringh, bytes));
+    FIRCHK(hipMemset(s.ringh, 0, bytes));
+    FIRCHK(hipMalloc((void **)&s.peaks, (size_t)s.tiles * s.peak_slots * TILE_C * sizeof(float)));
+    FIRCHK(hipMemset(s.peaks, 0, (size_t)s.tiles * s.peak_slots * TILE_C * sizeof(float)));
+    return 0;
+}
+
 static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps) {
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
@@ -1072,6 +1390,8 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
             FIRCHK(hipMalloc((void **)&s.taps_half, tab.size() * sizeof(uint32_t)));
             FIRCHK(hipMemcpy(s.taps_half, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             FIRCHK(hipFuncSetAttribute((const void *)fir_half_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)half_lds_bytes(n_taps)));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_halfp_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)half_lds_bytes(n_taps)));
+            FIRCHK(hipFuncSetAttribute((const void *)fir_halfp_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)half_lds_bytes(n_taps)));
         }
     }
     // DSPFX_FIR_KERNEL: 0 = exact f64 VALU kernel, 1 = MFMA; default MFMA unless the filter is tiny
@@ -1093,6 +1413,17 @@ static int upload_taps(FirState &s, const double *taps_reversed, uint32_t n_taps
         if (sk2 > 64 * 1024 && sk2 <= LDS_PER_CU)
             FIRCHK(hipFuncSetAttribute((const void *)fir_skew_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sk2));
     }
+    // the two-part f16 sweep can serve this filter: it gets its own packed copy of the history (FirState::ringh).  A ring that
+    // already holds samples (a tap reload) is re-packed by the next block.
+    if (s.kernel == 1 && s.taps_half && s.redo) {
+        if (!s.ringh) {
+            const int rc = alloc_packed(s);
+            if (rc) return rc;
+            s.packed_ok = s.n_seen == 0;
+        }
+    } else {
+        free_packed(s);
+    }
     return 0;
 }
 
@@ -1111,6 +1442,8 @@ int fir_configure(FirState &s, const double *taps_reversed, uint32_t n_taps, int
         s.env.split = env_int("DSPFX_FIR_SPLIT");
         s.env.half = env_int("DSPFX_FIR_HALF");
         s.env.dist = env_int("DSPFX_FIR_DIST");
+        s.env.packed = env_int("DSPFX_FIR_PACKED");
+        s.env.slots = env_int("DSPFX_FIR_SLOTS");
     }
     s.N = N;
     s.max_frames = max_frames;
@@ -1152,6 +1485,10 @@ static int grow_ring(FirState &s, uint32_t need) {
     (void)hipFree(s.ring);
     s.ring = nr;
     s.R = need;
+    if (s.ringh) {                                       // same geometry as the f32 ring: rebuilt from it by the next block
+        const int rc = alloc_packed(s);
+        if (rc) return rc;
+    }
     return 0;
 }
 
@@ -1170,6 +1507,7 @@ int fir_set_taps(FirState &s, const double *taps_reversed, uint32_t n_taps, int 
 }
 
 void fir_free(FirState &s) {
+    free_packed(s);
     if (s.ring) (void)hipFree(s.ring);
     if (s.taps64) (void)hipFree(s.taps64);
     if (s.taps32) (void)hipFree(s.taps32);
@@ -1192,6 +1530,11 @@ void fir_free(FirState &s) {
 void fir_reset(FirState &s, hipStream_t stream) {
     // queued on the caller's stream: behind the blocks in flight there, ahead of the next one
     if (s.ring) (void)hipMemsetAsync(s.ring, 0, ring_bytes_for(s.tiles, s.R), stream);
+    if (s.ringh) {
+        (void)hipMemsetAsync(s.ringh, 0, ring_bytes_for(s.tiles, s.R), stream);
+        (void)hipMemsetAsync(s.peaks, 0, (size_t)s.tiles * s.peak_slots * TILE_C * sizeof(float), stream);
+        s.packed_ok = true;                              // an empty history, in both forms
+    }
     if (s.nf_time) (void)hipMemsetAsync(s.nf_time, 0, (size_t)s.tiles * sizeof(unsigned long long), stream);
     if (s.warm_acc) (void)hipMemsetAsync(s.warm_acc, 0, (size_t)s.N * sizeof(double), stream);
     s.warm_ok = s.warm_acc != nullptr;
@@ -1274,7 +1617,25 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
         const bool steady = len0 + 1 >= s.T;                 // the first output already sees T samples
         const uint64_t d = len0 > s.T ? len0 - s.T : 0;      // deque longer than the taps: a pure extra delay (fir.rs:195-197 pops one per step)
         const bool mfma = s.kernel == 1;
-        {
+        // Which sweep will this node's steady state take?  The two-part f16 sweep keeps a packed copy of the history that only
+        // ITS append pass maintains; while another sweep is selected the cheaper append runs and the copy goes stale.
+        const bool want_split = s.precision == DSPFX_FIR_PRECISION_SPLIT || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && s.env.split != 0);
+        const bool want_half = s.precision == DSPFX_FIR_PRECISION_HALF || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && want_split && s.env.half != 0);
+        const bool packed = want_half && s.kernel == 1 && s.ringh && s.taps_half && s.taps_split && s.redo;
+        if (packed && !s.packed_ok) {                    // after an import / re-base / unpark / a spell on another sweep: rebuild from the f32 ring
+            const uint64_t t_lo = n0 > (uint64_t)s.R ? n0 - s.R : 0;
+            if (n0 > t_lo) {
+                hipLaunchKernelGGL(fir_repack_kernel, dim3((s.N + 255) / 256, (unsigned)std::min<uint64_t>(64, (n0 - t_lo + EPOCH - 1) / EPOCH + 1)), dim3(256), 0,
+                                   stream, s.ring, s.ringh, s.peaks, s.N, s.R, s.peak_slots, (unsigned long long)t_lo, (unsigned long long)n0);
+            }
+            s.packed_ok = true;
+        }
+        if (packed) {
+            FirAppend2Args ap{in_s, s.ring, s.ringh, s.peaks, s.nf_time, s.N, nf, s.R, s.peak_slots, (unsigned long long)n0, hop, hop_div, lay};
+            const unsigned n_epochs = (unsigned)((n0 + nf - 1) / EPOCH - n0 / EPOCH + 1);
+            hipLaunchKernelGGL(fir_append2_kernel, dim3((s.N + APPEND2_CH - 1) / APPEND2_CH, n_epochs), dim3(256), 0, stream, ap);
+        } else {
+            s.packed_ok = false;
             const uint32_t row0 = (uint32_t)(n0 % s.R);
             hipLaunchKernelGGL(fir_append_kernel, dim3((s.N + 255) / 256, append_pieces(row0, nf)), dim3(256), 0, stream, in_s, s.ring,
                                s.nf_time, s.N, nf, row0, s.R, (unsigned long long)n0, hop, hop_div, lay);
@@ -1334,14 +1695,12 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
             // 3 (as accurate as the f32 sweep against the f64 oracle -- 2.9e-7 vs 3.3e-7 relative RMS at 4096 taps -- bit-exact on
             // integer data, x 1.5); dspfx_set_fir_precision(F32) or DSPFX_FIR_SPLIT=0 in the environment (for nodes left at the
             // default) select the f32 sweep.
-            const bool want_split = s.precision == DSPFX_FIR_PRECISION_SPLIT || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && s.env.split != 0);
             // two-part f16 (three f16 products per term + a bf16 x 3 second pass over the tiles it lists): the DEFAULT since round 4
             // -- same bar, bit-exact on data that is exact in f16's 22 bits, config 4 1.33 -> see DESIGN 5; DSPFX_FIR_HALF=0 (for
             // nodes left at the default) or dspfx_set_fir_precision(SPLIT / F32) select the others.
-            const bool want_half = s.precision == DSPFX_FIR_PRECISION_HALF || (s.precision == DSPFX_FIR_PRECISION_DEFAULT && want_split && s.env.half != 0);
             const bool half = steady && nf > 64 && s.taps_half && s.taps_split && s.redo && want_half;
             const bool split = !half && steady && nf > 64 && s.taps_split && want_split;
-            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : half ? "fir_half_kernel" : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
+            s.last_kernel = !steady ? "fir_mfma_kernel<warm>" : half ? (packed ? "fir_halfp_kernel" : "fir_half_kernel") : split ? "fir_split_kernel" : skew ? "fir_skew_kernel" : "fir_mfma_kernel";
             const unsigned grid_sweep = (split || half) ? (s.tiles + SPLIT_WAVES - 1) / SPLIT_WAVES : grid;
             if (mp_pending) {
                 if (steady && (split || skew || half) && grid_sweep > MIX_SLICES) a.mp = *mixpipe;     // rides in the sweep's first workgroups
@@ -1358,7 +1717,15 @@ int fir_process(FirState &s, const float *in, float *out, uint32_t nframes, int 
                 a.redo_count = s.redo + par;
                 a.redo_tiles = s.redo + 2 + (size_t)par * s.tiles;
                 a.redo_clear = s.redo + (par ^ 1);
-                hipLaunchKernelGGL(fir_half_kernel, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), half_lds_bytes(s.T), stream, a);
+                if (packed) {
+                    a.ringh = s.ringh;
+                    a.peaks = s.peaks;
+                    a.peak_slots = s.peak_slots;
+                    if (s.env.slots == 16) hipLaunchKernelGGL(fir_halfp_kernel<16>, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), half_lds_bytes(s.T), stream, a);
+                    else hipLaunchKernelGGL(fir_halfp_kernel<12>, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), half_lds_bytes(s.T), stream, a);
+                } else {
+                    hipLaunchKernelGGL(fir_half_kernel, dim3(grid_sweep), dim3(64 * SPLIT_WAVES), half_lds_bytes(s.T), stream, a);
+                }
                 if (ev_end && f0 + SLICE >= nframes) {      // (the dominant kernel ends here; the second pass is usually empty)
                     (void)hipEventRecord(ev_end, stream);
                     ev_end = nullptr;
@@ -1476,6 +1843,7 @@ int fir_state_import(FirState &s, const void *host_src) {
         FIRCHK(hipGetLastError());
     }
     s.n_seen = held;
+    s.packed_ok = false;                                 // the packed copy is rebuilt from the imported rows by the next block
     // the VecDeque's own bookkeeping: as exported when it is consistent with the length, else that of a deque that was
     // pushed `held` times from empty
     uint32_t cap = hdr32[0], head = hdr32[1];
@@ -1529,6 +1897,7 @@ void fir_rewind(FirState &s, const FirPark &p) {
 int fir_unpark(FirState &s, FirPark &p, hipStream_t stream) {
     fir_rewind(s, p);
     if (!p.rows) return 0;
+    s.packed_ok = false;                                 // the probes' appends wrote their samples into the packed copy too
     hipLaunchKernelGGL(fir_rows_kernel, dim3((s.N + 255) / 256, std::min<uint32_t>(p.nframes, 256)), dim3(256), 0, stream, s.ring, p.rows, s.N, s.R,
                        (long long)s.n_seen + (long long)s.R * 4, p.nframes, 0);
     FIRCHK(hipGetLastError());

@@ -111,7 +111,7 @@ def test_config4_fir_262144_channels(dspfx, tc, monkeypatch, sweep):
         monkeypatch.setenv("DSPFX_FIR_HALF", "0")
     info = {}
     got, _ = run_noise_engine(dspfx, tc, chain, N, 128, blocks, 256, chans, info=info)
-    assert {"half": "fir_half_kernel", "split": "fir_split_kernel", "f32": "fir_skew_kernel"}[sweep] in info["describe"], info["describe"]
+    assert {"half": "fir_halfp_kernel", "split": "fir_split_kernel", "f32": "fir_skew_kernel"}[sweep] in info["describe"], info["describe"]
     ref = oracle_channels(chain, chans, blocks)
     err = got.astype(np.float64) - ref.astype(np.float64)
     rms = np.sqrt(np.mean(err ** 2)) / np.sqrt(np.mean(ref.astype(np.float64) ** 2))

@@ -786,7 +786,7 @@ def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_c
     eng = dspfx.Engine(N, 128, link_flags=3)
     eng.set_chain(ch)
     y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
-    assert "fir_half_kernel" in eng.describe(), eng.describe()
+    assert "fir_halfp_kernel" in eng.describe(), eng.describe()
     ref = run_oracle(ch, x, 3)
     assert fir_rel_rms(y[T:], ref[T:]) < FIR_RMS_TOL
     _run_fir_blocks(dspfx, torch_cuda, eng, x[:64], block=64)            # a 64-frame slice: the f32 sweep serves
@@ -800,7 +800,7 @@ def test_the_default_fir_sweep_is_the_split_one_and_meets_the_bar(dspfx, torch_c
     ei = dspfx.Engine(96, 128, link_flags=0)
     ei.set_chain([dspfx.Fir(h)])
     yi = _run_fir_blocks(dspfx, torch_cuda, ei, xi)
-    assert "fir_half_kernel" in ei.describe()
+    assert "fir_halfp_kernel" in ei.describe()
     assert np.array_equal(yi, run_oracle([dspfx.Fir(h)], xi, 0))
 
 
@@ -826,7 +826,7 @@ def test_fir_two_part_f16_sweep_range_and_accuracy_per_channel(dspfx, torch_cuda
     eng.set_chain(ch)
     eng.set_fir_precision(0, dspfx.FIR_PRECISION_HALF)
     y = _run_fir_blocks(dspfx, torch_cuda, eng, x)
-    assert "fir_half_kernel" in eng.describe(), eng.describe()
+    assert "fir_halfp_kernel" in eng.describe(), eng.describe()
     ref = run_oracle(ch, x, 0)
     assert np.array_equal(np.isfinite(y), np.isfinite(ref))
     steady = slice(T, None)
@@ -940,6 +940,60 @@ def test_fir_state_export_import(dspfx, torch_cuda):
         b.process(dx[f0:f0 + 128], out=dy[f0:f0 + 128])
     torch_cuda.cuda.synchronize()
     assert np.allclose(dy.cpu().numpy()[384:], full[384:], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("packed", ["1", "0"])
+def test_fir_packed_history_stays_in_step_with_the_f32_ring(dspfx, torch_cuda, monkeypatch, packed):
+    """Round 5: the two-part f16 sweep reads a copy of the history that the append pass has ALREADY split into f16 hi / lo
+    (FirState::ringh + a per-channel peak per 128 sample times) instead of splitting the f32 ring 33 times over.  Only that
+    append pass maintains the copy; everything else that writes history -- a spell on another sweep, ragged blocks that start
+    and end inside a half chunk, a tap reload that re-bases the ring, state import, reset, placement tuning's park / unpark --
+    must leave the two in step (or rebuild the copy).  One stream of blocks through all of them against the oracle, with the
+    integer part of the data bit for bit; DSPFX_FIR_PACKED=0 is round 4's sweep on the same stream."""
+    monkeypatch.setenv("DSPFX_FIR_PACKED", packed)
+    name = "fir_halfp_kernel" if packed == "1" else "fir_half_kernel"
+    rng = np.random.default_rng(21)
+    N, T = 70, 700
+    h = rng.integers(-4, 5, T).astype(np.float64)
+    nodes = [O.Node(O.FIR, taps_reversed=h[::-1]) for _ in range(N)]
+    eng = dspfx.Engine(N, 128, link_flags=0)
+    eng.set_chain([dspfx.Fir(h)])
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_HALF)
+    xi = lambda n: rng.integers(-3, 4, (n, N)).astype(F)              # exact in f16's 11 + 11 bits, inside its range
+
+    def both(x, block=128):
+        got = _run_fir_blocks(dspfx, torch_cuda, eng, x, block)
+        ref = np.stack([np.concatenate([nodes[c].process(x[i:i + block, c]) for i in range(0, len(x), block)]) for c in range(N)], axis=1)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), np.abs(got - ref).max()
+
+    both(xi(128 * 8))                                                   # fill phase, then steady state
+    assert name in eng.describe(), eng.describe()
+    both(xi(100 * 5), block=100)                                        # ragged: blocks start / end inside a half chunk and an epoch
+    assert name in eng.describe(), eng.describe()
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_F32)                   # a spell on another sweep: the copy goes stale ...
+    both(xi(128 * 3))
+    assert "fir_skew_kernel" in eng.describe()
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_HALF)                  # ... and is rebuilt from the f32 ring
+    both(xi(128 * 2))
+    assert name in eng.describe(), eng.describe()
+    h2 = rng.integers(-4, 5, 1500).astype(np.float64)                   # a longer impulse response: the ring is re-based
+    eng.set_taps(0, h2)
+    for nd in nodes:
+        nd.set_taps(h2[::-1])
+    both(xi(128 * 14))
+    assert name in eng.describe(), eng.describe()
+    st = eng.state_export(0)                                            # out and in again: the copy is rebuilt from the imported rows
+    eng.reset()
+    eng.state_import(0, st)
+    both(xi(128 * 3))
+    x_t = torch_cuda.zeros((128, N), device="cuda")                     # placement tuning parks and restores the FIR history
+    eng.tune_placement(x_t, torch_cuda.empty_like(x_t), 128)
+    both(xi(128 * 3))
+    eng.reset()                                                         # fresh nodes
+    nodes = [O.Node(O.FIR, taps_reversed=h2[::-1]) for _ in range(N)]
+    both(xi(128 * 14))
+    assert name in eng.describe(), eng.describe()
+    eng.close()
 
 
 def _run_fir_blocks(dspfx, torch_cuda, eng, x, block=128):
