@@ -3,6 +3,7 @@
 #include "engine.h"
 #include <pthread.h>
 #include <chrono>
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -124,22 +125,56 @@ static void mkdirs(const std::string &dir) {
     for (size_t i = 0; i <= dir.size(); ++i)
         if (i == dir.size() || dir[i] == '/') {
             cur = dir.substr(0, i);
-            if (!cur.empty()) (void)mkdir(cur.c_str(), 0777);
+            if (!cur.empty()) (void)mkdir(cur.c_str(), 0700);      // this user's code objects: nobody else's business
         }
+}
+// Code objects from the cache are handed to hipModuleLoadData and RUN in this process: the directory and the file must belong to
+// this user and be writable by nobody else (a lax umask or a shared DSPFX_CACHE_DIR would let another local user plant GPU code:
+// ADVICE r04).  Anything else is treated like a missing file -- the kernel is compiled, and written only if the directory is ours.
+static bool owned_and_private(const std::string &path) {
+    struct stat st;
+    if (stat(path.c_str(), &st) != 0) return false;
+    return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
+}
+// digest of the two kernel headers as the compiler will see them, computed once per header directory and process (the text is
+// ~200 KB: hashing it on every look-up -- up to three per plan(), and one from the block path when a control port is first
+// connected -- cost milliseconds: ADVICE r04)
+static bool header_digest(const std::string &hdr_dir, uint64_t &da, uint64_t &db) {
+    static std::mutex mu;
+    static std::map<std::string, std::pair<bool, std::pair<uint64_t, uint64_t>>> memo;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = memo.find(hdr_dir);
+    if (it == memo.end()) {
+        std::string h1, h2;
+        const bool ok = kernel_headers(hdr_dir, h1, h2);
+        uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+        if (ok)
+            for (uint64_t *h : {&a, &b}) {
+                fnv(*h, h1.data(), h1.size());
+                fnv(*h, "\x01", 1);
+                fnv(*h, h2.data(), h2.size());
+                fnv(*h, "\x02", 1);
+            }
+        // an override directory is for kernel development: its files change under the process, so it is not memoised
+        if (!hdr_dir.empty()) {
+            da = a;
+            db = b;
+            return ok;
+        }
+        it = memo.emplace(hdr_dir, std::make_pair(ok, std::make_pair(a, b))).first;
+    }
+    da = it->second.second.first;
+    db = it->second.second.second;
+    return it->second.first;
 }
 // name of the cache file for (translation unit, kernel expression) given the headers in `hdr_dir`; "" when there is no cache
 static std::string cache_file(const std::string &hdr_dir, const std::string &src, const std::string &expr) {
     const std::string dir = cache_dir_now();
     if (dir.empty()) return "";
-    std::string h1, h2;
-    if (!kernel_headers(hdr_dir, h1, h2)) return "";
-    uint64_t a = 0xcbf29ce484222325ull, b = 0x84222325cbf29ce4ull;
+    uint64_t a = 0, b = 0;
+    if (!header_digest(hdr_dir, a, b)) return "";
     const int ver_major = hiprtc_version().first, ver_minor = hiprtc_version().second;
     for (uint64_t *h : {&a, &b}) {
-        fnv(*h, h1.data(), h1.size());
-        fnv(*h, "\x01", 1);
-        fnv(*h, h2.data(), h2.size());
-        fnv(*h, "\x02", 1);
         fnv(*h, src.data(), src.size());
         fnv(*h, "\x03", 1);
         fnv(*h, expr.data(), expr.size());
@@ -152,32 +187,48 @@ static std::string cache_file(const std::string &hdr_dir, const std::string &src
     snprintf(name, sizeof name, "/%016llx%016llx.co", (unsigned long long)a, (unsigned long long)b);
     return dir + name;
 }
-// file = "DSPFXCO1" u32 name_len, name bytes, u64 code_len, code bytes
+// file = "DSPFXCO2" u32 name_len, name bytes, u64 code_len, u64 fnv-1a of the code bytes, code bytes
+static uint64_t code_sum(const char *p, size_t n) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    fnv(h, p, n);
+    return h;
+}
 static bool cache_read(const std::string &path, std::string &lowered, std::vector<char> &code) {
     std::string all;
-    if (path.empty() || !read_file(path, all) || all.size() < 8 + 4 + 8 || memcmp(all.data(), "DSPFXCO1", 8) != 0) return false;
+    if (path.empty() || !owned_and_private(path.substr(0, path.find_last_of('/'))) || !owned_and_private(path)) return false;
+    if (!read_file(path, all) || all.size() < 8 + 4 + 16 || memcmp(all.data(), "DSPFXCO2", 8) != 0) return false;
     uint32_t nl = 0;
     memcpy(&nl, all.data() + 8, 4);
-    if (all.size() < 12 + (size_t)nl + 8) return false;
-    uint64_t cl = 0;
+    if (all.size() < 12 + (size_t)nl + 16) return false;
+    uint64_t cl = 0, sum = 0;
     memcpy(&cl, all.data() + 12 + nl, 8);
-    if (all.size() != 12 + (size_t)nl + 8 + cl || cl == 0) return false;
+    memcpy(&sum, all.data() + 12 + nl + 8, 8);
+    if (all.size() != 12 + (size_t)nl + 16 + cl || cl == 0) return false;
+    if (code_sum(all.data() + 12 + nl + 16, (size_t)cl) != sum) return false;       // a damaged file is ignored and rewritten
     lowered.assign(all.data() + 12, nl);
-    code.assign(all.begin() + 12 + nl + 8, all.end());
+    code.assign(all.begin() + 12 + nl + 16, all.end());
     return true;
 }
 static void cache_write(const std::string &path, const char *lowered, const std::vector<char> &code) {
     if (path.empty()) return;
-    mkdirs(path.substr(0, path.find_last_of('/')));
+    const std::string dir = path.substr(0, path.find_last_of('/'));
+    mkdirs(dir);
+    if (!owned_and_private(dir)) return;               // somebody else's (or a world-writable) directory: do not feed it
     char tmp[64];
     snprintf(tmp, sizeof tmp, ".tmp.%ld.%p", (long)getpid(), (void *)&code);
     const std::string tpath = path + tmp;
-    FILE *f = fopen(tpath.c_str(), "wb");
-    if (!f) return;
+    const int fd = open(tpath.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (fd < 0) return;
+    FILE *f = fdopen(fd, "wb");
+    if (!f) {
+        close(fd);
+        (void)remove(tpath.c_str());
+        return;
+    }
     const uint32_t nl = (uint32_t)strlen(lowered);
-    const uint64_t cl = code.size();
-    bool ok = fwrite("DSPFXCO1", 1, 8, f) == 8 && fwrite(&nl, 4, 1, f) == 1 && fwrite(lowered, 1, nl, f) == nl && fwrite(&cl, 8, 1, f) == 1 &&
-              fwrite(code.data(), 1, code.size(), f) == code.size();
+    const uint64_t cl = code.size(), sum = code_sum(code.data(), code.size());
+    bool ok = fwrite("DSPFXCO2", 1, 8, f) == 8 && fwrite(&nl, 4, 1, f) == 1 && fwrite(lowered, 1, nl, f) == nl && fwrite(&cl, 8, 1, f) == 1 &&
+              fwrite(&sum, 8, 1, f) == 1 && fwrite(code.data(), 1, code.size(), f) == code.size();
     ok = fclose(f) == 0 && ok;
     if (ok && rename(tpath.c_str(), path.c_str()) == 0) g_jit_disk_written.fetch_add(1);
     else (void)remove(tpath.c_str());

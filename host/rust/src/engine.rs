@@ -26,6 +26,13 @@ pub struct NodeDesc {
     taps: Vec<f64>, // stored time-reversed, like fir.rs:163,168
 }
 
+// `dspfx_node_desc.taps` is a raw pointer, which makes the struct !Send / !Sync by default -- and with it GpuChain / GpuBank, which
+// keep their chain as `Mutex<Vec<NodeDesc>>`, while the reference's `trait Node: Send + Sync` (node.rs:105) demands both (ADVICE
+// r04).  The pointer is only ever null or aimed into this value's own `taps` Vec (set right before the FFI call in `raw()`), so
+// moving or sharing a NodeDesc between threads moves / shares plain data.
+unsafe impl Send for NodeDesc {}
+unsafe impl Sync for NodeDesc {}
+
 impl NodeDesc {
     fn defaults(kind: c_int) -> Self {
         let mut d = dspfx_node_desc { kind, mode: 0, params: [0.0; 8], delay_len: 0, n_taps: 0, taps: ptr::null() };
@@ -218,6 +225,17 @@ impl Engine {
     }
     pub fn reset(&mut self) -> Result<(), Error> {
         let rc = unsafe { dspfx_reset(self.h) };
+        self.check(rc)
+    }
+    /// Capacity hint: the 128-row groups a delay of `seconds` at `node` would need are allocated now (no engine lock taken), so
+    /// that no later seconds store allocates.  `dspfx_delay_len(1.0, 0)` covers the whole slider (reverb.rs:34-37).
+    pub fn reserve_delay_seconds(&mut self, node: usize, seconds: f32) -> Result<(), Error> {
+        let rc = unsafe { dspfx_reserve_delay_len(self.h, node as c_int, dspfx_delay_len(seconds, 0)) };
+        self.check(rc)
+    }
+    /// Give back delay-ring capacity beyond the rings' current lengths (waits for the device).
+    pub fn ring_trim(&mut self) -> Result<(), Error> {
+        let rc = unsafe { dspfx_ring_trim(self.h) };
         self.check(rc)
     }
 

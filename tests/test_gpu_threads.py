@@ -760,8 +760,13 @@ def test_a_damaged_cache_file_is_ignored_and_rewritten(dspfx, torch_cuda, monkey
     files = sorted(cdir.glob("*.co"))
     assert files, "nothing was written to the disk cache"
     for f in files:
-        assert f.read_bytes()[:8] == b"DSPFXCO1" and f.stat().st_size > 1000
-        f.write_bytes(b"DSPFXCO1" + b"\0" * 100)             # truncated / garbage
+        raw = f.read_bytes()
+        assert raw[:8] == b"DSPFXCO2" and f.stat().st_size > 1000
+        assert (f.stat().st_mode & 0o077) == 0 and (cdir.stat().st_mode & 0o022) == 0      # this user's alone
+        if f is files[0]:
+            f.write_bytes(raw[:-7] + bytes([raw[-7] ^ 0x10]) + raw[-6:])                    # one flipped bit inside the code: the checksum catches it
+        else:
+            f.write_bytes(b"DSPFXCO2" + b"\0" * 100)                                        # truncated / garbage
     # (this process holds the kernels in memory: a fresh process must cope with the damaged files)
     import subprocess
     import sys
