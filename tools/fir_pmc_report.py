@@ -54,18 +54,28 @@ if o:
     res["instructions"] = o
     if "SQ_INSTS_MFMA" in o:
         res["instructions"]["busy_cycles_per_mfma"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / o["SQ_INSTS_MFMA"] if m else None
-fa, _ = counters("pmc_fetch", "fir_append_kernel")
-wa, _ = counters("pmc_write", "fir_append_kernel")
+v, _ = counters("pmc_valu", kname)
+if v:                                                   # per-wave instruction counts by unit (VERDICT r04 #3a: VALU next to MFMA)
+    res.setdefault("instructions", {}).update(v)
+    if o and o.get("SQ_INSTS_MFMA") and v.get("SQ_INSTS_VALU"):
+        # SQ_INSTS_VALU counts the MFMAs too: what is left is the conversion / masking / address work per matrix instruction
+        res["instructions"]["valu_non_mfma_per_mfma"] = (v["SQ_INSTS_VALU"] - o["SQ_INSTS_MFMA"]) / o["SQ_INSTS_MFMA"]
+# the append pass of the same run calibrates the two counters: fir_append_kernel reads N*B*4 bytes and writes N*B*4; fir_append2_kernel
+# (the packed history of the two-part f16 sweep, round 5) reads N*B*4 and writes 2*N*B*4 + one peak per channel
+app = "fir_append2_kernel" if counters("pmc_fetch", "fir_append2_kernel")[0] else "fir_append_kernel"
+fa, _ = counters("pmc_fetch", app)
+wa, _ = counters("pmc_write", app)
 fk, _ = counters("pmc_fetch", kname)
 wk, _ = counters("pmc_write", kname)
 if fa and wa and fk and wk:
     known = N * B * 4.0
-    ff, wf = known / fa["FETCH_SIZE"], known / wa["WRITE_SIZE"]
+    known_w = known if app == "fir_append_kernel" else 2.0 * known + N * 4.0
+    ff, wf = known / fa["FETCH_SIZE"], known_w / wa["WRITE_SIZE"]
     fetch, write = fk["FETCH_SIZE"] * ff, wk["WRITE_SIZE"] * wf
     alg = (4.0 * (T - 1) / B + 4.0) * N * B
-    res["hbm"] = {"calibration_kernel": "fir_append_kernel: reads N*B*4 = %d B and writes the same" % known,
+    res["hbm"] = {"calibration_kernel": "%s: reads N*B*4 = %d B and writes %d B" % (app, known, known_w),
                   "FETCH_SIZE_bytes_per_count": ff, "WRITE_SIZE_bytes_per_count": wf,
                   "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
                   "algorithmic_bytes_of_this_kernel": alg, "traffic_over_algorithmic": (fetch + write) / alg,
-                  "whole_block_bytes": fetch + write + 2 * known, "survey_8d_bytes": 140.0 * N * B}
+                  "whole_block_bytes": fetch + write + known + known_w, "survey_8d_bytes": 140.0 * N * B}
 print(json.dumps(res, indent=1))
