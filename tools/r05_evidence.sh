@@ -49,6 +49,15 @@ fir r05half fir_half_kernel r05_fir_half_unpacked_pmc.json DSPFX_FIR_PACKED=0
 fir r05split fir_split_kernel r05_fir_split_pmc.json DSPFX_FIR_HALF=0
 fir r05f32 fir_skew_kernel r05_fir_pmc.json DSPFX_FIR_SPLIT=0
 find gpurun_out/pmc_chain -name "*.db" -delete 2>/dev/null
+# gpurun brings back at most 64 MiB: keep the summaries, drop the raw counter / trace files they were made from
+mkdir -p $OUT/pmc_chain_profiles && cp gpurun_out/pmc_chain/profiles/* $OUT/pmc_chain_profiles/ 2>/dev/null
+for d in gpurun_out/firpmc_r05halfp gpurun_out/firpmc_r05half gpurun_out/firpmc_r05split gpurun_out/firpmc_r05f32; do
+  mkdir -p $OUT/$(basename $d); cp $d/*_bench.json $d/trace_bench.json $OUT/$(basename $d)/ 2>/dev/null; rm -rf $d
+done
+rm -rf gpurun_out/pmc_chain
+find $OUT/trace -name "*kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*.db" -delete 2>/dev/null
+du -sh gpurun_out | tail -1
 python3 - <<PY
 import json
 for f in ("bench_run1", "bench_under_rocprof", "bench_run2"):
