@@ -439,6 +439,12 @@ struct ExitGuard {
     }
 };
 thread_local ExitGuard t_exit_guard;
+// Armed when the library is LOADED, if that happens on the main thread (a linked-in library, or a dlopen from main -- the usual
+// cases): a host whose main thread never creates an engine or submits a shape itself (engines made on worker threads) is then
+// covered too.  A library loaded from another thread falls back on the threads that use it and the atexit handler.
+__attribute__((constructor)) void arm_exit_guard_on_load() {
+    if ((long)getpid() == (long)syscall(SYS_gettid)) t_exit_guard.armed = true;
+}
 }  // namespace
 
 void jit_arm_exit_guard() {
