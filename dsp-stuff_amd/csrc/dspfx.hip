@@ -515,7 +515,7 @@ void publish_kinds(dspfx_engine *e) {
         for (size_t i = 0; i < e->nodes.size(); ++i) {
             const Node &n = e->nodes[i];
             e->pub_kinds.push_back(n.d.kind);
-            if (n.d.kind == DSPFX_REVERB) e->pub_rev[i] = dspfx_engine::PubReverb{n.d.params[1], n.d.mode, n.D, n.groups.size()};
+            if (n.d.kind == DSPFX_REVERB) e->pub_rev[i] = dspfx_engine::PubReverb{n.d.params[1], n.d.mode, n.D, n.groups.size(), n.seconds_given};
         }
         e->pending.clear();                 // stores aimed at the nodes that no longer exist
         ++e->chain_gen;                     // ... and ring capacity being allocated for them is dropped by its allocator
@@ -541,6 +541,7 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
         return DSPFX_OK;
     }
     n.d.params[st.param] = st.value;
+    if (n.d.kind == DSPFX_REVERB && st.param == 1) n.seconds_given = true;      // (0.0 included: a 128-sample ring, reverb.rs:58)
     if (st.param < 3) n.latch_valid &= ~(1 << st.param);   // a slider store overwrites the latched values
     if (n.d.kind == DSPFX_BIQUAD) {   // after_settings_change: renormalise + reset_state (biquad.rs:62-76)
         biquad_regenerate(n);
@@ -570,7 +571,7 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
 // picks the page-rounded reading -- so a node fresh from the menu (make_buffer's 128-sample ring under a 0.5 s slider,
 // reverb.rs:44-52) jumps to 24000 samples at its first slider change like the reference's; without one the ring keeps its length.
 uint32_t reverb_refresh_len(const Node &n) {
-    return n.d.params[1] > 0.0f ? dspfx_delay_len(n.d.params[1], n.d.mode & 1) : n.D;
+    return n.seconds_given ? dspfx_delay_len(n.d.params[1], n.d.mode & 1) : n.D;
 }
 // A NEW zero ring of D samples for node n -- Reverb::refresh_seconds (reverb.rs:55-71), which in the reference is an
 // allocation of at most 192 KB and a pointer swap under the node's mutex, made on every frame a drag moves a slider
@@ -975,7 +976,10 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
         n.d = nodes[i];
         n.d.taps = nullptr;
         if (n.d.kind == DSPFX_BIQUAD) biquad_regenerate(n);
-        if (n.d.kind == DSPFX_REVERB) n.D = nodes[i].delay_len;
+        if (n.d.kind == DSPFX_REVERB) {
+            n.D = nodes[i].delay_len;
+            n.seconds_given = nodes[i].params[1] > 0.0f;
+        }
         if (n.d.kind == DSPFX_FIR) n.taps.assign(nodes[i].taps, nodes[i].taps + nodes[i].n_taps);
         rc = alloc_node_state(e, n);
     }
@@ -1100,7 +1104,7 @@ int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *s
             // the ring this store will swap in (reverb_refresh_len, with the stores queued before it applied)
             const dspfx_engine::PubReverb &pr = e->pub_rev[(size_t)node];
             const float seconds = param == 1 ? value : pr.seconds;
-            if (seconds > 0.0f) want_groups = ring_groups_for(dspfx_delay_len(seconds, pr.mode & 1));
+            if (param == 1 || pr.given) want_groups = ring_groups_for(dspfx_delay_len(seconds, pr.mode & 1));
             if (want_groups <= pr.have) want_groups = 0;
             gen = e->chain_gen;
         }
@@ -1116,7 +1120,10 @@ int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *s
         std::lock_guard<std::mutex> lk(e->pend_mu);
         if (node >= (int)e->pub_kinds.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);   // (the chain was replaced meanwhile)
         if (e->pub_kinds[(size_t)node] == DSPFX_REVERB) {
-            if (param == 1) e->pub_rev[(size_t)node].seconds = value;
+            if (param == 1) {
+                e->pub_rev[(size_t)node].seconds = value;
+                e->pub_rev[(size_t)node].given = true;
+            }
             if (param < 0) e->pub_rev[(size_t)node].mode = (int)value;
         }
         const uint64_t seq = e->next_seq++;

@@ -68,6 +68,9 @@ struct Node {
     // (Reverb::refresh_seconds on a slider change, dspfx_reset, dspfx_set_delay_len with an unchanged D) is this counter set
     // to D: O(1), no memset of up to 94 GiB, placement kept.  Counted down by every block (SlotArgs::zero_rows).
     uint32_t zero_left = 0;
+    // REVERB: the seconds slider is known -- given with the node (params[1] > 0) or stored since.  A STORE of exactly 0.0 is a value
+    // like any other (reverb.rs:58: max(0, 128) = a 128-sample ring), while 0 in a descriptor means "not given: keep delay_len".
+    bool seconds_given = false;
     // FIR
     std::vector<double> taps;      // reversed, as given
     FirState fir;
@@ -220,7 +223,7 @@ struct dspfx_engine {
     std::mutex alloc_mu, pool_mu;
     std::vector<std::vector<float *>> ring_pool;      // [node]: allocated groups not yet part of the node's ring
     std::vector<void *> retired;                      // group tables replaced while blocks were in flight: freed when the device is idle
-    struct PubReverb { float seconds = 0.0f; int mode = 0; uint32_t D = 0; size_t have = 0; };
+    struct PubReverb { float seconds = 0.0f; int mode = 0; uint32_t D = 0; size_t have = 0; bool given = false; };
     std::vector<PubReverb> pub_rev;                   // [node] (REVERB nodes only carry meaning)
     uint64_t chain_gen = 0;                           // bumped by every chain / graph set (under pend_mu)
     mutable std::mutex err_mu;                        // err (also kept per calling thread: dspfx_last_error)

@@ -232,7 +232,8 @@ int dspfx_kernels_ready(dspfx_engine *e, int wait_ms);
  *          that MAKES the store, before the store is queued (the reference's GUI thread allocates the new ring too,
  *          reverb.rs:55-71); dspfx_chain_set reserves them up front for a menu-fresh node; a shorter ring keeps the surplus
  *          as capacity (dspfx_ring_trim returns it).  DSPFX_ERR_OOM: the store was NOT made, the node keeps ring and slider.
- *          params[1] outside 0..=1 (the slider's range, reverb.rs:34-37) is DSPFX_ERR_INVALID;
+ *          params[1] outside 0..=1 (the slider's range, reverb.rs:34-37) is DSPFX_ERR_INVALID; a STORED 0.0 is a value like any other
+ *          (a 128-sample ring, reverb.rs:58) -- only in a node DESCRIPTOR does params[1] = 0 mean "no seconds slider: keep delay_len";
  *   other kinds just take the value from the next block on.  Nothing is launched or compiled by a slider store (the
  * exactness of a DISTORT level as a constant divisor is decided on the host; only a level that is an even integer
  * other than a power of two runs the 2 ms device check, once per value and process).

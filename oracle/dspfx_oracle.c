@@ -96,6 +96,7 @@ orc_node *orc_node_new(int kind) {
                         second the slider shows: refresh_seconds has not run on a node fresh from the menu */
         n->p[0] = 0.5f;
         n->p[1] = 0.5f;
+        n->seconds_given = 1;
         orc_reverb_set_len(n, 128);
         break;
     case ORC_DISTORT: /* distort.rs:46-50: level Default (0.0), mode SoftClip */
@@ -159,6 +160,7 @@ orc_node *orc_node_clone(const orc_node *src) {
 void orc_node_init_param(orc_node *n, int idx, float v) {
     if (idx < 0 || idx >= 8) return;
     n->p[idx] = v;
+    if (n->kind == ORC_REVERB && idx == 1) n->seconds_given = v > 0.0f;   /* 0 in a descriptor: "not given", the explicit ring length stands */
 }
 
 /* The node's `after_settings_change` hook, where it has one (grep over nodes/: biquad.rs:15 and reverb.rs:19, no other):
@@ -173,12 +175,13 @@ void orc_node_init_param(orc_node *n, int idx, float v) {
  * from the menu (NodeStatic::new) has NOT run it: a Reverb keeps make_buffer()'s 128-sample ring until its first change. */
 void orc_node_after_settings_change(orc_node *n) {
     if (n->kind == ORC_BIQUAD) biquad_regenerate(n);
-    if (n->kind == ORC_REVERB) orc_reverb_set_len(n, n->p[1] > 0.0f ? orc_delay_len(n->p[1], n->mode & 1) : n->ring_len);
+    if (n->kind == ORC_REVERB) orc_reverb_set_len(n, n->seconds_given ? orc_delay_len(n->p[1], n->mode & 1) : n->ring_len);
 }
 
 void orc_node_set_param(orc_node *n, int idx, float v) {
     if (idx < 0 || idx >= 8) return;
     n->p[idx] = v;                       /* lib.rs:487-492: the slider's Relaxed store */
+    if (n->kind == ORC_REVERB && idx == 1) n->seconds_given = 1;   /* a stored 0.0 is a value: max(0, 128) = 128 samples (reverb.rs:58) */
     orc_node_after_settings_change(n);   /* lib.rs:560-568 */
 }
 

@@ -150,6 +150,7 @@ typedef struct orc_node {
     int mode;
     float p[8];
     uint32_t ip[2];
+    int seconds_given; /* REVERB: the seconds slider is known (initialised > 0, or stored since -- a stored 0.0 counts: reverb.rs:58 gives 128) */
 
     /* biquad: normalised coefficients + DirectForm1 state */
     float bq_a1, bq_a2, bq_b0, bq_b1, bq_b2;

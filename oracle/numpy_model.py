@@ -404,6 +404,7 @@ class NodeModel:
         elif kind == K_REVERB:                                    # make_buffer(): 128 zeros (reverb.rs:44-52) unless D is named
             if params is None or len(params) < 2:                 # no seconds slider given: the default one (0.5 s) for a fresh
                 self.p[1] = F(0.0) if delay_len else F(0.5)       # node, none to refresh from beside an explicit ring
+            self.seconds_given = bool(self.p[1] > 0)              # 0 in a descriptor: "not given"; a STORED 0.0 is a value (128 samples)
             # ... 128 zeros, or the 1024 of the page-rounded reading (mode bit 0): make_buffer() is refresh_seconds' three calls
             self.impl = Reverb(delay_len or delay_len_from_seconds(0.0, bool(self.mode & 1)), self.p[0])
         elif kind == K_FIR:
@@ -415,6 +416,8 @@ class NodeModel:
 
     def set_param(self, idx, v):
         self.p[idx] = F(v)
+        if self.kind == K_REVERB and idx == 1:
+            self.seconds_given = True
         if self.kind == K_BIQUAD:                                 # after_settings_change: new filter, state reset
             self.impl = Biquad(*[float(q) for q in self.p[:6]])
         elif self.kind in (K_LOW_PASS, K_HIGH_PASS):
@@ -424,7 +427,7 @@ class NodeModel:
             # ANY widget of the node changed (dsp-stuff-derive/src/lib.rs:487-497, 560-568): decay AND seconds both swap in
             # a NEW zero ring of max((seconds * 48000) as usize, 128) samples -- of the current length when the node was
             # not given its seconds slider (the ring length is explicit in this restatement)
-            d = delay_len_from_seconds(self.p[1], bool(self.mode & 1)) if self.p[1] > 0 else self.impl.d
+            d = delay_len_from_seconds(self.p[1], bool(self.mode & 1)) if self.seconds_given else self.impl.d
             self.impl = Reverb(d, self.p[0])
         elif self.kind == K_ENVELOPE:
             self.impl.attack, self.impl.release = self.p[0], self.p[1]

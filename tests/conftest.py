@@ -26,6 +26,14 @@ def _product_defaults_unless_a_test_opts_out(monkeypatch, request):
         monkeypatch.setenv("DSPFX_JIT_ASYNC", "0")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _package_is_importable():
+    """`from dsp_stuff_amd import graph` in a test works whatever test a worker happens to run first (pytest-xdist deals them out
+    in any order): the package directory `dsp-stuff_amd/` is registered under its importable name once per session."""
+    from __graft_entry__ import load_package
+    load_package()
+
+
 @pytest.fixture(scope="session")
 def dspfx():
     """The product package (dsp-stuff_amd/), loaded through its in-tree HIP library."""

@@ -2014,6 +2014,17 @@ def test_reverb_fresh_node_and_seconds_slider_resize_the_ring(dspfx, torch_cuda)
     eng.set_param(0, 0, 0.5)
     assert len(eng.state_export(0)) == 4 * 64 * 24000
     eng.close()
+    # a node given an explicit ring and no seconds slider keeps its length through decay stores; a STORED seconds of 0.0 is a
+    # value like any other: max((0 * 48000) as usize, 128) = 128 samples (reverb.rs:58), and it stays the slider for later hooks
+    eng = dspfx.Engine(64, B, link_flags=0)
+    eng.set_chain([dspfx.Reverb(delay_samples=300)])
+    eng.set_param(0, 0, 0.4)
+    assert len(eng.state_export(0)) == 4 * 64 * 300
+    eng.set_param(0, 1, 0.0)
+    assert len(eng.state_export(0)) == 4 * 64 * 128
+    eng.set_param(0, 0, 0.3)
+    assert len(eng.state_export(0)) == 4 * 64 * 128
+    eng.close()
 
 
 @pytest.mark.parametrize("N,tile,variant,block", [

@@ -488,6 +488,13 @@ def test_kat13_reverb_fresh_node_becomes_a_half_second_delay_at_its_first_slider
         assert list(echo_at(node, 4))[:2] == [3, 303]
         node.set_param(1, 0.002)                                     # the seconds slider itself
         assert list(echo_at(node, 3)) == [3, 131, 259]
+    for node in _both(O.REVERB, [0.5], delay_len=300):               # no seconds slider with the node: decay stores keep the 300 ...
+        node.set_param(0, 0.5)
+        assert list(echo_at(node, 4))[:2] == [3, 303]
+        node.set_param(1, 0.0)                                       # ... a STORED 0.0 is a value like any other: max(0, 128) = 128 (reverb.rs:58)
+        assert list(echo_at(node, 3)) == [3, 131, 259]
+        node.set_param(0, 0.5)                                       # and it stays the slider's value for later hooks
+        assert list(echo_at(node, 3)) == [3, 131, 259]
     assert M.delay_len_from_seconds(0.5) == O.delay_len(0.5) == 24000 and M.delay_len_from_seconds(0.5, True) == O.delay_len(0.5, True) == 24576
     for s in (0.0, 0.001, 0.0026666, 0.0026667, 0.3333, 1.0):
         assert M.delay_len_from_seconds(s) == O.delay_len(s), s
