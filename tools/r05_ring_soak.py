@@ -128,9 +128,11 @@ for seed in range(s0, s0 + cnt):
     for th, _ in pending_threads:
         th.join()
     s.synchronize()
-    for seq, frame, node, param, value in eng.param_log():
-        if seq not in direct:             # a store from the second thread: it landed where the engine's log says
-            applied.setdefault(frame // block, []).append((seq, ("param", node, param, value)))
+    log_copy = eng.param_log()
+    for seq, frame, node, param, value in log_copy:
+        if seq not in direct:             # a store from the second thread: it landed where the engine's log says -- and BEFORE that block's
+            # direct actions: the thread is joined before those are made, and a store still queued then is drained on entry of the first of them
+            applied.setdefault(frame // block, []).append((seq - 10 ** 6, ("param", node, param, value)))
     y = np.concatenate([E.from_layout(dy[k * per:(k + 1) * per].cpu().numpy(), block, N, tile) for k in range(nblocks)])
     eng.close()
     descs = [n.oracle_desc() for n in chain]
@@ -159,6 +161,13 @@ for seed in range(s0, s0 + cnt):
     worst = max(worst, w)
     if w > 1 or not np.array_equal(np.signbit(got[ok]), np.signbit(ref[ok])):
         bad.append((seed, w, N, tile, block, lf, use_thread, [n.kind for n in chain]))
+        if os.environ.get("DSPFX_SOAK_VERBOSE"):
+            dd = ulp_diff(got, ref)
+            first = int(np.argwhere(dd.max(axis=1) > 1)[0][0])
+            print("seed", seed, "first bad frame", first, "= block", first // block, "+", first % block, "chain", [(n.kind, list(n.params[:2]), n.mode, n.delay_len) for n in chain])
+            print("  acts", {k: v for k, v in sorted(acts.items())})
+            print("  applied", {k: v for k, v in sorted(applied.items())})
+            print("  log", log_copy)
     if (seed - s0) % 10 == 9:
         print("... %d runs, worst %d ulp, failures %s, %.0f s" % (ran, worst, bad, time.time() - t0), flush=True)
 print("seeds %d..%d: %d runs, %d actions (%d blocks with stores from a second thread); worst ulp vs oracle %d, failures %s, %.0f s" % (
