@@ -364,3 +364,32 @@ def test_seconds_slider_dragged_on_config5_shard_with_blocks_in_flight(dspfx, tc
     # the stores mattered: the echo of the 36000-sample ring is in the last phase
     last = max(stores)
     assert np.abs(ref[(last + 282) * B:]).max() > 0
+
+
+def test_bench_py_prints_one_compact_contract_line(tmp_path):
+    """bench.py end to end on the GPU (a reduced headline config so that it takes seconds): ONE JSON line on stdout that carries
+    every contract field, is small enough for the driver's 8 KB tail, and agrees with itself (value = samples / time); the full
+    record on stderr.  The line the driver parses must never break unnoticed."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--channels", "65536", "--delay", "1024",
+                        "--cpu-seconds", "1", "--paced-seconds", "0.2"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert len(lines[0]) < 7000
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["warmup"] == 2 and d["dtype"] == "f32" and d["vs_baseline"] is None
+    assert abs(d["value"] - 65536 * 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0.05 < rf["frac"] < 1.0 and rf["frac_by_step"] <= rf["frac"] * 1.001
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["paced"]["deadline_misses"] == 0
+    assert "region_fixed_cost_us" in d and "workload" in d["config"]
+    detail = [l for l in r.stderr.splitlines() if l.startswith("bench.py detail: ")]
+    assert len(detail) == 1 and json.loads(detail[0][len("bench.py detail: "):])["value"] == d["value"]
