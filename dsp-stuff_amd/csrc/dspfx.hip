@@ -567,9 +567,10 @@ int apply_store(dspfx_engine *e, const dspfx_engine::Store &st, std::vector<char
 
 // Reverb::refresh_seconds (reverb.rs:55-71): `num_samples = max((seconds * 48000) as usize, 128)` from the CURRENT seconds
 // slider, a new ring of that length, zero-filled.  The ring length is explicit in this ABI (rivulet's capacity rounding is not
-// in the reference tree): a node that was given its seconds slider (params[1] > 0) derives the new length from it -- mode bit 0
-// picks the page-rounded reading -- so a node fresh from the menu (make_buffer's 128-sample ring under a 0.5 s slider,
-// reverb.rs:44-52) jumps to 24000 samples at its first slider change like the reference's; without one the ring keeps its length.
+// in the reference tree): a node whose seconds slider is known (given with the node, params[1] > 0, or stored since -- a stored 0.0
+// included: 128 samples) derives the new length from it -- mode bit 0 picks the page-rounded reading -- so a node fresh from the
+// menu (make_buffer's ring under a 0.5 s slider, reverb.rs:44-52) jumps to 24000 samples at its first slider change like the
+// reference's; without one the ring keeps its length.
 uint32_t reverb_refresh_len(const Node &n) {
     return n.seconds_given ? dspfx_delay_len(n.d.params[1], n.d.mode & 1) : n.D;
 }
