@@ -266,11 +266,14 @@ uint64_t dspfx_frames_submitted(const dspfx_engine *e);
  * thread (DSPFX_ERR_OOM leaves the ring as it was); dspfx_reserve_delay_len beforehand, from any thread, moves that cost off
  * the thread that drives the blocks.  The node's seconds slider (params[1]) is left as it is. */
 int dspfx_set_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
-/* Capacity hint: allocate (not zero, not yet use) the 128-row groups a ring of delay_len samples at `node` would need beyond
+/* Capacity hint -- the allocation half of Reverb::refresh_seconds (reverb.rs:60: `circular_buffer::<f32>(num_samples)`) made ahead of
+ * the swap half (reverb.rs:70): allocate (not zero, not yet use) the 128-row groups a ring of delay_len samples at `node` would need beyond
  * what the node already has -- e.g. dspfx_delay_len(1.0f, page_round) once after dspfx_chain_set, and no seconds store can
  * allocate again.  Callable from any thread while blocks are running; takes no engine lock, launches nothing. */
 int dspfx_reserve_delay_len(dspfx_engine *e, int node, uint32_t delay_len);
-/* Give back delay-ring capacity beyond the rings' current lengths (and reservations not yet used).  Waits for the device. */
+/* Give back delay-ring capacity beyond the rings' current lengths (and reservations not yet used) -- what dropping the old ring does in
+ * the reference (reverb.rs:70: the previous (source, sink) pair is freed when `*guard` is overwritten), made explicit because here a
+ * shorter ring keeps its groups.  Waits for the device. */
 int dspfx_ring_trim(dspfx_engine *e);
 /* Fir tap reload (fir.rs:153-171).  Like the reference it replaces the taps ONLY: the history is kept (`state`,
  * fir.rs:64-65, is never cleared), and because at most one sample is popped per step (fir.rs:193-197) a history longer
