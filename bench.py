@@ -12,6 +12,10 @@ decay .5) -> biquad(HP 80 Hz) -> gain(.5), B=128, link scaling on every hop,
 mix bus.  Other BASELINE configs are parity-test cases; `--config` can time them
 for DESIGN.md but the driver's line is the default.
 
+Output: ONE JSON line on stdout -- compact_line() of the full record: every contract field as measured, every config's numbers,
+under 7 KB so that a driver that keeps the last 8 KB of stdout keeps all of it; the full record (plans, notes, the CPU baseline's
+thread legs) goes to stderr ("bench.py detail: ...") and to gpurun_out/bench_detail_<N>gpu.json.
+
     python bench.py --gpus 1 --steps 200 --warmup 200
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
         --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 200
