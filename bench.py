@@ -32,7 +32,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_PEAK_TFLOPS = 2500.0       # dense bf16 MFMA peak (MI355X_MICROARCH.md)
@@ -88,7 +87,7 @@ def parse():
 
 
 def build_chain(pkg, cfg):
-    import chains
+    from dsp_stuff_amd import workloads as chains      # BASELINE's chains live in the package, not under tests/
     if cfg["chain"] == "chain5":
         return chains.chain5(pkg, cfg["delay"])
     if cfg["chain"] == "chain3":
@@ -227,6 +226,8 @@ def cpu_baseline(chain, cfg, link_flags, target_s, with_single=True):
     res = {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "physical_cores": physical,
            "threads": logical, "sockets": sockets, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
            "cpu_model": cpu_model(), "kind": "port",
+           # which object ran: the oracle rebuilt for THIS host's ISA, or -- on a box without gcc -- the prebuilt in-tree one
+           "build": ("gcc -O3 -march=native -ffp-contract=off, built on this box" if native else "prebuilt oracle/liboracle.so (-O2 -ffp-contract=off): no compiler on this box"),
            "sample": f"{best['channels']} channels x {nb} blocks of 128 frames on {best['threads']} threads, same chain/params, "
                      f"hashed-noise input table made before the timed region, {best['seconds']} s; "
                      f"oracle/dspfx_oracle.c {'-O3 -march=native' if native else '-O2'} -ffp-contract=off, "
@@ -558,21 +559,29 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     # (tools/trace_phases.py).  Both are outside the host-clock window AND off the GPU's timeline of the region: the first has
     # finished before the clock starts (it used to be queued right in front of the first step, whose launch then waited for it),
     # the second is queued after the clock has stopped (round 5: VERDICT r04 #5, the fixed cost of a 20-launch region).
-    ctx.mark.sin_()
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()
-    for k in range(steps):
-        step(k)
-    ev1.record()
-    t_submitted = time.perf_counter() - t0     # host-side submission time of the K steps
-    ev1.synchronize()                          # a spinning wait on the region's own event: the synchronize below finds an idle device
-    t_event = time.perf_counter() - t0
-    drain()
-    fence()
-    dt = time.perf_counter() - t0
-    ctx.mark.cos_()
-    torch.cuda.synchronize()
+    def timed_region(step_fn, drain_fn, e0, e1):
+        """The contract's timed region: barrier + synchronize, K steps, barrier + synchronize; returns the host-clock seconds (this rank),
+        the submit time and the moment the region's closing event was seen.  What is still pending behind the K-th step (the pipelined
+        forms' flush and last exchange) is SUBMITTED before the host waits for anything (round 6, ADVICE r05: the wait used to come first,
+        which serialised the flush's launch latency behind an idle device)."""
+        ctx.mark.sin_()
+        fence()
+        t0_ = time.perf_counter()
+        e0.record()
+        for k in range(steps):
+            step_fn(k)
+        e1.record()
+        t_sub_ = time.perf_counter() - t0_     # host-side submission time of the K steps
+        drain_fn()
+        e1.synchronize()                       # a spinning wait on the region's own event: the synchronize below finds an idle device
+        t_evt_ = time.perf_counter() - t0_
+        fence()
+        dt_ = time.perf_counter() - t0_
+        ctx.mark.cos_()
+        torch.cuda.synchronize()
+        return dt_, t_sub_, t_evt_
+
+    dt, t_submitted, t_event = timed_region(step, drain, ev0, ev1)
     region_ms = ev0.elapsed_time(ev1)
     if region_timing:
         kern_ms_total, kern_launches = region_ms, steps
@@ -709,6 +718,36 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
                               start_at=float(t0.item()))
             pbus.drain()
             fence()
+    # ---- several ranks: BOTH forms of the bus exchange in the same run.  `value` above is the same-block form -- the
+    # Output node's semantics (nodes/output.rs:215-249 over node.rs:162-194: the GLOBAL bus of block k with block k's samples), its
+    # exchange queued on the compute stream behind every chain kernel.  The overlapped form lets the bus ride two calls late
+    # (dspfx_process_mixpipe) and exchanges it on the second stream, under the next blocks' chain kernels: the weak-scaling ceiling
+    # without the exchange on the critical path.  Same engine, same buffers, same K, same barrier + MAX-over-ranks clock.
+    forms = None
+    if dist_run and use_mix and pbus is not None and pbus.inline and os.environ.get("DSPFX_BENCH_FORMS", "1") == "1":
+        forms = {"inline": {"what": "same-block bus, exchange on the compute stream behind each chain kernel (= value)",
+                            "value": value, "ms_per_step": dt * 1e3 / steps, "bus_delay_blocks": 0}}
+        try:
+            ovl_batch = int(os.environ.get("DSPFX_BENCH_OVERLAP_BATCH", "1"))
+            pb2 = P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=ovl_batch, device=dev,
+                                    comm=ctx.comm, same_block=False)
+            for k in range(max(warmup, 3 * ovl_batch + 8)):
+                pb2.step(xs[k % n_in], y)
+            pb2.drain()
+            fence()
+            eo0, eo1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dt2, _, _ = timed_region(lambda k: pb2.step(xs[k % n_in], y), pb2.drain, eo0, eo1)
+            if ctx.use_dist:
+                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            forms["overlapped"] = {"what": "bus two calls late (dspfx_process_mixpipe), exchanged on the second stream, %d block(s) per exchange" % ovl_batch,
+                                   "value": samples / dt2, "ms_per_step": dt2 * 1e3 / steps, "gpu_event_ms_per_step": eo0.elapsed_time(eo1) / steps,
+                                   "bus_delay_blocks": 2 + ovl_batch - 1}
+            del pb2
+        except Exception as ex:          # reporting only: never lose the headline line
+            forms["overlapped"] = {"error": str(ex)[:300]}
+            fence()
     res = {
         "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced, "alt_bus": alt_bus,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
@@ -718,7 +757,7 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
                                       ctx.comm.backend, BATCH, "".join(" [not %s]" % n for n in getattr(ctx, "comm_notes", []))))
                                   if ctx.comm is not None
                                   else "torch.distributed all_reduce" + (" (fallback: %s)" % ctx.comm_fallback if getattr(ctx, "comm_fallback", None) else "")),
-                   "bus_exchange": exchange,
+                   "bus_exchange": exchange, "scaling_forms": forms,
                    "placement_probe": probe_log, "placement_tuning": tune_log,
                    "settle": {"steps": settle_steps, "ms_per_step": round(settle_ms, 4)},
                    "layout": f"channel-tiled [N/{tile}][B][{tile}]" if tile else "frame-major [B][N]",
@@ -736,18 +775,105 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
     return res
 
 
+def host_path(ctx, args, blocks=20):
+    """The boundary a Rust host actually crosses: dspfx_process_host from page-locked host buffers (dspfx_host_alloc), H2D + chain + D2H
+    per block -- what host/rust/src/gpu_bank.rs's GpuBank::process costs per 128-frame block (node.rs:135-146, 271-288).  PCIe-bound and
+    NEVER `value`: (a) config 5's shard, (b) the largest power-of-two channel count whose p99 block time stays inside the 2.667 ms block
+    period (= channels one GPU serves in real time from host memory).  `blocks` blocks each after 4 untimed ones; every block timed on
+    its own with the host clock (the call returns when `out` is complete in host memory)."""
+    import numpy as np
+    pkg = ctx.pkg
+    B = 128
+    period = B / 48.0
+
+    def leg(n_channels):
+        cfg = dict(CONFIGS["cfg5"], channels=n_channels)
+        eng = pkg.Engine(n_channels, B, link_flags=args.link_flags, device=ctx.local_rank)
+        eng.set_chain(build_chain(pkg, cfg))
+        eng.kernels_ready(120000)
+        px, py = pkg.PinnedArray((B, n_channels)), pkg.PinnedArray((B, n_channels))
+        try:
+            rng = np.random.default_rng(SEED)
+            px.array[:] = rng.uniform(-1.0, 1.0, (B, n_channels)).astype(np.float32)
+            for _ in range(4):
+                eng.process_host(px.array, out=py.array)
+            ms = np.empty(blocks)
+            for k in range(blocks):
+                t0 = time.perf_counter()
+                eng.process_host(px.array, out=py.array)
+                ms[k] = (time.perf_counter() - t0) * 1e3
+            nbytes = float(px.array.nbytes)
+            p50 = float(np.percentile(ms, 50))
+            return {"channels": n_channels, "blocks": blocks, "ms_per_block_p50": p50, "ms_per_block_p99": float(np.percentile(ms, 99)),
+                    "ms_per_block_max": float(ms.max()), "gbps_each_direction": nbytes / (p50 * 1e-3) / 1e9,
+                    "samples_per_s": n_channels * B / (p50 * 1e-3), "realtime_channels": n_channels * B / (p50 * 1e-3) / 48000.0,
+                    "block_budget_ms": period, "inside_budget_p99": bool(np.percentile(ms, 99) < period)}
+        finally:
+            px.close()
+            py.close()
+            eng.close()
+
+    out = {"what": "dspfx_process_host from dspfx_host_alloc buffers: H2D + 5-node chain + D2H per 128-frame block (GpuBank::process); PCIe-bound, never `value`",
+           "cfg5_shard": leg(CONFIGS["cfg5"]["channels"]), "largest_realtime_pow2": None, "tried": []}
+    n = 1 << 18
+    while n >= 1 << 12:
+        r = leg(n)
+        out["tried"].append({"channels": n, "ms_per_block_p99": r["ms_per_block_p99"]})
+        if r["inside_budget_p99"]:
+            out["largest_realtime_pow2"] = r
+            break
+        n >>= 1
+    return out
+
+
 def launch_env(args, ctx):
-    """One process per GPU, launched by torch.distributed.run: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    """One process per GPU: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment torch.distributed.run (the driver's
+    launcher, or self_launch below) sets."""
     world = ctx.world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = ctx.rank = int(os.environ.get("RANK", "0"))
     ctx.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1: launch with torch.distributed.run, or with no launcher environment at all "
+                         "(bench.py then starts its own ranks)")
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
     return world, rank
+
+
+def visible_gpus():
+    """GPUs this process could use, WITHOUT initialising one (torch.cuda.device_count() only counts on this image)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def self_launch(args, argv):
+    """`python3 bench.py --gpus N` (N > 1) with no launcher environment: start the N ranks as FRESH child processes -- the
+    driver's own launcher command, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same arguments>` -- BEFORE this process makes any GPU call, let rank 0's one JSON line through
+    on stdout, and exit with the launcher's status.  Fewer than N visible GPUs is an error with a one-line reason, never a
+    silent N = 1 (DSPFX_BENCH_SHARE_GPU=1, the one-GPU test rig, needs one; --dry-run needs none)."""
+    import socket
+    n = args.gpus
+    if not args.dry_run:
+        need = 1 if os.environ.get("DSPFX_BENCH_SHARE_GPU") == "1" else n
+        have = visible_gpus()
+        if have < need:
+            print(f"bench.py: --gpus {n} needs {need} visible GPU(s), this host shows {have}: not running", file=sys.stderr)
+            raise SystemExit(3)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: the mailbox communicator's peer mappings and RCCL need it on this pool
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    print("bench.py: no launcher environment; starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr)
+    sys.stderr.flush()
+    rc = subprocess.call(cmd, env=env)
+    raise SystemExit(rc if rc >= 0 else 128 - rc)
 
 
 class _DryEngine:
@@ -789,6 +915,8 @@ def dry_run(args):
     ctx = Ctx()
     ctx.dry = True
     world, rank = launch_env(args, ctx)
+    if os.environ.get("DSPFX_BENCH_DRY_FAIL_RANK") == str(rank):        # tests: a rank that dies must fail the whole launch
+        raise SystemExit("dry run: rank %d told to fail" % rank)
     ctx.use_dist = world > 1
     ctx.dev = torch.device("cpu")
     if ctx.use_dist:
@@ -820,6 +948,23 @@ def dry_run(args):
     for j, row in pbus.results().items():
         want = sum(eng.bus(j, r) for r in range(world)) / div
         ok = ok and bool(torch.allclose(row, want, rtol=1e-6))
+    # the overlapped form of measure()'s scaling_forms: bus two calls late, exchanged off the compute stream's order
+    forms = None
+    if ctx.use_dist and mix_mode == "inline":
+        eng2 = _DryEngine(torch, rank, B, div)
+        pb2 = P.PipelinedMixBus(eng2, shard.total_channels, B, None, None, world, batch=int(os.environ.get("DSPFX_BENCH_OVERLAP_BATCH", "1")),
+                                device="cpu", same_block=False, order=P.HostOrder())
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            pb2.step(None, None)
+        pb2.drain()
+        dist.barrier()
+        dt2 = time.perf_counter() - t1
+        for j, row in pb2.results().items():
+            want = sum(eng2.bus(j, r) for r in range(world)) / div
+            ok = ok and bool(torch.allclose(row, want, rtol=1e-6))
+        forms = {"inline": {"ms_per_step": dt * 1e3 / (args.warmup + args.steps), "bus_delay_blocks": 0},
+                 "overlapped": {"ms_per_step": dt2 * 1e3 / args.steps, "bus_delay_blocks": 2 + pb2.batch - 1, "bus_checked_blocks": len(pb2.results())}}
     t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64)
     if ctx.use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -832,7 +977,7 @@ def dry_run(args):
                        "frames_per_block": B, "mix_bus": mix_mode, "parallelism": f"channel-shard x{world}",
                        "collective": ("torch.distributed all_reduce (fallback: %s)" % ctx.comm_fallback) if getattr(ctx, "comm_fallback", None) else
                                      ("dspfx_mix_allreduce" if ctx.comm is not None else None)},
-            "bus_checked_blocks": len(pbus.results()), "bus_ok": bool(t[1] == 0.0)}))
+            "scaling_forms": forms, "bus_checked_blocks": len(pbus.results()), "bus_ok": bool(t[1] == 0.0)}))
     if ctx.use_dist:
         dist.destroy_process_group()
     if t[1] != 0.0:
@@ -841,6 +986,8 @@ def dry_run(args):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        return self_launch(args, sys.argv[1:])
     if args.dry_run:
         return dry_run(args)
     import torch
@@ -857,6 +1004,8 @@ def main():
     if share_gpu:
         ctx.local_rank = 0
         os.environ.setdefault("DSPFX_BENCH_COMM", "torch")
+    if visible_gpus() <= ctx.local_rank:
+        raise SystemExit(f"bench.py rank {rank}: local rank {ctx.local_rank} has no GPU (this host shows {visible_gpus()}): not running")
     torch.cuda.set_device(ctx.local_rank)
     dev = ctx.dev = torch.device("cuda", ctx.local_rank)
     # DSPFX_BENCH_FORCE_DIST=1 initialises RCCL even for one rank so the collective code path can be
@@ -986,6 +1135,7 @@ def main():
     # what one exchange cost, and any fallback that was taken on the way there
     if ctx.use_dist:
         line["bus_exchange"] = r["config"].get("bus_exchange")
+        line["scaling_forms"] = r["config"].get("scaling_forms")
         line["collective_backend"] = (ctx.comm.backend if ctx.comm is not None else "torch.distributed all_reduce")
         line["collective_fallback"] = (getattr(ctx, "comm_fallback", None) or "; ".join(getattr(ctx, "comm_notes", []) or []) or None)
     line["region_fixed_cost_us"] = r.get("region_fixed_cost_us")
@@ -1009,6 +1159,11 @@ def main():
                                     "sample": f"failed: {ex}"}
     else:
         line["cpu_baseline"] = None      # N > 1, or switched off with --no-cpu-baseline
+    if world == 1 and want_others and os.environ.get("DSPFX_BENCH_HOST_PATH", "1") == "1":
+        try:
+            line["host_path"] = host_path(ctx, args)
+        except Exception as ex:          # reporting only
+            line["host_path"] = {"error": str(ex)[:300]}
     # The driver keeps the last 8 KB of stdout: the line that goes there is the COMPACT one (every contract field, every
     # config's numbers); the full record -- plans, notes, the CPU baseline's thread legs -- goes to stderr and to
     # gpurun_out/bench_detail_<N>gpu.json.
@@ -1054,18 +1209,21 @@ def compact_line(line):
     c = dict(line.get("config") or {})
     plan = [l for l in (c.pop("plan", None) or []) if l.startswith(("stage", "node"))]
     c.pop("placement_probe", None)
+    if "scaling_forms" in line:                      # several ranks: both are top-level keys of the line
+        c.pop("scaling_forms", None)
+        c.pop("bus_exchange", None)
     c["plan"] = [l[:160] for l in plan]
     out["config"] = c
     out["roofline"] = roof(line.get("roofline"))
     cb = line.get("cpu_baseline")
     if cb:
-        cb = {k: cb[k] for k in ("value", "unit", "cores", "kind", "cpu_model", "cgroup_cpu_quota", "gpu_over_cpu") if k in cb}
+        cb = {k: cb[k] for k in ("value", "unit", "cores", "kind", "build", "cpu_model", "cgroup_cpu_quota", "gpu_over_cpu") if k in cb}
         full = line["cpu_baseline"]
         cb["sample"] = (full.get("sample") or "")[:150]
         if full.get("single_thread"):
             cb["single_thread_value"] = full["single_thread"]["value"]
     out["cpu_baseline"] = cb
-    for k in ("bus_exchange", "collective_backend", "collective_fallback", "region_fixed_cost_us", "realtime_channels", "block_latency_ms",
+    for k in ("bus_exchange", "scaling_forms", "collective_backend", "collective_fallback", "region_fixed_cost_us", "realtime_channels", "block_latency_ms",
               "block_budget_ms", "gpu_event_ms_per_step", "host_submit_ms_per_step", "timed_order"):
         if k in line:
             out[k] = line[k]
@@ -1073,6 +1231,11 @@ def compact_line(line):
         out["cold"] = {k: line["cold"][k] for k in ("idle_ms", "steps", "ms_per_step")}
     if line.get("paced"):
         out["paced"] = {k: v for k, v in line["paced"].items() if k != "what"}
+    if line.get("host_path"):
+        h = line["host_path"]
+        out["host_path"] = h if "error" in h else {
+            k: ({kk: v[kk] for kk in ("channels", "ms_per_block_p50", "ms_per_block_p99", "gbps_each_direction", "realtime_channels", "inside_budget_p99")}
+                if isinstance(v, dict) else v) for k, v in h.items() if k in ("cfg5_shard", "largest_realtime_pow2")}
     if line.get("bus_two_calls_late"):
         out["bus_two_calls_late"] = {k: v for k, v in line["bus_two_calls_late"].items() if k != "what"}
     if line.get("other_configs"):

@@ -1,39 +1,18 @@
-"""Chains and parameters shared by the parity tests and bench.py."""
-import math
+"""Chains and parameters shared by the parity tests.  The workloads themselves live in the package
+(dsp-stuff_amd/workloads.py: bench.py times them without importing from tests/); this module re-exports them and adds the
+tests' own ulp distance."""
+import os
+import sys
 
 import numpy as np
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from __graft_entry__ import load_package  # noqa: E402
 
-def rbj_lowpass(fc, q, fs=48000.0):
-    """RBJ cookbook low-pass; computed in f64, handed over as the six raw sliders."""
-    w0 = 2 * math.pi * fc / fs
-    al = math.sin(w0) / (2 * q)
-    c = math.cos(w0)
-    return [1 + al, -2 * c, 1 - al, (1 - c) / 2, 1 - c, (1 - c) / 2]   # a0,a1,a2,b0,b1,b2
+load_package()
+from dsp_stuff_amd import workloads as _w  # noqa: E402
 
-
-def rbj_highpass(fc, q, fs=48000.0):
-    w0 = 2 * math.pi * fc / fs
-    al = math.sin(w0) / (2 * q)
-    c = math.cos(w0)
-    return [1 + al, -2 * c, 1 - al, (1 + c) / 2, -(1 + c), (1 + c) / 2]
-
-
-def chain3(pkg, delay=24000):
-    """BASELINE configs 1/2: gain(0.8) -> biquad LP 1 kHz -> delay(D, 0.5)"""
-    return [pkg.Gain(0.8), pkg.BiQuad(*rbj_lowpass(1000.0, 0.7071)), pkg.Reverb(delay_samples=delay, decay=0.5)]
-
-
-def chain5(pkg, delay=24000):
-    """BASELINE configs 3/5: biquad LP 1k -> SoftClip(3) -> delay(D,0.5) -> biquad HP 80 -> gain(0.5)"""
-    return [pkg.BiQuad(*rbj_lowpass(1000.0, 0.7071)), pkg.Distort(3.0, pkg.SOFT_CLIP),
-            pkg.Reverb(delay_samples=delay, decay=0.5), pkg.BiQuad(*rbj_highpass(80.0, 0.7071)), pkg.Gain(0.5)]
-
-
-def fir_taps(T, seed=0x5EED0004):
-    """Config 4: h[j] = u_j * exp(-6.9 j / T), f64"""
-    rng = np.random.default_rng(seed)
-    return rng.uniform(-1.0, 1.0, T) * np.exp(-6.9 * np.arange(T) / T)
+rbj_lowpass, rbj_highpass, chain3, chain5, fir_taps = _w.rbj_lowpass, _w.rbj_highpass, _w.chain3, _w.chain5, _w.fir_taps
 
 
 def ulp_diff(a, b):

@@ -53,10 +53,47 @@ def test_gpus_flag_must_match_the_launcher():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "torch.distributed.run" in r.stderr
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def _no_launcher_env():
+    return {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+
+
+def test_gpus_2_without_a_launcher_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2 ...` as the driver records the N = 1 command, with no torch.distributed.run in front of it: the
+    process starts its two ranks itself (fresh children, before any GPU call of its own), rank 0's ONE line comes through on stdout,
+    the exit status is the launcher's.  Both forms of the bus exchange are driven and checked against the sum over ranks."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"],
+                       cwd=ROOT, env=_no_launcher_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] and d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["bus_ok"]
+    assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
+    f = d["scaling_forms"]
+    assert f["inline"]["bus_delay_blocks"] == 0 and f["overlapped"]["bus_delay_blocks"] == 2 and f["overlapped"]["bus_checked_blocks"] >= 3
+
+
+def test_gpus_2_without_enough_gpus_fails_with_one_line_and_never_runs_on_one():
+    """No GPU in this container: the real (non-dry) command must exit non-zero with the reason, before starting anything."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       cwd=ROOT, env=_no_launcher_env(), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs 2 visible GPU(s)" in r.stderr and "starting" not in r.stderr
+
+
+def test_a_failing_rank_fails_the_self_launched_run():
+    env = _no_launcher_env()
+    env["DSPFX_BENCH_DRY_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "0", "--dry-run"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
 
 
 def test_single_process_dry_run():

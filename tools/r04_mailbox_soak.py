@@ -41,18 +41,32 @@ if len(sys.argv) > 1 and sys.argv[1] == "rank":
     print(json.dumps(dict(rank=rank, bad=int(bad.item()), seconds=round(time.time() - t0, 1), backend=comm.backend)))
     comm.close()
     sys.exit(0)
-world = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-count = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
-sys.path.insert(0, ROOT)
-from __graft_entry__ import load_package
-fx = load_package()
-uid = fx.comm_unique_id("mailbox")
-procs = [subprocess.Popen([sys.executable, __file__, "rank", str(r), str(world), uid.hex(), str(count)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
-         for r in range(world)]
-res = []
-for p in procs:
-    o, e = p.communicate(timeout=3000)
-    res.append(o.strip().splitlines()[-1] if p.returncode == 0 and o.strip() else "rc=%d %s" % (p.returncode, e[-500:]))
-print("%d ranks x %d exchanges through the mailboxes:" % (world, count))
-for r in res:
-    print("  ", r)
+
+
+def run(world=4, count=100000, timeout=3000):
+    """Start `world` rank processes (this file with the `rank` argument) on GPU 0; returns one dict per rank (or a string with the
+    failing rank's exit status and stderr tail)."""
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import load_package
+    fx = load_package()
+    uid = fx.comm_unique_id("mailbox")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "rank", str(r), str(world), uid.hex(), str(count)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    res = []
+    for p in procs:
+        try:
+            o, e = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, e = p.communicate()
+            res.append("timeout %s" % e[-500:])
+            continue
+        res.append(json.loads(o.strip().splitlines()[-1]) if p.returncode == 0 and o.strip() else "rc=%d %s" % (p.returncode, e[-500:]))
+    print("%d ranks x %d exchanges through the mailboxes:" % (world, count))
+    for r in res:
+        print("  ", json.dumps(r) if isinstance(r, dict) else r)
+    return res
+
+
+if __name__ == "__main__":
+    run(int(sys.argv[1]) if len(sys.argv) > 1 else 4, int(sys.argv[2]) if len(sys.argv) > 2 else 100000)
