@@ -665,9 +665,11 @@ int ring_resize(dspfx_engine *e, int idx, uint32_t D, hipStream_t s) {
 // engine.h).  No api_mu: a process call in progress is not held up, and the blocks it queues are not either (hipMalloc does
 // not wait for the device).  keep_free: leave that many bytes of device memory alone (0: take what is needed).  gen: the
 // chain generation the caller looked at -- groups made for a chain that was replaced meanwhile are freed again.
-int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free) {
+// quiet: a best-effort caller (dspfx_chain_set's up-front reservation) -- a reservation that is not made leaves NO trace in
+// dspfx_last_error; max_share: when non-zero, do not take more than free memory / max_share for it either.
+int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free, bool quiet, size_t max_share) {
     std::lock_guard<std::mutex> alloc_lk(e->alloc_mu);
-    if (hipSetDevice(e->device) != hipSuccess) return fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
+    if (hipSetDevice(e->device) != hipSuccess) return quiet ? DSPFX_ERR_HIP : fail(e, DSPFX_ERR_HIP, "hipSetDevice(%d) failed", e->device);
     const size_t gbytes = (size_t)RING_GROUP_ROWS * e->desc.channels * sizeof(float);
     size_t have = 0;
     {
@@ -683,7 +685,9 @@ int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, si
     const size_t short_by = want_groups - have;
     // all or nothing: a reservation that cannot be completed holds no memory
     size_t fb = 0, tb = 0;
-    if (hipMemGetInfo(&fb, &tb) == hipSuccess && fb < keep_free + short_by * gbytes)
+    const bool info = hipMemGetInfo(&fb, &tb) == hipSuccess;
+    if (quiet && (!info || fb < keep_free + short_by * gbytes || (max_share && short_by * gbytes > fb / max_share))) return DSPFX_ERR_OOM;
+    if (info && fb < keep_free + short_by * gbytes)
         return fail(e, DSPFX_ERR_OOM, "no room for a delay ring of %zu groups of %zu MiB at node %d: %zu more needed, %zu MiB free", want_groups, gbytes >> 20,
                     node, short_by, fb >> 20);
     std::vector<float *> got;
@@ -692,6 +696,7 @@ int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, si
         if (big_alloc((void **)&g, gbytes) != hipSuccess) {
             (void)hipGetLastError();
             for (float *x : got) (void)hipFree(x);        // (nobody ever saw them)
+            if (quiet) return DSPFX_ERR_OOM;
             return fail(e, DSPFX_ERR_OOM, "no room for a delay ring of %zu groups of %zu MiB at node %d (%zu short)", want_groups, gbytes >> 20, node,
                         short_by - got.size());
         }
@@ -994,19 +999,25 @@ int set_nodes(dspfx_engine *e, const dspfx_node_desc *nodes, int n_nodes) {
     rc = plan(e);
     publish_kinds(e);
     // A node fresh from the menu sits on make_buffer()'s short ring under a seconds slider that asks for a longer one
-    // (reverb.rs:44-52): its first slider change -- any slider -- jumps to that length (reverb.rs:55-71).  The groups for it are
-    // reserved now, while nothing is running (best effort, leaving 8 GiB alone: a failed reservation only means the store
-    // allocates), so that first touch is the same O(1) swap as every later one.
+    // (reverb.rs:44-52): its first slider change -- any slider -- jumps to that length (reverb.rs:55-71), and the thread that
+    // makes that store allocates the groups for it (enqueue_store), like the reference's GUI thread.  As a convenience the groups
+    // are reserved NOW, while nothing is running, when that is cheap: by default only if they take no more than 1/16 of the
+    // device's free memory and leave 8 GiB alone (at 262 144 channels the half-second ring is 23.5 GiB, at 2^20
+    // channels 94 GiB -- memory a host that never touches the slider would lose to a ring it never uses, and that only
+    // dspfx_ring_trim gives back).  DSPFX_MENU_RING_RESERVE=0: never; =1: whenever it fits (8 GiB left).  A host that wants
+    // the O(1) first touch at any size says so itself: dspfx_reserve_delay_len.  Best effort and QUIET: a reservation that is
+    // not made is not an error of dspfx_chain_set and leaves dspfx_last_error alone.
     uint64_t gen = 0;
     {
         std::lock_guard<std::mutex> lk(e->pend_mu);
         gen = e->chain_gen;
     }
-    for (int i = 0; i < n_nodes && rc == DSPFX_OK; ++i) {
+    const bool never = e->env.menu_ring_reserve == 0, always = e->env.menu_ring_reserve > 0;     // (read at setup: EnvSwitches)
+    for (int i = 0; i < n_nodes && rc == DSPFX_OK && !never; ++i) {
         const Node &n = e->nodes[(size_t)i];
         if (n.d.kind != DSPFX_REVERB) continue;
         const uint32_t want = reverb_refresh_len(n);
-        if (ring_groups_for(want) > n.groups.size()) (void)ring_reserve(e, i, gen, ring_groups_for(want), (size_t)8 << 30);
+        if (ring_groups_for(want) > n.groups.size()) (void)ring_reserve(e, i, gen, ring_groups_for(want), (size_t)8 << 30, true, always ? 0 : 16);
     }
     const int rs = settle_null_stream(e);
     return rc ? rc : rs;
@@ -1107,19 +1118,22 @@ int enqueue_store(dspfx_engine *e, int node, int param, float value, uint64_t *s
             const float seconds = param == 1 ? value : pr.seconds;
             if (param == 1 || pr.given) want_groups = ring_groups_for(dspfx_delay_len(seconds, pr.mode & 1));
             if (want_groups <= pr.have) want_groups = 0;
-            gen = e->chain_gen;
         }
+        gen = e->chain_gen;                             // every kind: what was validated above was THIS chain's node
     }
     // Reverb::refresh_seconds allocates the new ring on the thread that moved the slider (reverb.rs:55-71).  So does this: a
     // ring longer than the node's capacity gets its groups HERE, before the store is queued -- the thread that drives the blocks
     // finds them at the block boundary and only swaps.  Out of memory: the store is not made, the node keeps ring and slider.
     if (want_groups) {
-        const int rc = ring_reserve(e, node, gen, want_groups, 0);
+        const int rc = ring_reserve(e, node, gen, want_groups, 0, false, 0);
         if (rc) return rc;
     }
     {
         std::lock_guard<std::mutex> lk(e->pend_mu);
-        if (node >= (int)e->pub_kinds.size()) return fail(e, DSPFX_ERR_INVALID, "node %d out of range", node);   // (the chain was replaced meanwhile)
+        // dspfx_chain_set from another thread between the two locked sections (the lock is dropped for the allocation): the kind,
+        // range and ring length were checked against a node that is gone -- the store is NOT made
+        if (e->chain_gen != gen || node >= (int)e->pub_kinds.size())
+            return fail(e, DSPFX_ERR_STATE, "the chain was replaced while the store to node %d was being made: not stored", node);
         if (e->pub_kinds[(size_t)node] == DSPFX_REVERB) {
             if (param == 1) {
                 e->pub_rev[(size_t)node].seconds = value;
@@ -1200,7 +1214,7 @@ extern "C" int dspfx_reserve_delay_len(dspfx_engine *e, int node, uint32_t delay
         gen = e->chain_gen;
     }
     if (delay_len < DSPFX_BUF_SIZE) return fail(e, DSPFX_ERR_INVALID, "delay_len %u < 128", delay_len);
-    return ring_reserve(e, node, gen, ring_groups_for(delay_len), 0);
+    return ring_reserve(e, node, gen, ring_groups_for(delay_len), 0, false, 0);
 }
 
 extern "C" int dspfx_ring_trim(dspfx_engine *e) {

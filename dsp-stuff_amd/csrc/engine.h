@@ -114,6 +114,7 @@ struct EnvSwitches {
     int fast_div = -1;           // DSPFX_FAST_DIV (0: IEEE division everywhere)
     int jit = -1, jit_async = -1;   // DSPFX_JIT, DSPFX_JIT_ASYNC
     int ts_tail = -1;            // DSPFX_TS_TAIL
+    int menu_ring_reserve = -1;  // DSPFX_MENU_RING_RESERVE (0: never reserve a menu-fresh delay node's slider ring at chain set; 1: whenever it fits; unset: when cheap)
     bool has_variant = false;    // DSPFX_VARIANT set at all
     int variant_ts = -1;         // its ts= field
     bool variant_static0 = false;   // it contains "static=0"
@@ -312,7 +313,7 @@ void adopt_async_jit(dspfx_engine *e, const Stage &st);      // plan.hip: run_su
 void request_mod_kernel(dspfx_engine *e, const Stage &st);   // plan.hip: the stage's control-port kernel, on first use
 int ring_rows_copy(dspfx_engine *e, Node &n, uint32_t r0, uint32_t nrows, char *host, bool to_host);
 inline size_t ring_groups_for(uint32_t D) { return ((size_t)D + RING_GROUP_ROWS - 1) / RING_GROUP_ROWS; }
-int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free);   // any thread, no api_mu
+int ring_reserve(dspfx_engine *e, int node, uint64_t gen, size_t want_groups, size_t keep_free, bool quiet, size_t max_share);   // any thread, no api_mu
 int ring_resize(dspfx_engine *e, int node, uint32_t D, hipStream_t s);          // api_mu held
 void recompute_min_delay(dspfx_engine *e);
 int run_subblock(dspfx_engine *e, const float *in, const float *side, float *out, float *mix, uint32_t nframes, uint32_t tile_frames,
@@ -359,6 +360,7 @@ struct JitDirScope {
 };
 void jit_arm_exit_guard();   // the calling thread waits for a background compile in flight when it ends (jit.hip: ExitGuard)
 extern std::atomic<uint64_t> g_jit_compiled, g_jit_from_disk, g_jit_disk_written;
+std::string jit_cache_rejected();     // "" or the cache directory this process refused to use (not this user's / not private)
 int launch_variant(const Variant *v, const ChainArgs &a, unsigned grid, unsigned block, unsigned lds_bytes, hipStream_t s);
 const Variant *jit_variant(const dspfx_engine *e, const Stage &st, bool mod, int mode);
 const Variant *graph_variant(const dspfx_engine *e, const Stage &st);

@@ -1122,17 +1122,49 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
     const int wofs = (int)PAD_LO + 8 * kh - (int)a.koff - cl;      // table index of (iteration i, K element e) = wofs + 16 i + e
     const uint32_t n_iter = (a.koff + a.T + 30) / KC + 1;
 
-    // the window's peak per channel: the epochs that hold the sample times [max(t_k0, 0), t_k0 + kvalid) -- at most 34 entries of
-    // 128 bytes per tile; the channel's two lanes take every other one
-    float peak = 0.0f;
+    // Could this sweep serve every channel of the tile?  Decided HERE, before the sweep, from the append pass' per-epoch peaks of the
+    // epochs that hold the window's sample times [max(t_k0, 0), t_k0 + kvalid) -- at most 34 entries of 128 bytes per tile, the
+    // channel's two lanes take every other one -- and kept as one wave-uniform mask (no register lives through the sweep).
+    //   `peak`: over every epoch that overlaps the window.  An upper bound of the window's true peak (a boundary epoch reaches up
+    //           to 127 samples past either end of it): the right side for HALF_PEAK_MAX, for non-finite samples (infinite peak)
+    //           and for "all zero".
+    //   `pin` : over the epochs that lie INSIDE the window -- a LOWER bound of the true peak, the right side for HALF_PEAK_MIN.
+    //           Only when the sole loud samples sit in the boundary epochs (a loud-to-quiet transition, the first blocks of a
+    //           stream) is their in-window part scanned exactly in the f32 ring (with `peak` on both sides a loud
+    //           sample just outside the window hid a window below 2^-13, whose f16 lo parts go subnormal; fir_half_kernel,
+    //           which measures the window it sweeps, would have redone it).
+    bool ok = true;
     {
+        float peak = 0.0f, pin = 0.0f;
         const long long t_last = a.t_k0 + (long long)a.kvalid - 1;
         if (t_last >= 0) {
-            const unsigned long long e_lo = (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0) / EPOCH, e_hi = (unsigned long long)t_last / EPOCH;
+            const unsigned long long t_lo = (unsigned long long)(a.t_k0 > 0 ? a.t_k0 : 0);
+            const unsigned long long e_lo = t_lo / EPOCH, e_hi = (unsigned long long)t_last / EPOCH;
             const float *pk = a.peaks + (size_t)tile * a.peak_slots * TILE_C + cl;
-            for (unsigned long long e = e_lo + kh; e <= e_hi; e += 2) peak = __builtin_fmaxf(peak, pk[(size_t)(e % a.peak_slots) * TILE_C]);
+            for (unsigned long long e = e_lo + kh; e <= e_hi; e += 2) {
+                const float v = pk[(size_t)(e % a.peak_slots) * TILE_C];
+                peak = __builtin_fmaxf(peak, v);
+                if (e * EPOCH >= t_lo && (e + 1) * EPOCH - 1 <= (unsigned long long)t_last) pin = __builtin_fmaxf(pin, v);
+            }
+            peak = __builtin_fmaxf(peak, __shfl_xor(peak, 32));                    // the channel's two lanes
+            pin = __builtin_fmaxf(pin, __shfl_xor(pin, 32));
+            if (c_ok && pin < HALF_PEAK_MIN && peak >= HALF_PEAK_MIN && peak <= HALF_PEAK_MAX) {
+                // the boundary epochs' samples inside the window, exactly (<= 2 x 127 per channel, split between its two lanes)
+                const float *rc = a.ring + (size_t)tile * ring_tile_stride(a.R);
+                auto scan = [&](unsigned long long e) {
+                    const unsigned long long b0 = e * EPOCH > t_lo ? e * EPOCH : t_lo;
+                    const unsigned long long b1 = (e + 1) * EPOCH - 1 < (unsigned long long)t_last ? (e + 1) * EPOCH - 1 : (unsigned long long)t_last;
+                    for (unsigned long long t = b0 + kh; t <= b1; t += 2)
+                        pin = __builtin_fmaxf(pin, __builtin_fabsf(rc[ring_in_tile((uint32_t)(t % a.R), cl)]) * HALF_APPEND_SCALE);
+                };
+                if (e_lo * EPOCH < t_lo || (e_lo + 1) * EPOCH - 1 > (unsigned long long)t_last) scan(e_lo);
+                if (e_hi != e_lo && (e_hi + 1) * EPOCH - 1 > (unsigned long long)t_last) scan(e_hi);
+            }
+            pin = __builtin_fmaxf(pin, __shfl_xor(pin, 32));
         }
+        ok = peak == 0.0f || (pin >= HALF_PEAK_MIN && peak <= HALF_PEAK_MAX);
     }
+    const bool tile_ok = __ballot(ok) == ~0ull;
 
     f32x16 acc[NJT], tot0;
     f32x4 *tl = (f32x4 *)(tps + 2 * (size_t)ntp4) + (size_t)wave * ((NJT - 1) * 4 * 64) + lane;   // [jt - 1][q][lane]
@@ -1219,11 +1251,9 @@ __global__ void __launch_bounds__(64 * SPLIT_WAVES) __attribute__((amdgpu_waves_
         });
     }
     flush();
-    // Could this sweep serve every channel of the tile?  (The peak covers whole 128-sample epochs, up to 127 samples older than
-    // the window: conservative.)  A non-finite sample makes its epoch's peak infinite: listed too (and redone exactly besides).
-    peak = __builtin_fmaxf(peak, __shfl_xor(peak, 32));                            // the channel's two lanes
-    const bool ok = peak == 0.0f || (peak >= HALF_PEAK_MIN && peak <= HALF_PEAK_MAX);
-    if (__ballot(ok) != ~0ull && lane == 0) a.redo_tiles[atomicAdd(a.redo_count, 1u)] = tile;
+    // a tile this sweep could not serve (decided above) is listed for the bf16 x 3 second pass; a non-finite sample made its
+    // epoch's peak infinite: listed too (and redone exactly besides)
+    if (!tile_ok && lane == 0) a.redo_tiles[atomicAdd(a.redo_count, 1u)] = tile;
     const float us = a.half_unscale;
     fir_epilogue<NJT>(a, tile, c, c_ok, 0, kh, lane,
                       [&](int jt, int r) { return (jt == 0 ? tot0[r] : tl[((jt > 0 ? jt - 1 : 0) * 4 + (r >> 2)) * 64][r & 3]) * us; });

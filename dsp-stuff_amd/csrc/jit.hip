@@ -136,6 +136,24 @@ static bool owned_and_private(const std::string &path) {
     if (stat(path.c_str(), &st) != 0) return false;
     return st.st_uid == geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
+// A cache DIRECTORY that exists but is not ours / not private is a condition the user should hear about: every process then
+// recompiles its kernels (0.3 - 1.5 s each, in the background) although dspfx_describe names an active cache.
+// The first such directory is remembered per process and reported by dspfx_describe (jit_cache_rejected).
+static std::mutex g_rej_mu;
+static std::string g_rejected_dir;
+static bool cache_dir_usable(const std::string &dir) {
+    if (owned_and_private(dir)) return true;
+    struct stat st;
+    if (stat(dir.c_str(), &st) == 0) {                 // it exists: somebody else's, or group / world writable (umask 002, a shared DSPFX_CACHE_DIR)
+        std::lock_guard<std::mutex> lk(g_rej_mu);
+        if (g_rejected_dir.empty()) g_rejected_dir = dir;
+    }
+    return false;
+}
+std::string jit_cache_rejected() {
+    std::lock_guard<std::mutex> lk(g_rej_mu);
+    return g_rejected_dir;
+}
 // digest of the two kernel headers as the compiler will see them, computed once per header directory and process (the text is
 // ~200 KB: hashing it on every look-up -- up to three per plan(), and one from the block path when a control port is first
 // connected -- cost milliseconds: ADVICE r04)
@@ -195,7 +213,7 @@ static uint64_t code_sum(const char *p, size_t n) {
 }
 static bool cache_read(const std::string &path, std::string &lowered, std::vector<char> &code) {
     std::string all;
-    if (path.empty() || !owned_and_private(path.substr(0, path.find_last_of('/'))) || !owned_and_private(path)) return false;
+    if (path.empty() || !cache_dir_usable(path.substr(0, path.find_last_of('/'))) || !owned_and_private(path)) return false;
     if (!read_file(path, all) || all.size() < 8 + 4 + 16 || memcmp(all.data(), "DSPFXCO2", 8) != 0) return false;
     uint32_t nl = 0;
     memcpy(&nl, all.data() + 8, 4);
@@ -213,12 +231,12 @@ static void cache_write(const std::string &path, const char *lowered, const std:
     if (path.empty()) return;
     const std::string dir = path.substr(0, path.find_last_of('/'));
     mkdirs(dir);
-    if (!owned_and_private(dir)) return;               // somebody else's (or a world-writable) directory: do not feed it
-    char tmp[64];
-    snprintf(tmp, sizeof tmp, ".tmp.%ld.%p", (long)getpid(), (void *)&code);
-    const std::string tpath = path + tmp;
-    const int fd = open(tpath.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW | O_CLOEXEC, 0600);
+    if (!cache_dir_usable(dir)) return;                // somebody else's (or a world-writable) directory: do not feed it
+    // a unique temporary name from mkstemp (O_EXCL, 0600): a file left behind by a crashed process can never block this one
+    std::string tpath = path + ".tmp.XXXXXX";
+    const int fd = mkstemp(&tpath[0]);
     if (fd < 0) return;
+    (void)fcntl(fd, F_SETFD, FD_CLOEXEC);
     FILE *f = fdopen(fd, "wb");
     if (!f) {
         close(fd);

@@ -94,6 +94,7 @@ EnvSwitches read_env_switches() {
     s.jit = env_int("DSPFX_JIT");
     s.jit_async = env_int("DSPFX_JIT_ASYNC");
     s.ts_tail = env_int("DSPFX_TS_TAIL");
+    s.menu_ring_reserve = env_int("DSPFX_MENU_RING_RESERVE");
     if (const char *v = getenv("DSPFX_VARIANT")) {
         s.has_variant = true;
         const char *q;

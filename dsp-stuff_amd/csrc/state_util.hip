@@ -321,6 +321,12 @@ extern "C" int dspfx_describe(const dspfx_engine *e, char *dst, size_t cap) {
                  (unsigned long long)g_jit_compiled.load(), (unsigned long long)g_jit_from_disk.load(), (unsigned long long)g_jit_disk_written.load(),
                  cdir.empty() ? "no disk cache" : cdir.c_str());
         s += buf;
+        const std::string rej = jit_cache_rejected();
+        if (!rej.empty()) {
+            snprintf(buf, sizeof buf, "note: the disk cache %s is NOT used: the directory must belong to this user and be writable by nobody else "
+                                      "(chmod go-w, or point DSPFX_CACHE_DIR elsewhere); kernels are recompiled by every process\n", rej.c_str());
+            s += buf;
+        }
     }
     if (e->jit_unavailable)
         s += "note: a run-time specialised kernel was wanted but could not be compiled (hiprtc unavailable, or DSPFX_KERNEL_HEADERS "

@@ -230,7 +230,9 @@ int dspfx_kernels_ready(dspfx_engine *e, int wait_ms);
  *          frame counter in the kernel arguments), in order with the blocks in flight, which carry their own copies.  Groups a
  *          LONGER ring needs are allocated -- not zeroed: every row is written before it is read unmasked -- by the thread
  *          that MAKES the store, before the store is queued (the reference's GUI thread allocates the new ring too,
- *          reverb.rs:55-71); dspfx_chain_set reserves them up front for a menu-fresh node; a shorter ring keeps the surplus
+ *          reverb.rs:55-71); dspfx_chain_set reserves them up front for a menu-fresh node when that is cheap (at most 1/16 of the
+ *          device's free memory; DSPFX_MENU_RING_RESERVE=0 never, =1 whenever it fits -- dspfx_reserve_delay_len is the explicit
+ *          form and dspfx_ring_trim gives unused reservations back); a shorter ring keeps the surplus
  *          as capacity (dspfx_ring_trim returns it).  DSPFX_ERR_OOM: the store was NOT made, the node keeps ring and slider.
  *          params[1] outside 0..=1 (the slider's range, reverb.rs:34-37) is DSPFX_ERR_INVALID; a STORED 0.0 is a value like any other
  *          (a 128-sample ring, reverb.rs:58) -- only in a node DESCRIPTOR does params[1] = 0 mean "no seconds slider: keep delay_len";

@@ -943,6 +943,42 @@ def test_fir_state_export_import(dspfx, torch_cuda):
 
 
 @pytest.mark.parametrize("packed", ["1", "0"])
+def test_fir_two_part_sweep_quiet_window_right_behind_a_loud_epoch(dspfx, torch_cuda, monkeypatch, packed):
+    """the packed sweep takes its window's peak from per-epoch (128 sample times) peaks; with T = 200 the window of the
+    block at n0 starts at n0 - 208, 48 samples into an epoch.  Loud samples that end INSIDE those 48 (outside the window) must not
+    count for the lower bound 2^-13: the window itself holds only samples of 2^-24, whose f16 lo parts are subnormal (14 significant
+    bits instead of 22), so the tile has to be redone by the bf16 x 3 pass -- as fir_half_kernel (DSPFX_FIR_PACKED=0), which
+    measures the window it sweeps, always did.  A decaying stream that crosses 2^-13 rides along.  Stated bar: relative RMS
+    < 1e-6 in EVERY block against the oracle's f64 accumulation (fir.rs:201-216)."""
+    monkeypatch.setenv("DSPFX_FIR_PACKED", packed)
+    rng = np.random.default_rng(5)
+    N, T, B, m = 64, 200, 128, 6
+    h = rng.uniform(-1.0, 1.0, T) * np.exp(-np.arange(T) / 40.0)
+    nblocks = m + 8
+    x = rng.uniform(-1.0, 1.0, (nblocks * B, N)).astype(F)
+    L = 128 * m + 40                                    # the last loud sample is L - 1: 40 samples into epoch m
+    x[L:] *= F(2.0 ** -24)
+    x[:, 32:] = (x[:, 32:] * (0.5 * np.exp(-np.arange(nblocks * B) / 150.0))[:, None]).astype(F)       # channels 32..63: a fade through 2^-13 and on
+    eng = dspfx.Engine(N, B, link_flags=0)
+    eng.set_chain([dspfx.Fir(h)])
+    eng.set_fir_precision(0, dspfx.FIR_PRECISION_HALF)
+    got = _run_fir_blocks(dspfx, torch_cuda, eng, x, B).astype(np.float64)
+    assert ("fir_halfp_kernel" if packed == "1" else "fir_half_kernel") in eng.describe(), eng.describe()
+    ref = O.run_channels([dspfx.Fir(h).oracle_desc()], x, 0).astype(np.float64)
+    worst = 0.0
+    for half in (slice(0, 32), slice(32, 64)):
+        for k in range(nblocks):
+            r, g = ref[k * B:(k + 1) * B, half], got[k * B:(k + 1) * B, half]
+            rel = float(np.sqrt(np.mean((g - r) ** 2)) / np.sqrt(np.mean(r ** 2)))
+            worst = max(worst, rel)
+            assert rel < 1e-6, (packed, "block", k, "channels", half, rel)
+    # the block in question: its window [128 (m + 2) - 208, 128 (m + 2) + 127] holds no loud sample, its oldest epoch does
+    k = m + 2
+    assert np.abs(x[128 * k - 208:128 * (k + 1), :32]).max() < 2.0 ** -23 and np.abs(x[128 * m:128 * k - 208, :32]).max() > 0.5
+    eng.close()
+
+
+@pytest.mark.parametrize("packed", ["1", "0"])
 def test_fir_packed_history_stays_in_step_with_the_f32_ring(dspfx, torch_cuda, monkeypatch, packed):
     """Round 5: the two-part f16 sweep reads a copy of the history that the append pass has ALREADY split into f16 hi / lo
     (FirState::ringh + a per-channel peak per 128 sample times) instead of splitting the f32 ring 33 times over.  Only that
@@ -2065,6 +2101,42 @@ def test_reverb_length_changes_reuse_the_rings_groups(dspfx, torch_cuda, monkeyp
     eng.ring_trim()
     assert "128 samples in 1 of 1 groups" in eng.describe(), eng.describe()
     eng.close()
+
+
+def test_menu_fresh_reverb_ring_is_reserved_only_when_cheap_and_quietly(dspfx, torch_cuda, monkeypatch):
+    """dspfx_chain_set used to reserve the whole seconds-slider ring of every menu-fresh REVERB node -- 23.5 GiB
+    at 262 144 channels, 94 GiB at 2^20 -- for a slider that may never move.  Now: only when the missing groups take at most 1/16
+    of the device's free memory (DSPFX_MENU_RING_RESERVE=1: whenever they fit; =0: never), never with a trace in dspfx_last_error;
+    the first slider store allocates on the storing thread like the reference's GUI thread (reverb.rs:55-71) and
+    dspfx_reserve_delay_len is the explicit hint."""
+    B = 128
+    small = dspfx.Engine(4096, B, link_flags=0)
+    small.set_chain([dspfx.Reverb()])                                     # 187 more groups of 2 MiB: cheap
+    assert "128 samples in 1 of 1 groups" in small.describe() and "(+187 reserved)" in small.describe(), small.describe()
+    small.close()
+    big = dspfx.Engine(1 << 18, B, link_flags=0)
+    big.set_chain([dspfx.Reverb()])                                       # 187 groups of 128 MiB = 23.4 GiB: not taken behind the host's back
+    assert "(+0 reserved)" in big.describe(), big.describe()
+    assert big.L.dspfx_last_error(big.h).decode() == "", big.L.dspfx_last_error(big.h)
+    x = torch_cuda.zeros((B, 1 << 18), dtype=torch_cuda.float32, device="cuda")
+    x[0, :] = 1.0
+    y = torch_cuda.empty_like(x)
+    big.process(x, out=y, n_frames=B)
+    big.set_param(0, 0, 0.25)                                             # the first touch: the storing thread allocates, the swap is O(1)
+    assert "24000 samples in 188 of 188 groups" in big.describe(), big.describe()
+    big.reserve_delay_len(0, 48000)                                       # the explicit hint still works at any size
+    assert "(+187 reserved)" in big.describe(), big.describe()
+    big.ring_trim()
+    assert "(+0 reserved)" in big.describe()
+    monkeypatch.setenv("DSPFX_MENU_RING_RESERVE", "1")
+    big.set_chain([dspfx.Reverb()])
+    assert "(+187 reserved)" in big.describe(), big.describe()
+    big.close()
+    monkeypatch.setenv("DSPFX_MENU_RING_RESERVE", "0")
+    small = dspfx.Engine(4096, B, link_flags=0)
+    small.set_chain([dspfx.Reverb()])
+    assert "(+0 reserved)" in small.describe(), small.describe()
+    small.close()
 
 
 def test_reverb_seconds_store_that_cannot_be_had_leaves_the_node_alone(dspfx, torch_cuda):
