@@ -13,6 +13,15 @@
  * itself.  It is pinned only by known-answer tests derived from the cited source
  * lines (tests/test_oracle_kat.py) and by an independent numpy-float32 model
  * (oracle/numpy_model.py).
+ * To pin it, ONE command in a checkout of the reference (oracle/pin_kit/README.md):
+ *   cp oracle/pin_kit/golden_dump.rs <reference>/dsp-stuff/src/  (+ `mod golden_dump;`
+ *   and the early return in main.rs shown there), then
+ *   DSPFX_GOLDEN_DUMP=oracle/pin_kit/cases.json DSPFX_GOLDEN_OUT=pin_out.json cargo run --release
+ *   python tools/compare_pin.py pin_out.json
+ * runs the REAL nodes over every golden vector of this repository through
+ * Perform::perform and compares bit patterns with the parity tests' bars; it also
+ * reports the two facts restated "as recalled" below (rivulet's granted view length,
+ * DirectForm1::run's operation order).
  *
  * Third-party arithmetic that is NOT under /root/reference and is restated from
  * its published definition (Cargo.lock pins):

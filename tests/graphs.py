@@ -153,7 +153,7 @@ def cab_rig(taps=64, bypass=False, cut="fir", dry=False):
     h = [math.exp(-6.0 * j / taps) * (1.0 if j % 3 else -0.7) / 4.0 for j in range(taps)]
     nodes = [(0, "input", {}), (1, "gain", {"level": 1.5}), (2, "distort", {"level": 4.0, "mode": "SoftClip"}),
              (3, "biquad", BQ), (4, "add", {}),
-             (5, "fir", {"taps": h[::-1], "mode": "Balanced"}) if cut == "fir" else (5, "distort", {"level": 5.0, "mode": "Fuzz"}),
+             (5, "fir", {"taps": h[::-1], "mode": "Balanced", "file_name": None}) if cut == "fir" else (5, "distort", {"level": 5.0, "mode": "Fuzz"}),
              (6, "reverb", {"seconds": 0.005, "decay": 0.4}), (7, "mix", {"ratio": 0.3}), (8, "high_pass", {"ratio": 0.1}),
              (9, "output", {})]
     links = [(0, 1, "in"), (1, 2, "in"), (1, 3, "in"), (2, 4, "a"), (3, 4, "b"), (4, 5, "in"), (2, 5, "in"),
@@ -217,7 +217,7 @@ def long_rig(seed, n_blocks=10, fir_at=None, dry_mix=False):
             s = d
         if fir_at == b:
             h = [math.exp(-5.0 * j / 32) * (1.0 if j % 2 else -0.5) / 3.0 for j in range(32)]
-            f = add("fir", {"taps": h[::-1], "mode": "Balanced"})
+            f = add("fir", {"taps": h[::-1], "mode": "Balanced", "file_name": None})
             links.append((s, f, "in"))
             s = f
     if dry_mix:
