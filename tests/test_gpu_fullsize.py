@@ -393,3 +393,40 @@ def test_bench_py_prints_one_compact_contract_line(tmp_path):
     assert "region_fixed_cost_us" in d and "workload" in d["config"]
     detail = [l for l in r.stderr.splitlines() if l.startswith("bench.py detail: ")]
     assert len(detail) == 1 and json.loads(detail[0][len("bench.py detail: "):])["value"] == d["value"]
+
+
+def test_bare_gpus_2_command_starts_its_own_ranks_and_reports_both_exchange_forms():
+    """`python3 bench.py --gpus 2 ...` with NO torch.distributed.run in front of it and no launcher environment --
+    the shape of the driver's recorded N = 1 command -- must start its own ranks (fresh children, before any GPU call of the
+    parent), exchange the bus of every block between them, and print ONE line with both forms of the exchange.  On this one-GPU
+    box both ranks share device 0 (DSPFX_BENCH_SHARE_GPU=1: gloo for torch's group, the C ABI's mailbox communicator for the bus);
+    a reduced shard so that it takes seconds.  Without that switch the same command must refuse to run on one GPU -- never a silent
+    N = 1."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID")}
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--channels", "65536", "--delay", "1024"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root, env=env)
+        assert r.returncode != 0 and r.stdout.strip() == "" and "needs 2 visible GPU(s)" in r.stderr, r.stderr[-2000:]
+    env.update(DSPFX_BENCH_SHARE_GPU="1", DSPFX_BENCH_COMM="abi", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["scaling"] == "weak" and d["cpu_baseline"] is None
+    assert d["config"]["parallelism"] == "channel-shard x2" and d["collective_backend"] == "mailbox" and d["collective_fallback"] is None
+    assert abs(d["value"] - 2 * 65536 * 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    f = d["scaling_forms"]
+    assert f["inline"]["value"] == pytest.approx(d["value"], rel=1e-6) and f["inline"]["bus_delay_blocks"] == 0
+    assert f["overlapped"]["value"] > 0 and f["overlapped"]["bus_delay_blocks"] == 2, f
+    assert d["bus_exchange"]["backend"] == "mailbox" and 0 < d["bus_exchange"]["us_p50"] < 1000
+    assert "starting 2 ranks" in r.stderr
+    print("bare --gpus 2 on one GPU: inline %.3g samples/s, overlapped %.3g, exchange p50 %.1f us" % (
+        f["inline"]["value"], f["overlapped"]["value"], d["bus_exchange"]["us_p50"]))
