@@ -748,6 +748,29 @@ def measure(ctx, args, cfg_name, steps, warmup, overrides=None, extras=False):
         except Exception as ex:          # reporting only: never lose the headline line
             forms["overlapped"] = {"error": str(ex)[:300]}
             fence()
+        # the third form: the SAME bus as `inline` (block k's, one exchange per block), but the exchange queued on the second
+        # stream behind one event -- block k + 1's chain kernel does not wait for it, the bus completes a few microseconds after
+        # its block's samples.  Same semantics as `value`, the exchange off the critical path.
+        try:
+            pb3 = P.PipelinedMixBus(eng, total_channels, B, ctx.compute_stream, mix_stream, bus_world, batch=1, device=dev,
+                                    comm=ctx.comm, same_block=True, exchange_on_compute=False)
+            for k in range(max(warmup, 8)):
+                pb3.step(xs[k % n_in], y)
+            pb3.drain()
+            fence()
+            ea0, ea1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            dt3, _, _ = timed_region(lambda k: pb3.step(xs[k % n_in], y), pb3.drain, ea0, ea1)
+            if ctx.use_dist:
+                t = torch.tensor([dt3], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt3 = float(t.item())
+            forms["same_block_second_stream"] = {"what": "same-block bus (as inline), exchange on the second stream behind one event per block",
+                                                 "value": samples / dt3, "ms_per_step": dt3 * 1e3 / steps,
+                                                 "gpu_event_ms_per_step": ea0.elapsed_time(ea1) / steps, "bus_delay_blocks": 0}
+            del pb3
+        except Exception as ex:
+            forms["same_block_second_stream"] = {"error": str(ex)[:300]}
+            fence()
     res = {
         "value": value, "ms_per_step": dt * 1e3 / steps, "roofline": roof, "chain": chain, "cfg": cfg, "cold": cold, "paced": paced, "alt_bus": alt_bus,
         "config": {"workload": cfg["desc"], "channels_per_gpu": N, "frames_per_block": B,
@@ -963,8 +986,21 @@ def dry_run(args):
         for j, row in pb2.results().items():
             want = sum(eng2.bus(j, r) for r in range(world)) / div
             ok = ok and bool(torch.allclose(row, want, rtol=1e-6))
+        eng3 = _DryEngine(torch, rank, B, div)
+        pb3 = P.PipelinedMixBus(eng3, shard.total_channels, B, None, None, world, batch=1, device="cpu", same_block=True, order=P.HostOrder(),
+                                exchange_on_compute=False)
+        t1 = time.perf_counter()
+        for k in range(args.steps):
+            pb3.step(None, None)
+        pb3.drain()
+        dist.barrier()
+        dt3 = time.perf_counter() - t1
+        for j, row in pb3.results().items():
+            want = sum(eng3.bus(j, r) for r in range(world)) / div
+            ok = ok and bool(torch.allclose(row, want, rtol=1e-6))
         forms = {"inline": {"ms_per_step": dt * 1e3 / (args.warmup + args.steps), "bus_delay_blocks": 0},
-                 "overlapped": {"ms_per_step": dt2 * 1e3 / args.steps, "bus_delay_blocks": 2 + pb2.batch - 1, "bus_checked_blocks": len(pb2.results())}}
+                 "overlapped": {"ms_per_step": dt2 * 1e3 / args.steps, "bus_delay_blocks": 2 + pb2.batch - 1, "bus_checked_blocks": len(pb2.results())},
+                 "same_block_second_stream": {"ms_per_step": dt3 * 1e3 / args.steps, "bus_delay_blocks": 0, "bus_checked_blocks": len(pb3.results())}}
     t = torch.tensor([dt, 0.0 if ok else 1.0], dtype=torch.float64)
     if ctx.use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

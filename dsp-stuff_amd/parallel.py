@@ -156,13 +156,18 @@ class PipelinedMixBus:
     """
 
     def __init__(self, engine, total_channels: int, n_frames: int, compute_stream, mix_stream, world: int,
-                 batch: int = 8, device=None, comm=None, same_block: bool = False, order=None, group=None):
+                 batch: int = 8, device=None, comm=None, same_block: bool = False, order=None, group=None,
+                 exchange_on_compute: Optional[bool] = None):
         import torch
         self.torch, self.eng = torch, engine
         self.nf, self.batch = int(n_frames), int(batch)
         self.order = order if order is not None else StreamOrder(torch, compute_stream, mix_stream)
         self.same_block = bool(same_block)
-        self.inline = self.same_block and self.batch == 1      # one exchange per block, on the compute stream itself
+        # one exchange per block on the compute stream itself (the default for same_block, batch = 1).  exchange_on_compute=False
+        # (round 6) keeps the SAME bus -- block k's, exchanged once per block -- but queues the exchange on the second stream behind
+        # one event, so block k + 1's chain kernel does not wait for it: the bus completes a few microseconds after its block's
+        # samples, off the critical path (bench.py: scaling_forms.same_block_second_stream).
+        self.inline = (self.same_block and self.batch == 1) if exchange_on_compute is None else (bool(exchange_on_compute) and self.same_block and self.batch == 1)
         self.lag = 0 if self.same_block else 2       # calls between a block's submission and its bus
         self.rings = [torch.zeros(self.batch * self.nf, dtype=torch.float32, device=device) for _ in range(3)]
         mh = self.order.compute_handle if self.inline else self.order.mix_handle

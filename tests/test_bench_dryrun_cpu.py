@@ -78,6 +78,7 @@ def test_gpus_2_without_a_launcher_starts_its_own_ranks():
     assert "starting 2 ranks" in r.stderr and "torch.distributed.run" in r.stderr
     f = d["scaling_forms"]
     assert f["inline"]["bus_delay_blocks"] == 0 and f["overlapped"]["bus_delay_blocks"] == 2 and f["overlapped"]["bus_checked_blocks"] >= 3
+    assert f["same_block_second_stream"]["bus_delay_blocks"] == 0 and f["same_block_second_stream"]["bus_checked_blocks"] >= 3
 
 
 def test_gpus_2_without_enough_gpus_fails_with_one_line_and_never_runs_on_one():

@@ -426,6 +426,7 @@ def test_bare_gpus_2_command_starts_its_own_ranks_and_reports_both_exchange_form
     f = d["scaling_forms"]
     assert f["inline"]["value"] == pytest.approx(d["value"], rel=1e-6) and f["inline"]["bus_delay_blocks"] == 0
     assert f["overlapped"]["value"] > 0 and f["overlapped"]["bus_delay_blocks"] == 2, f
+    assert f["same_block_second_stream"]["value"] > 0 and f["same_block_second_stream"]["bus_delay_blocks"] == 0, f
     assert d["bus_exchange"]["backend"] == "mailbox" and 0 < d["bus_exchange"]["us_p50"] < 1000
     assert "starting 2 ranks" in r.stderr
     print("bare --gpus 2 on one GPU: inline %.3g samples/s, overlapped %.3g, exchange p50 %.1f us" % (

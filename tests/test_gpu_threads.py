@@ -465,6 +465,63 @@ def test_many_stores_under_contention_replayed_from_the_log(dspfx, torch_cuda):
     print("stores landed on %d block boundaries" % len(stores))
 
 
+def test_stores_racing_a_chain_replacement_are_refused_not_misdelivered(dspfx, torch_cuda):
+    """a slider store is validated against the node it names, then -- for a Reverb store that needs ring capacity -- the
+    storing thread allocates OUTSIDE the engine's locks before the store is queued.  A dspfx_chain_set from the audio thread in that
+    window used to let a store checked against the old chain's REVERB node be queued for whatever node has that index now.  It is
+    refused (DSPFX_ERR_STATE) instead.  Two chains whose node 1 is a REVERB in one and a DISTORT in the other are swapped 60 times
+    while a second thread stores `seconds` values that need 188 fresh groups after every chain set.  Every store returns OK (it
+    met the chain it was checked against: a ring swap on the REVERB, an unused slider slot on the DISTORT), DSPFX_ERR_STATE (raced)
+    or DSPFX_ERR_INVALID -- never anything else; the engine never wedges, and a chain set afterwards runs to the oracle's result."""
+    torch = torch_cuda
+    N = 4096
+    a = [dspfx.Gain(0.9), dspfx.Reverb(delay_samples=256, decay=0.4), dspfx.Gain(0.8)]
+    b = [dspfx.Gain(0.9), dspfx.Distort(2.0, dspfx.HARD_CLIP), dspfx.Gain(0.8)]
+    eng = dspfx.Engine(N, B, link_flags=3)
+    eng.set_chain(a)
+    x = _noise(N, B * 4)
+    dx = torch.from_numpy(x).cuda()
+    dy = torch.empty_like(dx)
+    stop = threading.Event()
+    seen = {"ok": 0, "state": 0, "invalid": 0, "other": []}
+
+    def gui_thread():
+        k = 0
+        while not stop.is_set():
+            k += 1
+            try:
+                eng.set_param(1, 1, 0.5 if k % 2 else 0.004)       # REVERB: seconds (0.5 needs 188 groups after every chain set)
+                seen["ok"] += 1
+            except dspfx.DspfxError as ex:
+                if ex.status == -6:
+                    seen["state"] += 1
+                elif ex.status == -1:
+                    seen["invalid"] += 1
+                else:
+                    seen["other"].append(str(ex))
+
+    t = threading.Thread(target=gui_thread)
+    t.start()
+    for k in range(60):
+        eng.set_chain(b if k % 2 == 0 else a)
+        eng.process(dx[:B], out=dy[:B], n_frames=B)
+    stop.set()
+    t.join()
+    torch.cuda.synchronize()
+    assert seen["other"] == [], seen["other"][:3]
+    assert seen["ok"] + seen["state"] + seen["invalid"] > 0
+    print("stores: %d made, %d refused as raced (DSPFX_ERR_STATE), %d invalid for the node they met" % (seen["ok"], seen["state"], seen["invalid"]))
+    # the engine is whole: a fresh chain runs to the oracle's result
+    eng.set_chain(a)
+    for k in range(4):
+        eng.process(dx[k * B:(k + 1) * B], out=dy[k * B:(k + 1) * B], n_frames=B)
+    torch.cuda.synchronize()
+    sample = [0, 63, 64, N - 1]
+    ref = _oracle_blocks(a, x[:, sample], {})
+    assert ulp_diff(dy.cpu().numpy()[:, sample], ref).max() <= 1
+    eng.close()
+
+
 @pytest.mark.parametrize("N,which", [
     (1, "chain3"),            # config 1's single channel: the whole engine is the launch for the channels left over
     (63, "chain5"),

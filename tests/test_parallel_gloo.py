@@ -171,8 +171,11 @@ def _pipelined_worker(rank, world, port, total, blocks, batch, same_block, out_q
     _, part = O.run_noise_channels(descs, 0x5EED0001, sh.offset, sh.channels, 0, blocks, link_flags=3,
                                    want_out=False, want_mix=True)
     eng = _FakeEngine(part, B, O.link_divisor(total))
+    second = same_block == "second_stream"         # the same-block bus, exchanged off the compute stream's order (round 6)
+    same_block = bool(same_block)
     pb = P.PipelinedMixBus(eng, total, B, None, None, world, batch=batch, device="cpu", same_block=same_block,
-                           order=P.HostOrder())
+                           order=P.HostOrder(), exchange_on_compute=(False if second else None))
+    assert pb.inline == (same_block and batch == 1 and not second)
     lag = 0 if same_block else 2
     got = {}
     for k in range(blocks):
@@ -194,7 +197,7 @@ def _pipelined_worker(rank, world, port, total, blocks, batch, same_block, out_q
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("same_block", [False, True])
+@pytest.mark.parametrize("same_block", [False, True, "second_stream"])
 @pytest.mark.parametrize("blocks,batch", [(1, 4), (2, 4), (7, 4), (8, 4), (13, 4), (26, 8), (33, 2), (1, 1), (9, 1)])
 def test_pipelined_mix_bus_world2_every_block_matches_the_oracle(blocks, batch, same_block):
     """Two ranks, different channel shards, the batched collective path of bench.py --gpus N: rings, batches, the
