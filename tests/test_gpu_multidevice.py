@@ -179,3 +179,30 @@ def test_thread_ranks_of_one_process_on_two_devices(dspfx, torch_cuda):
     want = np.stack([np.arange(B, dtype=F) * 3 + 2 * k for k in range(blocks)])
     for r in range(world):
         assert np.array_equal(res[r], want), r
+
+
+@pytest.mark.skipif(NDEV < 2, reason="needs at least two GPUs (this box has %d)" % NDEV)
+@pytest.mark.parametrize("world", sorted({2, min(8, max(NDEV, 2))}))
+def test_the_bare_bench_command_scales_itself_across_devices(world):
+    """`python3 bench.py --gpus N` as the driver may issue it -- no launcher, one rank per DEVICE, RCCL for torch's group, the C ABI's
+    communicator for the bus: one line, the whole-job value = N x the shard, the backend that ran named at the top level, all three
+    forms of the exchange timed.  (A reduced shard: this test is about the launch and the exchange, the curve is the driver's.)  The
+    one-GPU twin of this test runs every round with both ranks on device 0 (tests/test_gpu_fullsize.py)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                            "GROUP_RANK", "ROLE_RANK", "TORCHELASTIC_RUN_ID", "DSPFX_BENCH_SHARE_GPU")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "20", "--warmup", "5", "--channels", "262144",
+                        "--delay", "1024"], capture_output=True, text=True, timeout=1800, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["config"]["parallelism"] == "channel-shard x%d" % world
+    assert abs(d["value"] - world * 262144 * 128 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["collective_backend"] in ("mailbox", "rccl", "torch.distributed all_reduce")
+    f = d["scaling_forms"]
+    assert all(f[k].get("value", 0) > 0 for k in ("inline", "overlapped", "same_block_second_stream")), f
+    print("bare --gpus %d: backend %s (fallback: %s), exchange p50 %s us; samples/s inline %.4g, second stream %.4g, two calls late %.4g" % (
+        world, d["collective_backend"], d["collective_fallback"], (d.get("bus_exchange") or {}).get("us_p50"),
+        f["inline"]["value"], f["same_block_second_stream"]["value"], f["overlapped"]["value"]))
