@@ -75,3 +75,22 @@ def test_the_printed_line_fits_the_drivers_stdout_tail():
 def pytest_approx(v):
     import pytest
     return pytest.approx(v, rel=1e-6)
+
+
+def test_round6_records_carry_the_host_boundary_and_say_which_cpu_build_ran():
+    """the driver-shaped line reports `host_path` (dspfx_process_host from page-locked buffers: what
+    GpuBank::process costs, PCIe-bound, never `value`) and `cpu_baseline.build` (rebuilt -O3 -march=native on the box, or the
+    prebuilt fallback); the self-launched N = 2 record reports all three forms of the bus exchange."""
+    recs = {os.path.basename(p): d for p, d in _records()}
+    d = recs["r06_bench_driver_cmd_run1.json"]
+    h = d["host_path"]
+    assert h["cfg5_shard"]["channels"] == 1 << 20 and h["cfg5_shard"]["ms_per_block_p50"] > d["ms_per_step"] * 5      # PCIe-bound: far from `value`
+    assert h["cfg5_shard"]["inside_budget_p99"] is False and h["largest_realtime_pow2"]["inside_budget_p99"] is True
+    assert h["largest_realtime_pow2"]["ms_per_block_p99"] < 128 / 48.0
+    assert d["cpu_baseline"]["build"].startswith("gcc -O3 -march=native")
+    two = json.loads(open(os.path.join(ROOT, "profiles", "r06_two_ranks_self_launched.json")).read().strip().splitlines()[-1])
+    assert two["n_gpus"] == 2 and two["cpu_baseline"] is None and two["collective_backend"] == "mailbox"
+    f = two["scaling_forms"]
+    assert abs(f["inline"]["value"] - two["value"]) / two["value"] < 1e-6 and f["inline"]["bus_delay_blocks"] == 0       # (the compact line rounds nested floats to 7 digits)
+    assert f["same_block_second_stream"]["bus_delay_blocks"] == 0 and f["overlapped"]["bus_delay_blocks"] == 2
+    assert all(f[k]["value"] > 0 for k in f)

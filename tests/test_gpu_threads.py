@@ -805,6 +805,30 @@ def test_a_large_engine_adopts_its_kernels_in_mid_stream_with_the_bus_unchanged(
     assert "jit_" in eng.describe(), eng.describe()
 
 
+def test_a_cache_directory_that_is_refused_is_named_by_describe(tmp_path):
+    """a cache directory that exists but is group / world writable (a umask 002 host, a shared DSPFX_CACHE_DIR) is not
+    used -- code objects found there would be RUN -- and every process recompiles its kernels.  That used to be silent while
+    dspfx_describe went on naming the directory as the active cache; now it carries a `note:` line.  (Fresh process: the refusal
+    is remembered per process.)"""
+    import subprocess
+    import sys
+    cdir = tmp_path / "shared"
+    cdir.mkdir()
+    os.chmod(cdir, 0o777)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = ("import sys; sys.path.insert(0, %r)\nimport torch\nfrom __graft_entry__ import load_package\nfx = load_package()\n"
+              "e = fx.Engine(256, 128, link_flags=3)\n"
+              "e.set_chain([fx.Gain(0.33), fx.LowPass(0.21), fx.Gain(0.7), fx.HighPass(0.4), fx.Gain(1.2)])\n"
+              "e.kernels_ready(120000)\nprint(e.describe())\n" % root)
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, DSPFX_CACHE_DIR=str(cdir), DSPFX_JIT="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    if "jit_" not in r.stdout:
+        pytest.skip("no run-time compiler on this box")
+    assert "note: the disk cache %s is NOT used" % cdir in r.stdout, r.stdout
+    assert " 0 written to it" in r.stdout and not list(cdir.glob("*")), (r.stdout, list(cdir.glob("*")))
+
+
 def test_a_damaged_cache_file_is_ignored_and_rewritten(dspfx, torch_cuda, monkeypatch, tmp_path):
     cdir = tmp_path / "c"
     monkeypatch.setenv("DSPFX_CACHE_DIR", str(cdir))
