@@ -351,7 +351,9 @@ pub struct ParamHandle {
     raw: std::sync::Arc<Raw>,
 }
 impl ParamHandle {
-    /// Returns the store's sequence number.
+    /// Returns the store's sequence number.  `Err(DSPFX_ERR_STATE)`: the node's task replaced the chain (`dspfx_chain_set`) while this
+    /// store was being made -- it was NOT stored (it had been checked against a node that is gone); `Err(DSPFX_ERR_OOM)`: a Reverb
+    /// store whose longer ring does not fit -- ring and slider stay as they were.  Either way the widget keeps its old value.
     pub fn set_param(&self, node: usize, param: usize, value: f32) -> Result<u64, c_int> {
         let mut seq = 0u64;
         let rc = unsafe { dspfx_set_param_seq(self.raw.0, node as c_int, param as c_int, value, &mut seq) };
