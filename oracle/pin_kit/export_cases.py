@@ -10,6 +10,7 @@ bit patterns + the expected Output signal (`want`, bit patterns) + the bar the p
                                      the oracle's node-by-node evaluation of THAT document (oracle/graph_eval.py: every hop of a real
                                      graph divides by f32(1.0001), the Output node's included) -- for the goldens stored with link
                                      scaling on (link_flags 3) this is cross-checked here against the stored vector + the Output hop;
+  * random DAGs                      24 seeded graphs of tests/graphs.py (every node kind, control ports fed by other nodes, fan-in);
   * menu-fresh nodes                 a Reverb built by `NodeStatic::new` (make_buffer's ring under a 0.5 s slider, reverb.rs:44-52) and a
                                      BiQuad on its initial filter (biquad.rs:48-60): `fresh` tells the harness to use the NODES table.
 
@@ -116,6 +117,24 @@ def build_cases(page_round=False):
         bar = dict(kind="ulp", ulp=int(b)) if b is not None else (dict(kind="rel_peak", tol=4e-6) if g["name"].startswith("distort") else dict(kind="rel_rms", tol=1e-6))
         cases.append(dict(name="chain_" + g["name"], doc=json.loads(text), fresh={}, x=[bits(x[:, 0])], want=[bits(y[:, 0])], bar=bar,
                           source="tests/golden/%s.npz as a document; expected = oracle/graph_eval.py on it" % g["name"]))
+    # ---- random DAGs (tests/graphs.py random_dag: fan-in, fan-out, unplugged ports, sliders driven by other nodes, generators, envelope
+    # followers): 16 of the exact-arithmetic kinds, 8 with the libm kinds (tanh / sin / atan modes, overdrive, chebyshev, sine generator)
+    import graphs
+    want_exact, want_libm, seed = 16, 8, 7000
+    while want_exact or want_libm:
+        libm = want_exact == 0
+        text = graphs.random_dag(seed, 8 + seed % 5, libm=libm)
+        seed += 1
+        x = O.noise(0x5EED00CC + seed, [0], np.arange(384))
+        y = graph_eval.run_graph(G.Graph(text, page_round), x)
+        if not np.isfinite(y).all() or np.abs(y).max() == 0:
+            continue
+        cases.append(dict(name="dag_%s_%d" % ("libm" if libm else "exact", seed - 1), doc=json.loads(text), fresh={}, x=[bits(x[:, 0])], want=[bits(y[:, 0])],
+                          bar=dict(kind="rel_peak", tol=4e-6) if libm else dict(kind="ulp", ulp=4), source="tests/graphs.py random_dag(%d); expected = oracle/graph_eval.py" % (seed - 1)))
+        if libm:
+            want_libm -= 1
+        else:
+            want_exact -= 1
     # ---- menu-fresh nodes (NodeStatic::new): make_buffer's 128-sample ring, the initial DirectForm1
     for name, node, title in (("fresh_reverb", E.Reverb(), "Reverb"), ("fresh_biquad", E.BiQuad(), "Biquad")):
         text = CFG.dump_dspconfig([node], faithful_lowpass_bug=False)

@@ -27,7 +27,7 @@ def test_cases_json_is_what_the_exporter_makes_from_the_committed_vectors(tmp_pa
     assert r.returncode == 0, r.stdout + r.stderr
     a, b = json.load(open(out)), json.load(open(os.path.join(KIT, "cases.json")))
     assert a == b, "oracle/pin_kit/cases.json is stale: python oracle/pin_kit/export_cases.py"
-    assert len(b["cases"]) >= 32 and {"fresh_reverb", "fresh_biquad", "chain_chain5_link3", "graph_fan_in_three"} <= {c["name"] for c in b["cases"]}
+    assert len(b["cases"]) >= 56 and {"fresh_reverb", "fresh_biquad", "chain_chain5_link3", "graph_fan_in_three", "dag_exact_7000"} <= {c["name"] for c in b["cases"]}
 
 
 def test_emulated_harness_reproduces_every_vector_and_the_comparator_can_fail(tmp_path):
@@ -35,7 +35,7 @@ def test_emulated_harness_reproduces_every_vector_and_the_comparator_can_fail(tm
     r = _run(os.path.join(ROOT, "tools", "compare_pin.py"), "--emulate", str(out))
     assert r.returncode == 0, r.stdout + r.stderr
     r = _run(os.path.join(ROOT, "tools", "compare_pin.py"), str(out))
-    assert r.returncode == 0 and r.stdout.count("PASS") >= 32 and "FAIL" not in r.stdout and "EMULATED" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and r.stdout.count("PASS") >= 56 and "FAIL" not in r.stdout and "EMULATED" in r.stdout, r.stdout + r.stderr
     d = json.load(open(out))
     d["results"][3]["y"][0][200] ^= 0x10                       # one sample, 16 ulp off
     bad = tmp_path / "bad.json"
