@@ -130,7 +130,9 @@ def build_cases(page_round=False):
         if not np.isfinite(y).all() or np.abs(y).max() == 0:
             continue
         cases.append(dict(name="dag_%s_%d" % ("libm" if libm else "exact", seed - 1), doc=json.loads(text), fresh={}, x=[bits(x[:, 0])], want=[bits(y[:, 0])],
-                          bar=dict(kind="rel_peak", tol=4e-6) if libm else dict(kind="ulp", ulp=4), source="tests/graphs.py random_dag(%d); expected = oracle/graph_eval.py" % (seed - 1)))
+                          # (libm DAGs: a 1-ulp difference between two math libraries at one node is amplified by whatever follows it -- clippers,
+                          # squarers, generators whose frequency it drives; the per-node ulp bars are the chain_* cases', these check the wiring)
+                          bar=dict(kind="rel_peak", tol=1e-4) if libm else dict(kind="ulp", ulp=4), source="tests/graphs.py random_dag(%d); expected = oracle/graph_eval.py" % (seed - 1)))
         if libm:
             want_libm -= 1
         else:

@@ -582,3 +582,52 @@ def test_golden_graphs_through_the_region_plan(dspfx, G):
         ref = np.tile(y, (1, -(-N // y.shape[1])))[:, :N]
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), (name, ge.describe())
         ge.close()
+
+
+def test_the_pin_kits_cases_through_the_hip_path(dspfx, G):
+    """oracle/pin_kit/cases.json is the set of cases the reference-side harness (golden_dump.rs) runs through the REAL nodes.  The same
+    documents and the same samples through the HIP engine, against the same expected vectors with the same bars
+    (tools/compare_pin.py's judge): when a maintainer's one command says the reference matches the vectors, this test has already
+    said the GPU does -- reference == vectors == GPU on one case set.  (The two menu-fresh cases are chains:
+    test_gpu_parity.py::test_reverb_fresh_from_the_menu_*; a document cannot say "fresh".)"""
+    import json
+    import os
+    import sys
+    import torch
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (os.path.join(root, "oracle", "pin_kit"), os.path.join(root, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import compare_pin
+    import export_cases
+    N, B = 64, 128
+    ran, forms = 0, {}
+    for c in export_cases.build_cases():
+        if c["fresh"]:
+            continue
+        ge = G.GraphEngine(json.dumps(c["doc"]), N, B)
+        kind = "one kernel" if ge.fused is not None else ("series" if ge.series else ("regions" if ge.regions else "run by run"))
+        forms[kind] = forms.get(kind, 0) + 1
+        for ch, (xb, wb) in enumerate(zip(c["x"], c["want"])):
+            if ch:
+                ge.close()
+                ge = G.GraphEngine(json.dumps(c["doc"]), N, B)          # every channel of a case is an independent run
+            x = compare_pin.f32(xb)
+            want = compare_pin.f32(wb)
+            got = np.empty_like(x)
+            for f0 in range(0, x.size, B):
+                dx = torch.from_numpy(np.repeat(x[f0:f0 + B, None], N, axis=1).copy()).cuda()
+                y = ge.process(dx, B)
+                torch.cuda.synchronize()
+                yy = y.cpu().numpy().reshape(B, N)
+                assert np.array_equal(yy.view(np.uint32), np.repeat(yy[:, :1], N, axis=1).view(np.uint32)), c["name"]     # identical channels
+                got[f0:f0 + B] = yy[:, 0]
+            bar = c["bar"]
+            if bar["kind"] == "ulp" and any(n["typename"] == "fir" for n in c["doc"]["nodes"]) and c["name"] != "chain_fir_int5":
+                bar = dict(kind="rel_peak", tol=1e-5)       # the MFMA sweeps' stated bar (test_graph_golden_vectors); the reference's f64 loop is held to ulps
+            ok, text = compare_pin.judge(got, want, bar)
+            assert ok, (c["name"], ch, text, kind)
+        ge.close()
+        ran += 1
+    assert ran >= 54
+    print("pin-kit cases through the HIP path: %d cases, %s" % (ran, forms))
