@@ -879,6 +879,12 @@ def self_launch(args, argv):
     silent N = 1 (DSPFX_BENCH_SHARE_GPU=1, the one-GPU test rig, needs one; --dry-run needs none)."""
     import socket
     n = args.gpus
+    # under a profiler whose preloaded library has already initialised the GPU in THIS process, starting other programs from it is
+    # what the GPU pool forbids (an exec from a GPU-initialised process): say so instead of trying
+    if any(k in os.environ for k in ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_LIBRARY", "ROCPROF_ATT_LIBRARY_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        print("bench.py: --gpus %d under a profiler: this process may already hold the GPU and must not start the ranks itself; "
+              "profile with the launcher in front (rocprofv3 ... -- python3 -m torch.distributed.run ... bench.py --gpus %d)" % (n, n), file=sys.stderr)
+        raise SystemExit(3)
     if not args.dry_run:
         need = 1 if os.environ.get("DSPFX_BENCH_SHARE_GPU") == "1" else n
         have = visible_gpus()
